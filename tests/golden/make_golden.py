@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own code (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Imports ``/root/reference`` (a pure-Python/PyTorch repo) on CPU with the three shims of
+SURVEY.md section 8(c): a SimpleNamespace cfg (yacs is absent), ``Tensor.cuda`` = identity (no
+GPU here; the reference hard-codes ``.cuda()``), and frame-id ray columns.  Every uniform draw
+the reference makes (``torch.rand`` at layers/RaySamplePoint.py:98 and utils/sample_pdf.py:31) is
+recorded so that the oracle and the HIP kernels can replay it.  Weights come from
+``stnerf_amd.synthetic.make_state_dict`` (frozen numpy RandomState stream) and are NOT stored.
+
+The fixtures are the pin for ``oracle/stnerf_oracle.py`` (the reference has no golden vectors of
+its own for this path).  ``/root/reference`` does not exist on the GPU box; nothing at test time
+reads it -- only these committed ``.npz`` files.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+torch.Tensor.cuda = lambda self, *a, **k: self  # shim 2
+
+import modeling as ref_modeling                      # noqa: E402
+import utils as ref_utils                            # noqa: E402
+from layers.RaySamplePoint import RaySamplePoint, intersection  # noqa: E402
+from layers.render_layer import VolumeRenderer, gen_weight       # noqa: E402
+from modeling.spacenet import SpaceNet               # noqa: E402
+from modeling.motion_net import MotionNet            # noqa: E402
+
+from stnerf_amd import synthetic as syn              # noqa: E402
+
+
+class RandRecorder:
+    """Wraps torch.rand: records every draw (in call order)."""
+
+    def __init__(self):
+        self.draws = []
+        self._orig = torch.rand
+
+    def __enter__(self):
+        def rec(*a, **k):
+            x = self._orig(*a, **k)
+            self.draws.append(x.clone())
+            return x
+        torch.rand = rec
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self._orig
+
+
+def make_cfg(layer_num, n1, n2, space_time, deform_time):
+    m = types.SimpleNamespace(BOARDER_WEIGHT=1e10, SAMPLE_METHOD="BBOX", SAME_SPACENET=False,
+                              TKERNEL_INC_RAW=True, POSE_REFINEMENT=False, USE_DIR=True,
+                              USE_DEFORM_VIEW=False, USE_DEFORM_TIME=deform_time, USE_SPACE_TIME=space_time,
+                              BKGD_USE_DEFORM_TIME=False, BKGD_USE_SPACE_TIME=False, DEEP_RGB=False,
+                              COARSE_RAY_SAMPLING=n1, FINE_RAY_SAMPLING=n2)
+    return types.SimpleNamespace(MODEL=m, DATASETS=types.SimpleNamespace(LAYER_NUM=layer_num))
+
+
+def save(name, meta, **arrays):
+    out = {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"wrote {name}.npz  ({sum(a.nbytes for a in out.values())} B raw)")
+
+
+def view_rays(h, w, layer_num, orbit=20.0, frame=2.5, per_ray_frames=False):
+    K, T = syn.camera(h, w, orbit)
+    rays, _ = ref_utils.generate_rays(K, T, None, h, w)
+    if per_ray_frames:
+        fid = (torch.arange(rays.shape[0]) % 3 + 1).float().reshape(-1, 1)
+        return torch.cat([rays, fid], -1)
+    return torch.cat([rays, syn.frame_id_columns(rays.shape[0], layer_num, frame)], -1)
+
+
+def flatten_out(out, prefix=""):
+    fm, cm, fl, cl, masks = out
+    d = {}
+    for tag, trip in (("fine_mixed", fm), ("coarse_mixed", cm)):
+        for nm, x in zip(("color", "depth", "acc"), trip):
+            d[f"{prefix}{tag}_{nm}"] = x
+    for tag, lst in (("fine_layer", fl), ("coarse_layer", cl)):
+        for i, trip in enumerate(lst):
+            for nm, x in zip(("color", "depth", "acc"), trip):
+                d[f"{prefix}{tag}{i}_{nm}"] = x
+    for i, mk in enumerate(masks):
+        d[f"{prefix}mask{i}"] = mk
+    return d
+
+
+# ----------------------------------------------------------------------------- op-level fixtures
+def g_generate_rays():
+    h, w = 6, 8
+    K, T = syn.camera(h, w, 33.0)
+    rays, _ = ref_utils.generate_rays(K, T, None, h, w)
+    rays2, _ = ref_utils.ray_sampling(K.unsqueeze(0), T.unsqueeze(0), (h, w))
+    assert torch.equal(rays, rays2)
+    save("generate_rays", dict(h=h, w=w), K=K, T=T, rays=rays)
+
+
+def g_sampler():
+    L, n1 = 2, 8
+    rays = view_rays(8, 8, L)
+    # edge cases: an axis-parallel ray (zero direction components), a ray starting inside a
+    # performer box, a ray pointing away from everything
+    extra = torch.tensor([[0.0, 0.0, -4.0, 0.0, 0.0, 1.0], [-0.5, 0.1, 0.0, 0.6, 0.0, 0.8],
+                          [0.0, 0.0, -4.0, 0.0, 0.0, -1.0], [5.0, 5.0, 5.0, 1.0, 0.0, 0.0]])
+    extra = torch.cat([extra, syn.frame_id_columns(4, L)], -1)
+    rays = torch.cat([rays, extra], 0)
+    bk, per = syn.scene_boxes(L)
+    boxes = torch.cat([bk, per[1]], 0).unsqueeze(0).repeat(rays.shape[0], 1, 1, 1)
+    fn = torch.stack([intersection(rays, boxes[:, i]) for i in range(L + 1)], 0)
+    torch.manual_seed(1)
+    with RandRecorder() as rr:
+        t, xyz, mask = RaySamplePoint(n1).forward(rays, boxes)
+    save("sampler", dict(L=L, n1=n1), rays=rays, boxes=boxes[0], far_near=fn,
+         jitter=torch.stack(rr.draws, 0), t=torch.stack(t, 0), xyz=torch.stack(xyz, 0),
+         mask=torch.stack(mask, 0))
+
+
+def g_encoding():
+    torch.manual_seed(2)
+    arrs = {}
+    for tag, nf, dim in (("pos", 10, 3), ("dir", 4, 3), ("time", 10, 1), ("motion", 10, 4)):
+        x = (torch.rand(16, dim) - 0.5) * 6.0
+        arrs[f"x_{tag}"] = x
+        arrs[f"y_{tag}"] = ref_utils.Trigonometric_kernel(L=nf, input_dim=dim)(x)
+    save("encoding", {}, **arrs)
+
+
+def _strip(sd, prefix):
+    return {k[len(prefix) + 1:]: v for k, v in sd.items() if k.startswith(prefix + ".")}
+
+
+def g_nets():
+    torch.manual_seed(3)
+    n, s = 6, 5
+    pos = (torch.rand(n, s, 3) - 0.5) * 5.0
+    d = torch.nn.functional.normalize(torch.rand(n, 3) - 0.5, dim=-1)
+    rays = torch.cat([torch.zeros(n, 3), d], -1)
+    times = torch.tensor([[1.0], [2.0], [2.5], [3.0], [1.25], [7.0]])
+    rs = np.random.RandomState(11)
+    sd_t = syn.spacenet_state("net", rs, True)
+    sd_n = syn.spacenet_state("net", rs, False)
+    sd_m = syn.motionnet_state("net", rs)
+    net_t = SpaceNet(use_time=True)
+    net_t.load_state_dict(_strip(sd_t, "net"))
+    net_n = SpaceNet(use_time=False)
+    net_n.load_state_dict(_strip(sd_n, "net"))
+    mot = MotionNet(c_input=4, input_time=True)
+    mot.load_state_dict(_strip(sd_m, "net"))
+    with torch.no_grad():
+        rgb_t, sig_t = net_t(pos.clone(), rays, times)
+        rgb_n, sig_n = net_n(pos.clone(), rays)
+        xt_frac = torch.cat([pos, times.view(n, 1, 1).repeat(1, s, 1)], -1)
+        flow_frac = mot(xt_frac)
+        xt_int = torch.cat([pos, torch.floor(times).view(n, 1, 1).repeat(1, s, 1)], -1)
+        flow_int = mot(xt_int)
+    save("nets", dict(weight_seed=11), pos=pos, dirs=d, times=times, rgb_t=rgb_t, sigma_t=sig_t,
+         rgb_n=rgb_n, sigma_n=sig_n, flow_frac=flow_frac, flow_int=flow_int)
+
+
+def g_composite():
+    torch.manual_seed(4)
+    n, s = 10, 12
+    t = torch.sort(torch.rand(n, s) * 6.0, -1)[0].unsqueeze(-1)
+    rgb = torch.randn(n, s, 3) * 2.0
+    sigma = torch.randn(n, s, 1) * 3.0
+    sigma[0] = -1.0                      # all-empty ray
+    sigma[1] = 50.0                      # opaque at the first sample
+    with torch.no_grad():
+        color, depth, acc, w = VolumeRenderer(boarder_weight=1e10)(t, rgb, sigma)
+        delta = torch.cat([(t[:, 1:] - t[:, :-1]).squeeze(-1), 1e10 * torch.ones(n, 1)], -1)
+        w2 = gen_weight(sigma, delta)
+    save("composite", dict(border=1e10), t=t, rgb=rgb, sigma=sigma, color=color, depth=depth, acc=acc,
+         weights=w, gen_weight=w2)
+
+
+def g_sample_pdf():
+    torch.manual_seed(5)
+    n, n1, n2 = 10, 12, 6
+    t = torch.sort(torch.rand(n, n1) * 6.0, -1)[0]
+    w = torch.rand(n, n1 - 2) ** 4
+    w[0] = 0.0                           # flat pdf (all 1e-5)
+    w[1] = 0.0
+    w[1, 4] = 1.0                        # one spike: den<1e-5 branches around it
+    with RandRecorder() as rr:
+        z = ref_utils.sample_pdf(t, w, n2)
+        z0 = ref_utils.sample_pdf(t, w, 0)
+    u = rr.draws[0]
+    save("sample_pdf", dict(n2=n2), t=t, w=w, u=u, z=z, z_empty=z0)
+
+
+# ----------------------------------------------------------------------------- whole-path fixtures
+def build_ref_model(L, n1, n2, st, dt, seed):
+    model = ref_modeling.build_layered_model(make_cfg(L, n1, n2, st, dt), camera_num=1).eval()
+    model.load_state_dict(syn.make_state_dict(L, st, dt, seed))
+    bk, per = syn.scene_boxes(L)
+    model.set_bkgd_bbox(bk)
+    model.set_bboxes(per)
+    return model
+
+
+def g_forward(name, L, n1, n2, st, dt, seed, h, w, frame=2.5, per_ray_frames=False, edit=None,
+              call_kwargs=None, chunk=None, only_coarse=False):
+    model = build_ref_model(L, n1, n2, st, dt, seed)
+    edit = edit or {}
+    for k in ("scale", "shift", "alpha", "near"):
+        if k in edit:
+            setattr(model, k, edit[k])
+    for i in edit.get("hide", []):
+        model.hide_layer(i)
+    rays = view_rays(h, w, L, frame=frame, per_ray_frames=per_ray_frames)
+    n = rays.shape[0]
+    labels, bb, nf = torch.zeros(n), torch.zeros(n, 8, 3), torch.zeros(n, 2)
+    kw = dict(call_kwargs or {})
+    torch.manual_seed(100 + seed)
+    with RandRecorder() as rr, torch.no_grad():
+        if chunk is None:
+            out = model(rays, labels, bb, only_coarse=only_coarse, near_far=nf, **kw)
+        else:
+            out = ref_utils.layered_batchify_ray(model, rays, labels, bb, chuncks=chunk, near_far=nf, **kw)
+    meta = dict(L=L, n1=n1, n2=n2, space_time=st, deform_time=dt, weight_seed=seed, h=h, w=w,
+                edit={k: v for k, v in edit.items()}, call_kwargs=kw, chunk=chunk, only_coarse=only_coarse,
+                n_draws=len(rr.draws))
+    arrays = flatten_out(out)
+    for i, dr in enumerate(rr.draws):
+        arrays[f"draw{i}"] = dr
+    save(name, meta, rays=rays, **arrays)
+
+
+def main():
+    g_generate_rays()
+    g_sampler()
+    g_encoding()
+    g_nets()
+    g_composite()
+    g_sample_pdf()
+    # C1-shaped: single performer, space-time only, no fine stage
+    g_forward("fwd_c1", 1, 8, 0, True, False, 21, 6, 8)
+    # C3-shaped: two performers, space-time + deform, fractional (retimed) frame id
+    g_forward("fwd_c3", 2, 12, 6, True, True, 22, 8, 8)
+    # every per-frame edit knob the renderer pokes (layered_neural_renderer.py:435-440) + thresholds
+    g_forward("fwd_edit", 2, 12, 6, True, True, 23, 8, 8, frame=2.0,
+              edit=dict(scale=[1.0, 1.2, 0.8], shift=[None, None, [-0.1, 0.02, 0.05]], alpha=0.5, near=1.5),
+              call_kwargs=dict(density_threshold=0.2, bkgd_density_threshold=0.1))
+    g_forward("fwd_hide", 2, 12, 6, True, True, 24, 8, 8, edit=dict(hide=[1]))
+    # non-retiming layout (training-style rays: one frame id per ray), deform only
+    g_forward("fwd_nonretime", 1, 10, 5, False, True, 25, 6, 8, per_ray_frames=True)
+    g_forward("fwd_only_coarse", 2, 12, 6, True, True, 26, 6, 8, only_coarse=True)
+    # chunked call surface (batchify_rays.py:51-140): >1 chunk incl. a ragged tail, and the N<chunk path
+    g_forward("batchify_chunked", 2, 12, 6, True, True, 27, 8, 8, chunk=24,
+              call_kwargs=dict(density_threshold=0.05, bkgd_density_threshold=0.02))
+    g_forward("batchify_small", 2, 12, 6, True, True, 28, 6, 8, chunk=3584,
+              call_kwargs=dict(density_threshold=0.05, bkgd_density_threshold=0.02))
+
+
+if __name__ == "__main__":
+    main()
