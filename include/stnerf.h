@@ -1,0 +1,168 @@
+/*
+ * stnerf.h -- C ABI of libstnerf_hip.so: the MI355X (gfx950) implementation of the st-nerf layered
+ * ray-march hot path.
+ *
+ * The reference (DarlingHang/st-nerf) has no FFI: its boundary for this path is the Python call
+ * surface of LayeredRFRender.forward / layered_batchify_ray and the ops they compose.  Each entry
+ * point below replaces one of those ops (cited as reference file:line, relative to
+ * /root/reference) and is what a ctypes / cffi / pybind binding in the reference would bind
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - Plain C: pointers + sizes.  Every `const float*` / `float*` / `uint8_t*` / `int32_t*` argument
+ *     is a DEVICE pointer unless its comment says "host".  All tensors are dense row-major fp32.
+ *   - The caller owns every buffer (inputs, outputs, packed weights).  The library allocates nothing
+ *     on the device and never frees caller memory.
+ *   - All work is enqueued on the caller's stream (`stream` = a hipStream_t, may be NULL for the
+ *     default stream).  No entry point synchronises the device or the stream.
+ *   - Return value: 0 on success, a negative STNERF_E* code otherwise; stnerf_last_error() gives
+ *     the message (thread-local).  Nothing throws or aborts across the ABI (the reference calls
+ *     exit(-1) on a bad ray layout, modeling/layered_rfrender.py:161-163; here that is -EINVAL).
+ *   - Layouts used by the chunk pipeline ("ray-major"): t[n][l][S], xyz[n][l][S][3],
+ *     raw[n][l][S][4] = {r, g, b, sigma} (network outputs before any activation), mask[n][l].
+ */
+#ifndef STNERF_H
+#define STNERF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STNERF_OK 0
+#define STNERF_EINVAL (-1)   /* bad argument / shape */
+#define STNERF_ELAUNCH (-2)  /* HIP launch or runtime error */
+#define STNERF_EARCH (-3)    /* device is not gfx950 */
+
+#define STNERF_MAX_LAYERS 16
+
+typedef void* stnerf_stream_t; /* hipStream_t */
+
+/* library / device ----------------------------------------------------------------------- */
+const char* stnerf_version(void);
+const char* stnerf_last_error(void);
+/* cu_count, lds_bytes_per_cu, clock_khz may be NULL; arch receives e.g. "gfx950" (host buffer). */
+int stnerf_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, char* arch, int arch_len);
+
+/* Per-layer edit applied to sample points (inverse of the box edit), host struct passed by value
+ * inside stnerf_scene.  modeling/layered_rfrender.py:293-303 (coarse) and :467-475 (fine). */
+typedef struct stnerf_layer_edit {
+    float shift[3];  /* x -= shift              (only if has_shift) */
+    float scale;     /* x = (x - pivot) / scale + pivot   (only if has_scale) */
+    int32_t has_shift;
+    int32_t has_scale;
+} stnerf_layer_edit;
+
+/* a1 + a2: pinhole rays of rows [first_ray, first_ray+n) of an h x w view, row-major over
+ * (row, col), written as [origin(3), dir(3), frame_ids(n_frame_cols)] with `ray_stride` floats per
+ * ray.  Replaces utils/render_helpers.py:42-128 (generate_rays), utils/ray_sampling.py:22-72 and
+ * data/datasets/ray_dataset.py:276-281.  Kinv = inverse intrinsics (host, 9 floats, row-major),
+ * T = camera-to-world (host, 16 floats), frame_ids host array of n_frame_cols floats (or NULL). */
+int stnerf_generate_rays(const float* Kinv_host, const float* T_host, int h, int w, int64_t first_ray,
+                         int64_t n, const float* frame_ids_host, int n_frame_cols, float* rays,
+                         int ray_stride, stnerf_stream_t stream);
+
+/* a5: ray / 8-corner-box slab test.  layers/RaySamplePoint.py:8-62 (intersection).
+ * boxes: [l][8][3] shared by all rays (box_ray_stride = 0) or per ray (box_ray_stride = l*24).
+ * far_near out: [n][l][2] = (far, near), (-1000,-1000) on a miss. */
+int stnerf_intersect(const float* rays, int64_t n, int ray_stride, const float* boxes,
+                     int64_t box_ray_stride, int l, float* far_near, stnerf_stream_t stream);
+
+/* a5 + a6 (+ the point un-edit of a4): stratified jittered coarse samples of every layer.
+ * layers/RaySamplePoint.py:70-107 (RaySamplePoint.forward).
+ * jitter: [l][n][n1] uniform draws to REPLAY (the reference's torch.rand tensors), or NULL to draw
+ * on the device: Philox4x32-10 keyed by (seed, ray_index_base + ray, layer, sample) -- independent
+ * of chunking.  edits: host array of l entries or NULL; pivot: host, 3 floats.
+ * Outputs: t[n][l][n1], xyz[n][l][n1][3] (may be NULL), mask[n][l] (|bin width| > 1e-5). */
+int stnerf_sample_coarse(const float* rays, int64_t n, int ray_stride, const float* boxes,
+                         int64_t box_ray_stride, int l, int n1, const float* jitter, uint64_t seed,
+                         int64_t ray_index_base, const stnerf_layer_edit* edits_host,
+                         const float* pivot_host, float* t, float* xyz, uint8_t* mask,
+                         stnerf_stream_t stream);
+
+/* Ragged work: list of rays whose mask[ray][layer] is set.  Replaces the boolean-mask indexing
+ * (and its host sync) at modeling/layered_rfrender.py:344-353,400-413,497-510,555-563.
+ * ray_list[layer][n] (int32; row `layer` gets the hits, in no particular order), ray_count[layer].
+ * ray_count must be zeroed by the caller before the call (it is accumulated with atomics). */
+int stnerf_compact_rays(const uint8_t* mask, int64_t n, int l, int32_t* ray_list, int32_t* ray_count,
+                        stnerf_stream_t stream);
+
+/* Network weights ------------------------------------------------------------------------- */
+#define STNERF_NET_SPACE 0      /* SpaceNet(use_time=False)  modeling/spacenet.py:16-86  */
+#define STNERF_NET_SPACE_TIME 1 /* SpaceNet(use_time=True)                               */
+#define STNERF_NET_MOTION 2     /* MotionNet(c_input=4, input_time=True)  modeling/motion_net.py:7-32 */
+
+/* Bytes of the packed (kernel-layout) weight blob of one network. */
+int64_t stnerf_packed_bytes(int kind);
+/* Repack reference-layout tensors (nn.Linear: weight (out,in) row-major, bias (out)) into the
+ * kernel layout.  HOST -> HOST; the caller uploads `dst` to the device (any allocator).
+ * SpaceNet order (10 tensors): stage1.{0,2,4,6}, stage2.{0,2,4}, density_net.0, rgb_net.{1,3}.
+ * MotionNet order (6): motion_net.{0,2,4,6,8,10}.  Checkpoint key names: SURVEY.md section 5. */
+int stnerf_pack_net(int kind, const float* const* weights_host, const float* const* biases_host,
+                    int n_tensors, void* dst_host, int64_t dst_bytes);
+
+/* a7 + a9: fused positional encoding + SpaceNet MLP (fp32 MFMA).  modeling/spacenet.py:101-160.
+ * Work list: ray slot s in [0, count) -> ray j = ray_list ? ray_list[s] : s, where count =
+ * ray_count ? min(*ray_count, n_rays) : n_rays; every ray contributes ns samples.
+ *   pos   of (j,k): xyz  + j*xyz_ray_stride  + 3k      (3 floats)
+ *   dir   of  j   : dirs + j*dirs_ray_stride           (3 floats)
+ *   time  of  j   : times + j*times_ray_stride         (1 float; STNERF_NET_SPACE_TIME only)
+ *   out   of (j,k): raw  + j*raw_ray_stride  + 4k      = {r, g, b, sigma}, no activation
+ * All strides in floats. */
+int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
+                        const int32_t* ray_count, const float* xyz, int64_t xyz_ray_stride,
+                        const float* dirs, int64_t dirs_ray_stride, const float* times,
+                        int64_t times_ray_stride, float* raw, int64_t raw_ray_stride,
+                        stnerf_stream_t stream);
+
+/* a7 + a8: fused positional encoding (with the fractional-time lerp) + MotionNet MLP.
+ * modeling/motion_net.py:34-71.  Same work list as above.  flow (may be NULL) gets the 3-vector at
+ * flow + j*flow_ray_stride + 3k; if add_to_xyz the point is updated in place (xyz += flow), which
+ * is what modeling/layered_rfrender.py:355-356,509-510 do. */
+int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
+                         const int32_t* ray_count, float* xyz, int64_t xyz_ray_stride,
+                         const float* times, int64_t times_ray_stride, float* flow,
+                         int64_t flow_ray_stride, int add_to_xyz, stnerf_stream_t stream);
+
+/* a10 + a11 + a12: post-network density edits, per-layer composite, cross-layer merge by depth
+ * and merged composite, one pass per ray.  layers/render_layer.py:8-58 (gen_weight,
+ * VolumeRenderer.forward); modeling/layered_rfrender.py:414-448 (coarse), :538-606 (fine). */
+typedef struct stnerf_composite_params {
+    float border;                              /* last interval, BOARDER_WEIGHT            */
+    float near;                                /* model.near                               */
+    int32_t fine;                              /* 0: coarse-stage rules, 1: fine-stage     */
+    int32_t cut_negative_t;                    /* coarse: performer sigma[t<0]=0  (:414)   */
+    float threshold[STNERF_MAX_LAYERS];        /* sigma < threshold -> 0 (retiming)        */
+    int32_t use_threshold[STNERF_MAX_LAYERS];
+    float sigma_scale[STNERF_MAX_LAYERS];      /* fine: layer 2 *= alpha (:575-576), else 1 */
+    int32_t evaluated[STNERF_MAX_LAYERS];      /* 0: layer's nets were skipped (hidden): raw is not read */
+} stnerf_composite_params;
+
+/* t[n][l][S], raw[n][l][S][4], mask[n][l] (NULL = all set; a clear bit means "not evaluated":
+ * rgb = sigma = 0 as the reference's zero tensors, :398-399).
+ * Outputs (any may be NULL): layer_out[n][l][5] = {color(3), depth, acc}; mixed_out[n][5];
+ * weights[n][l][S] per-layer weights (needed by stnerf_resample); order[n][l*S] int32 = source
+ * index (layer*S + k) of each merged sample (torch.sort's index, ties broken by source index). */
+int stnerf_composite(const float* t, const float* raw, const uint8_t* mask, int64_t n, int l, int S,
+                     const stnerf_composite_params* params_host, float* layer_out, float* mixed_out,
+                     float* weights, int32_t* order, stnerf_stream_t stream);
+
+/* a13 (+ the sort/merge and point generation of layered_rfrender.py:459-475): inverse-CDF
+ * resampling of every layer.  utils/sample_pdf.py:18-63.
+ * t[n][l][n1] coarse depths, weights[n][l][n1] coarse per-layer weights (interior [1:-1] used),
+ * u: [l][n][n2] uniform draws to replay, or NULL -> device Philox (seed, ray_index_base, stream 1).
+ * Outputs: t_fine[n][l][n1+n2] ascending; xyz_fine[n][l][n1+n2][3] (may be NULL) = un-edited points;
+ * optional debug/parity outputs z_new[n][l][n2] (unsorted new samples), inds[n][l][n2] int32
+ * (searchsorted index), cdf[n][l][n1-1]. */
+int stnerf_resample(const float* t, const float* weights, int64_t n, int l, int n1, int n2,
+                    const float* u, uint64_t seed, int64_t ray_index_base, const float* rays,
+                    int ray_stride, const stnerf_layer_edit* edits_host, const float* pivot_host,
+                    float* t_fine, float* xyz_fine, float* z_new, int32_t* inds, float* cdf,
+                    stnerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STNERF_H */

@@ -1,0 +1,66 @@
+"""Build libstnerf_hip.so (in-tree) with hipcc for gfx950.  No GPU needed (cross-compile).
+
+    python st-nerf_amd/build.py [--force] [--verbose]
+"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libstnerf_hip.so")
+
+# (source, extra flags).  The sampler/compositor set is compiled with contraction OFF so that its
+# elementwise arithmetic is bit-identical to the reference's ATen CPU ops (no implicit FMA).
+SOURCES = [
+    ("lib.hip", []),
+    ("sampler.hip", ["-ffp-contract=off"]),
+    ("render.hip", ["-ffp-contract=off"]),
+    ("mlp.hip", []),
+]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(REPO, "include", "stnerf.h"))
+    objs = []
+    os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
+    for src, extra in SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(PKG, "build", src.replace(".hip", ".o"))
+        if force or _stale(obj, [sp] + headers + [os.path.abspath(__file__)]):
+            cmd = [hipcc] + COMMON + extra + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True))

@@ -1,0 +1,649 @@
+// Fused positional-encoding + MLP kernels for SpaceNet and MotionNet on gfx950 (fp32 MFMA).
+//
+// Design (DESIGN.md section "MLP kernel"):
+//   * One workgroup = 4 waves (one per SIMD) = one tile of TM = 128 samples.  The tile's activations
+//     live in LDS for the whole network: `act` [64 quads][TM] float4 (feature quad-major, so a
+//     sample's 4 consecutive features are one 16-byte word) + `enc` [16 quads][TM] float4 for the
+//     positional encodings (skip connection / direction+time inputs).  128 KiB + 32 KiB = all 160 KiB
+//     of the CU's LDS -> 1 workgroup per CU, nothing ever spills to HBM between layers (the
+//     reference writes every 256-wide activation to memory: modeling/spacenet.py:136-151).
+//   * Each layer is computed transposed, out^T[feature][sample] = W[feature][k] * act^T[k][sample],
+//     with v_mfma_f32_32x32x2_f32: A operand = weights, B operand = activations.  With that
+//     orientation a lane's 16 accumulator registers are 4 runs of 4 consecutive FEATURES of one
+//     sample = exactly one float4 of the quad-major LDS layout: the epilogue is ds_write_b128 and
+//     the next layer's B operand is ds_read_b128, both conflict-free, no transposes anywhere.
+//   * Weights are pre-packed [K/4][N][4] (stnerf_pack_net) so a lane's A operand for 4 consecutive
+//     MFMAs is one coalesced 16-byte global load; every workgroup streams the same ~1.9 MB per
+//     network from L2.  The k index is permuted consistently for A and B (lane half h takes
+//     k = 8s + 4h + {0..3}), which only reorders the fp32 accumulation.
+//   * exact fp32 arithmetic (f32 MFMA == an fmaf chain); sin/cos are the accurate ocml versions
+//     (arguments reach 2^9 * |x|, utils/dimension_kernel.py:20-27).
+//
+// Reference: modeling/spacenet.py:16-160, modeling/motion_net.py:7-71, utils/dimension_kernel.py:3-73.
+#include <string.h>
+
+#include "common.h"
+
+namespace stnerf {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int TM = 128;        // samples per tile
+constexpr int NSB = TM / 32;   // 32-sample blocks per tile
+constexpr int NTHREADS = 256;  // 4 waves
+
+// ---------------------------------------------------------------------------------------------
+// Packed weight layouts (offsets in floats).  Shared by the host packer and the kernels.
+// ---------------------------------------------------------------------------------------------
+struct SpaceLayout {
+    int64_t w[7], b[7];        // backbone: stage1.{0,2,4,6}, stage2.{0,2,4};  W as [Kq][256][4]
+    int64_t w_sigma, b_sigma;  // density_net.0: 256 + 1(4)
+    int64_t w_rgb1, b_rgb1;    // rgb_net.1 as [Kq][128][4]
+    int64_t w_rgb2, b_rgb2;    // rgb_net.3 as [3][128] + 3(4)
+    int64_t total;
+    int kq[7];                 // K quads per backbone layer
+    int kq_rgb1;               // 64 + 12 (time) | 64 + 8
+};
+
+__host__ __device__ inline SpaceLayout space_layout(bool use_time) {
+    SpaceLayout L;
+    const int kq[7] = {16, 64, 64, 64, 80, 64, 64};
+    int64_t off = 0;
+    for (int i = 0; i < 7; ++i) {
+        L.kq[i] = kq[i];
+        L.w[i] = off;
+        off += (int64_t)kq[i] * 256 * 4;
+        L.b[i] = off;
+        off += 256;
+    }
+    L.w_sigma = off; off += 256;
+    L.b_sigma = off; off += 4;
+    L.kq_rgb1 = 64 + (use_time ? 12 : 8);
+    L.w_rgb1 = off; off += (int64_t)L.kq_rgb1 * 128 * 4;
+    L.b_rgb1 = off; off += 128;
+    L.w_rgb2 = off; off += 3 * 128;
+    L.b_rgb2 = off; off += 4;
+    L.total = off;
+    return L;
+}
+
+struct MotionLayout {
+    int64_t w[5], b[5];  // motion_net.{0,2,4,6,8} as [Kq][128][4]
+    int64_t w_out, b_out;  // motion_net.10 as [3][128] + 3(4)
+    int64_t total;
+    int kq[5];
+};
+
+__host__ __device__ inline MotionLayout motion_layout() {
+    MotionLayout L;
+    const int kq[5] = {22, 32, 32, 32, 32};
+    int64_t off = 0;
+    for (int i = 0; i < 5; ++i) {
+        L.kq[i] = kq[i];
+        L.w[i] = off;
+        off += (int64_t)kq[i] * 128 * 4;
+        L.b[i] = off;
+        off += 128;
+    }
+    L.w_out = off; off += 3 * 128;
+    L.b_out = off; off += 4;
+    L.total = off;
+    return L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One dense layer on the tile:  out[:, n] = act(bias[n] + sum_k W[n][k] in[k])   for the wave's
+// NFB*32 features and all TM samples.  K comes from up to two LDS segments (quads kqA then kqB).
+// ---------------------------------------------------------------------------------------------
+template <int NFB>
+__device__ __forceinline__ void mma_segment(f32x16 (&acc)[NFB][NSB], const float4* __restrict__ wp, int n_total,
+                                            const float4* in, int steps) {
+    // wp / in already point at this lane's first quad row; one step = 2 quad rows = 8 k values.
+    float4 w_cur[NFB], a_cur[NSB];
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) w_cur[fb] = wp[fb * 32];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) a_cur[sb] = in[sb * 32];
+    for (int s = 0; s < steps; ++s) {
+        // prefetch the next step (clamped: the last iteration re-loads itself, never out of bounds)
+        const int nx = (s + 1 < steps) ? (s + 1) : s;
+        float4 w_nxt[NFB], a_nxt[NSB];
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) w_nxt[fb] = wp[(int64_t)nx * 2 * n_total + fb * 32];
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) a_nxt[sb] = in[nx * 2 * TM + sb * 32];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) {
+                const float wv = kk == 0 ? w_cur[fb].x : kk == 1 ? w_cur[fb].y : kk == 2 ? w_cur[fb].z : w_cur[fb].w;
+#pragma unroll
+                for (int sb = 0; sb < NSB; ++sb) {
+                    const float av = kk == 0 ? a_cur[sb].x : kk == 1 ? a_cur[sb].y : kk == 2 ? a_cur[sb].z : a_cur[sb].w;
+                    acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, acc[fb][sb], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) w_cur[fb] = w_nxt[fb];
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) a_cur[sb] = a_nxt[sb];
+    }
+}
+
+template <int NFB, bool RELU>
+__device__ __forceinline__ void dense_layer(const float* __restrict__ base, int64_t w_off, int64_t b_off, int n_total,
+                                            const float4* inA, int kqA, const float4* inB, int kqB, float4* out,
+                                            int wave, int lane) {
+    const int h = lane >> 5, c = lane & 31;
+    const int n0 = wave * NFB * 32;
+    f32x16 acc[NFB][NSB];
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[fb][sb][r] = 0.f;
+    const float4* wp = reinterpret_cast<const float4*>(base + w_off) + ((int64_t)h * n_total + n0 + c);
+    mma_segment<NFB>(acc, wp, n_total, inA + h * TM + c, kqA / 2);
+    if (kqB > 0) mma_segment<NFB>(acc, wp + (int64_t)kqA * n_total, n_total, inB + h * TM + c, kqB / 2);
+    // every wave has finished READING the input tile before anyone overwrites it (out may alias inA)
+    __syncthreads();
+    const float* bias = base + b_off;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = n0 + fb * 32 + 8 * q + 4 * h;  // first of this lane's 4 consecutive features
+            const float4 bv = *reinterpret_cast<const float4*>(bias + f);
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) {
+                float4 v;
+                v.x = acc[fb][sb][4 * q + 0] + bv.x;
+                v.y = acc[fb][sb][4 * q + 1] + bv.y;
+                v.z = acc[fb][sb][4 * q + 2] + bv.z;
+                v.w = acc[fb][sb][4 * q + 3] + bv.w;
+                if (RELU) {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+                out[(f >> 2) * TM + sb * 32 + c] = v;
+            }
+        }
+    }
+}
+
+// out[c] partial dot products over a quad range, for heads with 1..3 outputs (VALU; the weights are
+// wave-uniform so they come through the scalar cache).
+template <int NOUT>
+__device__ __forceinline__ void head_partial(const float4* act, int s, int q_begin, int q_end,
+                                             const float* __restrict__ w, int ldw, float (&sum)[NOUT]) {
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) sum[o] = 0.f;
+    for (int q = q_begin; q < q_end; ++q) {
+        const float4 v = act[q * TM + s];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float4 wv = *reinterpret_cast<const float4*>(w + o * ldw + 4 * q);
+            sum[o] = fmaf(v.x, wv.x, sum[o]);
+            sum[o] = fmaf(v.y, wv.y, sum[o]);
+            sum[o] = fmaf(v.z, wv.z, sum[o]);
+            sum[o] = fmaf(v.w, wv.w, sum[o]);
+        }
+    }
+}
+
+struct WorkList {
+    int64_t n_rays;
+    int ns;
+    const int32_t* ray_list;
+    const int32_t* ray_count;
+};
+
+__device__ __forceinline__ int64_t worklist_rows(const WorkList& wl) {
+    int64_t cnt = wl.n_rays;
+    if (wl.ray_count) {
+        const int64_t c = *wl.ray_count;
+        cnt = c < cnt ? c : cnt;
+    }
+    return cnt * wl.ns;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpaceNet
+// ---------------------------------------------------------------------------------------------
+struct SpaceArgs {
+    const float* net;
+    WorkList wl;
+    const float* xyz;
+    int64_t xyz_ray_stride;
+    const float* dirs;
+    int64_t dirs_ray_stride;
+    const float* times;
+    int64_t times_ray_stride;
+    float* raw;
+    int64_t raw_ray_stride;
+};
+
+template <bool USE_TIME>
+__global__ __launch_bounds__(NTHREADS, 1) void spacenet_kernel(SpaceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    float4* act = smem;             // [64][TM]
+    float4* enc = smem + 64 * TM;   // [16][TM]
+    float* encf = reinterpret_cast<float*>(enc);
+    float* scratch = reinterpret_cast<float*>(enc + 12 * TM);  // quads 12..15: 2048 floats
+    const SpaceLayout L = space_layout(USE_TIME);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int s = tid & (TM - 1);
+    const int64_t rows = worklist_rows(a.wl);
+    const int ns = a.wl.ns;
+
+    for (int64_t tile = blockIdx.x; tile * TM < rows; tile += gridDim.x) {
+        // ---- row -> (ray, sample)
+        const int64_t row = tile * TM + s;
+        const bool valid = row < rows;
+        int64_t ray = 0;
+        int k = 0;
+        if (valid) {
+            const int64_t slot = row / ns;
+            k = (int)(row - slot * ns);
+            ray = a.wl.ray_list ? (int64_t)a.wl.ray_list[slot] : slot;
+        }
+        // ---- PE_10(pos) -> enc quads 0..15 (63 features + 1 zero pad); utils/dimension_kernel.py:8-33
+        {
+            float p[3] = {0.f, 0.f, 0.f};
+            if (valid) {
+                const float* src = a.xyz + ray * a.xyz_ray_stride + 3 * k;
+                p[0] = src[0];
+                p[1] = src[1];
+                p[2] = src[2];
+            }
+            float* col = encf + s * 4;  // feature f lives at col[(f>>2)*TM*4 + (f&3)]
+            if (half == 0) {
+#pragma unroll
+                for (int dmn = 0; dmn < 3; ++dmn) col[dmn] = p[dmn];
+            } else {
+                col[15 * TM * 4 + 3] = 0.f;  // feature 63: zero pad
+            }
+#pragma unroll
+            for (int fi = 0; fi < 5; ++fi) {
+                const int fq = half * 5 + fi;
+                const float freq = (float)(1 << fq);
+#pragma unroll
+                for (int dmn = 0; dmn < 3; ++dmn) {
+                    float sn, cs;
+                    sincosf(p[dmn] * freq, &sn, &cs);
+                    const int fs = 3 + fq * 6 + dmn, fc = fs + 3;
+                    col[(fs >> 2) * TM * 4 + (fs & 3)] = sn;
+                    col[(fc >> 2) * TM * 4 + (fc & 3)] = cs;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- stage1 (modeling/spacenet.py:45-54)
+        dense_layer<2, true>(a.net, L.w[0], L.b[0], 256, enc, 16, nullptr, 0, act, wave, lane);
+        __syncthreads();
+        dense_layer<2, true>(a.net, L.w[1], L.b[1], 256, act, 64, nullptr, 0, act, wave, lane);
+        __syncthreads();
+        dense_layer<2, true>(a.net, L.w[2], L.b[2], 256, act, 64, nullptr, 0, act, wave, lane);
+        __syncthreads();
+        dense_layer<2, true>(a.net, L.w[3], L.b[3], 256, act, 64, nullptr, 0, act, wave, lane);
+        __syncthreads();
+        // ---- stage2.0 on [h, PE(pos)] (:56-57, :137)
+        dense_layer<2, true>(a.net, L.w[4], L.b[4], 256, act, 64, enc, 16, act, wave, lane);
+        // enc is free now (all waves passed the barrier inside dense_layer): write
+        // relu(PE_4(dir)) (27) and relu(PE_10(time)) (21) -> enc features 0..47  (:80-86, :141-149)
+        {
+            float* col = encf + s * 4;
+            if (half == 0) {
+                float dv[3] = {0.f, 0.f, 0.f};
+                if (valid) {
+                    const float* src = a.dirs + ray * a.dirs_ray_stride;
+                    dv[0] = src[0];
+                    dv[1] = src[1];
+                    dv[2] = src[2];
+                }
+#pragma unroll
+                for (int dmn = 0; dmn < 3; ++dmn) col[dmn] = fmaxf(dv[dmn], 0.f);
+#pragma unroll
+                for (int fq = 0; fq < 4; ++fq) {
+                    const float freq = (float)(1 << fq);
+#pragma unroll
+                    for (int dmn = 0; dmn < 3; ++dmn) {
+                        float sn, cs;
+                        sincosf(dv[dmn] * freq, &sn, &cs);
+                        const int fs = 3 + fq * 6 + dmn, fc = fs + 3;
+                        col[(fs >> 2) * TM * 4 + (fs & 3)] = fmaxf(sn, 0.f);
+                        col[(fc >> 2) * TM * 4 + (fc & 3)] = fmaxf(cs, 0.f);
+                    }
+                }
+                if (!USE_TIME) {
+#pragma unroll
+                    for (int f = 27; f < 32; ++f) col[(f >> 2) * TM * 4 + (f & 3)] = 0.f;
+                }
+            } else if (USE_TIME) {
+                const float tv = valid ? a.times[ray * a.times_ray_stride] : 0.f;
+                col[(27 >> 2) * TM * 4 + (27 & 3)] = fmaxf(tv, 0.f);
+#pragma unroll
+                for (int fq = 0; fq < 10; ++fq) {
+                    float sn, cs;
+                    sincosf(tv * (float)(1 << fq), &sn, &cs);
+                    const int fs = 28 + 2 * fq, fc = fs + 1;
+                    col[(fs >> 2) * TM * 4 + (fs & 3)] = fmaxf(sn, 0.f);
+                    col[(fc >> 2) * TM * 4 + (fc & 3)] = fmaxf(cs, 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        dense_layer<2, true>(a.net, L.w[5], L.b[5], 256, act, 64, nullptr, 0, act, wave, lane);
+        __syncthreads();
+        dense_layer<2, true>(a.net, L.w[6], L.b[6], 256, act, 64, nullptr, 0, act, wave, lane);
+        __syncthreads();
+        // ---- sigma = density_net(h) (:139), raw
+        float sigma;
+        {
+            float part[1];
+            head_partial<1>(act, s, half * 32, half * 32 + 32, a.net + L.w_sigma, 256, part);
+            scratch[half * TM + s] = part[0];
+            __syncthreads();
+            sigma = scratch[s] + scratch[TM + s] + a.net[L.b_sigma];
+        }
+        // ---- rgb_net: relu -> Linear(283|304,128) -> relu -> Linear(128,3)   (:80-86)
+        // (h is already >= 0; the encodings were clamped when written)
+        dense_layer<1, true>(a.net, L.w_rgb1, L.b_rgb1, 128, act, 64, enc, L.kq_rgb1 - 64, act, wave, lane);
+        __syncthreads();
+        {
+            float part[3];
+            head_partial<3>(act, s, half * 16, half * 16 + 16, a.net + L.w_rgb2, 128, part);
+            scratch[256 + (half * 3 + 0) * TM + s] = part[0];
+            scratch[256 + (half * 3 + 1) * TM + s] = part[1];
+            scratch[256 + (half * 3 + 2) * TM + s] = part[2];
+            __syncthreads();
+            if (half == 0 && valid) {
+                float4 o;
+                o.x = scratch[256 + 0 * TM + s] + scratch[256 + 3 * TM + s] + a.net[L.b_rgb2 + 0];
+                o.y = scratch[256 + 1 * TM + s] + scratch[256 + 4 * TM + s] + a.net[L.b_rgb2 + 1];
+                o.z = scratch[256 + 2 * TM + s] + scratch[256 + 5 * TM + s] + a.net[L.b_rgb2 + 2];
+                o.w = sigma;
+                *reinterpret_cast<float4*>(a.raw + ray * a.raw_ray_stride + 4 * k) = o;
+            }
+        }
+        __syncthreads();  // scratch/enc/act are rewritten by the next tile's prologue
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MotionNet
+// ---------------------------------------------------------------------------------------------
+struct MotionArgs {
+    const float* net;
+    WorkList wl;
+    float* xyz;
+    int64_t xyz_ray_stride;
+    const float* times;
+    int64_t times_ray_stride;
+    float* flow;
+    int64_t flow_ray_stride;
+    int add_to_xyz;
+};
+
+constexpr int MOTION_LDS_BYTES = (32 + 22) * TM * 16 + 6 * TM * 4;
+
+__global__ __launch_bounds__(NTHREADS, 1) void motionnet_kernel(MotionArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    float4* act = smem;            // [32][TM]
+    float4* enc = smem + 32 * TM;  // [22][TM]: 84 features + 4 zero pads
+    float* encf = reinterpret_cast<float*>(enc);
+    float* scratch = reinterpret_cast<float*>(enc + 22 * TM);  // 6*TM floats
+    const MotionLayout L = motion_layout();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int s = tid & (TM - 1);
+    const int64_t rows = worklist_rows(a.wl);
+    const int ns = a.wl.ns;
+
+    for (int64_t tile = blockIdx.x; tile * TM < rows; tile += gridDim.x) {
+        const int64_t row = tile * TM + s;
+        const bool valid = row < rows;
+        int64_t ray = 0;
+        int k = 0;
+        if (valid) {
+            const int64_t slot = row / ns;
+            k = (int)(row - slot * ns);
+            ray = a.wl.ray_list ? (int64_t)a.wl.ray_list[slot] : slot;
+        }
+        float p[3] = {0.f, 0.f, 0.f};
+        float tv = 0.f;
+        if (valid) {
+            const float* src = a.xyz + ray * a.xyz_ray_stride + 3 * k;
+            p[0] = src[0];
+            p[1] = src[1];
+            p[2] = src[2];
+            tv = a.times[ray * a.times_ray_stride];
+        }
+        // ---- PE_10([x,y,z,t]) with the fractional-time lerp of modeling/motion_net.py:49-60:
+        // enc = (1-w) PE([xyz, floor t]) + w PE([xyz, floor t + 1]); w == 0 rows reduce to PE(input).
+        {
+            const float lo = floorf(tv);
+            const float wgt = tv - lo;
+            const bool frac = wgt != 0.f;
+            const float om = 1.f - wgt;
+            float* col = encf + s * 4;
+            auto mix = [&](float va, float vb) { return frac ? om * va + wgt * vb : va; };
+            if (half == 0) {
+#pragma unroll
+                for (int dmn = 0; dmn < 3; ++dmn) col[dmn] = mix(p[dmn], p[dmn]);
+                col[3] = mix(lo, lo + 1.f);
+            } else {
+#pragma unroll
+                for (int f = 84; f < 88; ++f) col[(f >> 2) * TM * 4 + (f & 3)] = 0.f;
+            }
+#pragma unroll
+            for (int fi = 0; fi < 5; ++fi) {
+                const int fq = half * 5 + fi;
+                const float freq = (float)(1 << fq);
+#pragma unroll
+                for (int dmn = 0; dmn < 4; ++dmn) {
+                    float sn, cs, sn2, cs2;
+                    if (dmn < 3) {
+                        sincosf(p[dmn] * freq, &sn, &cs);
+                        sn2 = sn;
+                        cs2 = cs;
+                    } else {
+                        sincosf(lo * freq, &sn, &cs);
+                        sn2 = sn;
+                        cs2 = cs;
+                        if (frac) sincosf((lo + 1.f) * freq, &sn2, &cs2);
+                    }
+                    const int fs = 4 + fq * 8 + dmn, fc = fs + 4;
+                    col[(fs >> 2) * TM * 4 + (fs & 3)] = mix(sn, sn2);
+                    col[(fc >> 2) * TM * 4 + (fc & 3)] = mix(cs, cs2);
+                }
+            }
+        }
+        __syncthreads();
+        dense_layer<1, true>(a.net, L.w[0], L.b[0], 128, enc, 22, nullptr, 0, act, wave, lane);
+        __syncthreads();
+        dense_layer<1, true>(a.net, L.w[1], L.b[1], 128, act, 32, nullptr, 0, act, wave, lane);
+        __syncthreads();
+        dense_layer<1, true>(a.net, L.w[2], L.b[2], 128, act, 32, nullptr, 0, act, wave, lane);
+        __syncthreads();
+        dense_layer<1, true>(a.net, L.w[3], L.b[3], 128, act, 32, nullptr, 0, act, wave, lane);
+        __syncthreads();
+        dense_layer<1, true>(a.net, L.w[4], L.b[4], 128, act, 32, nullptr, 0, act, wave, lane);
+        __syncthreads();
+        {
+            float part[3];
+            head_partial<3>(act, s, half * 16, half * 16 + 16, a.net + L.w_out, 128, part);
+            scratch[(half * 3 + 0) * TM + s] = part[0];
+            scratch[(half * 3 + 1) * TM + s] = part[1];
+            scratch[(half * 3 + 2) * TM + s] = part[2];
+            __syncthreads();
+            if (half == 0 && valid) {
+                float fl[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    fl[c] = scratch[c * TM + s] + scratch[(3 + c) * TM + s] + a.net[L.b_out + c];
+                if (a.flow) {
+                    float* dst = a.flow + ray * a.flow_ray_stride + 3 * k;
+                    dst[0] = fl[0];
+                    dst[1] = fl[1];
+                    dst[2] = fl[2];
+                }
+                if (a.add_to_xyz) {
+                    float* dst = a.xyz + ray * a.xyz_ray_stride + 3 * k;
+                    dst[0] = p[0] + fl[0];  // modeling/layered_rfrender.py:356,510
+                    dst[1] = p[1] + fl[1];
+                    dst[2] = p[2] + fl[2];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+// (out,in) row-major -> [ceil(in/4) (padded to kq)][out][4], zero padded.
+static void pack_linear(const float* w, int out_f, int in_f, int kq, float* dst) {
+    memset(dst, 0, sizeof(float) * (size_t)kq * out_f * 4);
+    for (int n = 0; n < out_f; ++n)
+        for (int k = 0; k < in_f; ++k) dst[((size_t)(k >> 2) * out_f + n) * 4 + (k & 3)] = w[(size_t)n * in_f + k];
+}
+
+static int grid_for(int64_t n_rays, int ns) {
+    const int64_t tiles = (n_rays * ns + TM - 1) / TM;
+    return (int)(tiles < 8192 ? tiles : 8192);
+}
+
+}  // namespace stnerf
+
+using namespace stnerf;
+
+extern "C" int64_t stnerf_packed_bytes(int kind) {
+    switch (kind) {
+        case STNERF_NET_SPACE: return space_layout(false).total * 4;
+        case STNERF_NET_SPACE_TIME: return space_layout(true).total * 4;
+        case STNERF_NET_MOTION: return motion_layout().total * 4;
+        default: set_error("packed_bytes: unknown net kind %d", kind); return STNERF_EINVAL;
+    }
+}
+
+extern "C" int stnerf_pack_net(int kind, const float* const* W, const float* const* B, int n_tensors, void* dst_host,
+                               int64_t dst_bytes) {
+    STNERF_REQUIRE(W && B && dst_host, "pack_net: null pointer");
+    float* dst = static_cast<float*>(dst_host);
+    if (kind == STNERF_NET_SPACE || kind == STNERF_NET_SPACE_TIME) {
+        const bool ut = kind == STNERF_NET_SPACE_TIME;
+        const SpaceLayout L = space_layout(ut);
+        STNERF_REQUIRE(n_tensors == 10, "pack_net: SpaceNet takes 10 tensors, got %d", n_tensors);
+        STNERF_REQUIRE(dst_bytes >= L.total * 4, "pack_net: dst too small");
+        for (int i = 0; i < 10; ++i) STNERF_REQUIRE(W[i] && B[i], "pack_net: tensor %d is null", i);
+        memset(dst, 0, (size_t)L.total * 4);
+        const int in_f[7] = {63, 256, 256, 256, 319, 256, 256};
+        for (int i = 0; i < 7; ++i) {
+            pack_linear(W[i], 256, in_f[i], L.kq[i], dst + L.w[i]);
+            memcpy(dst + L.b[i], B[i], 256 * sizeof(float));
+        }
+        memcpy(dst + L.w_sigma, W[7], 256 * sizeof(float));
+        dst[L.b_sigma] = B[7][0];
+        pack_linear(W[8], 128, 256 + 27 + (ut ? 21 : 0), L.kq_rgb1, dst + L.w_rgb1);
+        memcpy(dst + L.b_rgb1, B[8], 128 * sizeof(float));
+        memcpy(dst + L.w_rgb2, W[9], 3 * 128 * sizeof(float));
+        memcpy(dst + L.b_rgb2, B[9], 3 * sizeof(float));
+        return STNERF_OK;
+    }
+    if (kind == STNERF_NET_MOTION) {
+        const MotionLayout L = motion_layout();
+        STNERF_REQUIRE(n_tensors == 6, "pack_net: MotionNet takes 6 tensors, got %d", n_tensors);
+        STNERF_REQUIRE(dst_bytes >= L.total * 4, "pack_net: dst too small");
+        for (int i = 0; i < 6; ++i) STNERF_REQUIRE(W[i] && B[i], "pack_net: tensor %d is null", i);
+        memset(dst, 0, (size_t)L.total * 4);
+        const int in_f[5] = {84, 128, 128, 128, 128};
+        for (int i = 0; i < 5; ++i) {
+            pack_linear(W[i], 128, in_f[i], L.kq[i], dst + L.w[i]);
+            memcpy(dst + L.b[i], B[i], 128 * sizeof(float));
+        }
+        memcpy(dst + L.w_out, W[5], 3 * 128 * sizeof(float));
+        memcpy(dst + L.b_out, B[5], 3 * sizeof(float));
+        return STNERF_OK;
+    }
+    set_error("pack_net: unknown net kind %d", kind);
+    return STNERF_EINVAL;
+}
+
+extern "C" int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
+                                   const int32_t* ray_count, const float* xyz, int64_t xyz_ray_stride,
+                                   const float* dirs, int64_t dirs_ray_stride, const float* times,
+                                   int64_t times_ray_stride, float* raw, int64_t raw_ray_stride,
+                                   stnerf_stream_t stream) {
+    STNERF_REQUIRE(kind == STNERF_NET_SPACE || kind == STNERF_NET_SPACE_TIME, "spacenet_fwd: bad kind %d", kind);
+    STNERF_REQUIRE(packed && xyz && dirs && raw, "spacenet_fwd: null pointer");
+    STNERF_REQUIRE(kind == STNERF_NET_SPACE || times, "spacenet_fwd: net takes time but times is null");
+    STNERF_REQUIRE(n_rays >= 0 && ns >= 1, "spacenet_fwd: bad shape n_rays=%lld ns=%d", (long long)n_rays, ns);
+    STNERF_REQUIRE((raw_ray_stride & 3) == 0 && ((uintptr_t)raw & 15) == 0, "spacenet_fwd: raw must be 16-byte aligned");
+    STNERF_REQUIRE(((uintptr_t)packed & 15) == 0, "spacenet_fwd: packed weights must be 16-byte aligned");
+    if (n_rays == 0) return STNERF_OK;
+    static bool attr_set[2] = {false, false};
+    const int lds = (64 + 16) * TM * 16;
+    SpaceArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, dirs,
+                dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride};
+    const int grid = grid_for(n_rays, ns);
+    if (kind == STNERF_NET_SPACE_TIME) {
+        if (!attr_set[1]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(spacenet_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+                set_error("spacenet_fwd: cannot reserve %d B of LDS", lds);
+                return STNERF_ELAUNCH;
+            }
+            attr_set[1] = true;
+        }
+        hipLaunchKernelGGL(spacenet_kernel<true>, dim3(grid), dim3(NTHREADS), lds, as_stream(stream), a);
+    } else {
+        if (!attr_set[0]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(spacenet_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+                set_error("spacenet_fwd: cannot reserve %d B of LDS", lds);
+                return STNERF_ELAUNCH;
+            }
+            attr_set[0] = true;
+        }
+        hipLaunchKernelGGL(spacenet_kernel<false>, dim3(grid), dim3(NTHREADS), lds, as_stream(stream), a);
+    }
+    STNERF_CHECK_LAUNCH("spacenet_fwd");
+    return STNERF_OK;
+}
+
+extern "C" int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
+                                    const int32_t* ray_count, float* xyz, int64_t xyz_ray_stride, const float* times,
+                                    int64_t times_ray_stride, float* flow, int64_t flow_ray_stride, int add_to_xyz,
+                                    stnerf_stream_t stream) {
+    STNERF_REQUIRE(packed && xyz && times, "motionnet_fwd: null pointer");
+    STNERF_REQUIRE(flow || add_to_xyz, "motionnet_fwd: nothing to write");
+    STNERF_REQUIRE(n_rays >= 0 && ns >= 1, "motionnet_fwd: bad shape");
+    STNERF_REQUIRE(((uintptr_t)packed & 15) == 0, "motionnet_fwd: packed weights must be 16-byte aligned");
+    if (n_rays == 0) return STNERF_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(motionnet_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, MOTION_LDS_BYTES) != hipSuccess) {
+            set_error("motionnet_fwd: cannot reserve %d B of LDS", MOTION_LDS_BYTES);
+            return STNERF_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    MotionArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, times,
+                 times_ray_stride, flow, flow_ray_stride, add_to_xyz};
+    hipLaunchKernelGGL(motionnet_kernel, dim3(grid_for(n_rays, ns)), dim3(NTHREADS), MOTION_LDS_BYTES,
+                       as_stream(stream), a);
+    STNERF_CHECK_LAUNCH("motionnet_fwd");
+    return STNERF_OK;
+}

@@ -1,0 +1,393 @@
+// Compositor (density edits + per-layer composite + cross-layer depth merge + merged composite)
+// and inverse-CDF resampler.  One WAVE (64 lanes) owns one ray (compositor) or one (ray, layer)
+// pair (resampler); the ray's samples are staged once through LDS with coalesced loads and every
+// cumulative quantity (transmittance product, cdf) is a wavefront prefix scan.
+//
+// HBM-bound: compositor reads 20 B/sample (+1 B/layer mask) and writes 20 B per (ray, output);
+// resampler reads 8 B per coarse sample and writes 16 B per fine sample (t + xyz).
+//
+// Reference: layers/render_layer.py:8-58, utils/sample_pdf.py:18-63,
+//            modeling/layered_rfrender.py:414-475, :538-606.
+#include "common.h"
+
+namespace stnerf {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {  // inclusive
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float u = __shfl_up(v, o);
+        if (lane >= o) v *= u;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {  // inclusive
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    return v;
+}
+
+// #{x in a[0..n) : x < v}  /  #{x <= v}   for ascending a (LDS)
+__device__ __forceinline__ int lower_bound_lds(const float* a, int n, float v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ int upper_bound_lds(const float* a, int n, float v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Alpha-composite `count` samples read through accessor functors, in index order.
+// gen_weight + VolumeRenderer.forward: layers/render_layer.py:8-17, :37-49.
+//   delta_k = t_{k+1}-t_k, last = border;  alpha = 1-exp(-relu(sigma) delta);
+//   T_k = prod_{j<k} (1-alpha_j+1e-10);  w = alpha T;  color = sum w sigmoid(rgb); depth = sum w t.
+// ---------------------------------------------------------------------------------------------
+template <class TAt, class RawAt, class WOut>
+__device__ __forceinline__ void composite_run(int count, float border, int lane, TAt t_at, RawAt raw_at, WOut w_out,
+                                              float (&out)[5]) {
+    float carry = 1.f;
+    float cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
+    for (int base = 0; base < count; base += 64) {
+        const int k = base + lane;
+        const bool ok = k < count;
+        float tr = 1.f, alpha = 0.f, tk = 0.f;
+        float4 rw = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            tk = t_at(k);
+            rw = raw_at(k);
+            const float delta = (k + 1 < count) ? (t_at(k + 1) - tk) : border;
+            alpha = 1.f - expf(-fmaxf(rw.w, 0.f) * delta);
+            tr = (1.f - alpha) + 1e-10f;
+        }
+        const float incl = wave_scan_mul(tr, lane);
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.f;
+        const float w = alpha * (carry * excl);
+        carry = carry * __shfl(incl, 63);
+        if (ok) {
+            w_out(k, w);
+            cr += w * (1.f / (1.f + expf(-rw.x)));
+            cg += w * (1.f / (1.f + expf(-rw.y)));
+            cb += w * (1.f / (1.f + expf(-rw.z)));
+            cd += w * tk;
+            ca += w;
+        }
+    }
+    out[0] = wave_sum(cr);
+    out[1] = wave_sum(cg);
+    out[2] = wave_sum(cb);
+    out[3] = wave_sum(cd);
+    out[4] = wave_sum(ca);
+}
+
+struct CompositeArgs {
+    const float* t;
+    const float4* raw;
+    const uint8_t* mask;
+    int64_t n;
+    int l, S;
+    stnerf_composite_params p;
+    float* layer_out;
+    float* mixed_out;
+    float* weights;
+    int32_t* order;
+    int waves_per_block;
+};
+
+__global__ void composite_kernel(CompositeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int LS = a.l * a.S;
+    // per-wave LDS: raws[LS] float4 | ts[LS] | mt[LS] | mord[LS]
+    unsigned char* mine = smem_raw + (size_t)wave * LS * 28;
+    float4* raws = reinterpret_cast<float4*>(mine);
+    float* ts = reinterpret_cast<float*>(mine + (size_t)LS * 16);
+    float* mt = ts + LS;
+    int* mord = reinterpret_cast<int*>(mt + LS);
+
+    const int64_t rays_per_iter = (int64_t)gridDim.x * a.waves_per_block;
+    for (int64_t ray0 = (int64_t)blockIdx.x * a.waves_per_block; ray0 < a.n; ray0 += rays_per_iter) {
+        const int64_t ray = ray0 + wave;
+        const bool active = ray < a.n;
+        // ---- stage the ray, applying the post-network density edits (a10)
+        bool sorted_ok = true;
+        if (active) {
+            const float* tsrc = a.t + ray * LS;
+            const float4* rsrc = a.raw + ray * LS;
+            for (int e = lane; e < LS; e += 64) {
+                const int layer = e / a.S;
+                const float tv = tsrc[e];
+                const bool have = a.p.evaluated[layer] && (!a.mask || a.mask[ray * a.l + layer]);
+                float4 rw = have ? rsrc[e] : make_float4(0.f, 0.f, 0.f, 0.f);  // zero tensors, :398-399
+                if (!a.p.fine && a.p.cut_negative_t && layer > 0 && tv < 0.f) rw.w = 0.f;       // :414
+                if (a.p.use_threshold[layer] && rw.w < a.p.threshold[layer]) rw.w = 0.f;       // :416-418, :538-547, :564-566
+                rw.w = rw.w * a.p.sigma_scale[layer];                                          // :575-576
+                if (!a.p.fine && layer == 0 && tv < a.p.near) rw.w = 0.f;                      // :422
+                ts[e] = tv;
+                raws[e] = rw;
+            }
+        }
+        __syncthreads();
+        // ---- per-layer composites (:435-444 / :598-603)
+        if (active) {
+            for (int layer = 0; layer < a.l; ++layer) {
+                const float* tl = ts + layer * a.S;
+                const float4* rl = raws + layer * a.S;
+                float* wdst = a.weights ? a.weights + (ray * a.l + layer) * a.S : nullptr;
+                float o5[5];
+                composite_run(a.S, a.p.border, lane, [&](int k) { return tl[k]; }, [&](int k) { return rl[k]; },
+                              [&](int k, float w) { if (wdst) wdst[k] = w; }, o5);
+                if (a.layer_out && lane < 5) {
+                    const float v = lane == 0 ? o5[0] : lane == 1 ? o5[1] : lane == 2 ? o5[2] : lane == 3 ? o5[3] : o5[4];
+                    a.layer_out[(ray * a.l + layer) * 5 + lane] = v;
+                }
+                // is this layer's list ascending?  (it is, unless a box edit/miss made the bin width negative)
+                for (int k = lane; k + 1 < a.S; k += 64) sorted_ok = sorted_ok && !(tl[k + 1] < tl[k]);
+            }
+            sorted_ok = __all(sorted_ok);
+            // ---- cross-layer merge by depth (:425-429 / :587-592): rank of every sample in the union.
+            // Stable: ties resolve by source index (layer-major), the order a stable sort of the
+            // concatenation gives.
+            for (int e = lane; e < LS; e += 64) {
+                const int la = e / a.S;
+                const int k = e - la * a.S;
+                const float v = ts[e];
+                int rank;
+                if (sorted_ok) {
+                    rank = k;
+                    for (int lb = 0; lb < a.l; ++lb) {
+                        if (lb == la) continue;
+                        const float* tb = ts + lb * a.S;
+                        rank += (lb < la) ? upper_bound_lds(tb, a.S, v) : lower_bound_lds(tb, a.S, v);
+                    }
+                } else {  // general O(n^2) fallback
+                    rank = 0;
+                    for (int x = 0; x < LS; ++x) {
+                        const float xv = ts[x];
+                        rank += (xv < v || (xv == v && x < e)) ? 1 : 0;
+                    }
+                }
+                mt[rank] = v;
+                mord[rank] = e;
+            }
+        }
+        __syncthreads();
+        // ---- merged composite (:448 / :605-606)
+        if (active && (a.mixed_out || a.order)) {
+            float o5[5];
+            const bool cut_near = a.p.fine != 0;
+            const float nearv = a.p.near;
+            composite_run(LS, a.p.border, lane, [&](int m) { return mt[m]; },
+                          [&](int m) {
+                              float4 rw = raws[mord[m]];
+                              if (cut_near && mt[m] < nearv) rw.w = 0.f;  // :605
+                              return rw;
+                          },
+                          [&](int, float) {}, o5);
+            if (a.mixed_out && lane < 5) {
+                const float v = lane == 0 ? o5[0] : lane == 1 ? o5[1] : lane == 2 ? o5[2] : lane == 3 ? o5[3] : o5[4];
+                a.mixed_out[ray * 5 + lane] = v;
+            }
+            if (a.order)
+                for (int m = lane; m < LS; m += 64) a.order[ray * LS + m] = mord[m];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resampler: one wave per (ray, layer).
+// ---------------------------------------------------------------------------------------------
+struct ResampleArgs {
+    const float* t;
+    const float* weights;
+    int64_t n;
+    int l, n1, n2;
+    const float* u;
+    uint64_t seed;
+    int64_t ray_index_base;
+    const float* rays;
+    int ray_stride;
+    EditArgs ed;
+    float* t_fine;
+    float* xyz_fine;
+    float* z_new;
+    int32_t* inds;
+    float* cdf_out;
+};
+
+__global__ void resample_kernel(ResampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n1 = a.n1, n2 = a.n2, S = n1 + n2, nb = n1 - 1;  // nb = #bins = len(cdf)
+    float* mine = reinterpret_cast<float*>(smem_raw) + (size_t)wave * (3 * n1 + n2 + S);
+    float* tc = mine;          // [n1]  coarse depths
+    float* cdf = tc + n1;      // [n1-1]
+    float* bins = cdf + n1;    // [n1-1]
+    float* zs = bins + n1;     // [n2]
+    float* tf = zs + n2;       // [S]
+    const int64_t pairs = a.n * a.l;
+    const int64_t per_iter = (int64_t)gridDim.x * 4;
+    for (int64_t p0 = (int64_t)blockIdx.x * 4; p0 < pairs; p0 += per_iter) {
+        const int64_t pr = p0 + wave;
+        const bool active = pr < pairs;
+        const int64_t ray = active ? pr / a.l : 0;
+        const int layer = active ? (int)(pr - ray * a.l) : 0;
+        // ---- pdf / cdf / bins   (sample_pdf.py:20-24; the caller passes w[..., 1:-1], layered_rfrender.py:460)
+        if (active) {
+            const float* tsrc = a.t + pr * n1;
+            const float* wsrc = a.weights + pr * n1;
+            for (int k = lane; k < n1; k += 64) tc[k] = tsrc[k];
+            float part = 0.f;
+            for (int k = lane; k < n1 - 2; k += 64) part += wsrc[k + 1] + 1e-5f;
+            const float total = wave_sum(part);
+            float carry = 0.f;
+            if (lane == 0) cdf[0] = 0.f;
+            for (int base = 0; base < n1 - 2; base += 64) {
+                const int k = base + lane;
+                const float pdf = (k < n1 - 2) ? (wsrc[k + 1] + 1e-5f) / total : 0.f;
+                const float incl = wave_scan_add(pdf, lane);
+                if (k < n1 - 2) cdf[k + 1] = carry + incl;
+                carry = carry + __shfl(incl, 63);
+            }
+        }
+        __syncthreads();
+        if (active) {
+            for (int k = lane; k < nb; k += 64) bins[k] = 0.5f * (tc[k + 1] + tc[k]);
+            if (a.cdf_out)
+                for (int k = lane; k < nb; k += 64) a.cdf_out[pr * nb + k] = cdf[k];
+        }
+        __syncthreads();
+        // ---- invert the cdf (sample_pdf.py:44-61)
+        if (active) {
+            for (int j = lane; j < n2; j += 64) {
+                const float u = a.u ? a.u[((int64_t)layer * a.n + ray) * n2 + j]
+                                    : philox_uniform(a.seed, (uint64_t)(a.ray_index_base + ray), (uint32_t)layer, 1u,
+                                                     (uint32_t)j);
+                const int ind = upper_bound_lds(cdf, nb, u);          // searchsorted(right=True)
+                const int below = ind - 1 > 0 ? ind - 1 : 0;
+                const int above = ind < nb - 1 ? ind : nb - 1;
+                float den = cdf[above] - cdf[below];
+                if (den < 1e-5f) den = 1.f;
+                const float frac = (u - cdf[below]) / den;
+                const float z = bins[below] + frac * (bins[above] - bins[below]);
+                zs[j] = z;
+                if (a.z_new) a.z_new[pr * n2 + j] = z;
+                if (a.inds) a.inds[pr * n2 + j] = ind;
+            }
+        }
+        __syncthreads();
+        // ---- sort(cat[t, z])  (layered_rfrender.py:462): counting ranks == a stable sort, any input order
+        if (active) {
+            for (int e = lane; e < S; e += 64) {
+                const bool is_t = e < n1;
+                const float v = is_t ? tc[e] : zs[e - n1];
+                int rank = 0;
+                for (int x = 0; x < n1; ++x) {
+                    const float xv = tc[x];
+                    rank += (xv < v || (xv == v && (!is_t || x < e))) ? 1 : 0;
+                }
+                for (int x = 0; x < n2; ++x) {
+                    const float xv = zs[x];
+                    rank += (xv < v || (xv == v && !is_t && x < e - n1)) ? 1 : 0;
+                }
+                tf[rank] = v;
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const float* r = a.rays + ray * a.ray_stride;
+            const float o0 = r[0], o1 = r[1], o2 = r[2], d0 = r[3], d1 = r[4], d2 = r[5];
+            for (int m = lane; m < S; m += 64) {
+                const float z = tf[m];
+                a.t_fine[pr * S + m] = z;
+                if (a.xyz_fine) {
+                    float x = z * d0 + o0, y = z * d1 + o1, w = z * d2 + o2;  // :465
+                    if (a.ed.any) unedit_point(x, y, w, a.ed.e[layer], a.ed.pivot);
+                    float* dst = a.xyz_fine + (pr * S + m) * 3;
+                    dst[0] = x;
+                    dst[1] = y;
+                    dst[2] = w;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace stnerf
+
+using namespace stnerf;
+
+extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t* mask, int64_t n, int l, int S,
+                                const stnerf_composite_params* params_host, float* layer_out, float* mixed_out,
+                                float* weights, int32_t* order, stnerf_stream_t stream) {
+    STNERF_REQUIRE(t && raw && params_host, "composite: null pointer");
+    STNERF_REQUIRE(n >= 0 && l >= 1 && l <= STNERF_MAX_LAYERS && S >= 1, "composite: bad shape n=%lld l=%d S=%d",
+                   (long long)n, l, S);
+    STNERF_REQUIRE(((uintptr_t)raw & 15) == 0, "composite: raw must be 16-byte aligned");
+    if (n == 0) return STNERF_OK;
+    const int64_t per_wave = (int64_t)l * S * 28;
+    int wpb = (int)((150 * 1024) / per_wave);
+    STNERF_REQUIRE(wpb >= 1, "composite: %d samples per ray do not fit the 160 KiB LDS", l * S);
+    if (wpb > 4) wpb = 4;
+    static int lds_limit_set = 0;
+    const int lds = (int)(per_wave * wpb);
+    if (lds > 64 * 1024 && lds > lds_limit_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(composite_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            set_error("composite: cannot reserve %d B of LDS", lds);
+            return STNERF_ELAUNCH;
+        }
+        lds_limit_set = lds;
+    }
+    CompositeArgs a{t, reinterpret_cast<const float4*>(raw), mask, n, l, S, *params_host, layer_out, mixed_out,
+                    weights, order, wpb};
+    int64_t blocks = (n + wpb - 1) / wpb;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(wpb * 64), lds, as_stream(stream), a);
+    STNERF_CHECK_LAUNCH("composite");
+    return STNERF_OK;
+}
+
+extern "C" int stnerf_resample(const float* t, const float* weights, int64_t n, int l, int n1, int n2, const float* u,
+                               uint64_t seed, int64_t ray_index_base, const float* rays, int ray_stride,
+                               const stnerf_layer_edit* edits_host, const float* pivot_host, float* t_fine,
+                               float* xyz_fine, float* z_new, int32_t* inds, float* cdf, stnerf_stream_t stream) {
+    STNERF_REQUIRE(t && weights && rays && t_fine, "resample: null pointer");
+    STNERF_REQUIRE(n >= 0 && l >= 1 && l <= STNERF_MAX_LAYERS && n1 >= 3 && n2 >= 0 && ray_stride >= 6,
+                   "resample: bad shape n=%lld l=%d n1=%d n2=%d", (long long)n, l, n1, n2);
+    if (n == 0) return STNERF_OK;
+    ResampleArgs a;
+    a.t = t; a.weights = weights; a.n = n; a.l = l; a.n1 = n1; a.n2 = n2; a.u = u; a.seed = seed;
+    a.ray_index_base = ray_index_base; a.rays = rays; a.ray_stride = ray_stride;
+    fill_edit_args(a.ed, edits_host, pivot_host, l);
+    a.t_fine = t_fine; a.xyz_fine = xyz_fine; a.z_new = z_new; a.inds = inds; a.cdf_out = cdf;
+    const int lds = 4 * (3 * n1 + n2 + n1 + n2) * (int)sizeof(float);
+    STNERF_REQUIRE(lds <= 64 * 1024, "resample: %d+%d samples per ray exceed the LDS budget", n1, n2);
+    int64_t blocks = (n * l + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(256), lds, as_stream(stream), a);
+    STNERF_CHECK_LAUNCH("resample");
+    return STNERF_OK;
+}

@@ -1,0 +1,120 @@
+"""ctypes binding of the C ABI in ``include/stnerf.h`` (libstnerf_hip.so).
+
+This is the only place Python touches the native library.  There is NO fallback: if the shared
+library is missing, cannot be loaded, or a call returns an error code, a ``RuntimeError`` /
+``ValueError`` is raised -- nothing in this package computes the hot path in PyTorch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch  # imported first on purpose: the HIP runtime of the process must be torch's (same SONAME)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libstnerf_hip.so")
+
+OK, EINVAL, ELAUNCH, EARCH = 0, -1, -2, -3
+MAX_LAYERS = 16
+NET_SPACE, NET_SPACE_TIME, NET_MOTION = 0, 1, 2
+
+c_f32p = C.c_void_p  # device pointers travel as void*
+c_i64 = C.c_int64
+
+
+class LayerEdit(C.Structure):
+    _fields_ = [("shift", C.c_float * 3), ("scale", C.c_float), ("has_shift", C.c_int32), ("has_scale", C.c_int32)]
+
+
+class CompositeParams(C.Structure):
+    _fields_ = [("border", C.c_float), ("near", C.c_float), ("fine", C.c_int32), ("cut_negative_t", C.c_int32),
+                ("threshold", C.c_float * MAX_LAYERS), ("use_threshold", C.c_int32 * MAX_LAYERS),
+                ("sigma_scale", C.c_float * MAX_LAYERS), ("evaluated", C.c_int32 * MAX_LAYERS)]
+
+
+_PROTOS = {
+    "stnerf_version": (C.c_char_p, []),
+    "stnerf_last_error": (C.c_char_p, []),
+    "stnerf_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "stnerf_generate_rays": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, c_i64, c_i64,
+                                       C.POINTER(C.c_float), C.c_int, c_f32p, C.c_int, C.c_void_p]),
+    "stnerf_intersect": (C.c_int, [c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
+    "stnerf_sample_coarse": (C.c_int, [c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, C.c_int, c_f32p, C.c_uint64,
+                                       c_i64, C.POINTER(LayerEdit), C.POINTER(C.c_float), c_f32p, c_f32p, C.c_void_p,
+                                       C.c_void_p]),
+    "stnerf_compact_rays": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "stnerf_packed_bytes": (c_i64, [C.c_int]),
+    "stnerf_pack_net": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, c_i64]),
+    "stnerf_spacenet_fwd": (C.c_int, [C.c_int, C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_i64,
+                                      c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, C.c_void_p]),
+    "stnerf_motionnet_fwd": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_i64, c_f32p,
+                                       c_i64, c_f32p, c_i64, C.c_int, C.c_void_p]),
+    "stnerf_composite": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_i64, C.c_int, C.c_int, C.POINTER(CompositeParams),
+                                   c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
+    "stnerf_resample": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_uint64, c_i64, c_f32p,
+                                  C.c_int, C.POINTER(LayerEdit), C.POINTER(C.c_float), c_f32p, c_f32p, c_f32p,
+                                  C.c_void_p, c_f32p, C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library (loads on first use; raises if it is not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python st-nerf_amd/build.py` "
+                "(or __graft_entry__.build()).  There is no PyTorch fallback for the render path.")
+        handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_PROTOS)
+
+
+def last_error() -> str:
+    return lib().stnerf_last_error().decode()
+
+
+def check(rc: int, what: str) -> None:
+    if rc == OK:
+        return
+    msg = f"{what}: {last_error()} (code {rc})"
+    if rc == EINVAL:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def stream_ptr() -> C.c_void_p:
+    """The current torch stream as a hipStream_t."""
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t: Optional[torch.Tensor], dtype=torch.float32, name: str = "tensor") -> C.c_void_p:
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def device_info() -> dict:
+    cu, lds, clk = C.c_int(0), C.c_int(0), C.c_int(0)
+    arch = C.create_string_buffer(64)
+    rc = lib().stnerf_device_info(C.byref(cu), C.byref(lds), C.byref(clk), arch, 64)
+    info = dict(cu_count=cu.value, lds_bytes_per_cu=lds.value, clock_khz=clk.value, arch=arch.value.decode())
+    check(rc, "stnerf_device_info")
+    return info

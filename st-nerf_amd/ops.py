@@ -1,0 +1,258 @@
+"""Torch-tensor wrappers over the C ABI (one function per entry point of include/stnerf.h).
+
+PyTorch is plumbing here: device memory, streams.  Every function launches HIP kernels from
+``libstnerf_hip.so`` on the current torch stream and returns device tensors; none of them has a
+PyTorch implementation to fall back to.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from stnerf_amd import hip
+
+Tensor = torch.Tensor
+
+
+def _strided_view_ptr(t: Tensor, inner: Tuple[int, ...], name: str):
+    """(pointer, ray stride) of a tensor whose dim 0 is the ray and whose inner dims are dense."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32, got {t.dtype}")
+    if tuple(t.shape[1:]) != tuple(inner):
+        raise ValueError(f"{name}: expected shape (n, {inner}), got {tuple(t.shape)}")
+    expect = 1
+    for d in range(t.dim() - 1, 0, -1):
+        if t.shape[d] != 1 and t.stride(d) != expect:
+            raise ValueError(f"{name}: inner dimensions must be dense, got strides {t.stride()}")
+        expect *= t.shape[d]
+    return C.c_void_p(t.data_ptr()), (t.stride(0) if t.shape[0] > 1 else expect)
+
+
+def _edits(edits, pivot, l):
+    """-> (LayerEdit array | None, float[3] | None).  edits: per layer (shift|None, scale|None)."""
+    if edits is None:
+        return None, None
+    arr = (hip.LayerEdit * l)()
+    for i in range(l):
+        sh, sc = edits[i] if i < len(edits) else (None, None)
+        if sh is not None:
+            # the reference builds torch.tensor(shift[i]) (fp32), layered_rfrender.py:241,297
+            v = torch.tensor(sh, dtype=torch.float32).tolist()
+            arr[i].shift[0], arr[i].shift[1], arr[i].shift[2] = v
+            arr[i].has_shift = 1
+        if sc is not None:
+            arr[i].scale = float(sc)
+            arr[i].has_scale = 1
+    pv = (C.c_float * 3)(*(float(x) for x in (pivot if pivot is not None else (0.0, 0.0, 0.0))))
+    return arr, pv
+
+
+def _boxes_arg(boxes: Tensor, n: int):
+    if boxes.dim() == 3:  # (l,8,3) shared
+        return hip.dptr(boxes, name="boxes"), 0, boxes.shape[0]
+    if boxes.dim() == 4 and boxes.shape[0] == n:  # (n,l,8,3) per ray
+        return hip.dptr(boxes, name="boxes"), boxes.shape[1] * 24, boxes.shape[1]
+    raise ValueError(f"boxes must be (l,8,3) or (n,l,8,3), got {tuple(boxes.shape)}")
+
+
+# ---------------------------------------------------------------------------------------- a1/a2
+def generate_rays(K: Tensor, T: Tensor, h: int, w: int, frame_ids: Optional[Sequence[float]] = None,
+                  first_ray: int = 0, n: Optional[int] = None, device="cuda") -> Tensor:
+    """Rays of a view, generated on the device: (n, 6 + len(frame_ids)).
+    utils/render_helpers.py:42-128 + data/datasets/ray_dataset.py:276-281."""
+    n = h * w - first_ray if n is None else n
+    kinv = torch.inverse(K.detach().to("cpu", torch.float32)).contiguous()  # :103 (torch.inverse on the host)
+    Tm = torch.as_tensor(T, dtype=torch.float32).detach().cpu().contiguous()
+    fids = [float(x) for x in (frame_ids or [])]
+    rays = torch.empty(n, 6 + len(fids), dtype=torch.float32, device=device)
+    kin = (C.c_float * 9)(*kinv.reshape(-1).tolist())
+    tin = (C.c_float * 16)(*Tm.reshape(-1).tolist())
+    fin = (C.c_float * max(len(fids), 1))(*(fids or [0.0]))
+    hip.check(hip.lib().stnerf_generate_rays(kin, tin, h, w, first_ray, n, fin if fids else None, len(fids),
+                                             hip.dptr(rays), rays.shape[1], hip.stream_ptr()), "stnerf_generate_rays")
+    return rays
+
+
+# ---------------------------------------------------------------------------------------- a5/a6
+def intersect(rays: Tensor, boxes: Tensor) -> Tensor:
+    """(n,l,2) = (far, near); layers/RaySamplePoint.py:8-62."""
+    n = rays.shape[0]
+    bp, bstride, l = _boxes_arg(boxes, n)
+    out = torch.empty(n, l, 2, dtype=torch.float32, device=rays.device)
+    hip.check(hip.lib().stnerf_intersect(hip.dptr(rays, name="rays"), n, rays.shape[1], bp, bstride, l,
+                                         hip.dptr(out), hip.stream_ptr()), "stnerf_intersect")
+    return out
+
+
+def sample_coarse(rays: Tensor, boxes: Tensor, n1: int, jitter: Optional[Tensor] = None, seed: int = 0,
+                  ray_index_base: int = 0, edits=None, pivot=None, want_xyz: bool = True):
+    """-> t (n,l,n1), xyz (n,l,n1,3) | None, mask (n,l) uint8.  layers/RaySamplePoint.py:70-107."""
+    n = rays.shape[0]
+    bp, bstride, l = _boxes_arg(boxes, n)
+    if jitter is not None and tuple(jitter.shape) != (l, n, n1):
+        raise ValueError(f"jitter must be (l,n,n1) = {(l, n, n1)}, got {tuple(jitter.shape)}")
+    t = torch.empty(n, l, n1, dtype=torch.float32, device=rays.device)
+    xyz = torch.empty(n, l, n1, 3, dtype=torch.float32, device=rays.device) if want_xyz else None
+    mask = torch.empty(n, l, dtype=torch.uint8, device=rays.device)
+    ed, pv = _edits(edits, pivot, l)
+    hip.check(hip.lib().stnerf_sample_coarse(hip.dptr(rays, name="rays"), n, rays.shape[1], bp, bstride, l, n1,
+                                             hip.dptr(jitter, name="jitter"), seed, ray_index_base, ed, pv,
+                                             hip.dptr(t), hip.dptr(xyz), hip.dptr(mask, torch.uint8),
+                                             hip.stream_ptr()), "stnerf_sample_coarse")
+    return t, xyz, mask
+
+
+def compact_rays(mask: Tensor):
+    """-> ray_list (l,n) int32, ray_count (l,) int32 (device; no host sync)."""
+    n, l = mask.shape
+    ray_list = torch.empty(l, n, dtype=torch.int32, device=mask.device)
+    ray_count = torch.zeros(l, dtype=torch.int32, device=mask.device)
+    hip.check(hip.lib().stnerf_compact_rays(hip.dptr(mask, torch.uint8, "mask"), n, l,
+                                            hip.dptr(ray_list, torch.int32), hip.dptr(ray_count, torch.int32),
+                                            hip.stream_ptr()), "stnerf_compact_rays")
+    return ray_list, ray_count
+
+
+# ---------------------------------------------------------------------------------------- networks
+SPACENET_KEYS = ["stage1.0", "stage1.2", "stage1.4", "stage1.6", "stage2.0", "stage2.2", "stage2.4",
+                 "density_net.0", "rgb_net.1", "rgb_net.3"]
+MOTIONNET_KEYS = [f"motion_net.{j}" for j in (0, 2, 4, 6, 8, 10)]
+
+
+class PackedNet:
+    """Kernel-layout weights of one network, resident on the device."""
+
+    def __init__(self, kind: int, blob: Tensor):
+        self.kind, self.blob = kind, blob
+
+    @property
+    def use_time(self) -> bool:
+        return self.kind == hip.NET_SPACE_TIME
+
+
+def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cuda") -> PackedNet:
+    """Repack reference-layout nn.Linear tensors (host copy) and upload."""
+    nbytes = hip.lib().stnerf_packed_bytes(kind)
+    if nbytes < 0:
+        hip.check(int(nbytes), "stnerf_packed_bytes")
+    ws = [w.detach().to("cpu", torch.float32).contiguous() for w in weights]
+    bs = [b.detach().to("cpu", torch.float32).contiguous() for b in biases]
+    host = torch.empty(nbytes // 4, dtype=torch.float32)
+    wp = (C.c_void_p * len(ws))(*(w.data_ptr() for w in ws))
+    bp = (C.c_void_p * len(bs))(*(b.data_ptr() for b in bs))
+    hip.check(hip.lib().stnerf_pack_net(kind, wp, bp, len(ws), C.c_void_p(host.data_ptr()), nbytes), "stnerf_pack_net")
+    return PackedNet(kind, host.to(device))
+
+
+def pack_spacenet(state: dict, prefix: str, device="cuda") -> PackedNet:
+    """From reference state_dict keys ``{prefix}.stage1.0.weight`` ...."""
+    ws = [state[f"{prefix}.{k}.weight"] for k in SPACENET_KEYS]
+    bs = [state[f"{prefix}.{k}.bias"] for k in SPACENET_KEYS]
+    in1 = ws[8].shape[1]
+    if in1 not in (283, 304):
+        raise ValueError(f"{prefix}.rgb_net.1 has in-width {in1}; only USE_DIR with/without time is supported")
+    return pack_net(hip.NET_SPACE_TIME if in1 == 304 else hip.NET_SPACE, ws, bs, device)
+
+
+def pack_motionnet(state: dict, prefix: str, device="cuda") -> PackedNet:
+    ws = [state[f"{prefix}.{k}.weight"] for k in MOTIONNET_KEYS]
+    bs = [state[f"{prefix}.{k}.bias"] for k in MOTIONNET_KEYS]
+    return pack_net(hip.NET_MOTION, ws, bs, device)
+
+
+def _worklist(ray_list, ray_count):
+    return hip.dptr(ray_list, torch.int32, "ray_list"), hip.dptr(ray_count, torch.int32, "ray_count")
+
+
+def spacenet_fwd(net: PackedNet, xyz: Tensor, dirs: Tensor, times: Optional[Tensor], raw: Tensor,
+                 ray_list: Optional[Tensor] = None, ray_count: Optional[Tensor] = None) -> Tensor:
+    """xyz (n,ns,3), dirs (n,3), times (n,) | None, raw (n,ns,4) out; all may be strided views whose
+    dim 0 is the ray.  Writes raw {r,g,b,sigma} for the listed rays.  modeling/spacenet.py:101-160."""
+    n, ns = xyz.shape[0], xyz.shape[1]
+    xp, xs = _strided_view_ptr(xyz, (ns, 3), "xyz")
+    dp, ds = _strided_view_ptr(dirs, (3,), "dirs")
+    rp, rs = _strided_view_ptr(raw, (ns, 4), "raw")
+    if net.use_time:
+        if times is None:
+            raise ValueError("this SpaceNet takes time: pass times (n,)")
+        tp, ts = _strided_view_ptr(times.reshape(n), (), "times")
+    else:
+        tp, ts = C.c_void_p(0), 0
+    lp, cp = _worklist(ray_list, ray_count)
+    hip.check(hip.lib().stnerf_spacenet_fwd(net.kind, hip.dptr(net.blob), n, ns, lp, cp, xp, xs, dp, ds, tp, ts,
+                                            rp, rs, hip.stream_ptr()), "stnerf_spacenet_fwd")
+    return raw
+
+
+def motionnet_fwd(net: PackedNet, xyz: Tensor, times: Tensor, flow: Optional[Tensor] = None,
+                  add_to_xyz: bool = True, ray_list: Optional[Tensor] = None, ray_count: Optional[Tensor] = None):
+    """xyz (n,ns,3) (updated in place if add_to_xyz), times (n,), flow (n,ns,3) out | None.
+    modeling/motion_net.py:34-71 + layered_rfrender.py:355-356."""
+    n, ns = xyz.shape[0], xyz.shape[1]
+    xp, xs = _strided_view_ptr(xyz, (ns, 3), "xyz")
+    tp, ts = _strided_view_ptr(times.reshape(n), (), "times")
+    if flow is not None:
+        fp, fs = _strided_view_ptr(flow, (ns, 3), "flow")
+    else:
+        fp, fs = C.c_void_p(0), 0
+    lp, cp = _worklist(ray_list, ray_count)
+    hip.check(hip.lib().stnerf_motionnet_fwd(hip.dptr(net.blob), n, ns, lp, cp, xp, xs, tp, ts, fp, fs,
+                                             1 if add_to_xyz else 0, hip.stream_ptr()), "stnerf_motionnet_fwd")
+    return flow
+
+
+# ---------------------------------------------------------------------------------------- a10-a13
+def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e10, near: float = 0.0,
+              fine: bool = False, cut_negative_t: bool = False, thresholds: Optional[Sequence[Optional[float]]] = None,
+              sigma_scale: Optional[Sequence[float]] = None, evaluated: Optional[Sequence[bool]] = None,
+              want_weights: bool = False, want_order: bool = False):
+    """t (n,l,S), raw (n,l,S,4), mask (n,l) uint8 | None ->
+    layer_out (n,l,5), mixed_out (n,5), weights (n,l,S) | None, order (n,l*S) int32 | None.
+    layers/render_layer.py:8-58 + modeling/layered_rfrender.py:414-448 / :538-606."""
+    n, l, S = t.shape
+    p = hip.CompositeParams()
+    p.border, p.near, p.fine, p.cut_negative_t = border, near, int(fine), int(cut_negative_t)
+    for i in range(hip.MAX_LAYERS):
+        th = thresholds[i] if thresholds is not None and i < len(thresholds) else None
+        p.threshold[i] = 0.0 if th is None else float(th)
+        p.use_threshold[i] = 0 if th is None else 1
+        p.sigma_scale[i] = float(sigma_scale[i]) if sigma_scale is not None and i < len(sigma_scale) else 1.0
+        p.evaluated[i] = int(evaluated[i]) if evaluated is not None and i < len(evaluated) else 1
+    layer_out = torch.empty(n, l, 5, dtype=torch.float32, device=t.device)
+    mixed_out = torch.empty(n, 5, dtype=torch.float32, device=t.device)
+    weights = torch.empty(n, l, S, dtype=torch.float32, device=t.device) if want_weights else None
+    order = torch.empty(n, l * S, dtype=torch.int32, device=t.device) if want_order else None
+    hip.check(hip.lib().stnerf_composite(hip.dptr(t, name="t"), hip.dptr(raw, name="raw"),
+                                         hip.dptr(mask, torch.uint8, "mask"), n, l, S, C.byref(p), hip.dptr(layer_out),
+                                         hip.dptr(mixed_out), hip.dptr(weights), hip.dptr(order, torch.int32),
+                                         hip.stream_ptr()), "stnerf_composite")
+    return layer_out, mixed_out, weights, order
+
+
+def resample(t: Tensor, weights: Tensor, n2: int, rays: Tensor, u: Optional[Tensor] = None, seed: int = 0,
+             ray_index_base: int = 0, edits=None, pivot=None, want_xyz: bool = True, debug: bool = False):
+    """t (n,l,n1), weights (n,l,n1) -> t_fine (n,l,n1+n2) ascending, xyz_fine (n,l,n1+n2,3) | None
+    [, z_new (n,l,n2), inds (n,l,n2) int32, cdf (n,l,n1-1) if debug].
+    utils/sample_pdf.py:18-63 + modeling/layered_rfrender.py:459-475."""
+    n, l, n1 = t.shape
+    if u is not None and tuple(u.shape) != (l, n, n2):
+        raise ValueError(f"u must be (l,n,n2) = {(l, n, n2)}, got {tuple(u.shape)}")
+    dev = t.device
+    t_fine = torch.empty(n, l, n1 + n2, dtype=torch.float32, device=dev)
+    xyz = torch.empty(n, l, n1 + n2, 3, dtype=torch.float32, device=dev) if want_xyz else None
+    z_new = torch.empty(n, l, n2, dtype=torch.float32, device=dev) if debug else None
+    inds = torch.empty(n, l, n2, dtype=torch.int32, device=dev) if debug else None
+    cdf = torch.empty(n, l, n1 - 1, dtype=torch.float32, device=dev) if debug else None
+    ed, pv = _edits(edits, pivot, l)
+    hip.check(hip.lib().stnerf_resample(hip.dptr(t, name="t"), hip.dptr(weights, name="weights"), n, l, n1, n2,
+                                        hip.dptr(u, name="u"), seed, ray_index_base, hip.dptr(rays, name="rays"),
+                                        rays.shape[1], ed, pv, hip.dptr(t_fine), hip.dptr(xyz), hip.dptr(z_new),
+                                        hip.dptr(inds, torch.int32), hip.dptr(cdf), hip.stream_ptr()),
+              "stnerf_resample")
+    if debug:
+        return t_fine, xyz, z_new, inds, cdf
+    return t_fine, xyz

@@ -1,0 +1,103 @@
+"""The C-ABI library: loads, exports every symbol include/stnerf.h declares, host-side entry points
+(weight packing, argument validation) behave.  CPU only -- no kernel is launched."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from stnerf_amd import hip, synthetic as syn
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(hip.LIB_PATH):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("stnerf_build", os.path.join(REPO, "st-nerf_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    return hip.lib()
+
+
+def test_exports_every_declared_symbol(lib):
+    header = open(os.path.join(REPO, "include", "stnerf.h")).read()
+    declared = set(re.findall(r"\b(stnerf_[a-z_0-9]+)\s*\(", header))
+    assert declared, "header parse failed"
+    assert declared == set(hip.exported_symbols()), declared ^ set(hip.exported_symbols())
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert b"gfx950" in lib.stnerf_version()
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(hip.LayerEdit) == 24
+    assert C.sizeof(hip.CompositeParams) == 16 + 4 * 4 * hip.MAX_LAYERS
+
+
+def test_packed_sizes_and_bad_kind(lib):
+    # 7 backbone layers [Kq][256][4] + biases + heads (DESIGN.md "packed weight layout")
+    kq = [16, 64, 64, 64, 80, 64, 64]
+    base = sum(k * 256 * 4 + 256 for k in kq) + 256 + 4 + 128 + 3 * 128 + 4
+    assert lib.stnerf_packed_bytes(hip.NET_SPACE) == 4 * (base + 72 * 128 * 4)
+    assert lib.stnerf_packed_bytes(hip.NET_SPACE_TIME) == 4 * (base + 76 * 128 * 4)
+    assert lib.stnerf_packed_bytes(hip.NET_MOTION) == 4 * ((22 + 4 * 32) * 128 * 4 + 5 * 128 + 3 * 128 + 4)
+    assert lib.stnerf_packed_bytes(99) == hip.EINVAL
+    assert "unknown net kind" in hip.last_error()
+
+
+def _pack(lib, kind, ws, bs):
+    nbytes = lib.stnerf_packed_bytes(kind)
+    dst = np.full(nbytes // 4, np.nan, dtype=np.float32)
+    wp = (C.c_void_p * len(ws))(*(w.ctypes.data for w in ws))
+    bp = (C.c_void_p * len(bs))(*(b.ctypes.data for b in bs))
+    rc = lib.stnerf_pack_net(kind, wp, bp, len(ws), C.c_void_p(dst.ctypes.data), nbytes)
+    return rc, dst
+
+
+def test_pack_spacenet_layout(lib):
+    from stnerf_amd import ops
+    sd = syn.spacenet_state("net", np.random.RandomState(3), True)
+    ws = [np.ascontiguousarray(sd[f"net.{k}.weight"].numpy()) for k in ops.SPACENET_KEYS]
+    bs = [np.ascontiguousarray(sd[f"net.{k}.bias"].numpy()) for k in ops.SPACENET_KEYS]
+    rc, dst = _pack(lib, hip.NET_SPACE_TIME, ws, bs)
+    assert rc == 0 and np.isfinite(dst).all()
+    off = 0
+    for i, kq in enumerate([16, 64, 64, 64, 80, 64, 64]):
+        blk = dst[off:off + kq * 256 * 4].reshape(kq, 256, 4)          # [k/4][n][k%4]
+        w = ws[i]                                                      # (256, in)
+        dense = blk.transpose(1, 0, 2).reshape(256, kq * 4)
+        assert np.array_equal(dense[:, :w.shape[1]], w) and not dense[:, w.shape[1]:].any()
+        off += kq * 256 * 4
+        assert np.array_equal(dst[off:off + 256], bs[i])
+        off += 256
+    assert np.array_equal(dst[off:off + 256], ws[7][0]) and dst[off + 256] == bs[7][0]
+    off += 260
+    blk = dst[off:off + 76 * 128 * 4].reshape(76, 128, 4).transpose(1, 0, 2).reshape(128, 304)
+    assert np.array_equal(blk, ws[8])
+    # wrong tensor count / too-small destination are argument errors, not crashes
+    rc, _ = _pack(lib, hip.NET_SPACE_TIME, ws[:9], bs[:9])
+    assert rc == hip.EINVAL and "10 tensors" in hip.last_error()
+    wp = (C.c_void_p * 10)(*(w.ctypes.data for w in ws))
+    bp = (C.c_void_p * 10)(*(b.ctypes.data for b in bs))
+    small = np.zeros(16, dtype=np.float32)
+    assert lib.stnerf_pack_net(hip.NET_SPACE_TIME, wp, bp, 10, C.c_void_p(small.ctypes.data), 64) == hip.EINVAL
+
+
+def test_argument_errors_before_any_launch(lib):
+    null = C.c_void_p(0)
+    assert lib.stnerf_sample_coarse(null, 4, 9, null, 0, 3, 8, null, 0, 0, None, None, null, null, null, null) == hip.EINVAL
+    assert lib.stnerf_spacenet_fwd(7, null, 1, 1, null, null, null, 0, null, 0, null, 0, null, 0, null) == hip.EINVAL
+    assert "bad kind" in hip.last_error()
+
+
+def test_product_path_refuses_cpu_tensors():
+    """No silent fallback: handing the HIP path a CPU tensor is an error."""
+    from stnerf_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.intersect(torch.zeros(4, 9), torch.zeros(3, 8, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.composite(torch.zeros(2, 1, 4), torch.zeros(2, 1, 4, 4), None)

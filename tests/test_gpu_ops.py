@@ -1,0 +1,358 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against the CPU oracle and the golden
+fixtures produced by the reference.  Needs an MI355X: `pytest -m gpu`.
+
+Exactness classes:
+  * bit-exact   : hit masks, coarse depths/points (same jitter), searchsorted indices and merge
+                  order (same inputs);
+  * fp32 tol.   : network outputs, composited colours (accumulation order differs from ATen's).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import stnerf_oracle as O
+from stnerf_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+# Stated fp32 tolerances.  Network outputs are compared against an fp64 evaluation of the same
+# formulas: |err| <= NET_RTOL * |ref| + NET_ATOL * (scale of the output head).
+NET_RTOL = 2e-5
+NET_ATOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from stnerf_amd import ops as _ops
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return _ops
+
+
+def dev(x):
+    return x.cuda().contiguous()
+
+
+def test_device_is_gfx950():
+    from stnerf_amd import hip
+    info = hip.device_info()
+    assert info["arch"].startswith("gfx950"), info
+    assert info["cu_count"] == 256 and info["lds_bytes_per_cu"] >= 160 * 1024, info
+
+
+def test_generate_rays(ops):
+    meta, a = load_golden("generate_rays")
+    h, w = meta["h"], meta["w"]
+    rays = ops.generate_rays(a["K"], a["T"], h, w, frame_ids=[1.0, 2.5, 3.0])
+    assert rays.shape == (h * w, 9)
+    torch.testing.assert_close(rays[:, :6].cpu(), a["rays"], rtol=0, atol=1e-6)
+    assert torch.equal(rays[:, 6:].cpu(), torch.tensor([1.0, 2.5, 3.0]).repeat(h * w, 1))
+    # a window of a large view == the same rows of the oracle's full view
+    K, T = syn.camera(270, 480, 17.0)
+    full = O.generate_rays(K, T, 270, 480)
+    part = ops.generate_rays(K, T, 270, 480, first_ray=1000, n=5000)
+    torch.testing.assert_close(part.cpu(), full[1000:6000], rtol=0, atol=1e-6)
+
+
+def test_sampler_golden_bit_exact(ops):
+    meta, a = load_golden("sampler")
+    rays, boxes = dev(a["rays"]), dev(a["boxes"])
+    fn = ops.intersect(rays, boxes)
+    assert torch.equal(fn.cpu(), a["far_near"].permute(1, 0, 2))
+    t, xyz, mask = ops.sample_coarse(rays, boxes, meta["n1"], jitter=dev(a["jitter"]))
+    assert torch.equal(t.cpu(), a["t"].squeeze(-1).permute(1, 0, 2))
+    assert torch.equal(xyz.cpu(), a["xyz"].permute(1, 0, 2, 3))
+    assert torch.equal(mask.cpu().bool(), a["mask"].permute(1, 0))
+
+
+@pytest.mark.parametrize("edit", [False, True])
+def test_sampler_random_bit_exact(ops, edit):
+    torch.manual_seed(7)
+    n, L, n1 = 6000, 3, 24
+    K, T = syn.camera(60, 100, -25.0)
+    rays = torch.cat([O.generate_rays(K, T, 60, 100), syn.frame_id_columns(n, L)], -1)
+    bk, per = syn.scene_boxes(L)
+    boxes = torch.cat([bk, per[2]], 0)
+    jitter = torch.rand(L + 1, n, n1)
+    edits, pivot = None, None
+    if edit:
+        edits = [(None, 1.0), ([0.1, -0.05, 0.2], 1.3), (None, None), ([0.0, 0.3, 0.0], 0.7)]
+        pivot = torch.tensor([0.1, 0.0, -1.0])
+    # per-ray boxes path == shared boxes path
+    t, xyz, mask = ops.sample_coarse(dev(rays), dev(boxes), n1, jitter=dev(jitter), edits=edits, pivot=pivot)
+    t2, xyz2, mask2 = ops.sample_coarse(dev(rays), dev(boxes.unsqueeze(0).repeat(n, 1, 1, 1)), n1,
+                                        jitter=dev(jitter), edits=edits, pivot=pivot)
+    assert torch.equal(t, t2) and torch.equal(xyz, xyz2) and torch.equal(mask, mask2)
+    ts, pts, ms = O.sample_coarse(rays, boxes.unsqueeze(0).repeat(n, 1, 1, 1), n1, list(jitter))
+    for i in range(L + 1):
+        assert torch.equal(t[:, i].cpu(), ts[i].squeeze(-1)), i
+        assert torch.equal(mask[:, i].cpu().bool(), ms[i]), i
+        p = pts[i]
+        if edit:
+            sh, sc = edits[i]
+            if sh is not None:
+                p = p - torch.tensor(sh)
+            if sc is not None:
+                p = (p - pivot) / sc + pivot
+        assert torch.equal(xyz[:, i].cpu(), p), i
+    assert 0.05 < ms[1].float().mean() < 0.95
+
+
+def test_device_rng_statistics_and_chunk_invariance(ops):
+    n, L, n1 = 4096, 1, 32
+    K, T = syn.camera(64, 64, 5.0)
+    rays = dev(torch.cat([O.generate_rays(K, T, 64, 64), syn.frame_id_columns(n, L)], -1))
+    bk, per = syn.scene_boxes(L)
+    boxes = dev(torch.cat([bk, per[0]], 0))
+    t, _, _ = ops.sample_coarse(rays, boxes, n1, seed=1234)
+    fn = ops.intersect(rays, boxes)
+    start = fn[:, 0, 1].clamp(min=0)
+    width = (fn[:, 0, 0] - start) / n1
+    xi = (t[:, 0] - start[:, None]) / width[:, None] - torch.arange(n1, device="cuda")[None]
+    assert xi.min() > -1e-3 and xi.max() < 1 + 1e-3
+    assert abs(float(xi.mean()) - 0.5) < 5e-3 and abs(float(xi.var()) - 1 / 12) < 5e-3
+    # the draw of (ray, layer, sample) does not depend on chunking
+    ta, _, _ = ops.sample_coarse(rays[1000:3000].contiguous(), boxes, n1, seed=1234, ray_index_base=1000)
+    assert torch.equal(ta, t[1000:3000])
+    tb, _, _ = ops.sample_coarse(rays, boxes, n1, seed=1235)
+    assert not torch.equal(tb, t)
+
+
+def test_compact_rays(ops):
+    torch.manual_seed(3)
+    mask = (torch.rand(10000, 4) < torch.tensor([1.0, 0.3, 0.0, 0.7])).to(torch.uint8)
+    lst, cnt = ops.compact_rays(dev(mask))
+    for i in range(4):
+        c = int(cnt[i])
+        assert c == int(mask[:, i].sum())
+        got = lst[i, :c].cpu().long().sort()[0]
+        assert torch.equal(got, torch.nonzero(mask[:, i])[:, 0])
+
+
+def _net_close(got, ref64, scale, what):
+    err = (got.double() - ref64).abs()
+    bound = NET_RTOL * ref64.abs() + NET_ATOL * scale
+    assert bool((err <= bound).all()), f"{what}: max err {float(err.max()):.3e}, worst excess {float((err - bound).max()):.3e}"
+
+
+def test_nets_golden(ops):
+    meta, a = load_golden("nets")
+    rs = np.random.RandomState(meta["weight_seed"])
+    sd_t = syn.spacenet_state("net", rs, True)
+    sd_n = syn.spacenet_state("net", rs, False)
+    sd_m = syn.motionnet_state("net", rs)
+    pos, dirs, times = dev(a["pos"]), dev(a["dirs"]), dev(a["times"].reshape(-1))
+    n, s = pos.shape[:2]
+    for sd, rgb_k, sig_k, tm in ((sd_t, "rgb_t", "sigma_t", times), (sd_n, "rgb_n", "sigma_n", None)):
+        net = ops.pack_spacenet(sd, "net")
+        raw = torch.full((n, s, 4), float("nan"), device="cuda")
+        ops.spacenet_fwd(net, pos, dirs, tm, raw)
+        torch.testing.assert_close(raw[..., :3].cpu(), a[rgb_k], rtol=2e-5, atol=1e-4)
+        torch.testing.assert_close(raw[..., 3:].cpu(), a[sig_k], rtol=2e-5, atol=2e-3)
+    mot = ops.pack_motionnet(sd_m, "net")
+    for tv, key in ((times, "flow_frac"), (torch.floor(times), "flow_int")):
+        flow = torch.empty(n, s, 3, device="cuda")
+        x = pos.clone()
+        ops.motionnet_fwd(mot, x, tv, flow=flow, add_to_xyz=True)
+        torch.testing.assert_close(flow.cpu(), a[key], rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(x.cpu(), a["pos"] + a[key], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("use_time", [False, True])
+def test_spacenet_vs_fp64_oracle(ops, use_time):
+    torch.manual_seed(11)
+    rs = np.random.RandomState(5)
+    sd = syn.spacenet_state("net", rs, use_time)
+    n, s = 700, 13                       # 9100 rows: many tiles, ragged tail, rays straddling tiles
+    pos = (torch.rand(n, s, 3) - 0.5) * 6.0
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
+    times = torch.rand(n) * 100 + 1
+    net = ops.pack_spacenet(sd, "net")
+    raw = torch.full((n, s, 4), float("nan"), device="cuda")
+    ops.spacenet_fwd(net, dev(pos), dev(dirs), dev(times) if use_time else None, raw)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    rgb64, sig64 = O.space_net(sd64, "net", pos.double(), dirs.double(), times.double().reshape(-1, 1) if use_time else None)
+    _net_close(raw[..., :3].cpu(), rgb64, 4.0, "rgb")
+    _net_close(raw[..., 3:].cpu(), sig64, 60.0, "sigma")
+    # and it is at least as close to fp64 as the fp32 CPU oracle is (x4 slack)
+    rgb32, sig32 = O.space_net(sd, "net", pos, dirs, times.reshape(-1, 1) if use_time else None)
+    e_gpu = float((raw[..., 3:].cpu().double() - sig64).abs().max())
+    e_cpu = float((sig32.double() - sig64).abs().max())
+    assert e_gpu <= 4 * e_cpu + 1e-6, (e_gpu, e_cpu)
+
+
+def test_spacenet_worklist_and_strided_views(ops):
+    """Masked evaluation through (ray_list, ray_count) into ray-major strided buffers."""
+    torch.manual_seed(12)
+    rs = np.random.RandomState(6)
+    sd = syn.spacenet_state("net", rs, True)
+    n, l, s = 500, 3, 10
+    xyz = (torch.rand(n, l, s, 3) - 0.5) * 4.0
+    rays = torch.cat([torch.zeros(n, 3), torch.nn.functional.normalize(torch.randn(n, 3), dim=-1),
+                      torch.rand(n, l) * 5], -1)
+    mask = (torch.rand(n, l) < 0.4).to(torch.uint8)
+    net = ops.pack_spacenet(sd, "net")
+    dx, dr, dm = dev(xyz), dev(rays), dev(mask)
+    lst, cnt = ops.compact_rays(dm)
+    raw = torch.full((n, l, s, 4), 7.0, device="cuda")
+    layer = 2
+    ops.spacenet_fwd(net, dx[:, layer], dr[:, 3:6], dr[:, 6 + layer], raw[:, layer], ray_list=lst[layer], ray_count=cnt[layer:layer + 1])
+    idx = mask[:, layer].bool()
+    rgb, sig = O.space_net(sd, "net", xyz[idx, layer], rays[idx, 3:6], rays[idx, 6 + layer].reshape(-1, 1))
+    rc = raw.cpu()
+    torch.testing.assert_close(rc[idx][:, layer, :, :3], rgb, rtol=2e-5, atol=1e-4)
+    torch.testing.assert_close(rc[idx][:, layer, :, 3:], sig, rtol=2e-5, atol=2e-3)
+    assert bool((rc[~idx] == 7.0).all()) and bool((rc[:, :layer] == 7.0).all())  # untouched elsewhere
+    # determinism: same inputs twice -> bitwise equal
+    raw2 = torch.full((n, l, s, 4), 7.0, device="cuda")
+    ops.spacenet_fwd(net, dx[:, layer], dr[:, 3:6], dr[:, 6 + layer], raw2[:, layer], ray_list=lst[layer], ray_count=cnt[layer:layer + 1])
+    assert torch.equal(raw, raw2)
+
+
+def test_motionnet_vs_fp64_oracle(ops):
+    torch.manual_seed(13)
+    rs = np.random.RandomState(7)
+    sd = syn.motionnet_state("net", rs)
+    n, s = 333, 9
+    pos = (torch.rand(n, s, 3) - 0.5) * 4.0
+    times = torch.where(torch.rand(n) < 0.5, torch.floor(torch.rand(n) * 50), torch.rand(n) * 50)
+    net = ops.pack_motionnet(sd, "net")
+    flow = torch.empty(n, s, 3, device="cuda")
+    x = dev(pos)
+    ops.motionnet_fwd(net, x, dev(times), flow=flow, add_to_xyz=False)
+    assert torch.equal(x.cpu(), pos)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    xt = torch.cat([pos, times.view(n, 1, 1).repeat(1, s, 1)], -1)
+    ref64 = O.motion_net(sd64, "net", xt.double())
+    _net_close(flow.cpu(), ref64, 1.0, "flow")
+
+
+def test_composite_golden(ops):
+    meta, a = load_golden("composite")
+    t = dev(a["t"].squeeze(-1).unsqueeze(1))                      # (n,1,S)
+    raw = dev(torch.cat([a["rgb"], a["sigma"]], -1).unsqueeze(1))  # (n,1,S,4)
+    layer_out, mixed, w, order = ops.composite(t, raw, None, border=meta["border"], want_weights=True, want_order=True)
+    torch.testing.assert_close(w[:, 0].cpu(), a["weights"].squeeze(-1), rtol=1e-5, atol=1e-7)
+    for out in (layer_out[:, 0].cpu(), mixed.cpu()):  # with one layer the merged stream == the layer
+        torch.testing.assert_close(out[:, :3], a["color"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(out[:, 3:4], a["depth"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(out[:, 4:5], a["acc"], rtol=1e-5, atol=1e-6)
+    S = t.shape[-1]
+    assert torch.equal(order.cpu(), torch.arange(S, dtype=torch.int32).repeat(t.shape[0], 1))
+
+
+@pytest.mark.parametrize("fine", [False, True])
+def test_composite_merge_vs_oracle(ops, fine):
+    torch.manual_seed(21 + fine)
+    n, l, S = 300, 3, 40
+    t = torch.sort(torch.rand(n, l, S) * 6.0 - 0.5, -1)[0]
+    t[:, 2][torch.rand(n) < 0.3] = -1000.0                       # missed performers: all samples at -1000
+    raw = torch.randn(n, l, S, 4) * torch.tensor([2.0, 2.0, 2.0, 4.0])
+    mask = torch.ones(n, l, dtype=torch.uint8)
+    mask[:, 2] = (t[:, 2, 0] > -999).to(torch.uint8)
+    mask[:, 1] = (torch.rand(n) < 0.6).to(torch.uint8)
+    near, alpha, thr, bthr = 0.7, 0.4, 0.5, 0.3
+    # oracle: the same edits as render_chunk applies (layered_rfrender.py:414-422 / :538-576, :605)
+    sig = [raw[:, i, :, 3:].clone() for i in range(l)]
+    rgb = [raw[:, i, :, :3].clone() for i in range(l)]
+    for i in range(l):
+        dead = mask[:, i] == 0
+        sig[i][dead] = 0
+        rgb[i][dead] = 0
+    if fine:
+        sig[0][sig[0] < bthr] = 0
+    for i in range(1, l):
+        if not fine:
+            sig[i][t[:, i] < 0] = 0
+        sig[i][sig[i] < thr] = 0
+        if fine and i == 2:
+            sig[i] = sig[i] * alpha
+    if not fine:
+        sig[0][t[:, 0] < near] = 0
+    ts = [t[:, i].unsqueeze(-1) for i in range(l)]
+    t_mix, order = torch.sort(torch.cat(ts, -2), -2, stable=True)
+    rgb_mix = torch.cat(rgb, -2).gather(1, order.repeat(1, 1, 3))
+    sig_mix = torch.cat(sig, -2).gather(1, order)
+    per = [O.composite(ts[i], rgb[i], sig[i]) for i in range(l)]
+    if fine:
+        sig_mix[t_mix < near] = 0
+    mix = O.composite(t_mix, rgb_mix, sig_mix)
+    lo, mo, w, od = ops.composite(dev(t), dev(raw), dev(mask), near=near, fine=fine, cut_negative_t=not fine,
+                                  thresholds=[bthr if fine else None, thr, thr],
+                                  sigma_scale=[1.0, 1.0, alpha if fine else 1.0], want_weights=True, want_order=True)
+    assert torch.equal(od.cpu().long(), order.squeeze(-1))        # merge order: bit-exact
+    for i in range(l):
+        torch.testing.assert_close(w[:, i].cpu(), per[i][3].squeeze(-1), rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(lo[:, i, :3].cpu(), per[i][0], rtol=1e-5, atol=2e-6)
+        torch.testing.assert_close(lo[:, i, 3:4].cpu(), per[i][1], rtol=1e-5, atol=2e-3)   # depth carries -1000 terms
+        torch.testing.assert_close(lo[:, i, 4:5].cpu(), per[i][2], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(mo[:, :3].cpu(), mix[0], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(mo[:, 3:4].cpu(), mix[1], rtol=1e-5, atol=2e-3)
+    torch.testing.assert_close(mo[:, 4:5].cpu(), mix[2], rtol=1e-5, atol=2e-6)
+
+
+def test_composite_unsorted_layer_falls_back_to_general_sort(ops):
+    torch.manual_seed(23)
+    n, l, S = 50, 2, 17
+    t = torch.sort(torch.rand(n, l, S) * 4.0, -1)[0]
+    t[:, 0] = t[:, 0].flip(-1)                                    # descending layer (negative bin width)
+    raw = torch.randn(n, l, S, 4)
+    _, _, _, od = ops.composite(dev(t), dev(raw), None, want_order=True)
+    _, order = torch.sort(t.reshape(n, l * S), -1, stable=True)
+    assert torch.equal(od.cpu().long(), order)
+
+
+def test_resample_golden(ops):
+    meta, a = load_golden("sample_pdf")
+    n, n1 = a["t"].shape
+    n2 = meta["n2"]
+    # the reference passes interior weights w[..., 1:-1]; the kernel takes the full per-sample weights
+    wfull = torch.cat([torch.full((n, 1), 9.0), a["w"], torch.full((n, 1), 9.0)], -1)
+    rays = torch.cat([torch.rand(n, 3), torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)], -1)
+    tf, xyz, z, inds, cdf = ops.resample(dev(a["t"].unsqueeze(1)), dev(wfull.unsqueeze(1)), n2, dev(rays),
+                                         u=dev(a["u"].unsqueeze(0)), debug=True)
+    z_ref, cdf_ref, inds_ref = O.sample_pdf(a["t"], a["w"], a["u"], return_aux=True)
+    torch.testing.assert_close(cdf[:, 0].cpu(), cdf_ref, rtol=0, atol=5e-7)
+    # index contract: bit-exact given identical cdf and u
+    assert torch.equal(inds[:, 0].cpu().long(), torch.searchsorted(cdf[:, 0].cpu(), a["u"], right=True))
+    assert torch.equal(inds[:, 0].cpu().long(), inds_ref)         # (no u within 1 ulp of a cdf knot in this fixture)
+    torch.testing.assert_close(z[:, 0].cpu(), a["z"], rtol=1e-5, atol=1e-5)
+    ref_sorted = torch.sort(torch.cat([a["t"], z[:, 0].cpu()], -1), -1)[0]
+    assert torch.equal(tf[:, 0].cpu(), ref_sorted)                # sort/merge: bit-exact
+    assert torch.equal(xyz[:, 0].cpu(), ref_sorted.unsqueeze(-1) * rays[:, None, 3:6] + rays[:, None, 0:3])
+    # n2 = 0 (C1: no fine samples): the fine list is the coarse list
+    tf0, _ = ops.resample(dev(a["t"].unsqueeze(1)), dev(wfull.unsqueeze(1)), 0, dev(rays))
+    assert torch.equal(tf0[:, 0].cpu(), a["t"])
+
+
+def test_resample_random_layers_edits_and_device_rng(ops):
+    torch.manual_seed(31)
+    n, l, n1, n2 = 400, 3, 64, 48
+    t = torch.sort(torch.rand(n, l, n1) * 5.0, -1)[0]
+    w = torch.rand(n, l, n1) ** 6
+    u = torch.rand(l, n, n2)
+    rays = torch.cat([torch.rand(n, 3), torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)], -1)
+    edits = [(None, None), ([0.2, 0.0, -0.1], 1.25), (None, 0.8)]
+    pivot = torch.tensor([0.3, -0.2, 0.1])
+    tf, xyz, z, inds, cdf = ops.resample(dev(t), dev(w), n2, dev(rays), u=dev(u), edits=edits, pivot=pivot, debug=True)
+    for i in range(l):
+        z_ref, cdf_ref, inds_ref = O.sample_pdf(t[:, i], w[:, i, 1:-1], u[i], return_aux=True)
+        torch.testing.assert_close(cdf[:, i].cpu(), cdf_ref, rtol=0, atol=1e-6)
+        assert torch.equal(inds[:, i].cpu().long(), torch.searchsorted(cdf[:, i].cpu().contiguous(), u[i], right=True))
+        agree = inds[:, i].cpu().long() == inds_ref              # knots may differ in the last ulp of the cdf
+        assert agree.float().mean() > 0.999
+        torch.testing.assert_close(z[:, i].cpu()[agree], z_ref[agree], rtol=1e-5, atol=2e-5)
+        srt = torch.sort(torch.cat([t[:, i], z[:, i].cpu()], -1), -1)[0]
+        assert torch.equal(tf[:, i].cpu(), srt)
+        p = srt.unsqueeze(-1) * rays[:, None, 3:6] + rays[:, None, 0:3]
+        sh, sc = edits[i]
+        if sh is not None:
+            p = p - torch.tensor(sh)
+        if sc is not None:
+            p = (p - pivot) / sc + pivot
+        assert torch.equal(xyz[:, i].cpu(), p)
+    # device RNG: deterministic per (seed, ray index), sorted output, samples follow the pdf
+    ta, _ = ops.resample(dev(t), dev(w), n2, dev(rays), seed=99)
+    tb, _ = ops.resample(dev(t[100:300]), dev(w[100:300]), n2, dev(rays[100:300]), seed=99, ray_index_base=100)
+    assert torch.equal(ta[100:300], tb)
+    assert bool((ta[..., 1:] >= ta[..., :-1]).all())
