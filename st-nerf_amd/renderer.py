@@ -1,0 +1,447 @@
+"""Host-side mirror of the reference's call surface for the layered ray-march path.
+
+Same names, argument meaning and return structure as the reference:
+``LayeredRFRender`` (modeling/layered_rfrender.py:19-741), ``build_layered_model``
+(modeling/__init__.py:5), ``layered_batchify_ray`` (utils/batchify_rays.py:51-140), and the op-level
+modules ``SpaceNet``, ``MotionNet``, ``RaySamplePoint``, ``VolumeRenderer``, ``sample_pdf``.
+
+Everything numeric runs in the HIP library through ``stnerf_amd.ops``; this file only does what the
+reference does on the host: config, per-frame box interpolation/edit on l x 8 x 3 numbers, chunk
+bookkeeping and output packing.  Parameters are ordinary ``nn.Linear`` modules under the
+reference's attribute names, so ``state_dict()`` / ``load_state_dict()`` speak the reference's
+checkpoint keys; the kernel-layout copy of the weights is rebuilt lazily when they change.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from stnerf_amd import ops
+
+Tensor = torch.Tensor
+
+
+# ------------------------------------------------------------------------------------ networks
+def _params_fingerprint(module: nn.Module):
+    return tuple((p.data_ptr(), p._version, str(p.device)) for p in module.parameters())
+
+
+class _PackedMixin:
+    """Lazily (re)packs a module's nn.Linear weights into the kernel layout."""
+
+    def _packed(self):
+        fp = _params_fingerprint(self)
+        if getattr(self, "_pack_fp", None) != fp:
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("this network lives on %s: call .cuda() first -- the render path runs on the "
+                                   "MI355X only (no CPU fallback)" % dev)
+            sd = {k: v for k, v in self.state_dict().items()}
+            self._pack_net = self._pack(sd, dev)
+            self._pack_fp = fp
+        return self._pack_net
+
+
+class SpaceNet(nn.Module, _PackedMixin):
+    """Radiance MLP, modeling/spacenet.py:13-160 (same constructor, attribute names and forward)."""
+
+    def __init__(self, c_pos=3, include_input=True, use_dir=True, use_time=False, deep_rgb=False):
+        super().__init__()
+        if c_pos != 3 or not include_input or not use_dir or deep_rgb:
+            raise NotImplementedError("HIP SpaceNet supports c_pos=3, include_input=True, use_dir=True, "
+                                      "deep_rgb=False (the configuration of both shipped ymls)")
+        self.c_pos, self.use_dir, self.use_time = c_pos, use_dir, use_time
+        self.pos_dim, self.dir_dim, self.time_dim = 63, 27, (21 if use_time else 0)
+        bd, hd = 256, 128
+        self.stage1 = nn.Sequential(nn.Linear(self.pos_dim, bd), nn.ReLU(inplace=True), nn.Linear(bd, bd),
+                                    nn.ReLU(inplace=True), nn.Linear(bd, bd), nn.ReLU(inplace=True),
+                                    nn.Linear(bd, bd), nn.ReLU(inplace=True))
+        self.stage2 = nn.Sequential(nn.Linear(bd + self.pos_dim, bd), nn.ReLU(inplace=True), nn.Linear(bd, bd),
+                                    nn.ReLU(inplace=True), nn.Linear(bd, bd), nn.ReLU(inplace=True))
+        self.density_net = nn.Sequential(nn.Linear(bd, 1))
+        self.rgb_net = nn.Sequential(nn.ReLU(inplace=True), nn.Linear(bd + self.dir_dim + self.time_dim, hd),
+                                     nn.ReLU(inplace=True), nn.Linear(hd, 3))
+
+    def _pack(self, sd, dev):
+        return ops.pack_spacenet({"net." + k: v for k, v in sd.items()}, "net", dev)
+
+    def forward(self, pos, rays, times=None, maxs=None, mins=None):
+        """pos (N,L,3) or (N,3); rays (N,>=6); times (N,1) -> rgbs (N,L,3)|(N,3), density (N,L,1)|(N,1)."""
+        if maxs is not None:
+            raise NotImplementedError("maxs/mins normalisation is unused by the reference (always None)")
+        bins = pos.dim() > 2
+        x = pos if bins else pos.unsqueeze(1)
+        n, s = x.shape[0], x.shape[1]
+        x = x.contiguous()
+        raw = torch.empty(n, s, 4, dtype=torch.float32, device=x.device)
+        tm = times.reshape(n).contiguous() if (self.use_time and times is not None) else None
+        ops.spacenet_fwd(self._packed(), x, rays[:, 3:6], tm, raw)
+        rgb, sig = raw[..., :3], raw[..., 3:]
+        return (rgb, sig) if bins else (rgb[:, 0], sig[:, 0])
+
+
+class MotionNet(nn.Module, _PackedMixin):
+    """Deformation MLP, modeling/motion_net.py:5-71."""
+
+    def __init__(self, c_input=5, include_input=True, input_time=False):
+        super().__init__()
+        if c_input != 4 or not include_input or not input_time:
+            raise NotImplementedError("HIP MotionNet supports c_input=4, include_input=True, input_time=True "
+                                      "(the time-deformation nets of the layered model)")
+        self.c_input, self.input_time, self.pos_dim = c_input, input_time, 84
+        d = 128
+        self.motion_net = nn.Sequential(nn.Linear(self.pos_dim, d), nn.ReLU(inplace=False), nn.Linear(d, d),
+                                        nn.ReLU(inplace=True), nn.Linear(d, d), nn.ReLU(inplace=True),
+                                        nn.Linear(d, d), nn.ReLU(inplace=True), nn.Linear(d, d),
+                                        nn.ReLU(inplace=True), nn.Linear(d, 3))
+
+    def _pack(self, sd, dev):
+        return ops.pack_motionnet({"net." + k: v for k, v in sd.items()}, "net", dev)
+
+    def forward(self, input_0):
+        """input_0 (N,L,4) or (N,4) = [x,y,z,t] -> flow (N,L,3) or (N,3).  The time may differ per sample."""
+        bins = input_0.dim() > 2
+        x = input_0.reshape(-1, 1, 4)
+        xyz = x[..., :3].contiguous()
+        flow = torch.empty_like(xyz)
+        ops.motionnet_fwd(self._packed(), xyz, x[:, 0, 3].contiguous(), flow=flow, add_to_xyz=False)
+        return flow.reshape(*input_0.shape[:-1], 3) if bins else flow.reshape(-1, 3)
+
+
+# ------------------------------------------------------------------------------------ op-level layers
+class RaySamplePoint(nn.Module):
+    """layers/RaySamplePoint.py:64-107.  ``jitter`` (l,n,N) replays given uniform draws; otherwise the
+    device Philox stream (``seed``) is used -- the reference draws fresh torch.rand numbers (:98)."""
+
+    def __init__(self, coarse_num=64):
+        super().__init__()
+        self.coarse_num = coarse_num
+        self.seed = 0
+
+    def forward(self, rays, bbox, pdf=None, method="coarse", jitter=None):
+        t, xyz, mask = ops.sample_coarse(rays.contiguous(), bbox.contiguous(), self.coarse_num, jitter=jitter,
+                                         seed=self.seed)
+        l = t.shape[1]
+        return ([t[:, i].unsqueeze(-1) for i in range(l)], [xyz[:, i] for i in range(l)],
+                [mask[:, i].bool() for i in range(l)])
+
+
+def intersection(rays, bbox):
+    """layers/RaySamplePoint.py:8-62: rays (n,>=6), bbox (n,8,3) -> (n,2) = (far, near)."""
+    return ops.intersect(rays.contiguous(), bbox.unsqueeze(1).contiguous())[:, 0]
+
+
+class VolumeRenderer(nn.Module):
+    """layers/render_layer.py:19-58."""
+
+    def __init__(self, use_mask=False, boarder_weight=1e10):
+        super().__init__()
+        if use_mask:
+            raise NotImplementedError("use_mask is False everywhere in the reference")
+        self.boarder_weight, self.use_mask = boarder_weight, use_mask
+
+    def forward(self, depth, rgb, sigma, noise=0):
+        if noise > 0.:
+            raise NotImplementedError("density noise is a training-time feature")
+        n, s = depth.shape[0], depth.shape[1]
+        raw = torch.cat([rgb, sigma], -1).reshape(n, 1, s, 4).contiguous()
+        lo, _, w, _ = ops.composite(depth.reshape(n, 1, s).contiguous(), raw, None, border=self.boarder_weight,
+                                    want_weights=True)
+        return lo[:, 0, 0:3], lo[:, 0, 3:4], lo[:, 0, 4:5], w[:, 0].unsqueeze(-1)
+
+
+def sample_pdf(z_vals, weights, N_samples, det=False, pytest=False, u=None, seed=0):
+    """utils/sample_pdf.py:18-63: z_vals (n,N1), weights (n,N1-2) -> new samples (n,N_samples).
+    ``u`` (n,N_samples) replays uniform draws; default is the device Philox stream."""
+    if det or pytest:
+        n = z_vals.shape[0]
+        u = torch.linspace(0., 1., steps=N_samples, device=z_vals.device).expand(n, N_samples).contiguous()
+    n, n1 = z_vals.shape
+    pad = torch.zeros(n, 1, device=z_vals.device)
+    wfull = torch.cat([pad, weights, pad], -1).reshape(n, 1, n1).contiguous()
+    rays = torch.zeros(n, 6, device=z_vals.device)
+    out = ops.resample(z_vals.reshape(n, 1, n1).contiguous(), wfull, N_samples, rays,
+                       u=None if u is None else u.reshape(1, n, N_samples).contiguous(), seed=seed,
+                       want_xyz=False, debug=True)
+    return out[2][:, 0]
+
+
+# ------------------------------------------------------------------------------------ the layered model
+class LayeredRFRender(nn.Module):
+    """modeling/layered_rfrender.py:19-741 -- same constructor, attributes and forward signature."""
+
+    def __init__(self, cfg, camera_num, scale=None, shift=None):
+        super().__init__()
+        M = cfg.MODEL
+        if M.SAMPLE_METHOD != "BBOX":
+            raise NotImplementedError("only SAMPLE_METHOD 'BBOX' is on the render path (both shipped ymls)")
+        unsupported = dict(POSE_REFINEMENT=M.POSE_REFINEMENT, USE_DEFORM_VIEW=M.USE_DEFORM_VIEW,
+                           BKGD_USE_DEFORM_TIME=M.BKGD_USE_DEFORM_TIME, BKGD_USE_SPACE_TIME=M.BKGD_USE_SPACE_TIME,
+                           DEEP_RGB=(M.DEEP_RGB and M.USE_SPACE_TIME))
+        bad = [k for k, v in unsupported.items() if v]
+        if bad or not M.USE_DIR or not M.TKERNEL_INC_RAW:
+            raise NotImplementedError(f"config flags outside the MI355X hot path: {bad or 'USE_DIR/TKERNEL_INC_RAW'}")
+        if not (M.USE_DEFORM_TIME or M.USE_SPACE_TIME):
+            raise ValueError("one of USE_DEFORM_TIME / USE_SPACE_TIME must be on (the reference dereferences a "
+                             "missing frame id otherwise, layered_rfrender.py:193)")
+        layer_num = cfg.DATASETS.LAYER_NUM
+        self.coarse_ray_sample, self.fine_ray_sample = M.COARSE_RAY_SAMPLING, M.FINE_RAY_SAMPLING
+        self.sample_method = M.SAMPLE_METHOD
+        self.boarder_weight = M.BOARDER_WEIGHT
+        self.scale, self.shift = scale, shift
+        self.near, self.alpha = 0, 1
+        self.pose_refinement = False
+        self.layer_num, self.camera_num = layer_num, camera_num
+        self.use_deform_view, self.bkgd_use_deform_time = False, False
+        self.use_deform_time, self.use_space_time = M.USE_DEFORM_TIME, M.USE_SPACE_TIME
+
+        self.bkgd_spacenet = SpaceNet(use_time=False)
+        self.bkgd_spacenet_fine = SpaceNet(use_time=False)
+        self.spacenets, self.spacenets_fine = nn.ModuleList([]), nn.ModuleList([])
+        for i in range(layer_num):
+            self.spacenets.append(SpaceNet(use_time=self.use_space_time))
+            self.spacenets_fine.append(self.spacenets[i] if M.SAME_SPACENET else SpaceNet(use_time=self.use_space_time))
+        self.time_deform_nets = nn.ModuleList([])
+        if self.use_deform_time:
+            for i in range(layer_num):
+                self.time_deform_nets.append(MotionNet(c_input=4, input_time=True))
+        # the reference initialises the fine / other-layer nets as deep copies (:63-74); keep that for a
+        # freshly built model (a loaded checkpoint overwrites everything anyway)
+        self.bkgd_spacenet_fine.load_state_dict(self.bkgd_spacenet.state_dict())
+        for i in range(layer_num):
+            self.spacenets[i].load_state_dict(self.spacenets[0].state_dict())
+            self.spacenets_fine[i].load_state_dict(self.spacenets[i].state_dict())
+        self.maxs = self.mins = None
+        self.display_layers = {i: 1 for i in range(layer_num + 1)}
+        self.bkgd_bbox = None
+        self.bboxes = None
+        # MI355X-side knobs (not in the reference)
+        self.seed = 0                      # Philox seed of the on-device jitter / resampling draws
+        self.max_rays_per_launch = 1 << 17 # rays per kernel sequence (workspace bound, not a semantic chunk)
+        self.replay = None                 # {"jitter": (l,N,N1), "u": (l,N,N2)} to replay recorded uniforms
+        self.ray_index_base = 0            # global index of rays[0] (multi-GPU sharding keeps the RNG stream)
+
+    # ---- reference API -----------------------------------------------------------------------
+    def hide_layer(self, layer_id):
+        self.display_layers[layer_id] = 0
+
+    def show_layer(self, layer_id):
+        self.display_layers[layer_id] = 1
+
+    def is_shown_layer(self, layer_id):
+        return self.display_layers[layer_id] == 1
+
+    def set_bkgd_bbox(self, bbox):
+        self.bkgd_bbox = bbox
+
+    def set_bboxes(self, bboxes):
+        self.bboxes = bboxes
+
+    def set_bkgd_near_far(self, near_far):
+        self.bkgd_near_torchfar = near_far
+
+    def set_max_min(self, maxs, mins):
+        self.maxs, self.mins = maxs, mins
+
+    def bbox_interpolation(self, float_frame_id, layer_id):
+        start = self.bboxes[math.floor(float_frame_id), layer_id]
+        end = self.bboxes[math.ceil(float_frame_id), layer_id]
+        return torch.lerp(start, end, float_frame_id - math.floor(float_frame_id))
+
+    # ---- host-side scene maths (l x 8 x 3 numbers, same torch ops as the reference) -------------
+    def _pivot(self):
+        """Edit pivot, layered_rfrender.py:216-232: mean of the frame-0 centres of layers 1 and 2, with each
+        centre's z replaced by corner-1's z."""
+        first = torch.cat([self.bkgd_bbox.detach().cpu().float(), self.bboxes[0].detach().cpu().float()], 0)
+        centre = torch.mean(first, 1)
+        centre[:, 2] = first[:, 1, 2]
+        return (centre[2] + centre[1]) / 2
+
+    def _edit_boxes(self, boxes):
+        """boxes (..., l, 8, 3) on any device; returns edited boxes and the pivot (:230-242)."""
+        pivot = None
+        if self.scale is not None:
+            pivot = self._pivot()
+            pv = pivot.to(boxes.device)
+            for i in range(len(self.scale)):
+                boxes[..., i, :, :] = (boxes[..., i, :, :] - pv) * self.scale[i] + pv
+        if self.shift is not None:
+            for i in range(len(self.shift)):
+                if self.shift[i] is None:
+                    continue
+                boxes[..., i, :, :] += torch.tensor(self.shift[i], dtype=torch.float32, device=boxes.device)
+        return boxes, pivot
+
+    def _point_edits(self, l, fine):
+        """Per-layer inverse edit for sample points: coarse :293-303; fine :467-475 (where a None shift
+        skips that layer's scale step as well)."""
+        if self.shift is None and self.scale is None:
+            return None
+        out = []
+        for i in range(l):
+            sh = sc = None
+            if self.shift is not None:
+                if fine:
+                    if self.shift[i] is None:
+                        out.append((None, None))
+                        continue
+                    sh = self.shift[i]
+                elif i < len(self.shift):
+                    sh = self.shift[i]
+            if self.scale is not None and (fine or i < len(self.scale)):
+                sc = self.scale[i]
+            out.append((sh, sc))
+        return out
+
+    def _retimed_boxes(self, row0_frame_ids):
+        """One box per layer for a (reference) chunk from ROW 0's frame ids (:195-208), edited.
+        row0_frame_ids: CPU fp32 tensor (l,) = rays[0, 6:]."""
+        L = self.layer_num
+        bb = self.bboxes.detach().cpu().float()
+        per = torch.zeros(L, 8, 3)
+        for i in range(L):
+            f = row0_frame_ids[i + 1] - 1                        # fp32 0-dim tensor, as in the reference
+            per[i] = torch.lerp(bb[math.floor(f), i], bb[math.ceil(f), i], f - math.floor(f))
+        boxes = torch.cat([self.bkgd_bbox.detach().cpu().float(), per], 0)
+        return self._edit_boxes(boxes)
+
+    # ---- the chunk pipeline ------------------------------------------------------------------------
+    def _nets(self, fine):
+        return (self.bkgd_spacenet_fine, self.spacenets_fine) if fine else (self.bkgd_spacenet, self.spacenets)
+
+    def _stage(self, rays, xyz, raw, lst, cnt, times_col, fine):
+        """Deform + evaluate every layer's network on its (masked) rays.  :340-418 / :495-576."""
+        l = self.layer_num + 1
+        bk, nets = self._nets(fine)
+        if self.use_deform_time:
+            for i in range(1, l):
+                if not self.is_shown_layer(i):
+                    continue  # a hidden layer's points are never consumed
+                ops.motionnet_fwd(self.time_deform_nets[i - 1]._packed(), xyz[:, i], rays[:, times_col(i)],
+                                  add_to_xyz=True, ray_list=lst[i], ray_count=cnt[i:i + 1])
+        ops.spacenet_fwd(bk._packed(), xyz[:, 0], rays[:, 3:6], None, raw[:, 0])
+        for i in range(1, l):
+            if not self.is_shown_layer(i):
+                continue
+            tm = rays[:, times_col(i)] if self.use_space_time else None
+            ops.spacenet_fwd(nets[i - 1]._packed(), xyz[:, i], rays[:, 3:6], tm, raw[:, i], ray_list=lst[i],
+                             ray_count=cnt[i:i + 1])
+
+    def _render_launch(self, rays, boxes, pivot, retiming, only_coarse, thr, bthr, index_base, replay):
+        """One kernel sequence over `rays` (n <= max_rays_per_launch).  boxes: (l,8,3) shared or (n,l,8,3)."""
+        n, l = rays.shape[0], self.layer_num + 1
+        N1, N2 = self.coarse_ray_sample, self.fine_ray_sample
+        dev = rays.device
+        times_col = (lambda i: 6 + i) if retiming else (lambda i: 6)
+        shown = [self.is_shown_layer(i) for i in range(l)]
+        pv = None if pivot is None else pivot.tolist()
+        jitter = replay["jitter"] if replay else None
+        t_c, xyz_c, mask = ops.sample_coarse(rays, boxes, N1, jitter=jitter, seed=self.seed, ray_index_base=index_base,
+                                             edits=self._point_edits(l, False), pivot=pv)
+        lst, cnt = ops.compact_rays(mask)
+        raw_c = torch.empty(n, l, N1, 4, dtype=torch.float32, device=dev)
+        self._stage(rays, xyz_c, raw_c, lst, cnt, times_col, False)
+        perf_thr = [None] + [thr if retiming else None] * (l - 1)
+        lo_c, mix_c, w_c, _ = ops.composite(t_c, raw_c, mask, border=self.boarder_weight, near=float(self.near),
+                                            fine=False, cut_negative_t=True, thresholds=perf_thr, evaluated=shown,
+                                            want_weights=not only_coarse)
+        if only_coarse:
+            return mix_c, mix_c, lo_c, lo_c, mask
+        u = replay["u"] if replay else None
+        t_f, xyz_f = ops.resample(t_c, w_c, N2, rays, u=u, seed=self.seed, ray_index_base=index_base,
+                                  edits=self._point_edits(l, True), pivot=pv)
+        del xyz_c, raw_c, w_c
+        raw_f = torch.empty(n, l, N1 + N2, 4, dtype=torch.float32, device=dev)
+        self._stage(rays, xyz_f, raw_f, lst, cnt, times_col, True)
+        fine_thr = [bthr if retiming else None] + [thr if retiming else None] * (l - 1)
+        scale = [1.0] * l
+        if l > 2:
+            scale[2] = float(self.alpha)                                    # :575-576
+        lo_f, mix_f, _, _ = ops.composite(t_f, raw_f, mask, border=self.boarder_weight, near=float(self.near),
+                                          fine=True, thresholds=fine_thr, sigma_scale=scale, evaluated=shown)
+        return mix_f, mix_c, lo_f, lo_c, mask
+
+    def render_rays(self, rays, only_coarse=False, density_threshold=0.0001, bkgd_density_threshold=0.0,
+                    ref_chunk: Optional[int] = None):
+        """Render all `rays`; ``ref_chunk`` reproduces the reference's chunk semantics (boxes are taken
+        from row 0 of every ``ref_chunk``-ray piece) while launching kernels over far larger pieces."""
+        if not rays.is_cuda:
+            raise RuntimeError("rays must live on the GPU: the MI355X render path has no CPU fallback")
+        rays = rays.contiguous().float()
+        N, L = rays.shape[0], self.layer_num
+        width = rays.shape[1]
+        if width == 7:
+            retiming = False
+        elif width == 7 + L:
+            retiming = True
+        else:
+            raise ValueError(f"undefined ray format in LayeredRFRender, ray dimension is {width}")
+        if self.bkgd_bbox is None or self.bboxes is None:
+            raise RuntimeError("set_bkgd_bbox / set_bboxes must be called before rendering")
+        step = N if ref_chunk is None else ref_chunk
+        groups = []  # (start, end, boxes, pivot)
+        if retiming:
+            row0 = rays[0::step, 6:].cpu()  # one D2H: row-0 frame ids of every reference chunk
+            n_chunks, c0 = row0.shape[0], 0
+            for c in range(1, n_chunks + 1):  # merge runs of reference chunks that share their boxes
+                if c == n_chunks or not torch.equal(row0[c], row0[c0]):
+                    boxes, pivot = self._retimed_boxes(row0[c0])
+                    groups.append((c0 * step, min(c * step, N), boxes.to(rays.device), pivot))
+                    c0 = c
+        else:
+            fid = rays[:, 6].to(torch.int64) - 1
+            bb = self.bboxes.to(rays.device).float().index_select(0, fid)                          # :193
+            bk = self.bkgd_bbox.to(rays.device).float().unsqueeze(0).expand(N, 1, 8, 3)
+            boxes, pivot = self._edit_boxes(torch.cat([bk, bb], 1).contiguous())
+            groups.append((0, N, boxes, pivot))
+        outs = []
+        cap = self.max_rays_per_launch
+        for (g0, g1, boxes, pivot) in groups:
+            for s in range(g0, g1, cap):
+                e = min(s + cap, g1)
+                bx = boxes if boxes.dim() == 3 else boxes[s:e].contiguous()
+                rp = None
+                if self.replay is not None:
+                    rp = {k: v[:, s:e].contiguous() for k, v in self.replay.items()}
+                outs.append(self._render_launch(rays[s:e], bx, pivot, retiming, only_coarse, density_threshold,
+                                                bkgd_density_threshold, self.ray_index_base + s, rp))
+        cat = (lambda j: outs[0][j]) if len(outs) == 1 else (lambda j: torch.cat([o[j] for o in outs], 0))
+        mix_f, mix_c, lo_f, lo_c, mask = (cat(j) for j in range(5))
+        l = L + 1
+        trip = lambda x: (x[:, 0:3], x[:, 3:4], x[:, 4:5])
+        fine_layer = [trip(lo_f[:, i]) for i in range(l)]
+        coarse_layer = [trip(lo_c[:, i]) for i in range(l)]
+        ray_mask = [mask[:, i].bool() for i in range(l)]
+        return trip(mix_f), trip(mix_c), fine_layer, coarse_layer, ray_mask
+
+    def forward(self, rays, labels=None, bboxes=None, only_coarse=False, near_far=None, near_far_points=[],
+                density_threshold=0.0001, bkgd_density_threshold=0):
+        """(fine_mixed, coarse_mixed, fine_layer[l], coarse_layer[l], ray_mask[l]); every entry a
+        (color (N,3), depth (N,1), acc (N,1)) triple.  layered_rfrender.py:141-734.
+        labels / bboxes / near_far / near_far_points are accepted and ignored, as in the BBOX path."""
+        return self.render_rays(rays, only_coarse, density_threshold, bkgd_density_threshold, ref_chunk=None)
+
+
+def build_layered_model(cfg, camera_num=0, scale=None, shift=None):
+    """modeling/__init__.py:5."""
+    return LayeredRFRender(cfg, camera_num=camera_num, scale=scale, shift=shift)
+
+
+def layered_batchify_ray(model, rays, labels, bboxes, chuncks=512 * 7, near_far=None, near_far_points=[],
+                         density_threshold=0, bkgd_density_threshold=0):
+    """utils/batchify_rays.py:51-140.  Fewer rays than one chunk: the model is called WITHOUT the
+    thresholds (its defaults 1e-4 / 0 apply, :52-54).  Otherwise the reference loops over
+    ``chuncks``-ray pieces on the host; here the pieces only define which row supplies the per-chunk
+    boxes, and the kernels run over up to ``model.max_rays_per_launch`` rays at a time."""
+    N = rays.size(0)
+    if N < chuncks:
+        return model(rays, labels, bboxes, near_far=near_far, near_far_points=near_far_points)
+    return model.render_rays(rays, False, density_threshold, bkgd_density_threshold, ref_chunk=chuncks)
+
+
+def psnr(image_pred, image_gt):
+    """utils/metrics.py:16-17."""
+    return -10 * torch.log10(torch.mean((image_pred - image_gt) ** 2))
