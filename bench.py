@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Benchmark of the layered ray-march render path on MI355X (driver contract: one JSON line on rank 0).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one synthetic 1080p view per GPU: device ray generation
+(a1/a2) -> coarse sampler -> mask compaction -> MotionNet/SpaceNet (fp32 MFMA) -> composite + merge ->
+inverse-CDF resample -> fine MotionNet/SpaceNet -> composite + merge, followed (N > 1) by the RCCL
+all-gather of the rendered tiles.  Weak scaling: every rank renders its own full view of a novel-view
+sweep; value = total rays of all ranks / max-over-ranks time.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): Taekwondo-shaped
+scene, 2 performer layers + background, 1920x1080, 64 coarse + 64 fine samples (128/ray/layer),
+USE_SPACE_TIME + USE_DEFORM_TIME, synthetic boxes, random 'trained-like' weights (no dataset or
+checkpoint exists for the reference).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from stnerf_amd import ops, synthetic as syn          # noqa: E402
+from stnerf_amd.modeling import build_layered_model   # noqa: E402
+from stnerf_amd.utils import layered_batchify_ray     # noqa: E402
+
+# Algorithmic work per network evaluation: 2 * MACs of every nn.Linear.
+FLOP_SPACE, FLOP_SPACE_TIME, FLOP_MOTION = 924_672, 930_048, 153_344
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
+
+WORKLOADS = {
+    # name: (H, W, L, N1, N2, space_time, deform_time)
+    "taekwondo-1080p-64+64": (1080, 1920, 2, 64, 64, True, True),
+    "taekwondo-1080p-90+30": (1080, 1920, 2, 90, 30, True, True),
+    "single-512-64+64": (512, 512, 1, 64, 64, True, False),
+    "walking-1080p-L4-64+64": (1080, 1920, 4, 64, 64, False, True),
+    "tiny-64-32+0": (64, 64, 1, 32, 0, True, False),
+}
+
+
+def make_cfg(L, n1, n2, st, dt):
+    m = types.SimpleNamespace(BOARDER_WEIGHT=1e10, SAMPLE_METHOD="BBOX", SAME_SPACENET=False, TKERNEL_INC_RAW=True,
+                              POSE_REFINEMENT=False, USE_DIR=True, USE_DEFORM_VIEW=False, USE_DEFORM_TIME=dt,
+                              USE_SPACE_TIME=st, BKGD_USE_DEFORM_TIME=False, BKGD_USE_SPACE_TIME=False, DEEP_RGB=False,
+                              COARSE_RAY_SAMPLING=n1, FINE_RAY_SAMPLING=n2)
+    return types.SimpleNamespace(MODEL=m, DATASETS=types.SimpleNamespace(LAYER_NUM=L))
+
+
+def build_scene(workload, device):
+    H, W, L, n1, n2, st, dt = WORKLOADS[workload]
+    model = build_layered_model(make_cfg(L, n1, n2, st, dt), camera_num=1)
+    model.load_state_dict(syn.make_state_dict(L, st, dt, seed=0))
+    bk, per = syn.scene_boxes(L)
+    model.set_bkgd_bbox(bk)
+    model.set_bboxes(per)
+    return model.to(device).eval(), (H, W, L, n1, n2, st, dt)
+
+
+class KernelTimer:
+    """Collects per-launch HIP-event timings of the MLP kernels (events on the launch stream)."""
+
+    def __init__(self):
+        self.rec = []
+
+    def __call__(self, name, kind, n, ns, ray_count, e0, e1):
+        self.rec.append((name, kind, n, ns, ray_count, e0, e1))
+
+    def summarise(self):
+        out = {}
+        for name, kind, n, ns, ray_count, e0, e1 in self.rec:
+            rays = n if ray_count is None else min(int(ray_count.item()), n)
+            flop = FLOP_MOTION if name == "motionnet" else (FLOP_SPACE_TIME if kind == 1 else FLOP_SPACE)
+            d = out.setdefault(name, dict(launches=0, ms=0.0, evals=0, flop=0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["evals"] += rays * ns
+            d["flop"] += rays * ns * flop
+        return out
+
+
+def cpu_baseline(workload, budget_rays):
+    """The CPU oracle (a restatement of the reference algorithm, oracle/stnerf_oracle.py) timed on this
+    box's host cores on a bounded sample of the same workload: whole 3584-ray reference chunks taken
+    from the centre rows of the view (where rays hit the performers)."""
+    from oracle import stnerf_oracle as O
+    H, W, L, n1, n2, st, dt = WORKLOADS[workload]
+    K, T = syn.camera(H, W, 10.0)
+    bk, per = syn.scene_boxes(L)
+    m = O.OracleModel(layer_num=L, n_coarse=n1, n_fine=n2, params=syn.make_state_dict(L, st, dt, seed=0),
+                      use_deform_time=dt, use_space_time=st, bkgd_bbox=bk, bboxes=per)
+    chunk = 3584
+    n = max(chunk, (budget_rays // chunk) * chunk)
+    n = min(n, H * W)
+    full = O.generate_rays(K, T, H, W) if H * W <= 1 << 19 else None
+    if full is None:  # rows around the image centre only (generate the window analytically via the oracle on a crop)
+        r0 = (H // 2) * W - n // 2
+        rows0, rows1 = r0 // W, (r0 + n + W - 1) // W
+        Kc = K.clone()
+        Kc[1, 2] -= rows0
+        part = O.generate_rays(Kc, T, rows1 - rows0, W)
+        rays = part[r0 - rows0 * W: r0 - rows0 * W + n]
+    else:
+        r0 = max(0, (H * W - n) // 2)
+        rays = full[r0:r0 + n]
+    rays = torch.cat([rays, syn.frame_id_columns(rays.shape[0], L)], -1)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        O.render_chunk(m, rays[:256])  # warm the allocator / thread pool
+        t0 = time.perf_counter()
+        O.layered_batchify_ray(m, rays, chuncks=chunk)
+        dt_s = time.perf_counter() - t0
+    return dict(value=rays.shape[0] / dt_s, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{rays.shape[0]} rays ({rays.shape[0] // chunk} reference chunks of {chunk}) from the centre "
+                       f"rows of the {W}x{H} view, oracle/stnerf_oracle.py on torch {torch.__version__} CPU fp32, "
+                       f"{dt_s:.1f} s", seconds=dt_s)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="taekwondo-1080p-64+64", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-baseline-rays", type=int, default=7168, help="0 disables the CPU baseline leg")
+    ap.add_argument("--rays-per-launch", type=int, default=1 << 17)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the render path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
+
+    from stnerf_amd import hip
+    info = hip.device_info()
+    model, (H, W, L, n1, n2, st, dt) = build_scene(args.workload, device)
+    model.max_rays_per_launch = args.rays_per_launch
+    l = L + 1
+    n_rays = H * W
+    frame_ids = [1.0] + [2.5] * L
+
+    def step(i, gather=True):
+        # novel-view sweep: every rank its own pose (weak scaling), a new pose every step
+        K, T = syn.camera(H, W, orbit_deg=10.0 + 7.0 * rank + 1.5 * i)
+        rays = ops.generate_rays(K, T, H, W, frame_ids=frame_ids, device=device)
+        model.seed = i
+        with torch.no_grad():
+            fine, coarse, fine_layers, _, masks = layered_batchify_ray(model, rays, None, None)
+        tile = torch.cat(list(fine), dim=1).contiguous()      # (H*W, 5): colour, depth, acc of the final image
+        if world > 1 and gather:
+            frames = torch.empty(world * n_rays, 5, dtype=tile.dtype, device=device)
+            dist.all_gather_into_tensor(frames, tile)          # RCCL all-gather of the rendered tiles
+            tile = frames
+        return tile, masks
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(-1 - i)
+    timer = KernelTimer()
+    ops.set_launch_observer(timer)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        tile, masks = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.set_launch_observer(None)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    ksum = timer.summarise()  # this rank's launches over the K timed steps
+    evals = sum(d["evals"] for name, d in ksum.items() if name == "spacenet")
+    if world > 1:
+        ev = torch.tensor([evals], dtype=torch.float64, device=device)
+        dist.all_reduce(ev)
+        evals_all = float(ev.item())
+    else:
+        evals_all = float(evals)
+    assert bool(torch.isfinite(tile).all()), "non-finite pixels in the rendered tile"
+
+    if rank == 0:
+        sp = ksum["spacenet"]
+        achieved = sp["flop"] / (sp["ms"] * 1e-3) / 1e12
+        rec = {
+            "metric": "rendered rays/s (and ray-samples/s) per GPU, 1080p x 128-sample layered render",
+            "value": world * n_rays * args.steps / elapsed,
+            "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "height": H, "width": W, "performer_layers": L,
+                       "coarse_samples": n1, "fine_samples": n2, "use_space_time": st, "use_deform_time": dt,
+                       "rays_per_gpu_per_step": n_rays, "rays_per_launch": args.rays_per_launch,
+                       "weights": "random, density head scaled (synthetic.make_state_dict seed 0)",
+                       "parallelism": f"ray tiles: 1 view per GPU x {world}, RCCL all-gather of tiles"},
+            "ray_samples_per_s": evals_all / elapsed,
+            "ray_samples_per_step_per_gpu": evals / args.steps,
+            "mask_fraction": [float(m.float().mean()) for m in masks],
+            "roofline": {"kernel": "stnerf::spacenet_kernel (fused PE + 9-layer MLP, v_mfma_f32_32x32x2_f32)",
+                         "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "launches": sp["launches"], "avg_launch_ms": sp["ms"] / sp["launches"],
+                         "algorithmic_flop_per_launch": sp["flop"] / sp["launches"],
+                         "note": "algorithmic FLOPs = network evaluations x 924,672 (930,048 with time), "
+                                 "HIP events on the launch stream around every launch of the timed steps"},
+            "kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / args.steps,
+                            "tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12} for k, d in ksum.items()},
+            "device": info,
+        }
+        if world == 1 and args.cpu_baseline_rays > 0:
+            rec["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline_rays)
+        else:
+            rec["cpu_baseline"] = None
+        print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -164,6 +164,33 @@ def pack_motionnet(state: dict, prefix: str, device="cuda") -> PackedNet:
     return pack_net(hip.NET_MOTION, ws, bs, device)
 
 
+# Optional launch observer (bench.py): called as fn(name, kind, n_rays, ns, ray_count, start_evt, end_evt)
+# with torch events recorded on the launch stream around the kernel.  None in normal operation.
+_observer = None
+
+
+def set_launch_observer(fn):
+    global _observer
+    _observer = fn
+
+
+class _Observed:
+    def __init__(self, name, kind, n, ns, ray_count):
+        self.args = (name, kind, n, ns, ray_count)
+
+    def __enter__(self):
+        if _observer is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _observer is not None and exc[0] is None:
+            self.e1.record()
+            _observer(*self.args, self.e0, self.e1)
+
+
 def _worklist(ray_list, ray_count):
     return hip.dptr(ray_list, torch.int32, "ray_list"), hip.dptr(ray_count, torch.int32, "ray_count")
 
@@ -183,8 +210,9 @@ def spacenet_fwd(net: PackedNet, xyz: Tensor, dirs: Tensor, times: Optional[Tens
     else:
         tp, ts = C.c_void_p(0), 0
     lp, cp = _worklist(ray_list, ray_count)
-    hip.check(hip.lib().stnerf_spacenet_fwd(net.kind, hip.dptr(net.blob), n, ns, lp, cp, xp, xs, dp, ds, tp, ts,
-                                            rp, rs, hip.stream_ptr()), "stnerf_spacenet_fwd")
+    with _Observed("spacenet", net.kind, n, ns, ray_count):
+        hip.check(hip.lib().stnerf_spacenet_fwd(net.kind, hip.dptr(net.blob), n, ns, lp, cp, xp, xs, dp, ds, tp, ts,
+                                                rp, rs, hip.stream_ptr()), "stnerf_spacenet_fwd")
     return raw
 
 
@@ -200,8 +228,9 @@ def motionnet_fwd(net: PackedNet, xyz: Tensor, times: Tensor, flow: Optional[Ten
     else:
         fp, fs = C.c_void_p(0), 0
     lp, cp = _worklist(ray_list, ray_count)
-    hip.check(hip.lib().stnerf_motionnet_fwd(hip.dptr(net.blob), n, ns, lp, cp, xp, xs, tp, ts, fp, fs,
-                                             1 if add_to_xyz else 0, hip.stream_ptr()), "stnerf_motionnet_fwd")
+    with _Observed("motionnet", net.kind, n, ns, ray_count):
+        hip.check(hip.lib().stnerf_motionnet_fwd(hip.dptr(net.blob), n, ns, lp, cp, xp, xs, tp, ts, fp, fs,
+                                                 1 if add_to_xyz else 0, hip.stream_ptr()), "stnerf_motionnet_fwd")
     return flow
 
 

@@ -2,7 +2,7 @@
 the HIP kernels) against fixtures produced by the reference's own forward, with the reference's
 torch.rand draws replayed.  Needs an MI355X: `pytest -m gpu`.
 
-Stated fp32 tolerance for composited outputs: |color|, |acc| <= 2e-4 abs, depth <= 2e-3 abs (depths reach
+Stated fp32 tolerance for composited outputs: |color|, |acc| <= 5e-5 abs, depth <= 5e-4 abs (depths reach
 ~10 and hit-less layers carry t = -1000 samples), ray masks bit-exact.
 """
 import types
@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 FWD_CASES = ["fwd_c1", "fwd_c3", "fwd_edit", "fwd_hide", "fwd_nonretime", "fwd_only_coarse",
              "batchify_chunked", "batchify_small"]
-COLOR_ATOL, DEPTH_ATOL = 2e-4, 2e-3
+COLOR_ATOL, DEPTH_ATOL = 5e-5, 5e-4
 
 
 def make_cfg(layer_num, n1, n2, space_time, deform_time):
