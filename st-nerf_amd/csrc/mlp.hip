@@ -20,7 +20,12 @@
 //     (arguments reach 2^9 * |x|, utils/dimension_kernel.py:20-27).
 //
 // Reference: modeling/spacenet.py:16-160, modeling/motion_net.py:7-71, utils/dimension_kernel.py:3-73.
+#include <stdlib.h>
 #include <string.h>
+
+#ifndef STNERF_DEFAULT_TILE
+#define STNERF_DEFAULT_TILE 128
+#endif
 
 #include "common.h"
 
@@ -28,8 +33,6 @@ namespace stnerf {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int TM = 128;        // samples per tile
-constexpr int NSB = TM / 32;   // 32-sample blocks per tile
 constexpr int NTHREADS = 256;  // 4 waves
 
 // ---------------------------------------------------------------------------------------------
@@ -95,74 +98,102 @@ __host__ __device__ inline MotionLayout motion_layout() {
 // One dense layer on the tile:  out[:, n] = act(bias[n] + sum_k W[n][k] in[k])   for the wave's
 // NFB*32 features and all TM samples.  K comes from up to two LDS segments (quads kqA then kqB).
 // ---------------------------------------------------------------------------------------------
-template <int NFB>
-__device__ __forceinline__ void mma_segment(f32x16 (&acc)[NFB][NSB], const float4* __restrict__ wp, int n_total,
-                                            const float4* in, int steps) {
-    // wp / in already point at this lane's first quad row; one step = 2 quad rows = 8 k values.
-    float4 w_cur[NFB], a_cur[NSB];
+template <int NFB, int NSB>
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[NFB][NSB], const float4 (&w)[NFB], const float4 (&a)[NSB]) {
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) w_cur[fb] = wp[fb * 32];
+    for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-    for (int sb = 0; sb < NSB; ++sb) a_cur[sb] = in[sb * 32];
-    for (int s = 0; s < steps; ++s) {
-        // prefetch the next step (clamped: the last iteration re-loads itself, never out of bounds)
-        const int nx = (s + 1 < steps) ? (s + 1) : s;
-        float4 w_nxt[NFB], a_nxt[NSB];
+        for (int fb = 0; fb < NFB; ++fb) {
+            const float wv = kk == 0 ? w[fb].x : kk == 1 ? w[fb].y : kk == 2 ? w[fb].z : w[fb].w;
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) w_nxt[fb] = wp[(int64_t)nx * 2 * n_total + fb * 32];
-#pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) a_nxt[sb] = in[nx * 2 * TM + sb * 32];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) {
-                const float wv = kk == 0 ? w_cur[fb].x : kk == 1 ? w_cur[fb].y : kk == 2 ? w_cur[fb].z : w_cur[fb].w;
-#pragma unroll
-                for (int sb = 0; sb < NSB; ++sb) {
-                    const float av = kk == 0 ? a_cur[sb].x : kk == 1 ? a_cur[sb].y : kk == 2 ? a_cur[sb].z : a_cur[sb].w;
-                    acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, acc[fb][sb], 0, 0, 0);
-                }
+            for (int sb = 0; sb < NSB; ++sb) {
+                const float av = kk == 0 ? a[sb].x : kk == 1 ? a[sb].y : kk == 2 ? a[sb].z : a[sb].w;
+                acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, acc[fb][sb], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) w_cur[fb] = w_nxt[fb];
-#pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) a_cur[sb] = a_nxt[sb];
     }
 }
 
-template <int NFB, bool RELU>
+// Software-pipelined K loop: the operands of step s+1 are in flight (global weights, LDS activations)
+// while the 4*NFB*NSB MFMAs of step s issue.  Written as an explicit two-stage ping-pong (two register
+// sets, loop unrolled by two) -- a rotate-the-copy form gets collapsed by the compiler into
+// load -> wait -> use, which with one wave per SIMD exposes the full L2 latency every step.
+template <int TM, int NFB>
+__device__ __forceinline__ void mma_segment(f32x16 (&acc)[NFB][TM / 32], const float4* __restrict__ wp, int n_total,
+                                            const float4* in, int steps) {
+    // wp / in already point at this lane's first quad row; one step = 2 quad rows = 8 k values.
+    constexpr int NSB = TM / 32;
+    float4 w0[NFB], a0[NSB], w1[NFB], a1[NSB];
+    const int64_t wstep = 2 * (int64_t)n_total;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) w0[fb] = wp[fb * 32];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) a0[sb] = in[sb * 32];
+    int s = 0;
+#pragma unroll 1
+    for (; s + 2 <= steps; s += 2) {
+        // sched_barrier(0) pins "issue the next operands, THEN the MFMAs": left alone, the machine scheduler
+        // sinks each load to just before its first use (register-pressure heuristics at ~240 VGPRs).
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) w1[fb] = wp[(s + 1) * wstep + fb * 32];
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) a1[sb] = in[(s + 1) * 2 * TM + sb * 32];
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step<NFB, NSB>(acc, w0, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int nx = (s + 2 < steps) ? (s + 2) : (steps - 1);  // clamped: never out of bounds
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) w0[fb] = wp[nx * wstep + fb * 32];
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) a0[sb] = in[nx * 2 * TM + sb * 32];
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step<NFB, NSB>(acc, w1, a1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (s < steps) mma_step<NFB, NSB>(acc, w0, a0);
+}
+
+template <int TM, int NFB, bool RELU>
 __device__ __forceinline__ void dense_layer(const float* __restrict__ base, int64_t w_off, int64_t b_off, int n_total,
                                             const float4* inA, int kqA, const float4* inB, int kqB, float4* out,
                                             int wave, int lane) {
+    constexpr int NSB = TM / 32;
     const int h = lane >> 5, c = lane & 31;
     const int n0 = wave * NFB * 32;
+    // accumulators start from the bias: lane (h, c) register 4q+r holds feature n0 + fb*32 + 8q + 4h + r
+    const float* bias = base + b_off;
     f32x16 acc[NFB][NSB];
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb)
+    for (int fb = 0; fb < NFB; ++fb) {
 #pragma unroll
-        for (int sb = 0; sb < NSB; ++sb)
+        for (int q = 0; q < 4; ++q) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + fb * 32 + 8 * q + 4 * h);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[fb][sb][r] = 0.f;
+            for (int sb = 0; sb < NSB; ++sb) {
+                acc[fb][sb][4 * q + 0] = bv.x;
+                acc[fb][sb][4 * q + 1] = bv.y;
+                acc[fb][sb][4 * q + 2] = bv.z;
+                acc[fb][sb][4 * q + 3] = bv.w;
+            }
+        }
+    }
     const float4* wp = reinterpret_cast<const float4*>(base + w_off) + ((int64_t)h * n_total + n0 + c);
-    mma_segment<NFB>(acc, wp, n_total, inA + h * TM + c, kqA / 2);
-    if (kqB > 0) mma_segment<NFB>(acc, wp + (int64_t)kqA * n_total, n_total, inB + h * TM + c, kqB / 2);
+    mma_segment<TM, NFB>(acc, wp, n_total, inA + h * TM + c, kqA / 2);
+    if (kqB > 0) mma_segment<TM, NFB>(acc, wp + (int64_t)kqA * n_total, n_total, inB + h * TM + c, kqB / 2);
     // every wave has finished READING the input tile before anyone overwrites it (out may alias inA)
     __syncthreads();
-    const float* bias = base + b_off;
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int f = n0 + fb * 32 + 8 * q + 4 * h;  // first of this lane's 4 consecutive features
-            const float4 bv = *reinterpret_cast<const float4*>(bias + f);
 #pragma unroll
             for (int sb = 0; sb < NSB; ++sb) {
                 float4 v;
-                v.x = acc[fb][sb][4 * q + 0] + bv.x;
-                v.y = acc[fb][sb][4 * q + 1] + bv.y;
-                v.z = acc[fb][sb][4 * q + 2] + bv.z;
-                v.w = acc[fb][sb][4 * q + 3] + bv.w;
+                v.x = acc[fb][sb][4 * q + 0];
+                v.y = acc[fb][sb][4 * q + 1];
+                v.z = acc[fb][sb][4 * q + 2];
+                v.w = acc[fb][sb][4 * q + 3];
                 if (RELU) {
                     v.x = fmaxf(v.x, 0.f);
                     v.y = fmaxf(v.y, 0.f);
@@ -177,7 +208,7 @@ __device__ __forceinline__ void dense_layer(const float* __restrict__ base, int6
 
 // out[c] partial dot products over a quad range, for heads with 1..3 outputs (VALU; the weights are
 // wave-uniform so they come through the scalar cache).
-template <int NOUT>
+template <int TM, int NOUT>
 __device__ __forceinline__ void head_partial(const float4* act, int s, int q_begin, int q_end,
                                              const float* __restrict__ w, int ldw, float (&sum)[NOUT]) {
 #pragma unroll
@@ -227,23 +258,33 @@ struct SpaceArgs {
     int64_t raw_ray_stride;
 };
 
-template <bool USE_TIME>
-__global__ __launch_bounds__(NTHREADS, 1) void spacenet_kernel(SpaceArgs a) {
+// Positional-encoding feature f of a tile sample lives at col[(f >> 2) * TM * 4 + (f & 3)], col = encf + s * 4.
+#define ENC_AT(col, f) (col)[((f) >> 2) * TM * 4 + ((f) & 3)]
+
+template <int TM, bool USE_TIME>
+__global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void spacenet_kernel(SpaceArgs a) {
+    constexpr int NPARTS = NTHREADS / TM;  // threads cooperating on one sample in the VALU phases
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float4* act = smem;             // [64][TM]
     float4* enc = smem + 64 * TM;   // [16][TM]
     float* encf = reinterpret_cast<float*>(enc);
-    float* scratch = reinterpret_cast<float*>(enc + 12 * TM);  // quads 12..15: 2048 floats
+    float* scratch = reinterpret_cast<float*>(enc + 12 * TM);  // quads 12..15: 16*TM floats
     const SpaceLayout L = space_layout(USE_TIME);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int part = __builtin_amdgcn_readfirstlane(tid / TM);
     const int s = tid & (TM - 1);
     const int64_t rows = worklist_rows(a.wl);
     const int ns = a.wl.ns;
 
     for (int64_t tile = blockIdx.x; tile * TM < rows; tile += gridDim.x) {
+        // The weights/biases are loop-invariant; without this the compiler hoists ~10 layers of bias and
+        // head-weight loads out of the tile loop and then spills them.  An opaque zero keeps every load
+        // inside the iteration that uses it.
+        int64_t opaque_zero = 0;
+        asm volatile("" : "+s"(opaque_zero));
+        const float* net = a.net + opaque_zero;
         // ---- row -> (ray, sample)
         const int64_t row = tile * TM + s;
         const bool valid = row < rows;
@@ -254,6 +295,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void spacenet_kernel(SpaceArgs a) {
             k = (int)(row - slot * ns);
             ray = a.wl.ray_list ? (int64_t)a.wl.ray_list[slot] : slot;
         }
+        float* col = encf + s * 4;
         // ---- PE_10(pos) -> enc quads 0..15 (63 features + 1 zero pad); utils/dimension_kernel.py:8-33
         {
             float p[3] = {0.f, 0.f, 0.f};
@@ -263,112 +305,114 @@ __global__ __launch_bounds__(NTHREADS, 1) void spacenet_kernel(SpaceArgs a) {
                 p[1] = src[1];
                 p[2] = src[2];
             }
-            float* col = encf + s * 4;  // feature f lives at col[(f>>2)*TM*4 + (f&3)]
-            if (half == 0) {
+            if (part == 0) {
 #pragma unroll
-                for (int dmn = 0; dmn < 3; ++dmn) col[dmn] = p[dmn];
-            } else {
-                col[15 * TM * 4 + 3] = 0.f;  // feature 63: zero pad
+                for (int dmn = 0; dmn < 3; ++dmn) ENC_AT(col, dmn) = p[dmn];
             }
-#pragma unroll
-            for (int fi = 0; fi < 5; ++fi) {
-                const int fq = half * 5 + fi;
+            if (part == NPARTS - 1) ENC_AT(col, 63) = 0.f;  // zero pad
+            for (int fq = part; fq < 10; fq += NPARTS) {
                 const float freq = (float)(1 << fq);
 #pragma unroll
                 for (int dmn = 0; dmn < 3; ++dmn) {
                     float sn, cs;
                     sincosf(p[dmn] * freq, &sn, &cs);
                     const int fs = 3 + fq * 6 + dmn, fc = fs + 3;
-                    col[(fs >> 2) * TM * 4 + (fs & 3)] = sn;
-                    col[(fc >> 2) * TM * 4 + (fc & 3)] = cs;
+                    ENC_AT(col, fs) = sn;
+                    ENC_AT(col, fc) = cs;
                 }
             }
         }
         __syncthreads();
         // ---- stage1 (modeling/spacenet.py:45-54)
-        dense_layer<2, true>(a.net, L.w[0], L.b[0], 256, enc, 16, nullptr, 0, act, wave, lane);
+        dense_layer<TM, 2, true>(net, L.w[0], L.b[0], 256, enc, 16, nullptr, 0, act, wave, lane);
         __syncthreads();
-        dense_layer<2, true>(a.net, L.w[1], L.b[1], 256, act, 64, nullptr, 0, act, wave, lane);
+        dense_layer<TM, 2, true>(net, L.w[1], L.b[1], 256, act, 64, nullptr, 0, act, wave, lane);
         __syncthreads();
-        dense_layer<2, true>(a.net, L.w[2], L.b[2], 256, act, 64, nullptr, 0, act, wave, lane);
+        dense_layer<TM, 2, true>(net, L.w[2], L.b[2], 256, act, 64, nullptr, 0, act, wave, lane);
         __syncthreads();
-        dense_layer<2, true>(a.net, L.w[3], L.b[3], 256, act, 64, nullptr, 0, act, wave, lane);
+        dense_layer<TM, 2, true>(net, L.w[3], L.b[3], 256, act, 64, nullptr, 0, act, wave, lane);
         __syncthreads();
         // ---- stage2.0 on [h, PE(pos)] (:56-57, :137)
-        dense_layer<2, true>(a.net, L.w[4], L.b[4], 256, act, 64, enc, 16, act, wave, lane);
+        dense_layer<TM, 2, true>(net, L.w[4], L.b[4], 256, act, 64, enc, 16, act, wave, lane);
         // enc is free now (all waves passed the barrier inside dense_layer): write
         // relu(PE_4(dir)) (27) and relu(PE_10(time)) (21) -> enc features 0..47  (:80-86, :141-149)
         {
-            float* col = encf + s * 4;
-            if (half == 0) {
-                float dv[3] = {0.f, 0.f, 0.f};
-                if (valid) {
-                    const float* src = a.dirs + ray * a.dirs_ray_stride;
-                    dv[0] = src[0];
-                    dv[1] = src[1];
-                    dv[2] = src[2];
+            float dv[3] = {0.f, 0.f, 0.f};
+            if (valid) {
+                const float* src = a.dirs + ray * a.dirs_ray_stride;
+                dv[0] = src[0];
+                dv[1] = src[1];
+                dv[2] = src[2];
+            }
+            if (part == 0) {
+#pragma unroll
+                for (int dmn = 0; dmn < 3; ++dmn) ENC_AT(col, dmn) = fmaxf(dv[dmn], 0.f);
+            }
+            for (int fq = part; fq < 4; fq += NPARTS) {
+                const float freq = (float)(1 << fq);
+#pragma unroll
+                for (int dmn = 0; dmn < 3; ++dmn) {
+                    float sn, cs;
+                    sincosf(dv[dmn] * freq, &sn, &cs);
+                    const int fs = 3 + fq * 6 + dmn, fc = fs + 3;
+                    ENC_AT(col, fs) = fmaxf(sn, 0.f);
+                    ENC_AT(col, fc) = fmaxf(cs, 0.f);
                 }
-#pragma unroll
-                for (int dmn = 0; dmn < 3; ++dmn) col[dmn] = fmaxf(dv[dmn], 0.f);
-#pragma unroll
-                for (int fq = 0; fq < 4; ++fq) {
-                    const float freq = (float)(1 << fq);
-#pragma unroll
-                    for (int dmn = 0; dmn < 3; ++dmn) {
-                        float sn, cs;
-                        sincosf(dv[dmn] * freq, &sn, &cs);
-                        const int fs = 3 + fq * 6 + dmn, fc = fs + 3;
-                        col[(fs >> 2) * TM * 4 + (fs & 3)] = fmaxf(sn, 0.f);
-                        col[(fc >> 2) * TM * 4 + (fc & 3)] = fmaxf(cs, 0.f);
-                    }
-                }
-                if (!USE_TIME) {
-#pragma unroll
-                    for (int f = 27; f < 32; ++f) col[(f >> 2) * TM * 4 + (f & 3)] = 0.f;
-                }
-            } else if (USE_TIME) {
+            }
+            if (USE_TIME) {
                 const float tv = valid ? a.times[ray * a.times_ray_stride] : 0.f;
-                col[(27 >> 2) * TM * 4 + (27 & 3)] = fmaxf(tv, 0.f);
-#pragma unroll
-                for (int fq = 0; fq < 10; ++fq) {
+                if (part == NPARTS - 1) ENC_AT(col, 27) = fmaxf(tv, 0.f);
+                for (int fq = NPARTS - 1 - part; fq < 10; fq += NPARTS) {
                     float sn, cs;
                     sincosf(tv * (float)(1 << fq), &sn, &cs);
                     const int fs = 28 + 2 * fq, fc = fs + 1;
-                    col[(fs >> 2) * TM * 4 + (fs & 3)] = fmaxf(sn, 0.f);
-                    col[(fc >> 2) * TM * 4 + (fc & 3)] = fmaxf(cs, 0.f);
+                    ENC_AT(col, fs) = fmaxf(sn, 0.f);
+                    ENC_AT(col, fc) = fmaxf(cs, 0.f);
                 }
+            } else if (part == NPARTS - 1) {
+#pragma unroll
+                for (int f = 27; f < 32; ++f) ENC_AT(col, f) = 0.f;
             }
         }
         __syncthreads();
-        dense_layer<2, true>(a.net, L.w[5], L.b[5], 256, act, 64, nullptr, 0, act, wave, lane);
+        dense_layer<TM, 2, true>(net, L.w[5], L.b[5], 256, act, 64, nullptr, 0, act, wave, lane);
         __syncthreads();
-        dense_layer<2, true>(a.net, L.w[6], L.b[6], 256, act, 64, nullptr, 0, act, wave, lane);
+        dense_layer<TM, 2, true>(net, L.w[6], L.b[6], 256, act, 64, nullptr, 0, act, wave, lane);
         __syncthreads();
         // ---- sigma = density_net(h) (:139), raw
         float sigma;
         {
-            float part[1];
-            head_partial<1>(act, s, half * 32, half * 32 + 32, a.net + L.w_sigma, 256, part);
-            scratch[half * TM + s] = part[0];
+            float ps[1];
+            head_partial<TM, 1>(act, s, part * (64 / NPARTS), (part + 1) * (64 / NPARTS), net + L.w_sigma, 256, ps);
+            scratch[part * TM + s] = ps[0];
             __syncthreads();
-            sigma = scratch[s] + scratch[TM + s] + a.net[L.b_sigma];
+            sigma = net[L.b_sigma];
+#pragma unroll
+            for (int pp = 0; pp < NPARTS; ++pp) sigma += scratch[pp * TM + s];
         }
         // ---- rgb_net: relu -> Linear(283|304,128) -> relu -> Linear(128,3)   (:80-86)
         // (h is already >= 0; the encodings were clamped when written)
-        dense_layer<1, true>(a.net, L.w_rgb1, L.b_rgb1, 128, act, 64, enc, L.kq_rgb1 - 64, act, wave, lane);
+        dense_layer<TM, 1, true>(net, L.w_rgb1, L.b_rgb1, 128, act, 64, enc, L.kq_rgb1 - 64, act, wave, lane);
         __syncthreads();
         {
-            float part[3];
-            head_partial<3>(act, s, half * 16, half * 16 + 16, a.net + L.w_rgb2, 128, part);
-            scratch[256 + (half * 3 + 0) * TM + s] = part[0];
-            scratch[256 + (half * 3 + 1) * TM + s] = part[1];
-            scratch[256 + (half * 3 + 2) * TM + s] = part[2];
+            float ps[3];
+            head_partial<TM, 3>(act, s, part * (32 / NPARTS), (part + 1) * (32 / NPARTS), net + L.w_rgb2, 128, ps);
+            float* sc = scratch + 256;
+            sc[(part * 3 + 0) * TM + s] = ps[0];
+            sc[(part * 3 + 1) * TM + s] = ps[1];
+            sc[(part * 3 + 2) * TM + s] = ps[2];
             __syncthreads();
-            if (half == 0 && valid) {
+            if (part == 0 && valid) {
                 float4 o;
-                o.x = scratch[256 + 0 * TM + s] + scratch[256 + 3 * TM + s] + a.net[L.b_rgb2 + 0];
-                o.y = scratch[256 + 1 * TM + s] + scratch[256 + 4 * TM + s] + a.net[L.b_rgb2 + 1];
-                o.z = scratch[256 + 2 * TM + s] + scratch[256 + 5 * TM + s] + a.net[L.b_rgb2 + 2];
+                o.x = net[L.b_rgb2 + 0];
+                o.y = net[L.b_rgb2 + 1];
+                o.z = net[L.b_rgb2 + 2];
+#pragma unroll
+                for (int pp = 0; pp < NPARTS; ++pp) {
+                    o.x += sc[(pp * 3 + 0) * TM + s];
+                    o.y += sc[(pp * 3 + 1) * TM + s];
+                    o.z += sc[(pp * 3 + 2) * TM + s];
+                }
                 o.w = sigma;
                 *reinterpret_cast<float4*>(a.raw + ray * a.raw_ray_stride + 4 * k) = o;
             }
@@ -392,24 +436,30 @@ struct MotionArgs {
     int add_to_xyz;
 };
 
-constexpr int MOTION_LDS_BYTES = (32 + 22) * TM * 16 + 6 * TM * 4;
+template <int TM>
+constexpr int motion_lds_bytes() { return (32 + 22) * TM * 16 + 3 * NTHREADS * 4; }
 
-__global__ __launch_bounds__(NTHREADS, 1) void motionnet_kernel(MotionArgs a) {
+template <int TM>
+__global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void motionnet_kernel(MotionArgs a) {
+    constexpr int NPARTS = NTHREADS / TM;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float4* act = smem;            // [32][TM]
     float4* enc = smem + 32 * TM;  // [22][TM]: 84 features + 4 zero pads
     float* encf = reinterpret_cast<float*>(enc);
-    float* scratch = reinterpret_cast<float*>(enc + 22 * TM);  // 6*TM floats
+    float* scratch = reinterpret_cast<float*>(enc + 22 * TM);  // 3*NPARTS*TM floats
     const MotionLayout L = motion_layout();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int part = __builtin_amdgcn_readfirstlane(tid / TM);
     const int s = tid & (TM - 1);
     const int64_t rows = worklist_rows(a.wl);
     const int ns = a.wl.ns;
 
     for (int64_t tile = blockIdx.x; tile * TM < rows; tile += gridDim.x) {
+        int64_t opaque_zero = 0;  // see spacenet_kernel
+        asm volatile("" : "+s"(opaque_zero));
+        const float* net = a.net + opaque_zero;
         const int64_t row = tile * TM + s;
         const bool valid = row < rows;
         int64_t ray = 0;
@@ -437,17 +487,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void motionnet_kernel(MotionArgs a) {
             const float om = 1.f - wgt;
             float* col = encf + s * 4;
             auto mix = [&](float va, float vb) { return frac ? om * va + wgt * vb : va; };
-            if (half == 0) {
+            if (part == 0) {
 #pragma unroll
-                for (int dmn = 0; dmn < 3; ++dmn) col[dmn] = mix(p[dmn], p[dmn]);
-                col[3] = mix(lo, lo + 1.f);
-            } else {
-#pragma unroll
-                for (int f = 84; f < 88; ++f) col[(f >> 2) * TM * 4 + (f & 3)] = 0.f;
+                for (int dmn = 0; dmn < 3; ++dmn) ENC_AT(col, dmn) = mix(p[dmn], p[dmn]);
+                ENC_AT(col, 3) = mix(lo, lo + 1.f);
             }
+            if (part == NPARTS - 1) {
 #pragma unroll
-            for (int fi = 0; fi < 5; ++fi) {
-                const int fq = half * 5 + fi;
+                for (int f = 84; f < 88; ++f) ENC_AT(col, f) = 0.f;
+            }
+            for (int fq = part; fq < 10; fq += NPARTS) {
                 const float freq = (float)(1 << fq);
 #pragma unroll
                 for (int dmn = 0; dmn < 4; ++dmn) {
@@ -463,34 +512,37 @@ __global__ __launch_bounds__(NTHREADS, 1) void motionnet_kernel(MotionArgs a) {
                         if (frac) sincosf((lo + 1.f) * freq, &sn2, &cs2);
                     }
                     const int fs = 4 + fq * 8 + dmn, fc = fs + 4;
-                    col[(fs >> 2) * TM * 4 + (fs & 3)] = mix(sn, sn2);
-                    col[(fc >> 2) * TM * 4 + (fc & 3)] = mix(cs, cs2);
+                    ENC_AT(col, fs) = mix(sn, sn2);
+                    ENC_AT(col, fc) = mix(cs, cs2);
                 }
             }
         }
         __syncthreads();
-        dense_layer<1, true>(a.net, L.w[0], L.b[0], 128, enc, 22, nullptr, 0, act, wave, lane);
+        dense_layer<TM, 1, true>(net, L.w[0], L.b[0], 128, enc, 22, nullptr, 0, act, wave, lane);
         __syncthreads();
-        dense_layer<1, true>(a.net, L.w[1], L.b[1], 128, act, 32, nullptr, 0, act, wave, lane);
+        dense_layer<TM, 1, true>(net, L.w[1], L.b[1], 128, act, 32, nullptr, 0, act, wave, lane);
         __syncthreads();
-        dense_layer<1, true>(a.net, L.w[2], L.b[2], 128, act, 32, nullptr, 0, act, wave, lane);
+        dense_layer<TM, 1, true>(net, L.w[2], L.b[2], 128, act, 32, nullptr, 0, act, wave, lane);
         __syncthreads();
-        dense_layer<1, true>(a.net, L.w[3], L.b[3], 128, act, 32, nullptr, 0, act, wave, lane);
+        dense_layer<TM, 1, true>(net, L.w[3], L.b[3], 128, act, 32, nullptr, 0, act, wave, lane);
         __syncthreads();
-        dense_layer<1, true>(a.net, L.w[4], L.b[4], 128, act, 32, nullptr, 0, act, wave, lane);
+        dense_layer<TM, 1, true>(net, L.w[4], L.b[4], 128, act, 32, nullptr, 0, act, wave, lane);
         __syncthreads();
         {
-            float part[3];
-            head_partial<3>(act, s, half * 16, half * 16 + 16, a.net + L.w_out, 128, part);
-            scratch[(half * 3 + 0) * TM + s] = part[0];
-            scratch[(half * 3 + 1) * TM + s] = part[1];
-            scratch[(half * 3 + 2) * TM + s] = part[2];
+            float ps[3];
+            head_partial<TM, 3>(act, s, part * (32 / NPARTS), (part + 1) * (32 / NPARTS), net + L.w_out, 128, ps);
+            scratch[(part * 3 + 0) * TM + s] = ps[0];
+            scratch[(part * 3 + 1) * TM + s] = ps[1];
+            scratch[(part * 3 + 2) * TM + s] = ps[2];
             __syncthreads();
-            if (half == 0 && valid) {
+            if (part == 0 && valid) {
                 float fl[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    fl[c] = scratch[c * TM + s] + scratch[(3 + c) * TM + s] + a.net[L.b_out + c];
+                for (int c = 0; c < 3; ++c) {
+                    fl[c] = net[L.b_out + c];
+#pragma unroll
+                    for (int pp = 0; pp < NPARTS; ++pp) fl[c] += scratch[(pp * 3 + c) * TM + s];
+                }
                 if (a.flow) {
                     float* dst = a.flow + ray * a.flow_ray_stride + 3 * k;
                     dst[0] = fl[0];
@@ -519,9 +571,38 @@ static void pack_linear(const float* w, int out_f, int in_f, int kq, float* dst)
         for (int k = 0; k < in_f; ++k) dst[((size_t)(k >> 2) * out_f + n) * 4 + (k & 3)] = w[(size_t)n * in_f + k];
 }
 
-static int grid_for(int64_t n_rays, int ns) {
-    const int64_t tiles = (n_rays * ns + TM - 1) / TM;
+static int grid_for(int64_t n_rays, int ns, int tm) {
+    const int64_t tiles = (n_rays * ns + tm - 1) / tm;
     return (int)(tiles < 8192 ? tiles : 8192);
+}
+
+// Tile size: 64 samples per workgroup (80 KiB LDS -> 2 workgroups per CU whose non-MFMA phases overlap
+// each other's MFMA phases) or 128 (160 KiB, 1 per CU).  STNERF_TILE overrides for A/B measurements.
+static int tile_samples() {
+    static int tm = 0;
+    if (!tm) {
+        const char* e = getenv("STNERF_TILE");
+        tm = (e && atoi(e) == 128) ? 128 : (e && atoi(e) == 64) ? 64 : STNERF_DEFAULT_TILE;
+    }
+    return tm;
+}
+
+// One-time LDS opt-in + launch.  `slot` identifies the instantiation (static flags per kernel).
+template <class Args>
+static int launch_mlp(void (*kernel)(Args), bool* opted_in, int lds, int grid, stnerf_stream_t stream, const Args& a,
+                      const char* what) {
+    if (!*opted_in) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("%s: cannot reserve %d B of LDS", what, lds);
+            return STNERF_ELAUNCH;
+        }
+        *opted_in = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(NTHREADS), lds, as_stream(stream), a);
+    STNERF_CHECK_LAUNCH(what);
+    return STNERF_OK;
 }
 
 }  // namespace stnerf
@@ -592,34 +673,19 @@ extern "C" int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays,
     STNERF_REQUIRE((raw_ray_stride & 3) == 0 && ((uintptr_t)raw & 15) == 0, "spacenet_fwd: raw must be 16-byte aligned");
     STNERF_REQUIRE(((uintptr_t)packed & 15) == 0, "spacenet_fwd: packed weights must be 16-byte aligned");
     if (n_rays == 0) return STNERF_OK;
-    static bool attr_set[2] = {false, false};
-    const int lds = (64 + 16) * TM * 16;
+    static bool opted[2][2] = {{false, false}, {false, false}};
     SpaceArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, dirs,
                 dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride};
-    const int grid = grid_for(n_rays, ns);
-    if (kind == STNERF_NET_SPACE_TIME) {
-        if (!attr_set[1]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(spacenet_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-                set_error("spacenet_fwd: cannot reserve %d B of LDS", lds);
-                return STNERF_ELAUNCH;
-            }
-            attr_set[1] = true;
-        }
-        hipLaunchKernelGGL(spacenet_kernel<true>, dim3(grid), dim3(NTHREADS), lds, as_stream(stream), a);
-    } else {
-        if (!attr_set[0]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(spacenet_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-                set_error("spacenet_fwd: cannot reserve %d B of LDS", lds);
-                return STNERF_ELAUNCH;
-            }
-            attr_set[0] = true;
-        }
-        hipLaunchKernelGGL(spacenet_kernel<false>, dim3(grid), dim3(NTHREADS), lds, as_stream(stream), a);
+    const int tm = tile_samples();
+    const int lds = (64 + 16) * tm * 16;
+    const int grid = grid_for(n_rays, ns, tm);
+    const bool ut = kind == STNERF_NET_SPACE_TIME;
+    if (tm == 128) {
+        return ut ? launch_mlp(spacenet_kernel<128, true>, &opted[0][1], lds, grid, stream, a, "spacenet_fwd")
+                  : launch_mlp(spacenet_kernel<128, false>, &opted[0][0], lds, grid, stream, a, "spacenet_fwd");
     }
-    STNERF_CHECK_LAUNCH("spacenet_fwd");
-    return STNERF_OK;
+    return ut ? launch_mlp(spacenet_kernel<64, true>, &opted[1][1], lds, grid, stream, a, "spacenet_fwd")
+              : launch_mlp(spacenet_kernel<64, false>, &opted[1][0], lds, grid, stream, a, "spacenet_fwd");
 }
 
 extern "C" int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
@@ -631,19 +697,12 @@ extern "C" int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, 
     STNERF_REQUIRE(n_rays >= 0 && ns >= 1, "motionnet_fwd: bad shape");
     STNERF_REQUIRE(((uintptr_t)packed & 15) == 0, "motionnet_fwd: packed weights must be 16-byte aligned");
     if (n_rays == 0) return STNERF_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(motionnet_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, MOTION_LDS_BYTES) != hipSuccess) {
-            set_error("motionnet_fwd: cannot reserve %d B of LDS", MOTION_LDS_BYTES);
-            return STNERF_ELAUNCH;
-        }
-        attr_set = true;
-    }
+    static bool opted[2] = {false, false};
     MotionArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, times,
                  times_ray_stride, flow, flow_ray_stride, add_to_xyz};
-    hipLaunchKernelGGL(motionnet_kernel, dim3(grid_for(n_rays, ns)), dim3(NTHREADS), MOTION_LDS_BYTES,
-                       as_stream(stream), a);
-    STNERF_CHECK_LAUNCH("motionnet_fwd");
-    return STNERF_OK;
+    const int tm = tile_samples();
+    const int grid = grid_for(n_rays, ns, tm);
+    if (tm == 128)
+        return launch_mlp(motionnet_kernel<128>, &opted[0], motion_lds_bytes<128>(), grid, stream, a, "motionnet_fwd");
+    return launch_mlp(motionnet_kernel<64>, &opted[1], motion_lds_bytes<64>(), grid, stream, a, "motionnet_fwd");
 }
