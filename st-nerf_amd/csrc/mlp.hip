@@ -16,8 +16,8 @@
 //     MFMAs is one coalesced 16-byte global load; every workgroup streams the same ~1.9 MB per
 //     network from L2.  The k index is permuted consistently for A and B (lane half h takes
 //     k = 8s + 4h + {0..3}), which only reorders the fp32 accumulation.
-//   * exact fp32 arithmetic (f32 MFMA == an fmaf chain); sin/cos are the accurate ocml versions
-//     (arguments reach 2^9 * |x|, utils/dimension_kernel.py:20-27).
+//   * exact fp32 arithmetic (f32 MFMA == an fmaf chain); sin/cos are < 1 ulp Cody-Waite + minimax kernels
+//     (arguments reach 2^9 * |x|, utils/dimension_kernel.py:20-27): sincos_pe below.
 //
 // Reference: modeling/spacenet.py:16-160, modeling/motion_net.py:7-71, utils/dimension_kernel.py:3-73.
 #include <stdlib.h>
@@ -92,6 +92,37 @@ __host__ __device__ inline MotionLayout motion_layout() {
     L.b_out = off; off += 4;
     L.total = off;
     return L;
+}
+
+
+// sin and cos of one fp32 argument, |x| up to a few thousand (positional-encoding arguments are
+// 2^f * coordinate, f <= 9).  Cody-Waite reduction by pi/2 in three fma steps (fdlibm's 17-bit splits of
+// pi/2: the first step is exact, the total reduction error is < 1 ulp of the reduced argument), then
+// fdlibm's float minimax kernels on [-pi/4, pi/4] (< 1 ulp).  ~40 VALU instructions with no slow path --
+// ocml's sincosf spends about twice that and the encodings are ~45 % of this kernel's non-MFMA work.
+__device__ __forceinline__ void sincos_pe(float x, float& sn, float& cs) {
+    const float k = rintf(x * 0.63661977236758134308f);
+    float r = fmaf(-k, 1.5707855225e+00f, x);
+    r = fmaf(-k, 1.0804273188e-05f, r);
+    r = fmaf(-k, 6.0770999344e-11f, r);
+    const float z = r * r;
+    float ps = fmaf(z, 1.5896910177e-10f, -2.5050759689e-08f);
+    ps = fmaf(z, ps, 2.7557314297e-06f);
+    ps = fmaf(z, ps, -1.9841270114e-04f);
+    ps = fmaf(z, ps, 8.3333337680e-03f);
+    ps = fmaf(z, ps, -1.6666667163e-01f);
+    const float s0 = fmaf(r * z, ps, r);
+    float pc = fmaf(z, -1.1359647598e-11f, 2.0875723372e-09f);
+    pc = fmaf(z, pc, -2.7557314297e-07f);
+    pc = fmaf(z, pc, 2.4801587642e-05f);
+    pc = fmaf(z, pc, -1.3888889225e-03f);
+    pc = fmaf(z, pc, 4.1666667908e-02f);
+    const float c0 = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    const int q = (int)k;
+    const float sv = (q & 1) ? c0 : s0;
+    const float cv = (q & 1) ? s0 : c0;
+    sn = (q & 2) ? -sv : sv;
+    cs = ((q + 1) & 2) ? -cv : cv;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -315,7 +346,7 @@ __global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void spacenet_kernel
 #pragma unroll
                 for (int dmn = 0; dmn < 3; ++dmn) {
                     float sn, cs;
-                    sincosf(p[dmn] * freq, &sn, &cs);
+                    sincos_pe(p[dmn] * freq, sn, cs);
                     const int fs = 3 + fq * 6 + dmn, fc = fs + 3;
                     ENC_AT(col, fs) = sn;
                     ENC_AT(col, fc) = cs;
@@ -353,7 +384,7 @@ __global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void spacenet_kernel
 #pragma unroll
                 for (int dmn = 0; dmn < 3; ++dmn) {
                     float sn, cs;
-                    sincosf(dv[dmn] * freq, &sn, &cs);
+                    sincos_pe(dv[dmn] * freq, sn, cs);
                     const int fs = 3 + fq * 6 + dmn, fc = fs + 3;
                     ENC_AT(col, fs) = fmaxf(sn, 0.f);
                     ENC_AT(col, fc) = fmaxf(cs, 0.f);
@@ -364,7 +395,7 @@ __global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void spacenet_kernel
                 if (part == NPARTS - 1) ENC_AT(col, 27) = fmaxf(tv, 0.f);
                 for (int fq = NPARTS - 1 - part; fq < 10; fq += NPARTS) {
                     float sn, cs;
-                    sincosf(tv * (float)(1 << fq), &sn, &cs);
+                    sincos_pe(tv * (float)(1 << fq), sn, cs);
                     const int fs = 28 + 2 * fq, fc = fs + 1;
                     ENC_AT(col, fs) = fmaxf(sn, 0.f);
                     ENC_AT(col, fc) = fmaxf(cs, 0.f);
@@ -502,14 +533,14 @@ __global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void motionnet_kerne
                 for (int dmn = 0; dmn < 4; ++dmn) {
                     float sn, cs, sn2, cs2;
                     if (dmn < 3) {
-                        sincosf(p[dmn] * freq, &sn, &cs);
+                        sincos_pe(p[dmn] * freq, sn, cs);
                         sn2 = sn;
                         cs2 = cs;
                     } else {
-                        sincosf(lo * freq, &sn, &cs);
+                        sincos_pe(lo * freq, sn, cs);
                         sn2 = sn;
                         cs2 = cs;
-                        if (frac) sincosf((lo + 1.f) * freq, &sn2, &cs2);
+                        if (frac) sincos_pe((lo + 1.f) * freq, sn2, cs2);
                     }
                     const int fs = 4 + fq * 8 + dmn, fc = fs + 4;
                     ENC_AT(col, fs) = mix(sn, sn2);
