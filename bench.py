@@ -31,6 +31,7 @@ sys.path.insert(0, REPO)
 from stnerf_amd import ops, synthetic as syn          # noqa: E402
 from stnerf_amd.modeling import build_layered_model   # noqa: E402
 from stnerf_amd.utils import layered_batchify_ray     # noqa: E402
+from stnerf_amd.parallel import gather_tiles          # noqa: E402
 
 # Algorithmic work per network evaluation: 2 * MACs of every nn.Linear.
 FLOP_SPACE, FLOP_SPACE_TIME, FLOP_MOTION = 924_672, 930_048, 153_344
@@ -165,9 +166,7 @@ def main():
             fine, coarse, fine_layers, _, masks = layered_batchify_ray(model, rays, None, None)
         tile = torch.cat(list(fine), dim=1).contiguous()      # (H*W, 5): colour, depth, acc of the final image
         if world > 1 and gather:
-            frames = torch.empty(world * n_rays, 5, dtype=tile.dtype, device=device)
-            dist.all_gather_into_tensor(frames, tile)          # RCCL all-gather of the rendered tiles
-            tile = frames
+            tile = gather_tiles(tile, world * n_rays)          # ONE RCCL all-gather of the rendered tiles
         return tile, masks
 
     def fence():
