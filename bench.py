@@ -204,6 +204,14 @@ def main():
     if rank == 0:
         sp = ksum["spacenet"]
         achieved = sp["flop"] / (sp["ms"] * 1e-3) / 1e12
+        # HBM traffic cannot be counted inside this process: it comes from the committed rocprofv3 PMC passes
+        # of the same command (profiles/), per launch, with the gfx950 FETCH_SIZE correction applied.
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(REPO, "profiles", "r01_pmc_spacenet_traffic.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc.get("workload") == args.workload:
+                traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_pmc_spacenet_traffic.json"
         rec = {
             "metric": "rendered rays/s (and ray-samples/s) per GPU, 1080p x 128-sample layered render",
             "value": world * n_rays * args.steps / elapsed,
@@ -222,7 +230,8 @@ def main():
             "mask_fraction": [float(m.float().mean()) for m in masks],
             "roofline": {"kernel": "stnerf::spacenet_kernel (fused PE + 9-layer MLP, v_mfma_f32_32x32x2_f32)",
                          "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": 28 * sp["evals"] / sp["launches"],
                          "launches": sp["launches"], "avg_launch_ms": sp["ms"] / sp["launches"],
                          "algorithmic_flop_per_launch": sp["flop"] / sp["launches"],
                          "note": "algorithmic FLOPs = network evaluations x 924,672 (930,048 with time), "
