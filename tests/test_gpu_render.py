@@ -164,3 +164,91 @@ def test_sharded_render_is_bitwise_the_single_gpu_render():
         parts = [render_rows(*(lambda s, e: (s, e - s))(*shard_range(h * w, r, world))) for r in range(world)]
         assert torch.equal(torch.cat(parts, 0), whole)
     assert bool(torch.isfinite(whole).all()) and float(whole[:, 4].max()) > 0.5
+
+
+# ----------------------------------------------------------------------------------------------------
+# BASELINE.json configs at (or sampled from) their full sizes
+# ----------------------------------------------------------------------------------------------------
+def _oracle_model(meta, sd):
+    from oracle import stnerf_oracle as O
+    bk, per = syn.scene_boxes(meta["L"])
+    return O.OracleModel(layer_num=meta["L"], n_coarse=meta["n1"], n_fine=meta["n2"], params=sd,
+                         use_deform_time=meta["deform_time"], use_space_time=meta["space_time"], bkgd_bbox=bk,
+                         bboxes=per)
+
+
+@pytest.mark.parametrize("cfg_name, meta", [
+    ("C2: 512x512, L=1, 64+64", dict(L=1, n1=64, n2=64, space_time=True, deform_time=False, weight_seed=40, edit={}, H=512, W=512)),
+    ("C3: 1080p, L=2, 64+64", dict(L=2, n1=64, n2=64, space_time=True, deform_time=True, weight_seed=41, edit={}, H=1080, W=1920)),
+])
+def test_full_sample_counts_on_a_ray_subset_match_the_oracle(cfg_name, meta):
+    """The real sample counts of C2 / C3 on 768 rays spread over the view (what the oracle finishes in seconds)."""
+    from oracle import stnerf_oracle as O
+    model = build_model(meta)
+    sd = syn.make_state_dict(meta["L"], meta["space_time"], meta["deform_time"], meta["weight_seed"])
+    K, T = syn.camera(meta["H"], meta["W"], 8.0)
+    full = O.generate_rays(K, T, meta["H"], meta["W"])
+    g = torch.Generator().manual_seed(5)
+    pick = torch.randperm(full.shape[0], generator=g)[:768].sort()[0]
+    l = meta["L"] + 1
+    rays = torch.cat([full[pick], syn.frame_id_columns(768, meta["L"])], -1)
+    jitter, u = torch.rand(l, 768, meta["n1"], generator=g), torch.rand(l, 768, meta["n2"], generator=g)
+    model.replay = {"jitter": jitter.cuda(), "u": u.cuda()}
+    with torch.no_grad():
+        out = model(rays.cuda(), None, None)
+    draws = iter(list(jitter) + list(u))
+    with torch.no_grad():
+        ref = O.render_chunk(_oracle_model(meta, sd), rays, rand=lambda shape: next(draws))
+    for i in range(l):
+        assert torch.equal(out[4][i].cpu(), ref[4][i])
+    assert float((out[1][0].cpu() - ref[1][0]).abs().max()) <= COLOR_ATOL            # coarse: every ray
+    per_ray = (out[0][0].cpu() - ref[0][0]).abs().max(-1)[0]
+    assert float((per_ray <= COLOR_ATOL).float().mean()) >= FINE_FRACTION and float(per_ray.max()) <= FINE_CAP
+    assert O.psnr(out[0][0].cpu(), ref[0][0]) >= FINE_PSNR
+
+
+def test_c2_full_view_properties_and_determinism():
+    """C2 at its full size (262,144 rays, device RNG): size-independent properties."""
+    from stnerf_amd.render_pose import render_pose, to_uint8
+    meta = dict(L=1, n1=64, n2=64, space_time=True, deform_time=False, weight_seed=40, edit={})
+    model = build_model(meta)
+    K, T = syn.camera(512, 512, 8.0)
+    model.seed = 3
+    c1, d1, cl1, dl1 = render_pose(model, T, K, 512, 512, [(0, 1), (1, 2.5)], far=20.0)
+    c2, d2, _, _ = render_pose(model, T, K, 512, 512, [(0, 1), (1, 2.5)], far=20.0)
+    assert torch.equal(c1, c2) and torch.equal(d1, d2)                       # same inputs twice -> bitwise equal
+    assert c1.shape == (512, 512, 3) and len(cl1) == 2 and dl1[1].shape == (512, 512, 1)
+    assert bool(torch.isfinite(c1).all()) and float(c1.min()) >= 0.0 and float(c1.max()) <= 1.0 + 1e-5
+    assert float(d1.min()) >= 0.0
+    img = to_uint8(c1)
+    assert img.dtype == torch.uint8 and img.shape == (512, 512, 3)
+    model.seed = 4                                                           # another noise stream: close, not equal
+    c3, _, _, _ = render_pose(model, T, K, 512, 512, [(0, 1), (1, 2.5)], far=20.0)
+    assert not torch.equal(c1, c3)
+    assert float(-10 * torch.log10(torch.mean((c1 - c3) ** 2))) > 15.0
+
+
+def test_stage_invariants_at_c3_sample_counts():
+    """Ordering / range invariants of every stage on 20k rays of the 1080p C3 view."""
+    from stnerf_amd import ops
+    meta = dict(L=2, n1=64, n2=64, space_time=True, deform_time=True, weight_seed=41, edit={})
+    K, T = syn.camera(1080, 1920, 12.0)
+    rays = ops.generate_rays(K, T, 1080, 1920, frame_ids=[1.0, 2.5, 2.5], first_ray=1000000, n=20000)
+    bk, per = syn.scene_boxes(2)
+    boxes = torch.cat([bk, per[1]], 0).cuda()
+    t, xyz, mask = ops.sample_coarse(rays, boxes, 64, seed=9, ray_index_base=1000000)
+    hit = mask.bool()
+    assert bool(hit[:, 0].all()) and 0.05 < float(hit[:, 1].float().mean()) < 0.95
+    assert bool((t[..., 1:] >= t[..., :-1])[hit].all())                      # ascending inside a hit layer
+    assert bool((t[~hit] == -1000.0).all())                                  # misses park at -1000
+    raw = torch.randn(20000, 3, 64, 4, device="cuda")
+    lo, mix, w, order = ops.composite(t, raw, mask, cut_negative_t=True, want_weights=True, want_order=True)
+    assert bool((w >= 0).all()) and bool((w.sum(-1) <= 1 + 1e-4).all())
+    assert bool((mix[:, 4] <= 1 + 1e-4).all()) and bool((lo[..., 4] <= 1 + 1e-4).all())
+    srt = torch.gather(t.reshape(20000, -1), 1, order.long())
+    assert bool((srt[:, 1:] >= srt[:, :-1]).all())                           # merged order is a sort
+    assert torch.equal(order.long().sort(-1)[0], torch.arange(192, device="cuda").expand(20000, 192))  # a permutation
+    tf, xf = ops.resample(t, w, 64, rays, seed=9, ray_index_base=1000000)
+    assert bool((tf[..., 1:] >= tf[..., :-1]).all())
+    lo_t, hi_t = t.min(-1)[0], t.max(-1)[0]
+    assert bool((tf.min(-1)[0] >= lo_t - 1e-4).all()) and bool((tf.max(-1)[0] <= hi_t + 1e-4).all())
