@@ -19,7 +19,8 @@ SOURCES = [
     ("render.hip", ["-ffp-contract=off"]),
     ("mlp.hip", []),
 ]
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+EXTRA = os.environ.get("STNERF_EXTRA_FLAGS", "").split()   # e.g. -DSTNERF_PHASE_PROF (development only)
+COMMON = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
 
 

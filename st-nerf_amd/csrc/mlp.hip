@@ -24,7 +24,7 @@
 #include <string.h>
 
 #ifndef STNERF_DEFAULT_TILE
-#define STNERF_DEFAULT_TILE 128
+#define STNERF_DEFAULT_TILE 0 /* TILE_128 */
 #endif
 
 #include "common.h"
@@ -33,7 +33,24 @@ namespace stnerf {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int NTHREADS = 256;  // 4 waves
+// Optional per-phase cycle accounting (development builds: -DSTNERF_PHASE_PROF).  Thread 0 of every
+// workgroup accumulates s_memtime deltas per phase; read back with stnerf_debug_read_phases().
+#ifdef STNERF_PHASE_PROF
+__device__ unsigned long long g_phase[16];
+#define PH_DECL unsigned long long ph_t = clock64(); unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PH(i) do { const unsigned long long n_ = clock64(); ph_acc[i] += n_ - ph_t; ph_t = n_; } while (0)
+#define PH_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase[i_], ph_acc[i_]); atomicAdd(&g_phase[8], 1ull); } } while (0)
+#define PH_PARAMS , unsigned long long& ph_t, unsigned long long (&ph_acc)[8]
+#define PH_ARGS , ph_t, ph_acc
+#else
+#define PH_DECL
+#define PH(i) do { } while (0)
+#define PH_FLUSH do { } while (0)
+#define PH_PARAMS
+#define PH_ARGS
+#endif
+enum { PH_PE = 0, PH_MMA = 1, PH_BAR1 = 2, PH_EPI = 3, PH_BAR2 = 4, PH_ENC2 = 5, PH_HEAD = 6, PH_MISC = 7 };
+
 
 // ---------------------------------------------------------------------------------------------
 // Packed weight layouts (offsets in floats).  Shared by the host packer and the kernels.
@@ -129,7 +146,25 @@ __device__ __forceinline__ void sincos_pe(float x, float& sn, float& cs) {
 // One dense layer on the tile:  out[:, n] = act(bias[n] + sum_k W[n][k] in[k])   for the wave's
 // NFB*32 features and all TM samples.  K comes from up to two LDS segments (quads kqA then kqB).
 // ---------------------------------------------------------------------------------------------
-template <int NFB, int NSB>
+template <int NFB>
+struct WFrag {  // one K step (8 k values) of this lane's weight operands: NFB x 16 bytes
+    float4 w[NFB];
+};
+
+// This lane's pointer to quad row 0 of a packed [K/4][N][4] weight matrix (lane half h takes row h).
+__device__ __forceinline__ const float4* weight_lane_ptr(const float* base, int64_t w_off, int n_total, int n0, int lane) {
+    return reinterpret_cast<const float4*>(base + w_off) + ((int64_t)(lane >> 5) * n_total + n0 + (lane & 31));
+}
+
+template <int NFB>
+__device__ __forceinline__ void load_wfrag(WFrag<NFB>& f, const float4* __restrict__ lane_ptr) {
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) f.w[fb] = lane_ptr[fb * 32];
+}
+
+// 4 * NFB * NSB MFMAs of one K step.  ZERO_C: the first step of a layer accumulates onto the inline
+// constant 0 (no accumulator initialisation instructions).
+template <int NFB, int NSB, bool ZERO_C>
 __device__ __forceinline__ void mma_step(f32x16 (&acc)[NFB][NSB], const float4 (&w)[NFB], const float4 (&a)[NSB]) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -139,7 +174,12 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[NFB][NSB], const float4 (
 #pragma unroll
             for (int sb = 0; sb < NSB; ++sb) {
                 const float av = kk == 0 ? a[sb].x : kk == 1 ? a[sb].y : kk == 2 ? a[sb].z : a[sb].w;
-                acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, acc[fb][sb], 0, 0, 0);
+                if (ZERO_C && kk == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, zero, 0, 0, 0);
+                } else {
+                    acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, acc[fb][sb], 0, 0, 0);
+                }
             }
         }
     }
@@ -149,70 +189,113 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[NFB][NSB], const float4 (
 // while the 4*NFB*NSB MFMAs of step s issue.  Written as an explicit two-stage ping-pong (two register
 // sets, loop unrolled by two) -- a rotate-the-copy form gets collapsed by the compiler into
 // load -> wait -> use, which with one wave per SIMD exposes the full L2 latency every step.
-template <int TM, int NFB>
-__device__ __forceinline__ void mma_segment(f32x16 (&acc)[NFB][TM / 32], const float4* __restrict__ wp, int n_total,
-                                            const float4* in, int steps) {
-    // wp / in already point at this lane's first quad row; one step = 2 quad rows = 8 k values.
-    constexpr int NSB = TM / 32;
+// `wfirst` = the step-0 weights, already loaded by the caller (prefetched during the previous layer's
+// epilogue); requires steps >= 2.
+template <int TM, int NFB, int NSB, bool FIRST>
+__device__ __forceinline__ void mma_segment(f32x16 (&acc)[NFB][NSB], const WFrag<NFB>& wfirst,
+                                            const float4* __restrict__ wp, int n_total, const float4* in, int steps) {
+    // wp / in point at this lane's first quad row of the segment; one step = 2 quad rows = 8 k values.
     float4 w0[NFB], a0[NSB], w1[NFB], a1[NSB];
     const int64_t wstep = 2 * (int64_t)n_total;
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) w0[fb] = wp[fb * 32];
+    for (int fb = 0; fb < NFB; ++fb) w0[fb] = wfirst.w[fb];
 #pragma unroll
     for (int sb = 0; sb < NSB; ++sb) a0[sb] = in[sb * 32];
-    int s = 0;
+#if defined(STNERF_EXP_NOGLOBAL) || defined(STNERF_EXP_NOLDS)
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) w1[fb] = w0[fb];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) a1[sb] = a0[sb];
+#endif
+    // Scheduling of one half-iteration = {issue the operand loads of the NEXT step, 4*NFB*NSB MFMAs of this
+    // step}.  Two things are pinned: (1) sched_barrier(0) fences keep the loads in the half-iteration they
+    // were written in -- left alone the machine scheduler sinks each load to just before its first use and
+    // exposes the L2 latency; (2) inside the half-iteration the loads are interleaved ONE per MFMA
+    // (sched_group_barrier): issued as a clump, the 2 global + 4 LDS loads take ~120 issue cycles, more than
+    // the 64-cycle shadow of one MFMA, and the MFMA pipe idles ~3 % (measured with the loads stubbed out).
+#define STNERF_INTERLEAVE()                                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < NFB; ++i_) {                                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* MFMA */                               \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); /* VMEM read */                          \
+    }                                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < NSB; ++i_) {                                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* DS read */                            \
+    }                                                                                               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NFB * NSB - NFB - NSB, 0);                      \
+    __builtin_amdgcn_sched_barrier(0);
+#if defined(STNERF_EXP_NOGLOBAL)   /* development experiments only: wrong results, isolates a stall source */
+#define STNERF_LOAD_W(W, STEP) _Pragma("unroll") for (int fb = 0; fb < NFB; ++fb) asm volatile("" : "+v"(W[fb].x), "+v"(W[fb].y), "+v"(W[fb].z), "+v"(W[fb].w));
+#else
+#define STNERF_LOAD_W(W, STEP) _Pragma("unroll") for (int fb = 0; fb < NFB; ++fb) W[fb] = wp[(STEP) * wstep + fb * 32];
+#endif
+#if defined(STNERF_EXP_NOLDS)
+#define STNERF_LOAD_A(A, STEP) _Pragma("unroll") for (int sb = 0; sb < NSB; ++sb) asm volatile("" : "+v"(A[sb].x), "+v"(A[sb].y), "+v"(A[sb].z), "+v"(A[sb].w));
+#else
+#define STNERF_LOAD_A(A, STEP) _Pragma("unroll") for (int sb = 0; sb < NSB; ++sb) A[sb] = in[(STEP) * 2 * TM + sb * 32];
+#endif
+#define STNERF_LOAD_STEP(W, A, STEP) STNERF_LOAD_W(W, STEP) STNERF_LOAD_A(A, STEP)
+    __builtin_amdgcn_sched_barrier(0);
+    // peeled first pair of steps (the very first MFMAs of a layer take C = 0)
+    STNERF_LOAD_STEP(w1, a1, 1)
+    mma_step<NFB, NSB, FIRST>(acc, w0, a0);
+    STNERF_INTERLEAVE()
+    {
+        const int nx = 2 < steps ? 2 : steps - 1;
+        STNERF_LOAD_STEP(w0, a0, nx)
+    }
+    mma_step<NFB, NSB, false>(acc, w1, a1);
+    STNERF_INTERLEAVE()
+    int s = 2;
 #pragma unroll 1
     for (; s + 2 <= steps; s += 2) {
-        // sched_barrier(0) pins "issue the next operands, THEN the MFMAs": left alone, the machine scheduler
-        // sinks each load to just before its first use (register-pressure heuristics at ~240 VGPRs).
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) w1[fb] = wp[(s + 1) * wstep + fb * 32];
-#pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) a1[sb] = in[(s + 1) * 2 * TM + sb * 32];
-        __builtin_amdgcn_sched_barrier(0);
-        mma_step<NFB, NSB>(acc, w0, a0);
-        __builtin_amdgcn_sched_barrier(0);
+        STNERF_LOAD_STEP(w1, a1, s + 1)
+        mma_step<NFB, NSB, false>(acc, w0, a0);
+        STNERF_INTERLEAVE()
         const int nx = (s + 2 < steps) ? (s + 2) : (steps - 1);  // clamped: never out of bounds
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) w0[fb] = wp[nx * wstep + fb * 32];
-#pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) a0[sb] = in[nx * 2 * TM + sb * 32];
-        __builtin_amdgcn_sched_barrier(0);
-        mma_step<NFB, NSB>(acc, w1, a1);
-        __builtin_amdgcn_sched_barrier(0);
+        STNERF_LOAD_STEP(w0, a0, nx)
+        mma_step<NFB, NSB, false>(acc, w1, a1);
+        STNERF_INTERLEAVE()
     }
-    if (s < steps) mma_step<NFB, NSB>(acc, w0, a0);
+    if (s < steps) mma_step<NFB, NSB, false>(acc, w0, a0);
+#undef STNERF_INTERLEAVE
+#undef STNERF_LOAD_STEP
+#undef STNERF_LOAD_W
+#undef STNERF_LOAD_A
 }
 
-template <int TM, int NFB, bool RELU>
+// One dense layer.  The wave computes features [n0, n0 + NFB*32) for the samples of blocks
+// [sb0, sb0 + NSB) of the tile.  `wfirst` holds this layer's step-0 weights (already in flight);
+// before the barrier/epilogue the step-0 weights of the NEXT layer (`next_lane_ptr`) are issued into
+// `wnext`, so the next layer's pipeline fill overlaps this layer's epilogue instead of following it.
+template <int TM, int NFB, int NSB, bool RELU, int NFB_NEXT>
 __device__ __forceinline__ void dense_layer(const float* __restrict__ base, int64_t w_off, int64_t b_off, int n_total,
                                             const float4* inA, int kqA, const float4* inB, int kqB, float4* out,
-                                            int wave, int lane) {
-    constexpr int NSB = TM / 32;
+                                            int n0, int sb0, int lane, const WFrag<NFB>& wfirst,
+                                            const float4* next_lane_ptr, WFrag<NFB_NEXT>& wnext PH_PARAMS) {
     const int h = lane >> 5, c = lane & 31;
-    const int n0 = wave * NFB * 32;
-    // accumulators start from the bias: lane (h, c) register 4q+r holds feature n0 + fb*32 + 8q + 4h + r
+    const int s0 = sb0 * 32 + c;  // this lane's sample column within the tile (+ sb*32)
+    // bias of this lane's features (register 4q+r of a block <-> feature n0 + fb*32 + 8q + 4h + r):
+    // issued now, consumed in the epilogue
     const float* bias = base + b_off;
+    float4 bv[NFB][4];
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[fb][q] = *reinterpret_cast<const float4*>(bias + n0 + fb * 32 + 8 * q + 4 * h);
     f32x16 acc[NFB][NSB];
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + fb * 32 + 8 * q + 4 * h);
-#pragma unroll
-            for (int sb = 0; sb < NSB; ++sb) {
-                acc[fb][sb][4 * q + 0] = bv.x;
-                acc[fb][sb][4 * q + 1] = bv.y;
-                acc[fb][sb][4 * q + 2] = bv.z;
-                acc[fb][sb][4 * q + 3] = bv.w;
-            }
-        }
+    const float4* wp = weight_lane_ptr(base, w_off, n_total, n0, lane);
+    mma_segment<TM, NFB, NSB, true>(acc, wfirst, wp, n_total, inA + h * TM + s0, kqA / 2);
+    if (kqB > 0) {
+        WFrag<NFB> wseg;
+        load_wfrag<NFB>(wseg, wp + (int64_t)kqA * n_total);
+        mma_segment<TM, NFB, NSB, false>(acc, wseg, wp + (int64_t)kqA * n_total, n_total, inB + h * TM + s0, kqB / 2);
     }
-    const float4* wp = reinterpret_cast<const float4*>(base + w_off) + ((int64_t)h * n_total + n0 + c);
-    mma_segment<TM, NFB>(acc, wp, n_total, inA + h * TM + c, kqA / 2);
-    if (kqB > 0) mma_segment<TM, NFB>(acc, wp + (int64_t)kqA * n_total, n_total, inB + h * TM + c, kqB / 2);
+    load_wfrag<NFB_NEXT>(wnext, next_lane_ptr);
+    PH(PH_MMA);
     // every wave has finished READING the input tile before anyone overwrites it (out may alias inA)
     __syncthreads();
+    PH(PH_BAR1);
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb) {
 #pragma unroll
@@ -221,20 +304,21 @@ __device__ __forceinline__ void dense_layer(const float* __restrict__ base, int6
 #pragma unroll
             for (int sb = 0; sb < NSB; ++sb) {
                 float4 v;
-                v.x = acc[fb][sb][4 * q + 0];
-                v.y = acc[fb][sb][4 * q + 1];
-                v.z = acc[fb][sb][4 * q + 2];
-                v.w = acc[fb][sb][4 * q + 3];
+                v.x = acc[fb][sb][4 * q + 0] + bv[fb][q].x;
+                v.y = acc[fb][sb][4 * q + 1] + bv[fb][q].y;
+                v.z = acc[fb][sb][4 * q + 2] + bv[fb][q].z;
+                v.w = acc[fb][sb][4 * q + 3] + bv[fb][q].w;
                 if (RELU) {
                     v.x = fmaxf(v.x, 0.f);
                     v.y = fmaxf(v.y, 0.f);
                     v.z = fmaxf(v.z, 0.f);
                     v.w = fmaxf(v.w, 0.f);
                 }
-                out[(f >> 2) * TM + sb * 32 + c] = v;
+                out[(f >> 2) * TM + sb * 32 + s0] = v;
             }
         }
     }
+    PH(PH_EPI);
 }
 
 // out[c] partial dot products over a quad range, for heads with 1..3 outputs (VALU; the weights are
@@ -292,8 +376,28 @@ struct SpaceArgs {
 // Positional-encoding feature f of a tile sample lives at col[(f >> 2) * TM * 4 + (f & 3)], col = encf + s * 4.
 #define ENC_AT(col, f) (col)[((f) >> 2) * TM * 4 + ((f) & 3)]
 
-template <int TM, bool USE_TIME>
-__global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void spacenet_kernel(SpaceArgs a) {
+// Wave -> (feature block, sample blocks) decomposition of a layer with N outputs on a TM-sample tile, NW waves.
+//   N = 256: NW = 4 -> 64 features x all samples per wave;  NW = 8 -> 32 features x all samples
+//   N = 128: NW = 4 -> 32 features x all samples;           NW = 8 -> 32 features x half the samples
+template <int TM, int NW, int N>
+struct WaveSplit {
+    static constexpr int NFB = (N == 256 && NW == 4) ? 2 : 1;
+    static constexpr int NSB = (N == 128 && NW == 8) ? TM / 64 : TM / 32;
+    __device__ static __forceinline__ int n0(int wave) { return (N == 128 && NW == 8) ? (wave & 3) * 32 : wave * NFB * 32; }
+    __device__ static __forceinline__ int sb0(int wave) { return (N == 128 && NW == 8) ? (wave >> 2) * NSB : 0; }
+};
+
+// DENSE(TM, NW, N, N_NEXT, <dense_layer args up to `out`>, wfirst, next_w_off, wnext): one layer with N outputs;
+// prefetches step 0 of the following layer (N_NEXT outputs, packed at next_w_off) into wnext.
+#define DENSE(TM_, NW_, N_, NN_, BASE_, WOFF_, BOFF_, INA_, KQA_, INB_, KQB_, OUT_, WFIRST_, NEXT_WOFF_, WNEXT_)            \
+    dense_layer<TM_, WaveSplit<TM_, NW_, N_>::NFB, WaveSplit<TM_, NW_, N_>::NSB, true, WaveSplit<TM_, NW_, NN_>::NFB>(   \
+        BASE_, WOFF_, BOFF_, N_, INA_, KQA_, INB_, KQB_, OUT_, WaveSplit<TM_, NW_, N_>::n0(wave),                        \
+        WaveSplit<TM_, NW_, N_>::sb0(wave), lane, WFIRST_,                                                               \
+        weight_lane_ptr(BASE_, NEXT_WOFF_, NN_, WaveSplit<TM_, NW_, NN_>::n0(wave), lane), WNEXT_ PH_ARGS)
+
+template <int TM, int NW, bool USE_TIME>
+__global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_kernel(SpaceArgs a) {
+    constexpr int NTHREADS = NW * 64;
     constexpr int NPARTS = NTHREADS / TM;  // threads cooperating on one sample in the VALU phases
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float4* act = smem;             // [64][TM]
@@ -308,8 +412,15 @@ __global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void spacenet_kernel
     const int s = tid & (TM - 1);
     const int64_t rows = worklist_rows(a.wl);
     const int ns = a.wl.ns;
+    PH_DECL
+    // step-0 weight fragments, prefetched one layer ahead (layer 0 of the first tile here, of every later
+    // tile by the previous tile's last layer)
+    WFrag<WaveSplit<TM, NW, 256>::NFB> wA, wB;
+    WFrag<WaveSplit<TM, NW, 128>::NFB> wR;
+    load_wfrag(wA, weight_lane_ptr(a.net, L.w[0], 256, WaveSplit<TM, NW, 256>::n0(wave), lane));
 
     for (int64_t tile = blockIdx.x; tile * TM < rows; tile += gridDim.x) {
+        PH(PH_MISC);
         // The weights/biases are loop-invariant; without this the compiler hoists ~10 layers of bias and
         // head-weight loads out of the tile loop and then spills them.  An opaque zero keeps every load
         // inside the iteration that uses it.
@@ -353,18 +464,23 @@ __global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void spacenet_kernel
                 }
             }
         }
+        PH(PH_PE);
         __syncthreads();
+        PH(PH_BAR2);
         // ---- stage1 (modeling/spacenet.py:45-54)
-        dense_layer<TM, 2, true>(net, L.w[0], L.b[0], 256, enc, 16, nullptr, 0, act, wave, lane);
+        DENSE(TM, NW, 256, 256, net, L.w[0], L.b[0], enc, 16, nullptr, 0, act, wA, L.w[1], wB);
         __syncthreads();
-        dense_layer<TM, 2, true>(net, L.w[1], L.b[1], 256, act, 64, nullptr, 0, act, wave, lane);
+        PH(PH_BAR2);
+        DENSE(TM, NW, 256, 256, net, L.w[1], L.b[1], act, 64, nullptr, 0, act, wB, L.w[2], wA);
         __syncthreads();
-        dense_layer<TM, 2, true>(net, L.w[2], L.b[2], 256, act, 64, nullptr, 0, act, wave, lane);
+        PH(PH_BAR2);
+        DENSE(TM, NW, 256, 256, net, L.w[2], L.b[2], act, 64, nullptr, 0, act, wA, L.w[3], wB);
         __syncthreads();
-        dense_layer<TM, 2, true>(net, L.w[3], L.b[3], 256, act, 64, nullptr, 0, act, wave, lane);
+        PH(PH_BAR2);
+        DENSE(TM, NW, 256, 256, net, L.w[3], L.b[3], act, 64, nullptr, 0, act, wB, L.w[4], wA);
         __syncthreads();
         // ---- stage2.0 on [h, PE(pos)] (:56-57, :137)
-        dense_layer<TM, 2, true>(net, L.w[4], L.b[4], 256, act, 64, enc, 16, act, wave, lane);
+        DENSE(TM, NW, 256, 256, net, L.w[4], L.b[4], act, 64, enc, 16, act, wA, L.w[5], wB);
         // enc is free now (all waves passed the barrier inside dense_layer): write
         // relu(PE_4(dir)) (27) and relu(PE_10(time)) (21) -> enc features 0..47  (:80-86, :141-149)
         {
@@ -405,11 +521,15 @@ __global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void spacenet_kernel
                 for (int f = 27; f < 32; ++f) ENC_AT(col, f) = 0.f;
             }
         }
+        PH(PH_ENC2);
         __syncthreads();
-        dense_layer<TM, 2, true>(net, L.w[5], L.b[5], 256, act, 64, nullptr, 0, act, wave, lane);
+        PH(PH_BAR2);
+        DENSE(TM, NW, 256, 256, net, L.w[5], L.b[5], act, 64, nullptr, 0, act, wB, L.w[6], wA);
         __syncthreads();
-        dense_layer<TM, 2, true>(net, L.w[6], L.b[6], 256, act, 64, nullptr, 0, act, wave, lane);
+        PH(PH_BAR2);
+        DENSE(TM, NW, 256, 128, net, L.w[6], L.b[6], act, 64, nullptr, 0, act, wA, L.w_rgb1, wR);
         __syncthreads();
+        PH(PH_BAR2);
         // ---- sigma = density_net(h) (:139), raw
         float sigma;
         {
@@ -421,14 +541,15 @@ __global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void spacenet_kernel
 #pragma unroll
             for (int pp = 0; pp < NPARTS; ++pp) sigma += scratch[pp * TM + s];
         }
+        PH(PH_HEAD);
         // ---- rgb_net: relu -> Linear(283|304,128) -> relu -> Linear(128,3)   (:80-86)
         // (h is already >= 0; the encodings were clamped when written)
-        dense_layer<TM, 1, true>(net, L.w_rgb1, L.b_rgb1, 128, act, 64, enc, L.kq_rgb1 - 64, act, wave, lane);
+        DENSE(TM, NW, 128, 256, net, L.w_rgb1, L.b_rgb1, act, 64, enc, L.kq_rgb1 - 64, act, wR, L.w[0], wA);  // + next tile's layer 0
         __syncthreads();
         {
             float ps[3];
             head_partial<TM, 3>(act, s, part * (32 / NPARTS), (part + 1) * (32 / NPARTS), net + L.w_rgb2, 128, ps);
-            float* sc = scratch + 256;
+            float* sc = scratch + NTHREADS;
             sc[(part * 3 + 0) * TM + s] = ps[0];
             sc[(part * 3 + 1) * TM + s] = ps[1];
             sc[(part * 3 + 2) * TM + s] = ps[2];
@@ -449,7 +570,9 @@ __global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void spacenet_kernel
             }
         }
         __syncthreads();  // scratch/enc/act are rewritten by the next tile's prologue
+        PH(PH_HEAD);
     }
+    PH_FLUSH;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,11 +590,12 @@ struct MotionArgs {
     int add_to_xyz;
 };
 
-template <int TM>
-constexpr int motion_lds_bytes() { return (32 + 22) * TM * 16 + 3 * NTHREADS * 4; }
+template <int TM, int NW>
+constexpr int motion_lds_bytes() { return (32 + 22) * TM * 16 + 3 * NW * 64 * 4; }
 
-template <int TM>
-__global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void motionnet_kernel(MotionArgs a) {
+template <int TM, int NW>
+__global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_kernel(MotionArgs a) {
+    constexpr int NTHREADS = NW * 64;
     constexpr int NPARTS = NTHREADS / TM;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float4* act = smem;            // [32][TM]
@@ -486,6 +610,9 @@ __global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void motionnet_kerne
     const int s = tid & (TM - 1);
     const int64_t rows = worklist_rows(a.wl);
     const int ns = a.wl.ns;
+    PH_DECL
+    WFrag<WaveSplit<TM, NW, 128>::NFB> wA, wB;  // step-0 weights, prefetched one layer ahead
+    load_wfrag(wA, weight_lane_ptr(a.net, L.w[0], 128, WaveSplit<TM, NW, 128>::n0(wave), lane));
 
     for (int64_t tile = blockIdx.x; tile * TM < rows; tile += gridDim.x) {
         int64_t opaque_zero = 0;  // see spacenet_kernel
@@ -549,15 +676,16 @@ __global__ __launch_bounds__(NTHREADS, (TM == 128 ? 1 : 2)) void motionnet_kerne
             }
         }
         __syncthreads();
-        dense_layer<TM, 1, true>(net, L.w[0], L.b[0], 128, enc, 22, nullptr, 0, act, wave, lane);
+        DENSE(TM, NW, 128, 128, net, L.w[0], L.b[0], enc, 22, nullptr, 0, act, wA, L.w[1], wB);
         __syncthreads();
-        dense_layer<TM, 1, true>(net, L.w[1], L.b[1], 128, act, 32, nullptr, 0, act, wave, lane);
+        DENSE(TM, NW, 128, 128, net, L.w[1], L.b[1], act, 32, nullptr, 0, act, wB, L.w[2], wA);
         __syncthreads();
-        dense_layer<TM, 1, true>(net, L.w[2], L.b[2], 128, act, 32, nullptr, 0, act, wave, lane);
+        DENSE(TM, NW, 128, 128, net, L.w[2], L.b[2], act, 32, nullptr, 0, act, wA, L.w[3], wB);
         __syncthreads();
-        dense_layer<TM, 1, true>(net, L.w[3], L.b[3], 128, act, 32, nullptr, 0, act, wave, lane);
+        DENSE(TM, NW, 128, 128, net, L.w[3], L.b[3], act, 32, nullptr, 0, act, wB, L.w[4], wA);
         __syncthreads();
-        dense_layer<TM, 1, true>(net, L.w[4], L.b[4], 128, act, 32, nullptr, 0, act, wave, lane);
+        DENSE(TM, NW, 128, 128, net, L.w[4], L.b[4], act, 32, nullptr, 0, act, wA, L.w[0], wB);  // + next tile's layer 0
+        wA = wB;
         __syncthreads();
         {
             float ps[3];
@@ -607,21 +735,27 @@ static int grid_for(int64_t n_rays, int ns, int tm) {
     return (int)(tiles < 8192 ? tiles : 8192);
 }
 
-// Tile size: 64 samples per workgroup (80 KiB LDS -> 2 workgroups per CU whose non-MFMA phases overlap
-// each other's MFMA phases) or 128 (160 KiB, 1 per CU).  STNERF_TILE overrides for A/B measurements.
-static int tile_samples() {
-    static int tm = 0;
-    if (!tm) {
+// Tile configuration (STNERF_TILE overrides the default for A/B measurements):
+//   "128"   128 samples, 4 waves, 160 KiB LDS, 1 workgroup per CU (one wave per SIMD)
+//   "128x8" 128 samples, 8 waves (two per SIMD: the VALU phases of one hide in the issue gaps of the other)
+//   "64"    64 samples, 4 waves, 80 KiB LDS, 2 workgroups per CU
+enum TileCfg { TILE_128 = 0, TILE_128X8 = 1, TILE_64 = 2 };
+static TileCfg tile_config() {
+    static int cfg = -1;
+    if (cfg < 0) {
         const char* e = getenv("STNERF_TILE");
-        tm = (e && atoi(e) == 128) ? 128 : (e && atoi(e) == 64) ? 64 : STNERF_DEFAULT_TILE;
+        cfg = STNERF_DEFAULT_TILE;
+        if (e && !strcmp(e, "128")) cfg = TILE_128;
+        if (e && !strcmp(e, "128x8")) cfg = TILE_128X8;
+        if (e && !strcmp(e, "64")) cfg = TILE_64;
     }
-    return tm;
+    return (TileCfg)cfg;
 }
 
 // One-time LDS opt-in + launch.  `slot` identifies the instantiation (static flags per kernel).
 template <class Args>
-static int launch_mlp(void (*kernel)(Args), bool* opted_in, int lds, int grid, stnerf_stream_t stream, const Args& a,
-                      const char* what) {
+static int launch_mlp(void (*kernel)(Args), bool* opted_in, int lds, int grid, int nthreads, stnerf_stream_t stream,
+                      const Args& a, const char* what) {
     if (!*opted_in) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds) != hipSuccess) {
@@ -631,7 +765,7 @@ static int launch_mlp(void (*kernel)(Args), bool* opted_in, int lds, int grid, s
         }
         *opted_in = true;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(NTHREADS), lds, as_stream(stream), a);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(nthreads), lds, as_stream(stream), a);
     STNERF_CHECK_LAUNCH(what);
     return STNERF_OK;
 }
@@ -639,6 +773,17 @@ static int launch_mlp(void (*kernel)(Args), bool* opted_in, int lds, int grid, s
 }  // namespace stnerf
 
 using namespace stnerf;
+
+#ifdef STNERF_PHASE_PROF
+extern "C" int stnerf_debug_read_phases(unsigned long long* host16, int reset) {
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return STNERF_ELAUNCH;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return STNERF_ELAUNCH;
+    }
+    return STNERF_OK;
+}
+#endif
 
 extern "C" int64_t stnerf_packed_bytes(int kind) {
     switch (kind) {
@@ -704,19 +849,26 @@ extern "C" int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays,
     STNERF_REQUIRE((raw_ray_stride & 3) == 0 && ((uintptr_t)raw & 15) == 0, "spacenet_fwd: raw must be 16-byte aligned");
     STNERF_REQUIRE(((uintptr_t)packed & 15) == 0, "spacenet_fwd: packed weights must be 16-byte aligned");
     if (n_rays == 0) return STNERF_OK;
-    static bool opted[2][2] = {{false, false}, {false, false}};
+    static bool opted[3][2] = {{false, false}, {false, false}, {false, false}};
     SpaceArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, dirs,
                 dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride};
-    const int tm = tile_samples();
+    const TileCfg tc = tile_config();
+    const int tm = tc == TILE_64 ? 64 : 128;
     const int lds = (64 + 16) * tm * 16;
     const int grid = grid_for(n_rays, ns, tm);
     const bool ut = kind == STNERF_NET_SPACE_TIME;
-    if (tm == 128) {
-        return ut ? launch_mlp(spacenet_kernel<128, true>, &opted[0][1], lds, grid, stream, a, "spacenet_fwd")
-                  : launch_mlp(spacenet_kernel<128, false>, &opted[0][0], lds, grid, stream, a, "spacenet_fwd");
+    const char* what = "spacenet_fwd";
+    switch (tc) {
+        case TILE_128:
+            return ut ? launch_mlp(spacenet_kernel<128, 4, true>, &opted[0][1], lds, grid, 256, stream, a, what)
+                      : launch_mlp(spacenet_kernel<128, 4, false>, &opted[0][0], lds, grid, 256, stream, a, what);
+        case TILE_128X8:
+            return ut ? launch_mlp(spacenet_kernel<128, 8, true>, &opted[1][1], lds, grid, 512, stream, a, what)
+                      : launch_mlp(spacenet_kernel<128, 8, false>, &opted[1][0], lds, grid, 512, stream, a, what);
+        default:
+            return ut ? launch_mlp(spacenet_kernel<64, 4, true>, &opted[2][1], lds, grid, 256, stream, a, what)
+                      : launch_mlp(spacenet_kernel<64, 4, false>, &opted[2][0], lds, grid, 256, stream, a, what);
     }
-    return ut ? launch_mlp(spacenet_kernel<64, true>, &opted[1][1], lds, grid, stream, a, "spacenet_fwd")
-              : launch_mlp(spacenet_kernel<64, false>, &opted[1][0], lds, grid, stream, a, "spacenet_fwd");
 }
 
 extern "C" int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
@@ -728,12 +880,18 @@ extern "C" int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, 
     STNERF_REQUIRE(n_rays >= 0 && ns >= 1, "motionnet_fwd: bad shape");
     STNERF_REQUIRE(((uintptr_t)packed & 15) == 0, "motionnet_fwd: packed weights must be 16-byte aligned");
     if (n_rays == 0) return STNERF_OK;
-    static bool opted[2] = {false, false};
+    static bool opted[3] = {false, false, false};
     MotionArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, times,
                  times_ray_stride, flow, flow_ray_stride, add_to_xyz};
-    const int tm = tile_samples();
-    const int grid = grid_for(n_rays, ns, tm);
-    if (tm == 128)
-        return launch_mlp(motionnet_kernel<128>, &opted[0], motion_lds_bytes<128>(), grid, stream, a, "motionnet_fwd");
-    return launch_mlp(motionnet_kernel<64>, &opted[1], motion_lds_bytes<64>(), grid, stream, a, "motionnet_fwd");
+    const TileCfg tc = tile_config();
+    const int grid = grid_for(n_rays, ns, tc == TILE_64 ? 64 : 128);
+    const char* what = "motionnet_fwd";
+    switch (tc) {
+        case TILE_128:
+            return launch_mlp(motionnet_kernel<128, 4>, &opted[0], motion_lds_bytes<128, 4>(), grid, 256, stream, a, what);
+        case TILE_128X8:
+            return launch_mlp(motionnet_kernel<128, 8>, &opted[1], motion_lds_bytes<128, 8>(), grid, 512, stream, a, what);
+        default:
+            return launch_mlp(motionnet_kernel<64, 4>, &opted[2], motion_lds_bytes<64, 4>(), grid, 256, stream, a, what);
+    }
 }
