@@ -23,9 +23,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#ifndef STNERF_DEFAULT_TILE
-#define STNERF_DEFAULT_TILE 0 /* TILE_128 */
-#endif
 
 #include "common.h"
 
@@ -147,8 +144,9 @@ __device__ __forceinline__ void sincos_pe(float x, float& sn, float& cs) {
 // NFB*32 features and all TM samples.  K comes from up to two LDS segments (quads kqA then kqB).
 // ---------------------------------------------------------------------------------------------
 template <int NFB>
-struct WFrag {  // one K step (8 k values) of this lane's weight operands: NFB x 16 bytes
-    float4 w[NFB];
+struct WFrag {  // what a layer needs before its first MFMA, prefetched during the previous layer's tail:
+    float4 w[NFB];     // step-0 weight operands of this lane (8 k values x NFB feature blocks)
+    float4 b[NFB][4];  // bias of this lane's 16*NFB features = the C operand of the first MFMAs
 };
 
 // This lane's pointer to quad row 0 of a packed [K/4][N][4] weight matrix (lane half h takes row h).
@@ -156,16 +154,23 @@ __device__ __forceinline__ const float4* weight_lane_ptr(const float* base, int6
     return reinterpret_cast<const float4*>(base + w_off) + ((int64_t)(lane >> 5) * n_total + n0 + (lane & 31));
 }
 
+// lane_bias = bias + n0 + 4*(lane>>5): register 4q+r of block fb <-> feature n0 + fb*32 + 8q + 4h + r
 template <int NFB>
-__device__ __forceinline__ void load_wfrag(WFrag<NFB>& f, const float4* __restrict__ lane_ptr) {
+__device__ __forceinline__ void load_wfrag(WFrag<NFB>& f, const float4* __restrict__ lane_ptr,
+                                           const float* __restrict__ lane_bias) {
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) f.w[fb] = lane_ptr[fb * 32];
+    for (int fb = 0; fb < NFB; ++fb) {
+        f.w[fb] = lane_ptr[fb * 32];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f.b[fb][q] = *reinterpret_cast<const float4*>(lane_bias + fb * 32 + 8 * q);
+    }
 }
 
-// 4 * NFB * NSB MFMAs of one K step.  ZERO_C: the first step of a layer accumulates onto the inline
-// constant 0 (no accumulator initialisation instructions).
+// 4 * NFB * NSB MFMAs of one K step.  ZERO_C (first step of a layer): C = `cinit` = the bias, so neither an
+// accumulator initialisation nor a bias add in the epilogue is needed.
 template <int NFB, int NSB, bool ZERO_C>
-__device__ __forceinline__ void mma_step(f32x16 (&acc)[NFB][NSB], const float4 (&w)[NFB], const float4 (&a)[NSB]) {
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[NFB][NSB], const float4 (&w)[NFB], const float4 (&a)[NSB],
+                                         const f32x16 (&cinit)[NFB]) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -174,9 +179,8 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[NFB][NSB], const float4 (
 #pragma unroll
             for (int sb = 0; sb < NSB; ++sb) {
                 const float av = kk == 0 ? a[sb].x : kk == 1 ? a[sb].y : kk == 2 ? a[sb].z : a[sb].w;
-                if (ZERO_C && kk == 0) {
-                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, zero, 0, 0, 0);
+                if (ZERO_C && kk == 0) {  // first MFMAs of the layer: C = bias (the same registers for every sample block)
+                    acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, cinit[fb], 0, 0, 0);
                 } else {
                     acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, acc[fb][sb], 0, 0, 0);
                 }
@@ -192,13 +196,14 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[NFB][NSB], const float4 (
 // `wfirst` = the step-0 weights, already loaded by the caller (prefetched during the previous layer's
 // epilogue); requires steps >= 2.
 template <int TM, int NFB, int NSB, bool FIRST>
-__device__ __forceinline__ void mma_segment(f32x16 (&acc)[NFB][NSB], const WFrag<NFB>& wfirst,
-                                            const float4* __restrict__ wp, int n_total, const float4* in, int steps) {
+__device__ __forceinline__ void mma_segment(f32x16 (&acc)[NFB][NSB], const float4 (&wfirst)[NFB],
+                                            const f32x16 (&cinit)[NFB], const float4* __restrict__ wp, int n_total,
+                                            const float4* in, int steps) {
     // wp / in point at this lane's first quad row of the segment; one step = 2 quad rows = 8 k values.
     float4 w0[NFB], a0[NSB], w1[NFB], a1[NSB];
     const int64_t wstep = 2 * (int64_t)n_total;
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) w0[fb] = wfirst.w[fb];
+    for (int fb = 0; fb < NFB; ++fb) w0[fb] = wfirst[fb];
 #pragma unroll
     for (int sb = 0; sb < NSB; ++sb) a0[sb] = in[sb * 32];
 #if defined(STNERF_EXP_NOGLOBAL) || defined(STNERF_EXP_NOLDS)
@@ -238,26 +243,26 @@ __device__ __forceinline__ void mma_segment(f32x16 (&acc)[NFB][NSB], const WFrag
     __builtin_amdgcn_sched_barrier(0);
     // peeled first pair of steps (the very first MFMAs of a layer take C = 0)
     STNERF_LOAD_STEP(w1, a1, 1)
-    mma_step<NFB, NSB, FIRST>(acc, w0, a0);
+    mma_step<NFB, NSB, FIRST>(acc, w0, a0, cinit);
     STNERF_INTERLEAVE()
     {
         const int nx = 2 < steps ? 2 : steps - 1;
         STNERF_LOAD_STEP(w0, a0, nx)
     }
-    mma_step<NFB, NSB, false>(acc, w1, a1);
+    mma_step<NFB, NSB, false>(acc, w1, a1, cinit);
     STNERF_INTERLEAVE()
     int s = 2;
 #pragma unroll 1
     for (; s + 2 <= steps; s += 2) {
         STNERF_LOAD_STEP(w1, a1, s + 1)
-        mma_step<NFB, NSB, false>(acc, w0, a0);
+        mma_step<NFB, NSB, false>(acc, w0, a0, cinit);
         STNERF_INTERLEAVE()
         const int nx = (s + 2 < steps) ? (s + 2) : (steps - 1);  // clamped: never out of bounds
         STNERF_LOAD_STEP(w0, a0, nx)
-        mma_step<NFB, NSB, false>(acc, w1, a1);
+        mma_step<NFB, NSB, false>(acc, w1, a1, cinit);
         STNERF_INTERLEAVE()
     }
-    if (s < steps) mma_step<NFB, NSB, false>(acc, w0, a0);
+    if (s < steps) mma_step<NFB, NSB, false>(acc, w0, a0, cinit);
 #undef STNERF_INTERLEAVE
 #undef STNERF_LOAD_STEP
 #undef STNERF_LOAD_W
@@ -272,26 +277,31 @@ template <int TM, int NFB, int NSB, bool RELU, int NFB_NEXT>
 __device__ __forceinline__ void dense_layer(const float* __restrict__ base, int64_t w_off, int64_t b_off, int n_total,
                                             const float4* inA, int kqA, const float4* inB, int kqB, float4* out,
                                             int n0, int sb0, int lane, const WFrag<NFB>& wfirst,
-                                            const float4* next_lane_ptr, WFrag<NFB_NEXT>& wnext PH_PARAMS) {
+                                            const float4* next_lane_ptr, const float* next_lane_bias,
+                                            WFrag<NFB_NEXT>& wnext PH_PARAMS) {
     const int h = lane >> 5, c = lane & 31;
     const int s0 = sb0 * 32 + c;  // this lane's sample column within the tile (+ sb*32)
-    // bias of this lane's features (register 4q+r of a block <-> feature n0 + fb*32 + 8q + 4h + r):
-    // issued now, consumed in the epilogue
-    const float* bias = base + b_off;
-    float4 bv[NFB][4];
+    f32x16 cinit[NFB];
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bv[fb][q] = *reinterpret_cast<const float4*>(bias + n0 + fb * 32 + 8 * q + 4 * h);
+        for (int q = 0; q < 4; ++q) {
+            cinit[fb][4 * q + 0] = wfirst.b[fb][q].x;
+            cinit[fb][4 * q + 1] = wfirst.b[fb][q].y;
+            cinit[fb][4 * q + 2] = wfirst.b[fb][q].z;
+            cinit[fb][4 * q + 3] = wfirst.b[fb][q].w;
+        }
     f32x16 acc[NFB][NSB];
     const float4* wp = weight_lane_ptr(base, w_off, n_total, n0, lane);
-    mma_segment<TM, NFB, NSB, true>(acc, wfirst, wp, n_total, inA + h * TM + s0, kqA / 2);
+    mma_segment<TM, NFB, NSB, true>(acc, wfirst.w, cinit, wp, n_total, inA + h * TM + s0, kqA / 2);
     if (kqB > 0) {
-        WFrag<NFB> wseg;
-        load_wfrag<NFB>(wseg, wp + (int64_t)kqA * n_total);
-        mma_segment<TM, NFB, NSB, false>(acc, wseg, wp + (int64_t)kqA * n_total, n_total, inB + h * TM + s0, kqB / 2);
+        float4 wseg[NFB];
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) wseg[fb] = (wp + (int64_t)kqA * n_total)[fb * 32];
+        mma_segment<TM, NFB, NSB, false>(acc, wseg, cinit, wp + (int64_t)kqA * n_total, n_total, inB + h * TM + s0,
+                                         kqB / 2);
     }
-    load_wfrag<NFB_NEXT>(wnext, next_lane_ptr);
+    load_wfrag<NFB_NEXT>(wnext, next_lane_ptr, next_lane_bias);
     PH(PH_MMA);
     // every wave has finished READING the input tile before anyone overwrites it (out may alias inA)
     __syncthreads();
@@ -304,10 +314,10 @@ __device__ __forceinline__ void dense_layer(const float* __restrict__ base, int6
 #pragma unroll
             for (int sb = 0; sb < NSB; ++sb) {
                 float4 v;
-                v.x = acc[fb][sb][4 * q + 0] + bv[fb][q].x;
-                v.y = acc[fb][sb][4 * q + 1] + bv[fb][q].y;
-                v.z = acc[fb][sb][4 * q + 2] + bv[fb][q].z;
-                v.w = acc[fb][sb][4 * q + 3] + bv[fb][q].w;
+                v.x = acc[fb][sb][4 * q + 0];
+                v.y = acc[fb][sb][4 * q + 1];
+                v.z = acc[fb][sb][4 * q + 2];
+                v.w = acc[fb][sb][4 * q + 3];
                 if (RELU) {
                     v.x = fmaxf(v.x, 0.f);
                     v.y = fmaxf(v.y, 0.f);
@@ -389,11 +399,12 @@ struct WaveSplit {
 
 // DENSE(TM, NW, N, N_NEXT, <dense_layer args up to `out`>, wfirst, next_w_off, wnext): one layer with N outputs;
 // prefetches step 0 of the following layer (N_NEXT outputs, packed at next_w_off) into wnext.
-#define DENSE(TM_, NW_, N_, NN_, BASE_, WOFF_, BOFF_, INA_, KQA_, INB_, KQB_, OUT_, WFIRST_, NEXT_WOFF_, WNEXT_)            \
+#define DENSE(TM_, NW_, N_, NN_, BASE_, WOFF_, BOFF_, INA_, KQA_, INB_, KQB_, OUT_, WFIRST_, NEXT_WOFF_, NEXT_BOFF_, WNEXT_) \
     dense_layer<TM_, WaveSplit<TM_, NW_, N_>::NFB, WaveSplit<TM_, NW_, N_>::NSB, true, WaveSplit<TM_, NW_, NN_>::NFB>(   \
         BASE_, WOFF_, BOFF_, N_, INA_, KQA_, INB_, KQB_, OUT_, WaveSplit<TM_, NW_, N_>::n0(wave),                        \
         WaveSplit<TM_, NW_, N_>::sb0(wave), lane, WFIRST_,                                                               \
-        weight_lane_ptr(BASE_, NEXT_WOFF_, NN_, WaveSplit<TM_, NW_, NN_>::n0(wave), lane), WNEXT_ PH_ARGS)
+        weight_lane_ptr(BASE_, NEXT_WOFF_, NN_, WaveSplit<TM_, NW_, NN_>::n0(wave), lane),                               \
+        (BASE_) + (NEXT_BOFF_) + WaveSplit<TM_, NW_, NN_>::n0(wave) + 4 * (lane >> 5), WNEXT_ PH_ARGS)
 
 template <int TM, int NW, bool USE_TIME>
 __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_kernel(SpaceArgs a) {
@@ -417,7 +428,8 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_ke
     // tile by the previous tile's last layer)
     WFrag<WaveSplit<TM, NW, 256>::NFB> wA, wB;
     WFrag<WaveSplit<TM, NW, 128>::NFB> wR;
-    load_wfrag(wA, weight_lane_ptr(a.net, L.w[0], 256, WaveSplit<TM, NW, 256>::n0(wave), lane));
+    load_wfrag(wA, weight_lane_ptr(a.net, L.w[0], 256, WaveSplit<TM, NW, 256>::n0(wave), lane),
+               a.net + L.b[0] + WaveSplit<TM, NW, 256>::n0(wave) + 4 * (lane >> 5));
 
     for (int64_t tile = blockIdx.x; tile * TM < rows; tile += gridDim.x) {
         PH(PH_MISC);
@@ -468,19 +480,19 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_ke
         __syncthreads();
         PH(PH_BAR2);
         // ---- stage1 (modeling/spacenet.py:45-54)
-        DENSE(TM, NW, 256, 256, net, L.w[0], L.b[0], enc, 16, nullptr, 0, act, wA, L.w[1], wB);
+        DENSE(TM, NW, 256, 256, net, L.w[0], L.b[0], enc, 16, nullptr, 0, act, wA, L.w[1], L.b[1], wB);
         __syncthreads();
         PH(PH_BAR2);
-        DENSE(TM, NW, 256, 256, net, L.w[1], L.b[1], act, 64, nullptr, 0, act, wB, L.w[2], wA);
+        DENSE(TM, NW, 256, 256, net, L.w[1], L.b[1], act, 64, nullptr, 0, act, wB, L.w[2], L.b[2], wA);
         __syncthreads();
         PH(PH_BAR2);
-        DENSE(TM, NW, 256, 256, net, L.w[2], L.b[2], act, 64, nullptr, 0, act, wA, L.w[3], wB);
+        DENSE(TM, NW, 256, 256, net, L.w[2], L.b[2], act, 64, nullptr, 0, act, wA, L.w[3], L.b[3], wB);
         __syncthreads();
         PH(PH_BAR2);
-        DENSE(TM, NW, 256, 256, net, L.w[3], L.b[3], act, 64, nullptr, 0, act, wB, L.w[4], wA);
+        DENSE(TM, NW, 256, 256, net, L.w[3], L.b[3], act, 64, nullptr, 0, act, wB, L.w[4], L.b[4], wA);
         __syncthreads();
         // ---- stage2.0 on [h, PE(pos)] (:56-57, :137)
-        DENSE(TM, NW, 256, 256, net, L.w[4], L.b[4], act, 64, enc, 16, act, wA, L.w[5], wB);
+        DENSE(TM, NW, 256, 256, net, L.w[4], L.b[4], act, 64, enc, 16, act, wA, L.w[5], L.b[5], wB);
         // enc is free now (all waves passed the barrier inside dense_layer): write
         // relu(PE_4(dir)) (27) and relu(PE_10(time)) (21) -> enc features 0..47  (:80-86, :141-149)
         {
@@ -524,10 +536,10 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_ke
         PH(PH_ENC2);
         __syncthreads();
         PH(PH_BAR2);
-        DENSE(TM, NW, 256, 256, net, L.w[5], L.b[5], act, 64, nullptr, 0, act, wB, L.w[6], wA);
+        DENSE(TM, NW, 256, 256, net, L.w[5], L.b[5], act, 64, nullptr, 0, act, wB, L.w[6], L.b[6], wA);
         __syncthreads();
         PH(PH_BAR2);
-        DENSE(TM, NW, 256, 128, net, L.w[6], L.b[6], act, 64, nullptr, 0, act, wA, L.w_rgb1, wR);
+        DENSE(TM, NW, 256, 128, net, L.w[6], L.b[6], act, 64, nullptr, 0, act, wA, L.w_rgb1, L.b_rgb1, wR);
         __syncthreads();
         PH(PH_BAR2);
         // ---- sigma = density_net(h) (:139), raw
@@ -544,7 +556,7 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_ke
         PH(PH_HEAD);
         // ---- rgb_net: relu -> Linear(283|304,128) -> relu -> Linear(128,3)   (:80-86)
         // (h is already >= 0; the encodings were clamped when written)
-        DENSE(TM, NW, 128, 256, net, L.w_rgb1, L.b_rgb1, act, 64, enc, L.kq_rgb1 - 64, act, wR, L.w[0], wA);  // + next tile's layer 0
+        DENSE(TM, NW, 128, 256, net, L.w_rgb1, L.b_rgb1, act, 64, enc, L.kq_rgb1 - 64, act, wR, L.w[0], L.b[0], wA);  // + next tile's layer 0
         __syncthreads();
         {
             float ps[3];
@@ -612,7 +624,8 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_k
     const int ns = a.wl.ns;
     PH_DECL
     WFrag<WaveSplit<TM, NW, 128>::NFB> wA, wB;  // step-0 weights, prefetched one layer ahead
-    load_wfrag(wA, weight_lane_ptr(a.net, L.w[0], 128, WaveSplit<TM, NW, 128>::n0(wave), lane));
+    load_wfrag(wA, weight_lane_ptr(a.net, L.w[0], 128, WaveSplit<TM, NW, 128>::n0(wave), lane),
+               a.net + L.b[0] + WaveSplit<TM, NW, 128>::n0(wave) + 4 * (lane >> 5));
 
     for (int64_t tile = blockIdx.x; tile * TM < rows; tile += gridDim.x) {
         int64_t opaque_zero = 0;  // see spacenet_kernel
@@ -676,15 +689,15 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_k
             }
         }
         __syncthreads();
-        DENSE(TM, NW, 128, 128, net, L.w[0], L.b[0], enc, 22, nullptr, 0, act, wA, L.w[1], wB);
+        DENSE(TM, NW, 128, 128, net, L.w[0], L.b[0], enc, 22, nullptr, 0, act, wA, L.w[1], L.b[1], wB);
         __syncthreads();
-        DENSE(TM, NW, 128, 128, net, L.w[1], L.b[1], act, 32, nullptr, 0, act, wB, L.w[2], wA);
+        DENSE(TM, NW, 128, 128, net, L.w[1], L.b[1], act, 32, nullptr, 0, act, wB, L.w[2], L.b[2], wA);
         __syncthreads();
-        DENSE(TM, NW, 128, 128, net, L.w[2], L.b[2], act, 32, nullptr, 0, act, wA, L.w[3], wB);
+        DENSE(TM, NW, 128, 128, net, L.w[2], L.b[2], act, 32, nullptr, 0, act, wA, L.w[3], L.b[3], wB);
         __syncthreads();
-        DENSE(TM, NW, 128, 128, net, L.w[3], L.b[3], act, 32, nullptr, 0, act, wB, L.w[4], wA);
+        DENSE(TM, NW, 128, 128, net, L.w[3], L.b[3], act, 32, nullptr, 0, act, wB, L.w[4], L.b[4], wA);
         __syncthreads();
-        DENSE(TM, NW, 128, 128, net, L.w[4], L.b[4], act, 32, nullptr, 0, act, wA, L.w[0], wB);  // + next tile's layer 0
+        DENSE(TM, NW, 128, 128, net, L.w[4], L.b[4], act, 32, nullptr, 0, act, wA, L.w[0], L.b[0], wB);  // + next tile's layer 0
         wA = wB;
         __syncthreads();
         {
@@ -739,17 +752,19 @@ static int grid_for(int64_t n_rays, int ns, int tm) {
 //   "128"   128 samples, 4 waves, 160 KiB LDS, 1 workgroup per CU (one wave per SIMD)
 //   "128x8" 128 samples, 8 waves (two per SIMD: the VALU phases of one hide in the issue gaps of the other)
 //   "64"    64 samples, 4 waves, 80 KiB LDS, 2 workgroups per CU
+// Measured on MI355X (tools/bench_mlp.py, 8.4 M rows): SpaceNet 138 / 141 / 137 TF/s, MotionNet 120 / 121 / 127 TF/s
+// for "128" / "128x8" / "64" -> defaults: SpaceNet 128x8, MotionNet 64.
 enum TileCfg { TILE_128 = 0, TILE_128X8 = 1, TILE_64 = 2 };
-static TileCfg tile_config() {
-    static int cfg = -1;
-    if (cfg < 0) {
+static TileCfg tile_config(TileCfg dflt) {
+    static int cfg = -2;
+    if (cfg == -2) {
         const char* e = getenv("STNERF_TILE");
-        cfg = STNERF_DEFAULT_TILE;
+        cfg = -1;
         if (e && !strcmp(e, "128")) cfg = TILE_128;
         if (e && !strcmp(e, "128x8")) cfg = TILE_128X8;
         if (e && !strcmp(e, "64")) cfg = TILE_64;
     }
-    return (TileCfg)cfg;
+    return cfg < 0 ? dflt : (TileCfg)cfg;
 }
 
 // One-time LDS opt-in + launch.  `slot` identifies the instantiation (static flags per kernel).
@@ -852,7 +867,7 @@ extern "C" int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays,
     static bool opted[3][2] = {{false, false}, {false, false}, {false, false}};
     SpaceArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, dirs,
                 dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride};
-    const TileCfg tc = tile_config();
+    const TileCfg tc = tile_config(TILE_128X8);
     const int tm = tc == TILE_64 ? 64 : 128;
     const int lds = (64 + 16) * tm * 16;
     const int grid = grid_for(n_rays, ns, tm);
@@ -883,7 +898,7 @@ extern "C" int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, 
     static bool opted[3] = {false, false, false};
     MotionArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, times,
                  times_ray_stride, flow, flow_ray_stride, add_to_xyz};
-    const TileCfg tc = tile_config();
+    const TileCfg tc = tile_config(TILE_64);
     const int grid = grid_for(n_rays, ns, tc == TILE_64 ? 64 : 128);
     const char* what = "motionnet_fwd";
     switch (tc) {
