@@ -126,6 +126,18 @@ int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32
                          const float* times, int64_t times_ray_stride, float* flow,
                          int64_t flow_ray_stride, int add_to_xyz, stnerf_stream_t stream);
 
+/* a7 standalone: NeRF positional encoding [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)],
+ * each block `dim` wide.  utils/dimension_kernel.py:3-73 (Trigonometric_kernel.__call__).  In the render
+ * path the encoding is fused into the MLP kernels; this entry point serves the op-level API.
+ * x[n][dim] -> y[n][dim*(include_input + 2*n_freq)].  Same < 1 ulp sin/cos as the fused kernels. */
+int stnerf_encode(const float* x, int64_t n, int dim, int n_freq, int include_input, float* y,
+                  stnerf_stream_t stream);
+
+/* a12 standalone: gen_weight(sigma, delta), layers/render_layer.py:8-17.  sigma[n][S] raw, delta[n][S]
+ * -> weights[n][S] = alpha * exclusive cumprod(1 - alpha + 1e-10), alpha = 1 - exp(-relu(sigma) delta). */
+int stnerf_gen_weight(const float* sigma, const float* delta, int64_t n, int S, float* weights,
+                      stnerf_stream_t stream);
+
 /* a10 + a11 + a12: post-network density edits, per-layer composite, cross-layer merge by depth
  * and merged composite, one pass per ray.  layers/render_layer.py:8-58 (gen_weight,
  * VolumeRenderer.forward); modeling/layered_rfrender.py:414-448 (coarse), :538-606 (fine). */

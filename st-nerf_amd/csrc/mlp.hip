@@ -734,6 +734,31 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_k
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stand-alone positional encoding (op-level API; the render path uses the fused prologues above)
+// ---------------------------------------------------------------------------------------------
+__global__ void encode_kernel(const float* __restrict__ x, int64_t n, int dim, int n_freq, int include_input,
+                              float* __restrict__ y) {
+    const int out_dim = dim * (include_input + 2 * n_freq);
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per output element
+    if (e >= n * out_dim) return;
+    const int64_t row = e / out_dim;
+    int f = (int)(e - row * out_dim);
+    const float* xr = x + row * dim;
+    if (include_input) {
+        if (f < dim) {
+            y[e] = xr[f];
+            return;
+        }
+        f -= dim;
+    }
+    const int fq = f / (2 * dim), w = f - fq * 2 * dim;
+    const int d = w % dim;
+    float sn, cs;
+    sincos_pe(xr[d] * (float)(1 << fq), sn, cs);
+    y[e] = w < dim ? sn : cs;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
 // (out,in) row-major -> [ceil(in/4) (padded to kq)][out][4], zero padded.
@@ -850,6 +875,19 @@ extern "C" int stnerf_pack_net(int kind, const float* const* W, const float* con
     }
     set_error("pack_net: unknown net kind %d", kind);
     return STNERF_EINVAL;
+}
+
+extern "C" int stnerf_encode(const float* x, int64_t n, int dim, int n_freq, int include_input, float* y,
+                             stnerf_stream_t stream) {
+    STNERF_REQUIRE(x && y, "encode: null pointer");
+    STNERF_REQUIRE(n >= 0 && dim >= 1 && n_freq >= 0 && n_freq <= 30 && (include_input == 0 || include_input == 1),
+                   "encode: bad shape n=%lld dim=%d n_freq=%d", (long long)n, dim, n_freq);
+    const int64_t tot = n * dim * (include_input + 2 * n_freq);
+    if (tot == 0) return STNERF_OK;
+    hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, as_stream(stream), x, n, dim,
+                       n_freq, include_input, y);
+    STNERF_CHECK_LAUNCH("encode");
+    return STNERF_OK;
 }
 
 extern "C" int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,

@@ -98,6 +98,28 @@ __device__ __forceinline__ void composite_run(int count, float border, int lane,
     out[4] = wave_sum(ca);
 }
 
+// gen_weight stand-alone: one wave per row.
+__global__ void gen_weight_kernel(const float* __restrict__ sigma, const float* __restrict__ delta, int64_t n, int S,
+                                  float* __restrict__ weights) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float carry = 1.f;
+    for (int base = 0; base < S; base += 64) {
+        const int k = base + lane;
+        float tr = 1.f, alpha = 0.f;
+        if (k < S) {
+            alpha = 1.f - expf(-fmaxf(sigma[row * S + k], 0.f) * delta[row * S + k]);
+            tr = (1.f - alpha) + 1e-10f;
+        }
+        const float incl = wave_scan_mul(tr, lane);
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.f;
+        if (k < S) weights[row * S + k] = alpha * (carry * excl);
+        carry = carry * __shfl(incl, 63);
+    }
+}
+
 struct CompositeArgs {
     const float* t;
     const float4* raw;
@@ -338,6 +360,17 @@ __global__ void resample_kernel(ResampleArgs a) {
 }  // namespace stnerf
 
 using namespace stnerf;
+
+extern "C" int stnerf_gen_weight(const float* sigma, const float* delta, int64_t n, int S, float* weights,
+                                 stnerf_stream_t stream) {
+    STNERF_REQUIRE(sigma && delta && weights, "gen_weight: null pointer");
+    STNERF_REQUIRE(n >= 0 && S >= 1, "gen_weight: bad shape");
+    if (n == 0) return STNERF_OK;
+    hipLaunchKernelGGL(gen_weight_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), sigma, delta, n,
+                       S, weights);
+    STNERF_CHECK_LAUNCH("gen_weight");
+    return STNERF_OK;
+}
 
 extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t* mask, int64_t n, int l, int S,
                                 const stnerf_composite_params* params_host, float* layer_out, float* mixed_out,

@@ -50,6 +50,8 @@ _PROTOS = {
                                       c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, C.c_void_p]),
     "stnerf_motionnet_fwd": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_i64, c_f32p,
                                        c_i64, c_f32p, c_i64, C.c_int, C.c_void_p]),
+    "stnerf_encode": (C.c_int, [c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
+    "stnerf_gen_weight": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "stnerf_composite": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_i64, C.c_int, C.c_int, C.POINTER(CompositeParams),
                                    c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
     "stnerf_resample": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_uint64, c_i64, c_f32p,

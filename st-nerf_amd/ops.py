@@ -234,6 +234,26 @@ def motionnet_fwd(net: PackedNet, xyz: Tensor, times: Tensor, flow: Optional[Ten
     return flow
 
 
+def encode(x: Tensor, n_freq: int, include_input: bool = True) -> Tensor:
+    """Positional encoding of x (..., dim) -> (..., dim*(include_input + 2*n_freq)); utils/dimension_kernel.py:3-73."""
+    dim = x.shape[-1]
+    flat = x.reshape(-1, dim).contiguous()
+    y = torch.empty(flat.shape[0], dim * (int(include_input) + 2 * n_freq), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().stnerf_encode(hip.dptr(flat, name="x"), flat.shape[0], dim, n_freq, int(include_input),
+                                      hip.dptr(y), hip.stream_ptr()), "stnerf_encode")
+    return y.reshape(*x.shape[:-1], y.shape[-1])
+
+
+def gen_weight(sigma: Tensor, delta: Tensor) -> Tensor:
+    """sigma (n,S) raw, delta (n,S) -> weights (n,S); layers/render_layer.py:8-17."""
+    n, S = delta.shape
+    sg = sigma.reshape(n, S).contiguous()
+    w = torch.empty(n, S, dtype=torch.float32, device=delta.device)
+    hip.check(hip.lib().stnerf_gen_weight(hip.dptr(sg, name="sigma"), hip.dptr(delta.contiguous(), name="delta"), n, S,
+                                          hip.dptr(w), hip.stream_ptr()), "stnerf_gen_weight")
+    return w
+
+
 # ---------------------------------------------------------------------------------------- a10-a13
 def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e10, near: float = 0.0,
               fine: bool = False, cut_negative_t: bool = False, thresholds: Optional[Sequence[Optional[float]]] = None,

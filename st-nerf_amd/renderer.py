@@ -111,6 +111,40 @@ class MotionNet(nn.Module, _PackedMixin):
         return flow.reshape(*input_0.shape[:-1], 3) if bins else flow.reshape(-1, 3)
 
 
+class Trigonometric_kernel:
+    """Positional encoding, utils/dimension_kernel.py:54-73 (same constructor, __call__ and calc_dim)."""
+
+    def __init__(self, L=10, input_dim=3, include_input=True):
+        self.L, self.input_dim, self.include_input = L, input_dim, include_input
+        self.out_ch = input_dim * (int(include_input) + 2 * L)
+
+    def __call__(self, x):
+        return ops.encode(x, self.L, self.include_input)
+
+    def calc_dim(self, dims=0):
+        return self.out_ch
+
+
+def gen_weight(sigma, delta, act_fn=None):
+    """layers/render_layer.py:8-17 (act_fn is relu, as everywhere in the reference)."""
+    if act_fn is not None and act_fn is not torch.nn.functional.relu:
+        raise NotImplementedError("gen_weight: only the relu activation of the reference is implemented")
+    return ops.gen_weight(sigma.squeeze(-1) if sigma.dim() == delta.dim() + 1 else sigma, delta)
+
+
+def load_reference_checkpoint(model, path, map_location="cuda"):
+    """Load a reference ``layered_rfnr_checkpoint_N.pt`` ({'model': state_dict, ...}); keys the checkpoint
+    lacks keep the model's current values, as render/layered_neural_renderer.py:110-117 does."""
+    ckpt = torch.load(path, map_location=map_location)
+    sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
+    own = model.state_dict()
+    for k, v in own.items():
+        if k not in sd:
+            sd[k] = v
+    model.load_state_dict({k: v for k, v in sd.items() if k in own})
+    return model
+
+
 # ------------------------------------------------------------------------------------ op-level layers
 class RaySamplePoint(nn.Module):
     """layers/RaySamplePoint.py:64-107.  ``jitter`` (l,n,N) replays given uniform draws; otherwise the

@@ -366,3 +366,19 @@ def test_resample_random_layers_edits_and_device_rng(ops):
     tb, _ = ops.resample(dev(t[100:300]), dev(w[100:300]), n2, dev(rays[100:300]), seed=99, ray_index_base=100)
     assert torch.equal(ta[100:300], tb)
     assert bool((ta[..., 1:] >= ta[..., :-1]).all())
+
+
+def test_encode_and_gen_weight_op_level(ops):
+    _, a = load_golden("encoding")
+    for tag, nf in (("pos", 10), ("dir", 4), ("time", 10), ("motion", 10)):
+        y = ops.encode(dev(a[f"x_{tag}"]), nf)
+        torch.testing.assert_close(y.cpu(), a[f"y_{tag}"], rtol=0, atol=2.5e-7)   # < 1 ulp-of-1 sin/cos
+        assert torch.equal(y[:, : a[f"x_{tag}"].shape[1]].cpu(), a[f"x_{tag}"])
+    meta, c = load_golden("composite")
+    t = c["t"]
+    delta = torch.cat([(t[:, 1:] - t[:, :-1]).squeeze(-1), 1e10 * torch.ones(t.shape[0], 1)], -1)
+    w = ops.gen_weight(dev(c["sigma"].squeeze(-1)), dev(delta))
+    torch.testing.assert_close(w.cpu(), c["gen_weight"], rtol=1e-5, atol=1e-7)
+    from stnerf_amd.utils import Trigonometric_kernel
+    tk = Trigonometric_kernel(L=10, input_dim=3)
+    assert tk.calc_dim(3) == 63 and tk(dev(a["x_pos"])).shape == (16, 63)
