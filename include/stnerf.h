@@ -117,6 +117,24 @@ int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays, int ns, co
                         int64_t times_ray_stride, float* raw, int64_t raw_ray_stride,
                         stnerf_stream_t stream);
 
+/* "fp16x3" variant of the SpaceNet kernel: fp32-accurate matrix products on the fp16 MFMA pipe.  Every
+ * fp32 operand is split x = hi + lo into two fp16 numbers (22 significand bits) and a*b is evaluated as
+ * ah*bh + ah*bl + al*bh with fp32 accumulation (exact fp16 products); encodings, bias, ReLU, heads and
+ * outputs stay fp32.  Same work list, layouts and parity tolerances as stnerf_spacenet_fwd; needs its own
+ * packed blob (stnerf_packed_bytes_f16x3 / stnerf_pack_net_f16x3; |W| must be < 234).  All three net kinds. */
+int64_t stnerf_packed_bytes_f16x3(int kind);
+int stnerf_pack_net_f16x3(int kind, const float* const* weights_host, const float* const* biases_host,
+                          int n_tensors, void* dst_host, int64_t dst_bytes);
+int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
+                              const int32_t* ray_count, const float* xyz, int64_t xyz_ray_stride,
+                              const float* dirs, int64_t dirs_ray_stride, const float* times,
+                              int64_t times_ray_stride, float* raw, int64_t raw_ray_stride,
+                              stnerf_stream_t stream);
+int stnerf_motionnet_fwd_f16x3(const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
+                               const int32_t* ray_count, float* xyz, int64_t xyz_ray_stride,
+                               const float* times, int64_t times_ray_stride, float* flow,
+                               int64_t flow_ray_stride, int add_to_xyz, stnerf_stream_t stream);
+
 /* a7 + a8: fused positional encoding (with the fractional-time lerp) + MotionNet MLP.
  * modeling/motion_net.py:34-71.  Same work list as above.  flow (may be NULL) gets the 3-vector at
  * flow + j*flow_ray_stride + 3k; if add_to_xyz the point is updated in place (xyz += flow), which

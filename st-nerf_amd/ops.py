@@ -123,20 +123,29 @@ SPACENET_KEYS = ["stage1.0", "stage1.2", "stage1.4", "stage1.6", "stage2.0", "st
 MOTIONNET_KEYS = [f"motion_net.{j}" for j in (0, 2, 4, 6, 8, 10)]
 
 
+PRECISIONS = ("fp32", "fp16x3")
+
+
 class PackedNet:
     """Kernel-layout weights of one network, resident on the device."""
 
-    def __init__(self, kind: int, blob: Tensor):
-        self.kind, self.blob = kind, blob
+    def __init__(self, kind: int, blob: Tensor, precision: str = "fp32"):
+        self.kind, self.blob, self.precision = kind, blob, precision
 
     @property
     def use_time(self) -> bool:
         return self.kind == hip.NET_SPACE_TIME
 
 
-def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cuda") -> PackedNet:
-    """Repack reference-layout nn.Linear tensors (host copy) and upload."""
-    nbytes = hip.lib().stnerf_packed_bytes(kind)
+def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cuda", precision: str = "fp32") -> PackedNet:
+    """Repack reference-layout nn.Linear tensors (host copy) and upload.  precision: "fp32" (exact f32 MFMA)
+    or "fp16x3" (fp32-accurate split-fp16 MFMA; SpaceNet only)."""
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
+    f16 = precision == "fp16x3"
+    size_fn = hip.lib().stnerf_packed_bytes_f16x3 if f16 else hip.lib().stnerf_packed_bytes
+    pack_fn = hip.lib().stnerf_pack_net_f16x3 if f16 else hip.lib().stnerf_pack_net
+    nbytes = size_fn(kind)
     if nbytes < 0:
         hip.check(int(nbytes), "stnerf_packed_bytes")
     ws = [w.detach().to("cpu", torch.float32).contiguous() for w in weights]
@@ -144,24 +153,24 @@ def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cud
     host = torch.empty(nbytes // 4, dtype=torch.float32)
     wp = (C.c_void_p * len(ws))(*(w.data_ptr() for w in ws))
     bp = (C.c_void_p * len(bs))(*(b.data_ptr() for b in bs))
-    hip.check(hip.lib().stnerf_pack_net(kind, wp, bp, len(ws), C.c_void_p(host.data_ptr()), nbytes), "stnerf_pack_net")
-    return PackedNet(kind, host.to(device))
+    hip.check(pack_fn(kind, wp, bp, len(ws), C.c_void_p(host.data_ptr()), nbytes), "stnerf_pack_net")
+    return PackedNet(kind, host.to(device), precision)
 
 
-def pack_spacenet(state: dict, prefix: str, device="cuda") -> PackedNet:
+def pack_spacenet(state: dict, prefix: str, device="cuda", precision: str = "fp32") -> PackedNet:
     """From reference state_dict keys ``{prefix}.stage1.0.weight`` ...."""
     ws = [state[f"{prefix}.{k}.weight"] for k in SPACENET_KEYS]
     bs = [state[f"{prefix}.{k}.bias"] for k in SPACENET_KEYS]
     in1 = ws[8].shape[1]
     if in1 not in (283, 304):
         raise ValueError(f"{prefix}.rgb_net.1 has in-width {in1}; only USE_DIR with/without time is supported")
-    return pack_net(hip.NET_SPACE_TIME if in1 == 304 else hip.NET_SPACE, ws, bs, device)
+    return pack_net(hip.NET_SPACE_TIME if in1 == 304 else hip.NET_SPACE, ws, bs, device, precision)
 
 
-def pack_motionnet(state: dict, prefix: str, device="cuda") -> PackedNet:
+def pack_motionnet(state: dict, prefix: str, device="cuda", precision: str = "fp32") -> PackedNet:
     ws = [state[f"{prefix}.{k}.weight"] for k in MOTIONNET_KEYS]
     bs = [state[f"{prefix}.{k}.bias"] for k in MOTIONNET_KEYS]
-    return pack_net(hip.NET_MOTION, ws, bs, device)
+    return pack_net(hip.NET_MOTION, ws, bs, device, precision)
 
 
 # Optional launch observer (bench.py): called as fn(name, kind, n_rays, ns, ray_count, start_evt, end_evt)
@@ -210,9 +219,10 @@ def spacenet_fwd(net: PackedNet, xyz: Tensor, dirs: Tensor, times: Optional[Tens
     else:
         tp, ts = C.c_void_p(0), 0
     lp, cp = _worklist(ray_list, ray_count)
+    fwd = hip.lib().stnerf_spacenet_fwd_f16x3 if net.precision == "fp16x3" else hip.lib().stnerf_spacenet_fwd
     with _Observed("spacenet", net.kind, n, ns, ray_count):
-        hip.check(hip.lib().stnerf_spacenet_fwd(net.kind, hip.dptr(net.blob), n, ns, lp, cp, xp, xs, dp, ds, tp, ts,
-                                                rp, rs, hip.stream_ptr()), "stnerf_spacenet_fwd")
+        hip.check(fwd(net.kind, hip.dptr(net.blob), n, ns, lp, cp, xp, xs, dp, ds, tp, ts,
+                      rp, rs, hip.stream_ptr()), "stnerf_spacenet_fwd")
     return raw
 
 
@@ -228,8 +238,9 @@ def motionnet_fwd(net: PackedNet, xyz: Tensor, times: Tensor, flow: Optional[Ten
     else:
         fp, fs = C.c_void_p(0), 0
     lp, cp = _worklist(ray_list, ray_count)
+    fwd = hip.lib().stnerf_motionnet_fwd_f16x3 if net.precision == "fp16x3" else hip.lib().stnerf_motionnet_fwd
     with _Observed("motionnet", net.kind, n, ns, ray_count):
-        hip.check(hip.lib().stnerf_motionnet_fwd(hip.dptr(net.blob), n, ns, lp, cp, xp, xs, tp, ts, fp, fs,
+        hip.check(fwd(hip.dptr(net.blob), n, ns, lp, cp, xp, xs, tp, ts, fp, fs,
                                                  1 if add_to_xyz else 0, hip.stream_ptr()), "stnerf_motionnet_fwd")
     return flow
 

@@ -1,0 +1,107 @@
+"""The "fp16x3" SpaceNet kernel (fp32-accurate split-fp16 MFMA) against the same oracle, with the SAME stated
+tolerances as the exact-fp32 kernel.  Needs an MI355X: `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stnerf_oracle as O
+from stnerf_amd import synthetic as syn
+from test_gpu_ops import NET_ATOL, NET_RTOL, _net_close, dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from stnerf_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("use_time", [False, True])
+def test_spacenet_f16x3_vs_fp64_oracle(ops, use_time):
+    torch.manual_seed(11)
+    rs = np.random.RandomState(5)
+    sd = syn.spacenet_state("net", rs, use_time)
+    n, s = 700, 13
+    pos = (torch.rand(n, s, 3) - 0.5) * 6.0
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
+    times = torch.rand(n) * 100 + 1
+    net = ops.pack_spacenet(sd, "net", precision="fp16x3")
+    raw = torch.full((n, s, 4), float("nan"), device="cuda")
+    ops.spacenet_fwd(net, dev(pos), dev(dirs), dev(times) if use_time else None, raw)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    rgb64, sig64 = O.space_net(sd64, "net", pos.double(), dirs.double(), times.double().reshape(-1, 1) if use_time else None)
+    _net_close(raw[..., :3].cpu(), rgb64, 4.0, "rgb")
+    _net_close(raw[..., 3:].cpu(), sig64, 60.0, "sigma")
+    # accuracy class: no worse than 4x the fp32 CPU chain's own error vs fp64 (same bar as the fp32 kernel)
+    rgb32, sig32 = O.space_net(sd, "net", pos, dirs, times.reshape(-1, 1) if use_time else None)
+    e_gpu = float((raw[..., 3:].cpu().double() - sig64).abs().max())
+    e_cpu = float((sig32.double() - sig64).abs().max())
+    print(f"sigma max err: fp16x3 {e_gpu:.3e}  fp32 CPU chain {e_cpu:.3e}")
+    assert e_gpu <= 4 * e_cpu + 1e-6, (e_gpu, e_cpu)
+    # the exact-fp32 kernel on the same inputs agrees to fp32 rounding
+    net32 = ops.pack_spacenet(sd, "net")
+    raw32 = torch.empty_like(raw)
+    ops.spacenet_fwd(net32, dev(pos), dev(dirs), dev(times) if use_time else None, raw32)
+    torch.testing.assert_close(raw, raw32, rtol=2e-5, atol=2e-4)
+
+
+def test_spacenet_f16x3_worklist_determinism_and_untouched_rows(ops):
+    torch.manual_seed(12)
+    rs = np.random.RandomState(6)
+    sd = syn.spacenet_state("net", rs, True)
+    n, l, s = 500, 3, 10
+    xyz = (torch.rand(n, l, s, 3) - 0.5) * 4.0
+    rays = torch.cat([torch.zeros(n, 3), torch.nn.functional.normalize(torch.randn(n, 3), dim=-1), torch.rand(n, l) * 5], -1)
+    mask = (torch.rand(n, l) < 0.4).to(torch.uint8)
+    net = ops.pack_spacenet(sd, "net", precision="fp16x3")
+    dx, dr, dm = dev(xyz), dev(rays), dev(mask)
+    lst, cnt = ops.compact_rays(dm)
+    layer = 2
+    outs = []
+    for _ in range(2):
+        raw = torch.full((n, l, s, 4), 7.0, device="cuda")
+        ops.spacenet_fwd(net, dx[:, layer], dr[:, 3:6], dr[:, 6 + layer], raw[:, layer], ray_list=lst[layer],
+                         ray_count=cnt[layer:layer + 1])
+        outs.append(raw)
+    assert torch.equal(outs[0], outs[1])
+    idx = mask[:, layer].bool()
+    rgb, sig = O.space_net(sd, "net", xyz[idx, layer], rays[idx, 3:6], rays[idx, 6 + layer].reshape(-1, 1))
+    rc = outs[0].cpu()
+    torch.testing.assert_close(rc[idx][:, layer, :, :3], rgb, rtol=2e-5, atol=1e-4)
+    torch.testing.assert_close(rc[idx][:, layer, :, 3:], sig, rtol=2e-5, atol=2e-3)
+    assert bool((rc[~idx] == 7.0).all()) and bool((rc[:, :layer] == 7.0).all())
+
+
+def test_f16x3_rejects_weights_outside_the_split_range(ops):
+    sd = syn.spacenet_state("net", np.random.RandomState(1), False)
+    sd["net.stage1.2.weight"] = sd["net.stage1.2.weight"].clone()
+    sd["net.stage1.2.weight"][3, 5] = 400.0
+    with pytest.raises(ValueError, match="does not fit the fp16 split"):
+        ops.pack_spacenet(sd, "net", precision="fp16x3")
+
+
+def test_motionnet_f16x3_vs_fp64_oracle(ops):
+    torch.manual_seed(13)
+    rs = np.random.RandomState(7)
+    sd = syn.motionnet_state("net", rs)
+    n, s = 333, 9
+    pos = (torch.rand(n, s, 3) - 0.5) * 4.0
+    times = torch.where(torch.rand(n) < 0.5, torch.floor(torch.rand(n) * 50), torch.rand(n) * 50)
+    net = ops.pack_motionnet(sd, "net", precision="fp16x3")
+    flow = torch.empty(n, s, 3, device="cuda")
+    x = dev(pos)
+    ops.motionnet_fwd(net, x, dev(times), flow=flow, add_to_xyz=True)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    xt = torch.cat([pos, times.view(n, 1, 1).repeat(1, s, 1)], -1)
+    ref64 = O.motion_net(sd64, "net", xt.double())
+    _net_close(flow.cpu(), ref64, 1.0, "flow")
+    torch.testing.assert_close(x.cpu(), pos + flow.cpu(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["fwd_c1", "fwd_c3", "fwd_edit", "fwd_hide", "fwd_nonretime", "fwd_only_coarse",
+                                  "batchify_chunked", "batchify_small"])
+def test_whole_path_fp16x3_matches_reference_fixtures(name):
+    """The drop-in boundary in fp16x3 precision against the reference's own outputs: same tolerances as fp32."""
+    import test_gpu_render as R
+    R.run_forward_case(name, precision="fp16x3")

@@ -83,9 +83,13 @@ def flatten(out):
 
 @pytest.mark.parametrize("name", FWD_CASES)
 def test_forward_matches_reference(name):
+    run_forward_case(name, precision="fp32")
+
+
+def run_forward_case(name, precision):
     from stnerf_amd.utils import layered_batchify_ray
     meta, a = load_golden(name)
-    model = build_model(meta)
+    model = build_model(meta).set_precision(precision)
     rays = a["rays"].cuda()
     n = rays.shape[0]
     model.replay = assemble_replay(meta, a, n)

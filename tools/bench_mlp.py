@@ -13,8 +13,9 @@ dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1).cuda()
 times = (torch.rand(n) * 50).cuda()
 raw = torch.empty(n, ns, 4, device="cuda")
 res = {}
+prec = os.environ.get("PRECISION", "fp32")
 for name, kind_time, flop in (("space", False, 924672), ("space_time", True, 930048)):
-    net = ops.pack_spacenet(syn.spacenet_state("net", rs, kind_time), "net")
+    net = ops.pack_spacenet(syn.spacenet_state("net", rs, kind_time), "net", precision=prec)
     ops.spacenet_fwd(net, xyz, dirs, times if kind_time else None, raw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -34,4 +35,4 @@ for _ in range(iters):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 res["motion"] = (ms, n * ns * 153344 / ms / 1e9)
-print("TILE", os.environ.get("STNERF_TILE", "default"), " ".join(f"{k}: {v[0]:.2f} ms {v[1]:.1f} TF/s" for k, v in res.items()), "rows", n * ns)
+print(prec, "TILE", os.environ.get("STNERF_TILE", "default"), os.environ.get("STNERF_TILE_H", ""), " ".join(f"{k}: {v[0]:.2f} ms {v[1]:.1f} TF/s" for k, v in res.items()), "rows", n * ns)
