@@ -35,6 +35,7 @@ from stnerf_amd.parallel import gather_tiles          # noqa: E402
 
 # Algorithmic work per network evaluation: 2 * MACs of every nn.Linear.
 FLOP_SPACE, FLOP_SPACE_TIME, FLOP_MOTION = 924_672, 930_048, 153_344
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (spec, no sparsity)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
 
 WORKLOADS = {
@@ -132,6 +133,10 @@ def main():
     ap.add_argument("--workload", default="taekwondo-1080p-64+64", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-baseline-rays", type=int, default=7168, help="0 disables the CPU baseline leg")
     ap.add_argument("--rays-per-launch", type=int, default=1 << 17)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3"],
+                    help="arithmetic of the headline run: exact f32 MFMA (default) or fp32-accurate split-fp16 MFMA")
+    ap.add_argument("--no-second-precision", action="store_true",
+                    help="skip the extra (untimed-for-`value`) leg that measures the other precision mode")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,35 +180,50 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(-1 - i)
-    timer = KernelTimer()
-    ops.set_launch_observer(timer)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        tile, masks = step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    ops.set_launch_observer(None)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def measure(precision, steps, warmup):
+        """K timed steps (barrier + synchronize on both sides, MAX over ranks) in one precision mode."""
+        model.set_precision(precision)
+        for i in range(warmup):
+            step(-1 - i)
+        timer = KernelTimer()
+        ops.set_launch_observer(timer)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tile, masks = step(i)
+        fence()
+        elapsed = time.perf_counter() - t0
+        ops.set_launch_observer(None)
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        ksum = timer.summarise()  # this rank's launches over the timed steps
+        evals = sum(d["evals"] for name, d in ksum.items() if name == "spacenet")
+        if world > 1:
+            ev = torch.tensor([evals], dtype=torch.float64, device=device)
+            dist.all_reduce(ev)
+            evals_all = float(ev.item())
+        else:
+            evals_all = float(evals)
+        assert bool(torch.isfinite(tile).all()), "non-finite pixels in the rendered tile"
+        return elapsed, ksum, evals, evals_all, tile, masks
 
-    ksum = timer.summarise()  # this rank's launches over the K timed steps
-    evals = sum(d["evals"] for name, d in ksum.items() if name == "spacenet")
-    if world > 1:
-        ev = torch.tensor([evals], dtype=torch.float64, device=device)
-        dist.all_reduce(ev)
-        evals_all = float(ev.item())
-    else:
-        evals_all = float(evals)
-    assert bool(torch.isfinite(tile).all()), "non-finite pixels in the rendered tile"
+    elapsed, ksum, evals, evals_all, tile, masks = measure(args.precision, args.steps, args.warmup)
+    other = None
+    if not args.no_second_precision:
+        op = "fp16x3" if args.precision == "fp32" else "fp32"
+        o_el, o_ks, o_ev, o_eva, o_tile, _ = measure(op, max(1, min(args.steps, 2)), 1)
+        # same poses / seeds as the headline run's first steps: image agreement between the two arithmetic modes
+        other = dict(precision=op, steps=max(1, min(args.steps, 2)), elapsed=o_el, ksum=o_ks, evals_all=o_eva)
 
     if rank == 0:
         sp = ksum["spacenet"]
         achieved = sp["flop"] / (sp["ms"] * 1e-3) / 1e12
+        if args.precision == "fp16x3":   # executed MFMA work is 3 fp16 terms per algorithmic product
+            achieved, peak_used = 3.0 * achieved, PEAK_F16_MFMA_TFLOPS
+        else:
+            peak_used = PEAK_F32_MFMA_TFLOPS
         # HBM traffic cannot be counted inside this process: it comes from the committed rocprofv3 PMC passes
         # of the same command (profiles/), per launch, with the gfx950 FETCH_SIZE correction applied.
         traffic, traffic_src = None, None
@@ -219,8 +239,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "height": H, "width": W, "performer_layers": L,
+            "dtype": "f32" if args.precision == "fp32" else "f32-accurate products as 3 fp16 MFMA terms (22-bit split operands), f32 accumulate",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "precision": args.precision, "height": H, "width": W, "performer_layers": L,
                        "coarse_samples": n1, "fine_samples": n2, "use_space_time": st, "use_deform_time": dt,
                        "rays_per_gpu_per_step": n_rays, "rays_per_launch": args.rays_per_launch,
                        "weights": "random, density head scaled (synthetic.make_state_dict seed 0)",
@@ -229,8 +250,8 @@ def main():
             "ray_samples_per_step_per_gpu": evals / args.steps,
             "mask_fraction": [float(m.float().mean()) for m in masks],
             "roofline": {"kernel": "stnerf::spacenet_kernel (fused PE + 9-layer MLP, v_mfma_f32_32x32x2_f32)",
-                         "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "bound": "mfma", "achieved": achieved, "peak": peak_used, "unit": "TFLOP/s",
+                         "frac": achieved / peak_used, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": 28 * sp["evals"] / sp["launches"],
                          "launches": sp["launches"], "avg_launch_ms": sp["ms"] / sp["launches"],
                          "algorithmic_flop_per_launch": sp["flop"] / sp["launches"],
@@ -240,6 +261,24 @@ def main():
                             "tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12} for k, d in ksum.items()},
             "device": info,
         }
+        if other is not None:
+            osp = other["ksum"]["spacenet"]
+            o_ach = osp["flop"] / (osp["ms"] * 1e-3) / 1e12
+            peak_o = PEAK_F16_MFMA_TFLOPS if other["precision"] == "fp16x3" else PEAK_F32_MFMA_TFLOPS
+            mult = 3.0 if other["precision"] == "fp16x3" else 1.0
+            rec["other_precision"] = {
+                "precision": other["precision"],
+                "note": "same workload and poses, measured after the headline run; fp16x3 = every product a*b evaluated as "
+                        "ah*bh + ah*bl + al*bh on the fp16 MFMA pipe with f32 accumulation: passes the same parity tests "
+                        "and tolerances as the exact-f32 kernels (tests/test_gpu_f16x3.py)",
+                "value": world * n_rays * other["steps"] / other["elapsed"], "unit": "rays/s",
+                "ms_per_step": 1e3 * other["elapsed"] / other["steps"], "steps": other["steps"],
+                "ray_samples_per_s": other["evals_all"] / other["elapsed"],
+                "roofline": {"bound": "mfma", "algorithmic_tflops": o_ach, "executed_mfma_tflops": mult * o_ach,
+                             "peak": peak_o, "unit": "TFLOP/s", "frac": mult * o_ach / peak_o},
+                "kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / other["steps"],
+                                "algorithmic_tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12} for k, d in other["ksum"].items()},
+            }
         if world == 1 and args.cpu_baseline_rays > 0:
             rec["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline_rays)
         else:

@@ -112,20 +112,27 @@ __device__ __forceinline__ void load_hfrag(HFrag<NFB>& f, const half8* __restric
     }
 }
 
-// 3 * NFB * NSB MFMAs of one 16-k step: ah*bh + ah*bl + al*bh per (feature block, sample block).
+// 3 * NFB * NSB MFMAs of one 16-k step: ah*bh + ah*bl + al*bh per (feature block, sample block).  The three
+// terms of one accumulator are issued NFB*NSB instructions apart (term-major order): back-to-back dependent
+// 8-pass MFMAs would stall on the accumulator (issue 32 cycles, dependent latency ~40).
 template <int NFB, int NSB, bool FIRST>
 __device__ __forceinline__ void mma_step_h(f32x16 (&acc)[NFB][NSB], const half8 (&wh)[NFB], const half8 (&wl)[NFB],
                                            const half8 (&ah)[NSB], const half8 (&al)[NSB], const f32x16 (&cinit)[NFB]) {
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) {
+    for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) {
-            f32x16 c = FIRST ? cinit[fb] : acc[fb][sb];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[fb], ah[sb], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[fb], al[sb], c, 0, 0, 0);
-            acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[fb], ah[sb], c, 0, 0, 0);
-        }
-    }
+        for (int sb = 0; sb < NSB; ++sb)
+            acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[fb], ah[sb], FIRST ? cinit[fb] : acc[fb][sb], 0, 0, 0);
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb)
+            acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[fb], al[sb], acc[fb][sb], 0, 0, 0);
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb)
+            acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[fb], ah[sb], acc[fb][sb], 0, 0, 0);
 }
 
 // Two-stage ping-pong K loop (see mlp.hip: mma_segment); one step = 2 octet rows = 16 k values.
@@ -776,3 +783,14 @@ extern "C" int stnerf_motionnet_fwd_f16x3(const void* packed, int64_t n_rays, in
     if (big) return launch(motionnet_h_kernel<128, 8>, &opted[0], motion_h_lds_bytes<128, 8>(), 512, 128);
     return launch(motionnet_h_kernel<64, 4>, &opted[1], motion_h_lds_bytes<64, 4>(), 256, 64);
 }
+
+#ifdef STNERF_PHASE_PROF
+extern "C" int stnerf_debug_read_phases_h(unsigned long long* host16, int reset) {
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return STNERF_ELAUNCH;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return STNERF_ELAUNCH;
+    }
+    return STNERF_OK;
+}
+#endif
