@@ -105,3 +105,23 @@ def test_whole_path_fp16x3_matches_reference_fixtures(name):
     """The drop-in boundary in fp16x3 precision against the reference's own outputs: same tolerances as fp32."""
     import test_gpu_render as R
     R.run_forward_case(name, precision="fp16x3")
+
+
+def test_c2_full_view_fp16x3_agrees_with_fp32():
+    """C2 (512x512, 64+64) rendered in both arithmetic modes with the same device RNG stream."""
+    import test_gpu_render as R
+    from stnerf_amd.render_pose import render_pose
+    meta = dict(L=1, n1=64, n2=64, space_time=True, deform_time=False, weight_seed=40, edit={})
+    model = R.build_model(meta)
+    K, T = syn.camera(512, 512, 8.0)
+    model.seed = 3
+    imgs = {}
+    for prec in ("fp32", "fp16x3"):
+        model.set_precision(prec)
+        imgs[prec] = render_pose(model, T, K, 512, 512, [(0, 1), (1, 2.5)], far=20.0)[0]
+    a, b = imgs["fp32"], imgs["fp16x3"]
+    per_pix = (a - b).abs().max(-1)[0]
+    frac = float((per_pix <= R.COLOR_ATOL).float().mean())
+    quality = float(-10 * torch.log10(torch.mean((a - b) ** 2)))
+    print(f"fp16x3 vs fp32 at C2: {100 * frac:.3f} % of pixels within {R.COLOR_ATOL}, PSNR {quality:.1f} dB, max {float(per_pix.max()):.2e}")
+    assert frac >= R.FINE_FRACTION and quality >= R.FINE_PSNR
