@@ -153,15 +153,31 @@ __device__ __forceinline__ void mma_segment_h(f32x16 (&acc)[NFB][NSB], const hal
         ah0[sb] = in_hi[sb * 32];
         al0[sb] = in_lo[sb * 32];
     }
-#define H_LOAD_STEP(WH, WL, AH, AL, STEP)                          \
+#if defined(STNERF_EXP_NOGLOBAL) || defined(STNERF_EXP_NOLDS)
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) { wh1[fb] = wh0[fb]; wl1[fb] = wl0[fb]; }
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) { ah1[sb] = ah0[sb]; al1[sb] = al0[sb]; }
+#endif
+#if defined(STNERF_EXP_NOGLOBAL)  /* development experiments only (wrong results): isolate a stall source */
+#define H_LOAD_W(WH, WL, STEP) _Pragma("unroll") for (int fb = 0; fb < NFB; ++fb) { asm volatile("" : "+v"(WH[fb]), "+v"(WL[fb])); }
+#else
+#define H_LOAD_W(WH, WL, STEP)                                     \
     _Pragma("unroll") for (int fb = 0; fb < NFB; ++fb) {           \
         WH[fb] = whp[(STEP) * wstep + fb * 32];                    \
         WL[fb] = wlp[(STEP) * wstep + fb * 32];                    \
-    }                                                              \
+    }
+#endif
+#if defined(STNERF_EXP_NOLDS)
+#define H_LOAD_A(AH, AL, STEP) _Pragma("unroll") for (int sb = 0; sb < NSB; ++sb) { asm volatile("" : "+v"(AH[sb]), "+v"(AL[sb])); }
+#else
+#define H_LOAD_A(AH, AL, STEP)                                     \
     _Pragma("unroll") for (int sb = 0; sb < NSB; ++sb) {           \
         AH[sb] = in_hi[(STEP) * 2 * TM + sb * 32];                 \
         AL[sb] = in_lo[(STEP) * 2 * TM + sb * 32];                 \
     }
+#endif
+#define H_LOAD_STEP(WH, WL, AH, AL, STEP) H_LOAD_W(WH, WL, STEP) H_LOAD_A(AH, AL, STEP)
     // one load per MFMA (2*NFB global + 2*NSB LDS loads <= 3*NFB*NSB MFMAs), fenced per half-iteration
 #define H_INTERLEAVE()                                                                    \
     _Pragma("unroll") for (int i_ = 0; i_ < 2 * NFB; ++i_) {                              \
@@ -194,6 +210,8 @@ __device__ __forceinline__ void mma_segment_h(f32x16 (&acc)[NFB][NSB], const hal
     }
     if (s < steps) mma_step_h<NFB, NSB, false>(acc, wh1, wl1, ah1, al1, cinit);
 #undef H_LOAD_STEP
+#undef H_LOAD_W
+#undef H_LOAD_A
 #undef H_INTERLEAVE
 }
 
