@@ -162,12 +162,18 @@ struct MotionArgs {
 // Wave -> (feature block, sample blocks) decomposition of a layer with N outputs on a TM-sample tile, NW waves.
 //   N = 256: NW = 4 -> 64 features x all samples per wave;  NW = 8 -> 32 features x all samples
 //   N = 128: NW = 4 -> 32 features x all samples;           NW = 8 -> 32 features x half the samples
+// STNERF_WS_SQUARE (experiment): with 8 waves give a 256-wide layer 64 features x half the samples per wave
+// (2 x 2 blocks: 4 global + 4 LDS operand loads per step instead of 2 + 8).
+#ifndef STNERF_WS_SQUARE
+#define STNERF_WS_SQUARE 0
+#endif
 template <int TM, int NW, int N>
 struct WaveSplit {
-    static constexpr int NFB = (N == 256 && NW == 4) ? 2 : 1;
-    static constexpr int NSB = (N == 128 && NW == 8) ? TM / 64 : TM / 32;
-    __device__ static __forceinline__ int n0(int wave) { return (N == 128 && NW == 8) ? (wave & 3) * 32 : wave * NFB * 32; }
-    __device__ static __forceinline__ int sb0(int wave) { return (N == 128 && NW == 8) ? (wave >> 2) * NSB : 0; }
+    static constexpr bool HALF = (NW == 8) && (N == 128 || STNERF_WS_SQUARE);   // wave owns half the samples
+    static constexpr int NFB = (N == 256 && (NW == 4 || STNERF_WS_SQUARE)) ? 2 : 1;
+    static constexpr int NSB = HALF ? TM / 64 : TM / 32;
+    __device__ static __forceinline__ int n0(int wave) { return HALF ? (wave & 3) * NFB * 32 : wave * NFB * 32; }
+    __device__ static __forceinline__ int sb0(int wave) { return HALF ? (wave >> 2) * NSB : 0; }
 };
 
 

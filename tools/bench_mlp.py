@@ -25,7 +25,7 @@ for name, kind_time, flop in (("space", False, 924672), ("space_time", True, 930
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     res[name] = (ms, n * ns * flop / ms / 1e9)
-mot = ops.pack_motionnet(syn.motionnet_state("net", rs), "net")
+mot = ops.pack_motionnet(syn.motionnet_state("net", rs), "net", precision=prec)
 x2 = xyz.clone()
 ops.motionnet_fwd(mot, x2, times, add_to_xyz=True); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
