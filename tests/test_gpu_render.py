@@ -257,3 +257,32 @@ def test_stage_invariants_at_c3_sample_counts():
     assert bool((tf[..., 1:] >= tf[..., :-1]).all())
     lo_t, hi_t = t.min(-1)[0], t.max(-1)[0]
     assert bool((tf.min(-1)[0] >= lo_t - 1e-4).all()) and bool((tf.max(-1)[0] <= hi_t + 1e-4).all())
+
+
+def test_c5_shape_eight_performers_192_samples():
+    """C5's per-ray shape (8 performer layers + background, 128 coarse + 64 fine samples = 1728 merged samples
+    per ray) on a small ray window: every kernel handles l = 9, S = 192, and the result matches the oracle."""
+    from oracle import stnerf_oracle as O
+    meta = dict(L=8, n1=128, n2=64, space_time=False, deform_time=True, weight_seed=45, edit={})
+    model = build_model(meta)
+    sd = syn.make_state_dict(8, False, True, 45)
+    K, T = syn.camera(2160, 3840, 5.0)
+    full_rows = O.generate_rays(K.clone(), T, 2, 3840)          # two image rows of the 4K view
+    g = torch.Generator().manual_seed(9)
+    pick = torch.randperm(full_rows.shape[0], generator=g)[:96].sort()[0]
+    Kc = K.clone()
+    Kc[1, 2] -= 1079                                             # rows 1079..1080 (image centre)
+    rays = torch.cat([O.generate_rays(Kc, T, 2, 3840)[pick], syn.frame_id_columns(96, 8)], -1)
+    jitter, u = torch.rand(9, 96, 128, generator=g), torch.rand(9, 96, 64, generator=g)
+    model.replay = {"jitter": jitter.cuda(), "u": u.cuda()}
+    with torch.no_grad():
+        out = model(rays.cuda(), None, None)
+    draws = iter(list(jitter) + list(u))
+    with torch.no_grad():
+        ref = O.render_chunk(_oracle_model(meta, sd), rays, rand=lambda shape: next(draws))
+    for i in range(9):
+        assert torch.equal(out[4][i].cpu(), ref[4][i])
+    assert sum(int(m.sum()) for m in ref[4][1:]) > 20            # performers are actually hit
+    assert float((out[1][0].cpu() - ref[1][0]).abs().max()) <= COLOR_ATOL
+    per_ray = (out[0][0].cpu() - ref[0][0]).abs().max(-1)[0]
+    assert int((per_ray > COLOR_ATOL).sum()) <= 2 and float(per_ray.max()) <= FINE_CAP
