@@ -286,3 +286,51 @@ def test_c5_shape_eight_performers_192_samples():
     assert float((out[1][0].cpu() - ref[1][0]).abs().max()) <= COLOR_ATOL
     per_ray = (out[0][0].cpu() - ref[0][0]).abs().max(-1)[0]
     assert int((per_ray > COLOR_ATOL).sum()) <= 2 and float(per_ray.max()) <= FINE_CAP
+
+
+def test_per_chunk_boxes_follow_row0_of_every_reference_chunk():
+    """Retiming quirk (layered_rfrender.py:195-200): each reference chunk takes its boxes from ITS row 0.
+    Rays whose frame ids change between chunks must be grouped accordingly (one launch per run of equal ids)."""
+    from oracle import stnerf_oracle as O
+    from stnerf_amd.utils import layered_batchify_ray
+    meta = dict(L=2, n1=12, n2=6, space_time=True, deform_time=True, weight_seed=47, edit={})
+    model = build_model(meta)
+    sd = syn.make_state_dict(2, True, True, 47)
+    K, T = syn.camera(8, 12, 12.0)
+    base = O.generate_rays(K, T, 8, 12)                           # 96 rays = 4 chunks of 24
+    fid = torch.zeros(96, 3)
+    fid[:, 0] = 1.0
+    for c, (f1, f2) in enumerate([(1.0, 2.0), (1.0, 2.0), (2.5, 1.5), (3.0, 3.0)]):
+        fid[24 * c:24 * (c + 1), 1], fid[24 * c:24 * (c + 1), 2] = f1, f2
+    fid[30, 1] = 3.0                                              # NOT row 0 of its chunk: must not move the box
+    rays = torch.cat([base, fid], -1)
+    g = torch.Generator().manual_seed(3)
+    jitter, u = torch.rand(3, 96, 12, generator=g), torch.rand(3, 96, 6, generator=g)
+    model.replay = {"jitter": jitter.cuda(), "u": u.cuda()}
+    with torch.no_grad():
+        out = layered_batchify_ray(model, rays.cuda(), None, None, chuncks=24, density_threshold=0.05)
+    order = []                                                    # oracle draws per chunk: l jitter then l u tensors
+    for c in range(4):
+        order += [jitter[i, 24 * c:24 * (c + 1)] for i in range(3)] + [u[i, 24 * c:24 * (c + 1)] for i in range(3)]
+    draws = iter(order)
+    with torch.no_grad():
+        ref = O.layered_batchify_ray(_oracle_model(meta, sd), rays, chuncks=24, density_threshold=0.05,
+                                     rand=lambda shape: next(draws))
+    for i in range(3):
+        assert torch.equal(out[4][i].cpu(), ref[4][i])
+    assert float((out[1][0].cpu() - ref[1][0]).abs().max()) <= COLOR_ATOL
+    per_ray = (out[0][0].cpu() - ref[0][0]).abs().max(-1)[0]
+    assert int((per_ray > COLOR_ATOL).sum()) <= 2 and float(per_ray.max()) <= FINE_CAP
+
+
+def test_bad_inputs_raise_instead_of_exiting():
+    meta, a = load_golden("fwd_c3")
+    model = build_model(meta)
+    with pytest.raises(ValueError, match="undefined ray format"):     # the reference prints and calls exit(-1)
+        model(torch.zeros(10, 8, device="cuda"), None, None)
+    fresh = build_model(meta)
+    fresh.bboxes = None
+    with pytest.raises(RuntimeError, match="set_bkgd_bbox / set_bboxes"):
+        fresh(a["rays"].cuda(), None, None)
+    with pytest.raises(ValueError):
+        fresh.set_precision("bf16")
