@@ -324,7 +324,7 @@ __device__ __forceinline__ void head_partial_h(const half8* act_hi, const half8*
 // SpaceNet
 // ---------------------------------------------------------------------------------------------
 template <int TM, int NW, bool USE_TIME>
-__global__ __launch_bounds__(NW * 64, NW / 4) void spacenet_h_kernel(SpaceArgs a) {
+__global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_h_kernel(SpaceArgs a) {
     constexpr int NTHREADS = NW * 64;
     constexpr int NPARTS = NTHREADS / TM;
     extern __shared__ __attribute__((aligned(16))) half8 smem_h[];
@@ -741,13 +741,15 @@ extern "C" int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n
     STNERF_REQUIRE((raw_ray_stride & 3) == 0 && ((uintptr_t)raw & 15) == 0 && ((uintptr_t)packed & 15) == 0,
                    "spacenet_fwd_f16x3: raw / packed must be 16-byte aligned");
     if (n_rays == 0) return STNERF_OK;
-    static bool opted[2][2] = {{false, false}, {false, false}};
+    static bool opted[3][2] = {{false, false}, {false, false}, {false, false}};
     SpaceArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, dirs,
                 dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride};
     const char* e = getenv("STNERF_TILE_H");
     const bool four = e && !strcmp(e, "128");
-    const int lds = 80 * 128 * 16;
-    const int grid = grid_for_h(n_rays, ns, 128);
+    const bool small = e && !strcmp(e, "64");
+    const int tm = small ? 64 : 128;
+    const int lds = 80 * tm * 16;
+    const int grid = grid_for_h(n_rays, ns, tm);
     const bool ut = kind == STNERF_NET_SPACE_TIME;
     auto launch = [&](auto kernel, bool* flag, int nthreads) -> int {
         if (!*flag) {
@@ -763,6 +765,9 @@ extern "C" int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n
         STNERF_CHECK_LAUNCH("spacenet_fwd_f16x3");
         return STNERF_OK;
     };
+    if (small)
+        return ut ? launch(spacenet_h_kernel<64, 4, true>, &opted[2][1], 256)
+                  : launch(spacenet_h_kernel<64, 4, false>, &opted[2][0], 256);
     if (four)
         return ut ? launch(spacenet_h_kernel<128, 4, true>, &opted[0][1], 256)
                   : launch(spacenet_h_kernel<128, 4, false>, &opted[0][0], 256);

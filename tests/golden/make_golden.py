@@ -203,6 +203,96 @@ def g_sample_pdf():
     save("sample_pdf", dict(n2=n2), t=t, w=w, u=u, z=z, z_empty=z0)
 
 
+# ----------------------------------------------------------------------------- host path logic
+def _import_reference_renderer():
+    """render/layered_neural_renderer.py imports yacs, imageio, robopy, the dataset package ... none of which
+    exist here and none of which the path/retiming methods touch: stub them and load the module file."""
+    import importlib.util
+    for name in ("imageio", "robopy", "data"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["data"].make_ray_data_loader_render = None
+    sys.modules["data"].get_iteration_path = None
+    cfgmod = types.ModuleType("config")
+    cfgmod.cfg = None
+    sys.modules["config"] = cfgmod
+    rpkg = types.ModuleType("render")
+    rpkg.__path__ = [os.path.join(REF, "render")]
+    sys.modules["render"] = rpkg
+    rf = types.ModuleType("render.render_functions")
+    rf.__all__ = []
+    sys.modules["render.render_functions"] = rf
+    ref_utils.add_two_dim_dict = getattr(ref_utils, "add_two_dim_dict", None)
+    spec = importlib.util.spec_from_file_location("render.layered_neural_renderer",
+                                                  os.path.join(REF, "render", "layered_neural_renderer.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.LayeredNeuralRenderer
+
+
+def path_scene(C=5):
+    """C cameras on an arc looking at the origin, slightly different intrinsics per camera."""
+    poses, Ks = [], []
+    for i in range(C):
+        K, T = syn.camera(54, 96, orbit_deg=-30.0 + 15.0 * i, dist=4.0 + 0.2 * i)
+        T[1, 3] = 0.1 * i
+        poses.append(T)
+        K[0, 0] += 3.0 * i
+        K[1, 1] += 3.0 * i
+        Ks.append(K)
+    return torch.stack(poses, 0), Ks
+
+
+def g_path():
+    LNR = _import_reference_renderer()
+    gt_poses, gt_Ks = path_scene()
+
+    def fresh(L=2, frame_num=21, s_shift=None, s_scale=None, s_alpha=None):
+        r = object.__new__(LNR)                       # skip __init__ (it loads a dataset + checkpoint)
+        r.layer_num, r.frame_num = L, frame_num
+        r.display_layers = {i: 1 for i in range(L + 1)}
+        r.gt_poses, r.gt_Ks = gt_poses.clone(), [k.clone() for k in gt_Ks]
+        r.min_frame = [1 for _ in range(L + 1)]
+        r.max_frame = [frame_num for _ in range(L + 1)]
+        r.camera_num = gt_poses.shape[0]
+        r.min_camera_id, r.max_camera_id = 0, r.camera_num - 1
+        r.poses, r.Ks, r.layer_frame_pairs = [], [], []
+        r.s_shift, r.s_scale, r.s_alpha = s_shift, s_scale, s_alpha
+        r.dataset = types.SimpleNamespace(poses=r.gt_poses, Ks=r.gt_Ks)   # what set_path_gt_poses reads (:173,:198)
+        return r
+
+    arrays = {}
+
+    def dump(tag, r):
+        arrays[f"{tag}_poses"] = np.stack([np.asarray(p, dtype=np.float64) for p in r.poses], 0)
+        arrays[f"{tag}_Ks"] = np.stack([np.asarray(k, dtype=np.float64) for k in r.Ks], 0)
+        arrays[f"{tag}_pairs"] = np.array([[list(p) for p in row] for row in r.layer_frame_pairs], dtype=np.float64)
+
+    a = fresh(s_shift=[[[0.0, 0.0, 0.0], [0.1, 0.0, 0.0], [0.0, 0.1, 0.0]],
+                       [[0.0, 0.0, 0.0], [0.3, 0.0, 0.1], [0.0, -0.1, 0.0]]],
+              s_scale=[[1.0, 1.0, 1.0], [1.0, 1.5, 0.5]], s_alpha=[1.0, 0.2])
+    a.set_smooth_path_poses(9, around=True, smooth_time=True)
+    dump("around_smooth", a)
+    arrays["around_smooth_shift"] = np.array(a.s_shift_frame)
+    arrays["around_smooth_scale"] = np.array(a.s_scale_frame)
+    arrays["around_smooth_alpha"] = np.array(a.s_alpha_frame)
+    b = fresh()
+    b.set_smooth_path_poses(7, around=False, smooth_time=False)
+    dump("ends_int", b)
+    b.retime_by_key_frames(1, [5, 18, 20], [7, 11, 16])          # demo-style retiming of layer 1
+    b.retime_by_key_frames(2, [3], [12])
+    arrays["ends_int_retimed_pairs"] = np.array([[list(p) for p in row] for row in b.layer_frame_pairs], dtype=np.float64)
+    c = fresh()
+    c.display_layers[1] = 0                                        # hidden layer: absent from the pairs
+    c.set_path_gt_poses()
+    c.set_path_fixed_gt_poses(2, num=4)
+    arrays["gt_fixed_poses"] = np.stack([np.asarray(p, dtype=np.float64) for p in c.poses], 0)
+    arrays["gt_fixed_Ks"] = np.stack([np.asarray(k, dtype=np.float64) for k in c.Ks], 0)
+    arrays["gt_fixed_pairs_flat"] = np.array([v for row in c.layer_frame_pairs for p in row for v in p], dtype=np.float64)
+    arrays["gt_fixed_pairs_len"] = np.array([len(row) for row in c.layer_frame_pairs])
+    save("path", dict(C=int(gt_poses.shape[0]), L=2, frame_num=21), gt_poses=gt_poses, gt_Ks=torch.stack(gt_Ks, 0), **arrays)
+
+
 # ----------------------------------------------------------------------------- whole-path fixtures
 def build_ref_model(L, n1, n2, st, dt, seed):
     model = ref_modeling.build_layered_model(make_cfg(L, n1, n2, st, dt), camera_num=1).eval()
@@ -248,6 +338,7 @@ def main():
     g_nets()
     g_composite()
     g_sample_pdf()
+    g_path()
     # C1-shaped: single performer, space-time only, no fine stage
     g_forward("fwd_c1", 1, 8, 0, True, False, 21, 6, 8)
     # C3-shaped: two performers, space-time + deform, fractional (retimed) frame id

@@ -334,3 +334,32 @@ def test_bad_inputs_raise_instead_of_exiting():
         fresh(a["rays"].cuda(), None, None)
     with pytest.raises(ValueError):
         fresh.set_precision("bf16")
+
+
+def test_user_facing_render_path_runs_the_demo_flow():
+    """demo/taekwondo_demo.py:46-53 on the mirror: smooth path + retiming + per-frame edit schedule + render_path."""
+    import types as _t
+    from stnerf_amd.render import LayeredNeuralRenderer
+    meta = dict(L=2, n1=16, n2=8, space_time=True, deform_time=True, weight_seed=51, edit={})
+    model = build_model(meta)
+    C, h, w = 4, 36, 64
+    poses, Ks = [], []
+    for i in range(C):
+        K, T = syn.camera(h, w, orbit_deg=-20.0 + 12.0 * i)
+        poses.append(T)
+        Ks.append(K)
+    cfg = _t.SimpleNamespace(DATASETS=_t.SimpleNamespace(LAYER_NUM=2, FRAME_NUM=3, FRAME_OFFSET=0),
+                             INPUT=_t.SimpleNamespace(SIZE_TEST=[w, h]), OUTPUT_DIR="")
+    r = LayeredNeuralRenderer(cfg, s_alpha=[1.0, 0.3], model=model, gt_poses=torch.stack(poses), gt_Ks=Ks)
+    r.set_fps(25)
+    r.set_smooth_path_poses(3, around=True, smooth_time=True)
+    r.retime_by_key_frames(1, [1, 3], [2, 3])
+    seen = []
+    images, depths = r.render_path(density_threshold=0.01, bkgd_density_threshold=0.0,
+                                   on_frame=lambda idx, c, d, cl, dl: seen.append((idx, c.is_cuda, len(cl))))
+    assert len(images) == 3 and images[0].shape == (h, w, 3) and depths[0].shape == (h, w, 1)
+    assert seen == [(0, True, 3), (1, True, 3), (2, True, 3)]
+    assert all(bool(torch.isfinite(im).all()) for im in images) and float(images[1].max()) <= 1 + 1e-5
+    assert not torch.equal(images[0], images[2])                 # the camera actually moved
+    assert len(r.images_layer[1]) == 3 and r.image_num == 3
+    assert model.alpha == pytest.approx(0.3)                     # last frame of the alpha schedule was poked
