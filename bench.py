@@ -78,6 +78,12 @@ class KernelTimer:
     def summarise(self):
         out = {}
         for name, kind, n, ns, ray_count, e0, e1 in self.rec:
+            if name not in ("spacenet", "motionnet"):   # HBM-bound kernels: kind = algorithmic bytes per ray
+                d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
+                d["launches"] += 1
+                d["ms"] += e0.elapsed_time(e1)
+                d["bytes"] += kind * n
+                continue
             rays = n if ray_count is None else min(int(ray_count.item()), n)
             flop = FLOP_MOTION if name == "motionnet" else (FLOP_SPACE_TIME if kind == 1 else FLOP_SPACE)
             d = out.setdefault(name, dict(launches=0, ms=0.0, evals=0, flop=0))
@@ -258,7 +264,10 @@ def main():
                          "note": "algorithmic FLOPs = network evaluations x 924,672 (930,048 with time), "
                                  "HIP events on the launch stream around every launch of the timed steps"},
             "kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / args.steps,
-                            "tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12} for k, d in ksum.items()},
+                            "tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12} for k, d in ksum.items() if "flop" in d},
+            "hbm_kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / args.steps,
+                                "algorithmic_GBps": d["bytes"] / (d["ms"] * 1e-3) / 1e9, "peak_GBps": 8000.0,
+                                "frac": d["bytes"] / (d["ms"] * 1e-3) / 8e12} for k, d in ksum.items() if "bytes" in d},
             "device": info,
         }
         if other is not None:
@@ -277,7 +286,8 @@ def main():
                 "roofline": {"bound": "mfma", "algorithmic_tflops": o_ach, "executed_mfma_tflops": mult * o_ach,
                              "peak": peak_o, "unit": "TFLOP/s", "frac": mult * o_ach / peak_o},
                 "kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / other["steps"],
-                                "algorithmic_tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12} for k, d in other["ksum"].items()},
+                                "algorithmic_tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12}
+                            for k, d in other["ksum"].items() if "flop" in d},
             }
         if world == 1 and args.cpu_baseline_rays > 0:
             rec["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline_rays)

@@ -99,10 +99,11 @@ def sample_coarse(rays: Tensor, boxes: Tensor, n1: int, jitter: Optional[Tensor]
     xyz = torch.empty(n, l, n1, 3, dtype=torch.float32, device=rays.device) if want_xyz else None
     mask = torch.empty(n, l, dtype=torch.uint8, device=rays.device)
     ed, pv = _edits(edits, pivot, l)
-    hip.check(hip.lib().stnerf_sample_coarse(hip.dptr(rays, name="rays"), n, rays.shape[1], bp, bstride, l, n1,
-                                             hip.dptr(jitter, name="jitter"), seed, ray_index_base, ed, pv,
-                                             hip.dptr(t), hip.dptr(xyz), hip.dptr(mask, torch.uint8),
-                                             hip.stream_ptr()), "stnerf_sample_coarse")
+    with _Observed("sample_coarse", 16 * l * n1 + 4 * rays.shape[1] + l, n, 1, None):   # kind = algorithmic bytes per ray
+        hip.check(hip.lib().stnerf_sample_coarse(hip.dptr(rays, name="rays"), n, rays.shape[1], bp, bstride, l, n1,
+                                                 hip.dptr(jitter, name="jitter"), seed, ray_index_base, ed, pv,
+                                                 hip.dptr(t), hip.dptr(xyz), hip.dptr(mask, torch.uint8),
+                                                 hip.stream_ptr()), "stnerf_sample_coarse")
     return t, xyz, mask
 
 
@@ -175,6 +176,7 @@ def pack_motionnet(state: dict, prefix: str, device="cuda", precision: str = "fp
 
 # Optional launch observer (bench.py): called as fn(name, kind, n_rays, ns, ray_count, start_evt, end_evt)
 # with torch events recorded on the launch stream around the kernel.  None in normal operation.
+# For the HBM-bound kernels (sample_coarse / composite / resample) `kind` carries the algorithmic bytes per ray.
 _observer = None
 
 
@@ -286,10 +288,12 @@ def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e
     mixed_out = torch.empty(n, 5, dtype=torch.float32, device=t.device)
     weights = torch.empty(n, l, S, dtype=torch.float32, device=t.device) if want_weights else None
     order = torch.empty(n, l * S, dtype=torch.int32, device=t.device) if want_order else None
-    hip.check(hip.lib().stnerf_composite(hip.dptr(t, name="t"), hip.dptr(raw, name="raw"),
-                                         hip.dptr(mask, torch.uint8, "mask"), n, l, S, C.byref(p), hip.dptr(layer_out),
-                                         hip.dptr(mixed_out), hip.dptr(weights), hip.dptr(order, torch.int32),
-                                         hip.stream_ptr()), "stnerf_composite")
+    bytes_per_ray = 20 * l * S + l + 20 * (l + 1) + (4 * l * S if want_weights else 0) + (4 * l * S if want_order else 0)
+    with _Observed("composite", bytes_per_ray, n, 1, None):
+        hip.check(hip.lib().stnerf_composite(hip.dptr(t, name="t"), hip.dptr(raw, name="raw"),
+                                             hip.dptr(mask, torch.uint8, "mask"), n, l, S, C.byref(p), hip.dptr(layer_out),
+                                             hip.dptr(mixed_out), hip.dptr(weights), hip.dptr(order, torch.int32),
+                                             hip.stream_ptr()), "stnerf_composite")
     return layer_out, mixed_out, weights, order
 
 
@@ -308,11 +312,13 @@ def resample(t: Tensor, weights: Tensor, n2: int, rays: Tensor, u: Optional[Tens
     inds = torch.empty(n, l, n2, dtype=torch.int32, device=dev) if debug else None
     cdf = torch.empty(n, l, n1 - 1, dtype=torch.float32, device=dev) if debug else None
     ed, pv = _edits(edits, pivot, l)
-    hip.check(hip.lib().stnerf_resample(hip.dptr(t, name="t"), hip.dptr(weights, name="weights"), n, l, n1, n2,
-                                        hip.dptr(u, name="u"), seed, ray_index_base, hip.dptr(rays, name="rays"),
-                                        rays.shape[1], ed, pv, hip.dptr(t_fine), hip.dptr(xyz), hip.dptr(z_new),
-                                        hip.dptr(inds, torch.int32), hip.dptr(cdf), hip.stream_ptr()),
-              "stnerf_resample")
+    bytes_per_ray = l * (8 * n1 + (16 if want_xyz else 4) * (n1 + n2)) + 24
+    with _Observed("resample", bytes_per_ray, n, 1, None):
+        hip.check(hip.lib().stnerf_resample(hip.dptr(t, name="t"), hip.dptr(weights, name="weights"), n, l, n1, n2,
+                                            hip.dptr(u, name="u"), seed, ray_index_base, hip.dptr(rays, name="rays"),
+                                            rays.shape[1], ed, pv, hip.dptr(t_fine), hip.dptr(xyz), hip.dptr(z_new),
+                                            hip.dptr(inds, torch.int32), hip.dptr(cdf), hip.stream_ptr()),
+                  "stnerf_resample")
     if debug:
         return t_fine, xyz, z_new, inds, cdf
     return t_fine, xyz
