@@ -59,6 +59,8 @@ __device__ __forceinline__ int upper_bound_lds(const float* a, int n, float v) {
 // gen_weight + VolumeRenderer.forward: layers/render_layer.py:8-17, :37-49.
 //   delta_k = t_{k+1}-t_k, last = border;  alpha = 1-exp(-relu(sigma) delta);
 //   T_k = prod_{j<k} (1-alpha_j+1e-10);  w = alpha T;  color = sum w sigmoid(rgb); depth = sum w t.
+// raw_at(k) returns {sigmoid(r), sigmoid(g), sigmoid(b), sigma}: the sigmoid is evaluated once per sample when
+// the ray is staged and shared by the per-layer and the merged composite (3 of the 8 expf per sample saved).
 // ---------------------------------------------------------------------------------------------
 template <class TAt, class RawAt, class WOut>
 __device__ __forceinline__ void composite_run(int count, float border, int lane, TAt t_at, RawAt raw_at, WOut w_out,
@@ -84,9 +86,9 @@ __device__ __forceinline__ void composite_run(int count, float border, int lane,
         carry = carry * __shfl(incl, 63);
         if (ok) {
             w_out(k, w);
-            cr += w * (1.f / (1.f + expf(-rw.x)));
-            cg += w * (1.f / (1.f + expf(-rw.y)));
-            cb += w * (1.f / (1.f + expf(-rw.z)));
+            cr += w * rw.x;  // rw.xyz = sigmoid(raw rgb), applied once when the ray is staged
+            cg += w * rw.y;
+            cb += w * rw.z;
             cd += w * tk;
             ca += w;
         }
@@ -139,12 +141,12 @@ __global__ void composite_kernel(CompositeArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int LS = a.l * a.S;
-    // per-wave LDS: raws[LS] float4 | ts[LS] | mt[LS] | mord[LS]
-    unsigned char* mine = smem_raw + (size_t)wave * LS * 28;
+    // per-wave LDS: raws[LS] float4 | ts[LS] float | mord[LS] u16 (merged position -> source sample), 16-B rounded
+    const int per_wave = ((LS * 22 + 15) / 16) * 16;
+    unsigned char* mine = smem_raw + (size_t)wave * per_wave;
     float4* raws = reinterpret_cast<float4*>(mine);
     float* ts = reinterpret_cast<float*>(mine + (size_t)LS * 16);
-    float* mt = ts + LS;
-    int* mord = reinterpret_cast<int*>(mt + LS);
+    unsigned short* mord = reinterpret_cast<unsigned short*>(ts + LS);
 
     const int64_t rays_per_iter = (int64_t)gridDim.x * a.waves_per_block;
     for (int64_t ray0 = (int64_t)blockIdx.x * a.waves_per_block; ray0 < a.n; ray0 += rays_per_iter) {
@@ -164,6 +166,9 @@ __global__ void composite_kernel(CompositeArgs a) {
                 if (a.p.use_threshold[layer] && rw.w < a.p.threshold[layer]) rw.w = 0.f;       // :416-418, :538-547, :564-566
                 rw.w = rw.w * a.p.sigma_scale[layer];                                          // :575-576
                 if (!a.p.fine && layer == 0 && tv < a.p.near) rw.w = 0.f;                      // :422
+                rw.x = 1.f / (1.f + expf(-rw.x));  // torch.sigmoid(rgb), render_layer.py:47
+                rw.y = 1.f / (1.f + expf(-rw.y));
+                rw.z = 1.f / (1.f + expf(-rw.z));
                 ts[e] = tv;
                 raws[e] = rw;
             }
@@ -208,8 +213,7 @@ __global__ void composite_kernel(CompositeArgs a) {
                         rank += (xv < v || (xv == v && x < e)) ? 1 : 0;
                     }
                 }
-                mt[rank] = v;
-                mord[rank] = e;
+                mord[rank] = (unsigned short)e;
             }
         }
         __syncthreads();
@@ -218,10 +222,11 @@ __global__ void composite_kernel(CompositeArgs a) {
             float o5[5];
             const bool cut_near = a.p.fine != 0;
             const float nearv = a.p.near;
-            composite_run(LS, a.p.border, lane, [&](int m) { return mt[m]; },
+            composite_run(LS, a.p.border, lane, [&](int m) { return ts[mord[m]]; },
                           [&](int m) {
-                              float4 rw = raws[mord[m]];
-                              if (cut_near && mt[m] < nearv) rw.w = 0.f;  // :605
+                              const int src = mord[m];
+                              float4 rw = raws[src];
+                              if (cut_near && ts[src] < nearv) rw.w = 0.f;  // :605
                               return rw;
                           },
                           [&](int, float) {}, o5);
@@ -319,15 +324,25 @@ __global__ void resample_kernel(ResampleArgs a) {
             }
         }
         __syncthreads();
-        // ---- sort(cat[t, z])  (layered_rfrender.py:462): counting ranks == a stable sort, any input order
+        // ---- sort(cat[t, z])  (layered_rfrender.py:462) by ranks == a stable sort with t before z on ties.
+        // The coarse list is ascending (unless a box edit made the bin width negative), so a t keeps its
+        // index and a z finds its place among the t by binary search; only the n2 new samples are counted.
         if (active) {
+            bool asc = true;
+            for (int k = lane; k + 1 < n1; k += 64) asc = asc && !(tc[k + 1] < tc[k]);
+            asc = __all(asc);
             for (int e = lane; e < S; e += 64) {
                 const bool is_t = e < n1;
                 const float v = is_t ? tc[e] : zs[e - n1];
-                int rank = 0;
-                for (int x = 0; x < n1; ++x) {
-                    const float xv = tc[x];
-                    rank += (xv < v || (xv == v && (!is_t || x < e))) ? 1 : 0;
+                int rank;
+                if (asc) {
+                    rank = is_t ? e : upper_bound_lds(tc, n1, v);
+                } else {
+                    rank = 0;
+                    for (int x = 0; x < n1; ++x) {
+                        const float xv = tc[x];
+                        rank += (xv < v || (xv == v && (!is_t || x < e))) ? 1 : 0;
+                    }
                 }
                 for (int x = 0; x < n2; ++x) {
                     const float xv = zs[x];
@@ -380,7 +395,8 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
                    (long long)n, l, S);
     STNERF_REQUIRE(((uintptr_t)raw & 15) == 0, "composite: raw must be 16-byte aligned");
     if (n == 0) return STNERF_OK;
-    const int64_t per_wave = (int64_t)l * S * 28;
+    STNERF_REQUIRE((int64_t)l * S <= 65535, "composite: more than 65535 samples per ray");
+    const int64_t per_wave = (((int64_t)l * S * 22 + 15) / 16) * 16;
     int wpb = (int)((150 * 1024) / per_wave);
     STNERF_REQUIRE(wpb >= 1, "composite: %d samples per ray do not fit the 160 KiB LDS", l * S);
     if (wpb > 4) wpb = 4;

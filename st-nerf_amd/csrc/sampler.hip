@@ -131,6 +131,60 @@ __global__ void sample_coarse_kernel(const float* __restrict__ rays, int64_t n, 
     if (k == 0) mask_out[ray * l + layer] = fabsf(width) > 1e-5f ? 1 : 0;  // :105
 }
 
+// Same arithmetic, four consecutive samples of one (ray, layer) per thread: one slab test per four samples and
+// 16-byte stores (t: 1 x float4, xyz: 3 x float4).  Used when n1 % 4 == 0 (then every group is 16-B aligned).
+__global__ void sample_coarse_kernel_x4(const float* __restrict__ rays, int64_t n, int ray_stride,
+                                        const float* __restrict__ boxes, int64_t box_ray_stride, int l, int n1,
+                                        const float* __restrict__ jitter, uint64_t seed, int64_t ray_index_base,
+                                        EditArgs ed, float* __restrict__ t_out, float* __restrict__ xyz_out,
+                                        uint8_t* __restrict__ mask_out) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 samples
+    const int gpl = n1 >> 2;                                           // groups per (ray, layer)
+    const int64_t per_ray = (int64_t)l * gpl;
+    if (g >= n * per_ray) return;
+    const int64_t ray = g / per_ray;
+    const int rem = (int)(g - ray * per_ray);
+    const int layer = rem / gpl;
+    const int k0 = (rem - layer * gpl) * 4;
+    const float* r = rays + ray * ray_stride;
+    const float o[3] = {r[0], r[1], r[2]};
+    const float d[3] = {r[3], r[4], r[5]};
+    float far_t, near_t;
+    intersect_box(o, d, boxes + ray * box_ray_stride + layer * 24, far_t, near_t);
+    float start = near_t;
+    if (layer == 0 && start <= 0.f) start = 0.f;
+    const float width = (far_t - start) / (float)n1;
+    float xi[4];
+    if (jitter) {
+        const float4 j4 = *reinterpret_cast<const float4*>(jitter + ((int64_t)layer * n + ray) * n1 + k0);
+        xi[0] = j4.x; xi[1] = j4.y; xi[2] = j4.z; xi[3] = j4.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            xi[j] = philox_uniform(seed, (uint64_t)(ray_index_base + ray), (uint32_t)layer, 0u, (uint32_t)(k0 + j));
+    }
+    float tv[4], px[12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float t = ((float)(k0 + j) + xi[j]) * width + start;
+        tv[j] = t;
+        float x = t * d[0] + o[0], y = t * d[1] + o[1], z = t * d[2] + o[2];
+        if (ed.any) unedit_point(x, y, z, ed.e[layer], ed.pivot);
+        px[3 * j + 0] = x;
+        px[3 * j + 1] = y;
+        px[3 * j + 2] = z;
+    }
+    const int64_t e = (ray * l + layer) * n1 + k0;
+    *reinterpret_cast<float4*>(t_out + e) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+    if (xyz_out) {
+        float4* dst = reinterpret_cast<float4*>(xyz_out + e * 3);
+        dst[0] = make_float4(px[0], px[1], px[2], px[3]);
+        dst[1] = make_float4(px[4], px[5], px[6], px[7]);
+        dst[2] = make_float4(px[8], px[9], px[10], px[11]);
+    }
+    if (k0 == 0) mask_out[ray * l + layer] = fabsf(width) > 1e-5f ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------- compaction
 // grid.y = layer.  Order inside a block is preserved; blocks append in arrival order.
 __global__ void compact_rays_kernel(const uint8_t* __restrict__ mask, int64_t n, int l, int32_t* __restrict__ ray_list,
@@ -212,6 +266,16 @@ extern "C" int stnerf_sample_coarse(const float* rays, int64_t n, int ray_stride
     const int bs = 256;
     const int64_t tot = n * l * n1;
     STNERF_REQUIRE((tot + bs - 1) / bs < (1ll << 31), "sample_coarse: chunk too large");
+    const bool aligned = (n1 % 4 == 0) && ((uintptr_t)t % 16 == 0) && (!xyz || (uintptr_t)xyz % 16 == 0) &&
+                         (!jitter || (uintptr_t)jitter % 16 == 0);
+    if (aligned) {
+        const int64_t groups = tot / 4;
+        hipLaunchKernelGGL(sample_coarse_kernel_x4, dim3((unsigned)((groups + bs - 1) / bs)), dim3(bs), 0,
+                           as_stream(stream), rays, n, ray_stride, boxes, box_ray_stride, l, n1, jitter, seed,
+                           ray_index_base, ed, t, xyz, mask);
+        STNERF_CHECK_LAUNCH("sample_coarse");
+        return STNERF_OK;
+    }
     hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((tot + bs - 1) / bs)), dim3(bs), 0, as_stream(stream), rays,
                        n, ray_stride, boxes, box_ray_stride, l, n1, jitter, seed, ray_index_base, ed, t, xyz, mask);
     STNERF_CHECK_LAUNCH("sample_coarse");
