@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="taekwondo-1080p-64+64", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-baseline-rays", type=int, default=7168, help="0 disables the CPU baseline leg")
-    ap.add_argument("--rays-per-launch", type=int, default=1 << 17)
+    ap.add_argument("--rays-per-launch", type=int, default=1 << 19)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3"],
                     help="arithmetic of the headline run: exact f32 MFMA (default) or fp32-accurate split-fp16 MFMA")
     ap.add_argument("--no-second-precision", action="store_true",

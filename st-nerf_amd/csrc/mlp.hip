@@ -227,24 +227,33 @@ __device__ __forceinline__ void dense_layer(const float* __restrict__ base, int6
 template <int TM, int NOUT>
 __device__ __forceinline__ void head_partial(const float4* act, int s, int q_begin, int q_end,
                                              const float* __restrict__ w, int ldw, float (&sum)[NOUT]) {
+    // 4 quads per iteration: the 4 LDS reads and the scalar weight loads are issued together, then 16*NOUT FMAs on
+    // independent partial sums (a one-quad loop serialises on lgkmcnt(0) every iteration)
+    float part[4][NOUT];
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) sum[o] = 0.f;
-    for (int q = q_begin; q < q_end; ++q) {
-        const float4 v = act[q * TM + s];
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
-            const float4 wv = *reinterpret_cast<const float4*>(w + o * ldw + 4 * q);
-            sum[o] = fmaf(v.x, wv.x, sum[o]);
-            sum[o] = fmaf(v.y, wv.y, sum[o]);
-            sum[o] = fmaf(v.z, wv.z, sum[o]);
-            sum[o] = fmaf(v.w, wv.w, sum[o]);
+        for (int o = 0; o < NOUT; ++o) part[u][o] = 0.f;
+    for (int q = q_begin; q < q_end; q += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = act[(q + u) * TM + s];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                const float4 wv = *reinterpret_cast<const float4*>(w + o * ldw + 4 * (q + u));
+                part[u][o] = fmaf(v[u].x, wv.x, part[u][o]);
+                part[u][o] = fmaf(v[u].y, wv.y, part[u][o]);
+                part[u][o] = fmaf(v[u].z, wv.z, part[u][o]);
+                part[u][o] = fmaf(v[u].w, wv.w, part[u][o]);
+            }
         }
     }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) sum[o] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
 }
 
-// ---------------------------------------------------------------------------------------------
-// SpaceNet
-// ---------------------------------------------------------------------------------------------
 // DENSE(TM, NW, N, N_NEXT, <dense_layer args up to `out`>, wfirst, next_w_off, wnext): one layer with N outputs;
 // prefetches step 0 of the following layer (N_NEXT outputs, packed at next_w_off) into wnext.
 #define DENSE(TM_, NW_, N_, NN_, BASE_, WOFF_, BOFF_, INA_, KQA_, INB_, KQB_, OUT_, WFIRST_, NEXT_WOFF_, NEXT_BOFF_, WNEXT_) \

@@ -256,7 +256,7 @@ class LayeredRFRender(nn.Module):
         self.bboxes = None
         # MI355X-side knobs (not in the reference)
         self.seed = 0                      # Philox seed of the on-device jitter / resampling draws
-        self.max_rays_per_launch = 1 << 17 # rays per kernel sequence (workspace bound, not a semantic chunk)
+        self.max_rays_per_launch = 1 << 19 # rays per kernel sequence (workspace bound ~20 KB/ray, not a semantic chunk)
         self.replay = None                 # {"jitter": (l,N,N1), "u": (l,N,N2)} to replay recorded uniforms
         self.ray_index_base = 0            # global index of rays[0] (multi-GPU sharding keeps the RNG stream)
 
