@@ -10,7 +10,7 @@ only the ``render_rows`` callable passed in touches the GPU.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, Tuple
 
 import torch
 import torch.distributed as dist

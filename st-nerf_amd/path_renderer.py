@@ -18,7 +18,7 @@ The host logic below is pinned against fixtures produced by the reference's own 
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence
+from typing import Callable, List, Optional
 
 import numpy as np
 import torch

@@ -6,7 +6,7 @@ frame -- and the images stay on the device until the caller moves them.
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import Sequence, Tuple
 
 import torch
 

@@ -14,7 +14,7 @@ checkpoint keys; the kernel-layout copy of the weights is rebuilt lazily when th
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional, Sequence
+from typing import Optional
 
 import torch
 from torch import nn

@@ -8,7 +8,7 @@ RNG) under the reference's state_dict key names (checkpoint ro
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, Sequence, Tuple
 
 import numpy as np
 import torch

@@ -6,7 +6,7 @@ import torch
 
 from oracle import stnerf_oracle as O
 from stnerf_amd import synthetic as syn
-from test_gpu_ops import NET_ATOL, NET_RTOL, _net_close, dev
+from test_gpu_ops import _net_close, dev
 
 pytestmark = pytest.mark.gpu
 

@@ -5,7 +5,6 @@ import types
 
 import numpy as np
 import pytest
-import torch
 
 from conftest import load_golden
 
