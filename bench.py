@@ -67,30 +67,46 @@ def build_scene(workload, device):
 
 
 class KernelTimer:
-    """Collects per-launch HIP-event timings of the MLP kernels (events on the launch stream)."""
+    """Per-launch timings from the library's own profiler (HIP events recorded on the launch stream around every
+    kernel launch, stnerf_profile_begin/_end) joined with the hit masks of each stnerf_render_rays call, which
+    give the number of rows a masked performer launch really processed."""
 
     def __init__(self):
-        self.rec = []
+        self.masks = []
+        self._orig = None
 
-    def __call__(self, name, kind, n, ns, ray_count, e0, e1):
-        self.rec.append((name, kind, n, ns, ray_count, e0, e1))
+    def start(self):
+        self._orig = ops.render_rays
+
+        def wrapped(*a, **k):
+            out = self._orig(*a, **k)
+            self.masks.append(out[4])
+            return out
+        ops.render_rays = wrapped
+        ops.profile_begin()
+
+    def stop(self):
+        ops.render_rays = self._orig
+        self.records = ops.profile_end()
 
     def summarise(self):
-        out = {}
-        for name, kind, n, ns, ray_count, e0, e1 in self.rec:
-            if name not in ("spacenet", "motionnet"):   # HBM-bound kernels: kind = algorithmic bytes per ray
+        out, call = {}, -1
+        counts = [m.sum(0).tolist() for m in self.masks]          # hit rays per layer of every pipeline call
+        for r in self.records:
+            name = r["kernel"]
+            if name == "sample_coarse":
+                call += 1                                          # every pipeline call starts with the sampler
+            if name in ("spacenet", "motionnet"):
+                rays = r["n_rays"] if r["tag"] <= 0 else int(counts[call][r["tag"]])
+                flop = FLOP_MOTION if name == "motionnet" else (FLOP_SPACE_TIME if r["kind"] == 1 else FLOP_SPACE)
+                d = out.setdefault(name, dict(launches=0, ms=0.0, evals=0, flop=0))
+                d["evals"] += rays * r["ns"]
+                d["flop"] += rays * r["ns"] * flop
+            else:                                                  # HBM-bound kernels: algorithmic bytes per ray
                 d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
-                d["launches"] += 1
-                d["ms"] += e0.elapsed_time(e1)
-                d["bytes"] += kind * n
-                continue
-            rays = n if ray_count is None else min(int(ray_count.item()), n)
-            flop = FLOP_MOTION if name == "motionnet" else (FLOP_SPACE_TIME if kind == 1 else FLOP_SPACE)
-            d = out.setdefault(name, dict(launches=0, ms=0.0, evals=0, flop=0))
+                d["bytes"] += r["bytes_per_ray"] * r["n_rays"]
             d["launches"] += 1
-            d["ms"] += e0.elapsed_time(e1)
-            d["evals"] += rays * ns
-            d["flop"] += rays * ns * flop
+            d["ms"] += r["ms"]
         return out
 
 
@@ -192,14 +208,14 @@ def main():
         for i in range(warmup):
             step(-1 - i)
         timer = KernelTimer()
-        ops.set_launch_observer(timer)
+        timer.start()
         fence()
         t0 = time.perf_counter()
         for i in range(steps):
             tile, masks = step(i)
         fence()
         elapsed = time.perf_counter() - t0
-        ops.set_launch_observer(None)
+        timer.stop()
         if world > 1:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -262,7 +278,7 @@ def main():
                          "launches": sp["launches"], "avg_launch_ms": sp["ms"] / sp["launches"],
                          "algorithmic_flop_per_launch": sp["flop"] / sp["launches"],
                          "note": "algorithmic FLOPs = network evaluations x 924,672 (930,048 with time), "
-                                 "HIP events on the launch stream around every launch of the timed steps"},
+                                 "HIP events recorded by the library on the launch stream around every launch of the timed steps"},
             "kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / args.steps,
                             "tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12} for k, d in ksum.items() if "flop" in d},
             "hbm_kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / args.steps,

@@ -46,6 +46,22 @@ const char* stnerf_last_error(void);
 /* cu_count, lds_bytes_per_cu, clock_khz may be NULL; arch receives e.g. "gfx950" (host buffer). */
 int stnerf_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, char* arch, int arch_len);
 
+/* Launch profiler: between _begin and _end every kernel launch of the entry points below is bracketed by a
+ * HIP event pair recorded on the launch stream.  _end synchronises those events only and returns one record per
+ * launch, in launch order (n_records = number of launches, even if larger than max_records).
+ * kernel: 0 spacenet, 1 motionnet, 2 composite, 3 resample, 4 sample_coarse; kind: the net kind for 0/1;
+ * n_rays x ns = the launch's upper bound on rows (masked launches process ray_count x ns of them);
+ * tag: the layer a stnerf_render_rays launch belongs to (-1 otherwise); bytes_per_ray: algorithmic HBM bytes
+ * per ray for the HBM-bound kernels (2..4), 0 for the networks. */
+typedef struct stnerf_profile_record {
+    int32_t kernel, kind, ns, tag;
+    int64_t n_rays, bytes_per_ray;
+    float ms;
+    int32_t pad_;
+} stnerf_profile_record;
+int stnerf_profile_begin(void);
+int stnerf_profile_end(stnerf_profile_record* records_host, int max_records, int* n_records);
+
 /* Per-layer edit applied to sample points (inverse of the box edit), host struct passed by value
  * inside stnerf_scene.  modeling/layered_rfrender.py:293-303 (coarse) and :467-475 (fine). */
 typedef struct stnerf_layer_edit {
@@ -191,6 +207,46 @@ int stnerf_resample(const float* t, const float* weights, int64_t n, int l, int 
                     int ray_stride, const stnerf_layer_edit* edits_host, const float* pivot_host,
                     float* t_fine, float* xyz_fine, float* z_new, int32_t* inds, float* cdf,
                     stnerf_stream_t stream);
+
+/* The whole chunk pipeline of LayeredRFRender.forward (modeling/layered_rfrender.py:141-734) behind one call:
+ * coarse sampler -> mask compaction -> [MotionNet] -> SpaceNets -> composite/merge -> resample -> [MotionNet] ->
+ * fine SpaceNets -> composite/merge, all enqueued on `stream` into a caller-provided workspace.  Host-side
+ * box interpolation / editing (l x 8 x 3 numbers, :190-242) stays with the caller, who passes the edited boxes
+ * and the inverse point edits.  Packed-network pointers are device blobs of stnerf_pack_net[_f16x3]. */
+typedef struct stnerf_nets {
+    const void* bkgd;                           /* bkgd_spacenet            (STNERF_NET_SPACE)               */
+    const void* bkgd_fine;                      /* bkgd_spacenet_fine                                        */
+    const void* space[STNERF_MAX_LAYERS];       /* [i] = spacenets[i-1], i >= 1 ([0] unused)                 */
+    const void* space_fine[STNERF_MAX_LAYERS];  /* [i] = spacenets_fine[i-1]                                 */
+    const void* motion[STNERF_MAX_LAYERS];      /* [i] = time_deform_nets[i-1] (use_deform_time only)        */
+} stnerf_nets;
+
+typedef struct stnerf_render_params {
+    int32_t l, n1, n2;            /* layers incl. background, coarse / fine sample counts                     */
+    int32_t ray_stride;           /* floats per ray: 6 + l (retiming) or 7                                   */
+    int32_t retiming;             /* 1: frame id of layer i in column 6+i; 0: per-ray frame id in column 6   */
+    int32_t only_coarse;
+    int32_t use_deform_time, use_space_time;
+    int32_t precision;            /* 0: exact f32 MFMA, 1: fp16x3                                            */
+    int32_t has_edits;            /* edits_* / pivot are meaningful                                          */
+    int32_t shown[STNERF_MAX_LAYERS];                 /* display_layers (:99-112); [0] ignored               */
+    float border, near, alpha;                        /* BOARDER_WEIGHT, model.near, model.alpha             */
+    float density_threshold, bkgd_density_threshold;  /* applied in retiming mode only, as the reference     */
+    uint64_t seed;                                    /* device RNG (used where jitter / u are NULL)         */
+    int64_t ray_index_base;
+    stnerf_layer_edit edits_coarse[STNERF_MAX_LAYERS]; /* :293-303 */
+    stnerf_layer_edit edits_fine[STNERF_MAX_LAYERS];   /* :467-475 */
+    float pivot[3];
+} stnerf_render_params;
+
+int64_t stnerf_render_workspace_bytes(int64_t n, int l, int n1, int n2, int only_coarse);
+/* Outputs: mixed_*[n][5], layer_*[n][l][5] = {colour(3), depth, acc}; mask[n][l].  jitter [l][n][n1] / u [l][n][n2]
+ * replay uniform draws (NULL = device RNG).  With only_coarse the fine outputs may be NULL. */
+int stnerf_render_rays(const float* rays, int64_t n, const float* boxes, int64_t box_ray_stride,
+                       const stnerf_nets* nets_host, const stnerf_render_params* params_host, const float* jitter,
+                       const float* u, void* workspace, int64_t workspace_bytes, float* mixed_fine,
+                       float* mixed_coarse, float* layer_fine, float* layer_coarse, uint8_t* mask,
+                       stnerf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@ SOURCES = [
     ("render.hip", ["-ffp-contract=off"]),
     ("mlp.hip", []),
     ("mlp_f16x3.hip", []),
+    ("pipeline.hip", []),
 ]
 EXTRA = os.environ.get("STNERF_EXTRA_FLAGS", "").split()   # e.g. -DSTNERF_PHASE_PROF (development only)
 COMMON = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

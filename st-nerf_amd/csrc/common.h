@@ -10,6 +10,18 @@ void set_error(const char* fmt, ...);
 
 static inline hipStream_t as_stream(stnerf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Optional launch profiler (stnerf_profile_begin / _end): while enabled, every kernel launch of the op-level
+// entry points is bracketed by a HIP event pair recorded on the launch stream.
+enum ProfKernel { PROF_SPACENET = 0, PROF_MOTIONNET = 1, PROF_COMPOSITE = 2, PROF_RESAMPLE = 3, PROF_SAMPLE_COARSE = 4 };
+bool profiling_enabled();
+void set_launch_tag(int tag);  // e.g. the layer a pipeline launch works on; -1 = none
+struct LaunchTimer {            // RAII: records start on construction, stop + bookkeeping on destruction
+    LaunchTimer(int kernel, int kind, int64_t n_rays, int ns, int64_t bytes_per_ray, hipStream_t stream);
+    ~LaunchTimer();
+    void* rec_;
+    hipStream_t stream_;
+};
+
 #define STNERF_REQUIRE(cond, ...)                \
     do {                                         \
         if (!(cond)) {                           \

@@ -640,7 +640,7 @@ static TileCfg tile_config(TileCfg dflt) {
 // One-time LDS opt-in + launch.  `slot` identifies the instantiation (static flags per kernel).
 template <class Args>
 static int launch_mlp(void (*kernel)(Args), bool* opted_in, int lds, int grid, int nthreads, stnerf_stream_t stream,
-                      const Args& a, const char* what) {
+                      const Args& a, const char* what, int prof_kernel, int prof_kind) {
     if (!*opted_in) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds) != hipSuccess) {
@@ -650,6 +650,7 @@ static int launch_mlp(void (*kernel)(Args), bool* opted_in, int lds, int grid, i
         }
         *opted_in = true;
     }
+    LaunchTimer timer(prof_kernel, prof_kind, a.wl.n_rays, a.wl.ns, 0, as_stream(stream));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(nthreads), lds, as_stream(stream), a);
     STNERF_CHECK_LAUNCH(what);
     return STNERF_OK;
@@ -756,16 +757,17 @@ extern "C" int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays,
     const int grid = grid_for(n_rays, ns, tm);
     const bool ut = kind == STNERF_NET_SPACE_TIME;
     const char* what = "spacenet_fwd";
+    const int PROF_KERNEL_ID = PROF_SPACENET, PROF_KIND_ID = kind;
     switch (tc) {
         case TILE_128:
-            return ut ? launch_mlp(spacenet_kernel<128, 4, true>, &opted[0][1], lds, grid, 256, stream, a, what)
-                      : launch_mlp(spacenet_kernel<128, 4, false>, &opted[0][0], lds, grid, 256, stream, a, what);
+            return ut ? launch_mlp(spacenet_kernel<128, 4, true>, &opted[0][1], lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
+                      : launch_mlp(spacenet_kernel<128, 4, false>, &opted[0][0], lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
         case TILE_128X8:
-            return ut ? launch_mlp(spacenet_kernel<128, 8, true>, &opted[1][1], lds, grid, 512, stream, a, what)
-                      : launch_mlp(spacenet_kernel<128, 8, false>, &opted[1][0], lds, grid, 512, stream, a, what);
+            return ut ? launch_mlp(spacenet_kernel<128, 8, true>, &opted[1][1], lds, grid, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
+                      : launch_mlp(spacenet_kernel<128, 8, false>, &opted[1][0], lds, grid, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
         default:
-            return ut ? launch_mlp(spacenet_kernel<64, 4, true>, &opted[2][1], lds, grid, 256, stream, a, what)
-                      : launch_mlp(spacenet_kernel<64, 4, false>, &opted[2][0], lds, grid, 256, stream, a, what);
+            return ut ? launch_mlp(spacenet_kernel<64, 4, true>, &opted[2][1], lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
+                      : launch_mlp(spacenet_kernel<64, 4, false>, &opted[2][0], lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
     }
 }
 
@@ -784,12 +786,13 @@ extern "C" int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, 
     const TileCfg tc = tile_config(TILE_64);
     const int grid = grid_for(n_rays, ns, tc == TILE_64 ? 64 : 128);
     const char* what = "motionnet_fwd";
+    const int PROF_KERNEL_ID = PROF_MOTIONNET, PROF_KIND_ID = STNERF_NET_MOTION;
     switch (tc) {
         case TILE_128:
-            return launch_mlp(motionnet_kernel<128, 4>, &opted[0], motion_lds_bytes<128, 4>(), grid, 256, stream, a, what);
+            return launch_mlp(motionnet_kernel<128, 4>, &opted[0], motion_lds_bytes<128, 4>(), grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
         case TILE_128X8:
-            return launch_mlp(motionnet_kernel<128, 8>, &opted[1], motion_lds_bytes<128, 8>(), grid, 512, stream, a, what);
+            return launch_mlp(motionnet_kernel<128, 8>, &opted[1], motion_lds_bytes<128, 8>(), grid, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
         default:
-            return launch_mlp(motionnet_kernel<64, 4>, &opted[2], motion_lds_bytes<64, 4>(), grid, 256, stream, a, what);
+            return launch_mlp(motionnet_kernel<64, 4>, &opted[2], motion_lds_bytes<64, 4>(), grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
     }
 }

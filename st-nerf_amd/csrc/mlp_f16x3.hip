@@ -761,6 +761,7 @@ extern "C" int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n
             }
             *flag = true;
         }
+        LaunchTimer timer(PROF_SPACENET, kind, n_rays, ns, 0, as_stream(stream));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(nthreads), lds, as_stream(stream), a);
         STNERF_CHECK_LAUNCH("spacenet_fwd_f16x3");
         return STNERF_OK;
@@ -799,6 +800,7 @@ extern "C" int stnerf_motionnet_fwd_f16x3(const void* packed, int64_t n_rays, in
             }
             *flag = true;
         }
+        LaunchTimer timer(PROF_MOTIONNET, STNERF_NET_MOTION, n_rays, ns, 0, as_stream(stream));
         hipLaunchKernelGGL(kernel, dim3(grid_for_h(n_rays, ns, tm)), dim3(nthreads), lds, as_stream(stream), a);
         STNERF_CHECK_LAUNCH("motionnet_fwd_f16x3");
         return STNERF_OK;

@@ -1,0 +1,172 @@
+// stnerf_render_rays: the whole chunk pipeline of LayeredRFRender.forward (modeling/layered_rfrender.py:141-734)
+// behind ONE C-ABI call -- coarse sampler -> mask compaction -> [MotionNet] -> SpaceNets -> density edits +
+// per-layer composite + depth merge + merged composite -> inverse-CDF resample -> [MotionNet] -> fine SpaceNets ->
+// composite.  Host-side sequencing only: every stage is one of the kernels behind the op-level entry points,
+// enqueued on the caller's stream into a caller-provided workspace (no allocation, no synchronisation).
+#include <string.h>
+
+#include "common.h"
+
+using namespace stnerf;
+
+namespace {
+
+struct Carve {
+    char* base;
+    int64_t off, cap;
+    template <class T>
+    T* take(int64_t count) {
+        off = (off + 255) & ~int64_t(255);
+        T* p = reinterpret_cast<T*>(base + off);
+        off += count * (int64_t)sizeof(T);
+        return p;
+    }
+};
+
+// sizes of the workspace regions for n rays (shared by the size query and the carve)
+struct Plan {
+    int64_t t_c, xyz_c, raw_c, w_c, t_f, xyz_f, raw_f, list, count;
+};
+Plan make_plan(int64_t n, int l, int n1, int n2, int only_coarse) {
+    Plan p;
+    const int64_t S = n1 + n2;
+    p.t_c = n * l * n1;
+    p.xyz_c = n * l * n1 * 3;
+    p.raw_c = n * l * n1 * 4;
+    p.w_c = only_coarse ? 0 : n * l * n1;
+    p.t_f = only_coarse ? 0 : n * l * S;
+    p.xyz_f = only_coarse ? 0 : n * l * S * 3;
+    p.raw_f = only_coarse ? 0 : n * l * S * 4;
+    p.list = (int64_t)l * n;
+    p.count = STNERF_MAX_LAYERS;
+    return p;
+}
+
+}  // namespace
+
+extern "C" int64_t stnerf_render_workspace_bytes(int64_t n, int l, int n1, int n2, int only_coarse) {
+    if (n < 0 || l < 1 || l > STNERF_MAX_LAYERS || n1 < 3 || n2 < 0) {
+        set_error("render_workspace_bytes: bad shape");
+        return STNERF_EINVAL;
+    }
+    const Plan p = make_plan(n, l, n1, n2, only_coarse);
+    // xyz_c / raw_c are dead once the fine stage starts, but a single bump carve keeps the accounting obvious
+    const int64_t floats = p.t_c + p.xyz_c + p.raw_c + p.w_c + p.t_f + p.xyz_f + p.raw_f;
+    return floats * 4 + (p.list + p.count) * 4 + 16 * 256;
+}
+
+extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* boxes, int64_t box_ray_stride,
+                                  const stnerf_nets* nets, const stnerf_render_params* p, const float* jitter,
+                                  const float* u, void* workspace, int64_t workspace_bytes, float* mixed_fine,
+                                  float* mixed_coarse, float* layer_fine, float* layer_coarse, uint8_t* mask,
+                                  stnerf_stream_t stream) {
+    STNERF_REQUIRE(rays && boxes && nets && p && workspace && mask, "render_rays: null pointer");
+    STNERF_REQUIRE(mixed_coarse && layer_coarse, "render_rays: coarse outputs are required");
+    STNERF_REQUIRE(p->only_coarse || (mixed_fine && layer_fine), "render_rays: fine outputs are required");
+    const int l = p->l, n1 = p->n1, n2 = p->n2, S = n1 + n2, rs = p->ray_stride;
+    STNERF_REQUIRE(n >= 0 && l >= 1 && l <= STNERF_MAX_LAYERS && n1 >= 3 && n2 >= 0, "render_rays: bad shape");
+    STNERF_REQUIRE(rs >= (p->retiming ? 6 + l : 7), "render_rays: ray stride %d too small for the frame-id columns", rs);
+    STNERF_REQUIRE(p->precision == 0 || p->precision == 1, "render_rays: unknown precision %d", p->precision);
+    STNERF_REQUIRE(nets->bkgd && (p->only_coarse || nets->bkgd_fine), "render_rays: background network missing");
+    for (int i = 1; i < l; ++i) {
+        if (!p->shown[i]) continue;
+        STNERF_REQUIRE(nets->space[i] && (p->only_coarse || nets->space_fine[i]), "render_rays: SpaceNet of layer %d missing", i);
+        STNERF_REQUIRE(!p->use_deform_time || nets->motion[i], "render_rays: MotionNet of layer %d missing", i);
+    }
+    const int64_t need = stnerf_render_workspace_bytes(n, l, n1, n2, p->only_coarse);
+    STNERF_REQUIRE(workspace_bytes >= need, "render_rays: workspace of %lld B, need %lld", (long long)workspace_bytes,
+                   (long long)need);
+    if (n == 0) return STNERF_OK;
+
+    const Plan pl = make_plan(n, l, n1, n2, p->only_coarse);
+    Carve ws{static_cast<char*>(workspace), 0, workspace_bytes};
+    float* t_c = ws.take<float>(pl.t_c);
+    float* xyz_c = ws.take<float>(pl.xyz_c);
+    float* raw_c = ws.take<float>(pl.raw_c);
+    float* w_c = ws.take<float>(pl.w_c);
+    float* t_f = ws.take<float>(pl.t_f);
+    float* xyz_f = ws.take<float>(pl.xyz_f);
+    float* raw_f = ws.take<float>(pl.raw_f);
+    int32_t* ray_list = ws.take<int32_t>(pl.list);
+    int32_t* ray_count = ws.take<int32_t>(pl.count);
+    hipStream_t st = as_stream(stream);
+    int rc;
+
+    // ---- coarse samples + hit masks (+ un-edit), then the per-layer lists of hit rays
+    rc = stnerf_sample_coarse(rays, n, rs, boxes, box_ray_stride, l, n1, jitter, p->seed, p->ray_index_base,
+                              p->has_edits ? p->edits_coarse : nullptr, p->pivot, t_c, xyz_c, mask, stream);
+    if (rc) return rc;
+    if (hipMemsetAsync(ray_count, 0, sizeof(int32_t) * STNERF_MAX_LAYERS, st) != hipSuccess) {
+        set_error("render_rays: hipMemsetAsync failed");
+        return STNERF_ELAUNCH;
+    }
+    rc = stnerf_compact_rays(mask, n, l, ray_list, ray_count, stream);
+    if (rc) return rc;
+
+    // ---- one network stage: deform + evaluate every shown layer on its hit rays (:340-418 / :495-576)
+    auto stage = [&](float* xyz, float* raw, int ns, bool fine) -> int {
+        const int64_t xs = (int64_t)l * ns * 3, ws_ = (int64_t)l * ns * 4;
+        for (int i = 1; i < l && p->use_deform_time; ++i) {
+            if (!p->shown[i]) continue;  // a hidden layer's points are never consumed
+            set_launch_tag(i);
+            const float* times = rays + (p->retiming ? 6 + i : 6);
+            const int r2 = p->precision == 1
+                               ? stnerf_motionnet_fwd_f16x3(nets->motion[i], n, ns, ray_list + (int64_t)i * n, ray_count + i,
+                                                            xyz + (int64_t)i * ns * 3, xs, times, rs, nullptr, 0, 1, stream)
+                               : stnerf_motionnet_fwd(nets->motion[i], n, ns, ray_list + (int64_t)i * n, ray_count + i,
+                                                      xyz + (int64_t)i * ns * 3, xs, times, rs, nullptr, 0, 1, stream);
+            if (r2) return r2;
+        }
+        for (int i = 0; i < l; ++i) {
+            if (i > 0 && !p->shown[i]) continue;
+            set_launch_tag(i);
+            const void* net = i == 0 ? (fine ? nets->bkgd_fine : nets->bkgd) : (fine ? nets->space_fine[i] : nets->space[i]);
+            const int kind = (i > 0 && p->use_space_time) ? STNERF_NET_SPACE_TIME : STNERF_NET_SPACE;
+            const float* times = kind == STNERF_NET_SPACE_TIME ? rays + (p->retiming ? 6 + i : 6) : nullptr;
+            const int32_t* lst = i == 0 ? nullptr : ray_list + (int64_t)i * n;
+            const int32_t* cnt = i == 0 ? nullptr : ray_count + i;
+            const int r2 = p->precision == 1
+                               ? stnerf_spacenet_fwd_f16x3(kind, net, n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs, rays + 3,
+                                                           rs, times, rs, raw + (int64_t)i * ns * 4, ws_, stream)
+                               : stnerf_spacenet_fwd(kind, net, n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs, rays + 3, rs,
+                                                     times, rs, raw + (int64_t)i * ns * 4, ws_, stream);
+            if (r2) return r2;
+        }
+        set_launch_tag(-1);
+        return STNERF_OK;
+    };
+    rc = stage(xyz_c, raw_c, n1, false);
+    if (rc) return rc;
+
+    // ---- coarse: density edits, per-layer + merged composite (:414-448)
+    stnerf_composite_params cp;
+    memset(&cp, 0, sizeof(cp));
+    cp.border = p->border;
+    cp.near = p->near;
+    cp.fine = 0;
+    cp.cut_negative_t = 1;
+    for (int i = 0; i < STNERF_MAX_LAYERS; ++i) {
+        cp.sigma_scale[i] = 1.f;
+        cp.evaluated[i] = i < l ? (i == 0 ? 1 : p->shown[i]) : 1;
+        cp.use_threshold[i] = (p->retiming && i >= 1) ? 1 : 0;  // :416-418 (performers, retiming only)
+        cp.threshold[i] = p->density_threshold;
+    }
+    rc = stnerf_composite(t_c, raw_c, mask, n, l, n1, &cp, layer_coarse, mixed_coarse, p->only_coarse ? nullptr : w_c,
+                          nullptr, stream);
+    if (rc || p->only_coarse) return rc;
+
+    // ---- resample + fine points (:459-475), fine networks, fine composite (:538-606)
+    rc = stnerf_resample(t_c, w_c, n, l, n1, n2, u, p->seed, p->ray_index_base, rays, rs,
+                         p->has_edits ? p->edits_fine : nullptr, p->pivot, t_f, xyz_f, nullptr, nullptr, nullptr, stream);
+    if (rc) return rc;
+    rc = stage(xyz_f, raw_f, S, true);
+    if (rc) return rc;
+    cp.fine = 1;
+    cp.cut_negative_t = 0;
+    for (int i = 0; i < STNERF_MAX_LAYERS; ++i) {
+        cp.use_threshold[i] = p->retiming ? 1 : 0;                       // :538-547 (bkgd), :564-566 (performers)
+        cp.threshold[i] = i == 0 ? p->bkgd_density_threshold : p->density_threshold;
+    }
+    if (l > 2) cp.sigma_scale[2] = p->alpha;                             // :575-576
+    return stnerf_composite(t_f, raw_f, mask, n, l, S, &cp, layer_fine, mixed_fine, nullptr, nullptr, stream);
+}

@@ -414,6 +414,9 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
                     weights, order, wpb};
     int64_t blocks = (n + wpb - 1) / wpb;
     if (blocks > 256 * 16) blocks = 256 * 16;
+    LaunchTimer timer(PROF_COMPOSITE, 0, n, S,
+                      20ll * l * S + l + 20ll * (l + 1) + (weights ? 4ll * l * S : 0) + (order ? 4ll * l * S : 0),
+                      as_stream(stream));
     hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(wpb * 64), lds, as_stream(stream), a);
     STNERF_CHECK_LAUNCH("composite");
     return STNERF_OK;
@@ -436,6 +439,8 @@ extern "C" int stnerf_resample(const float* t, const float* weights, int64_t n, 
     STNERF_REQUIRE(lds <= 64 * 1024, "resample: %d+%d samples per ray exceed the LDS budget", n1, n2);
     int64_t blocks = (n * l + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
+    LaunchTimer timer(PROF_RESAMPLE, 0, n, n1 + n2, (int64_t)l * (8ll * n1 + (xyz_fine ? 16ll : 4ll) * (n1 + n2)) + 24,
+                      as_stream(stream));
     hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(256), lds, as_stream(stream), a);
     STNERF_CHECK_LAUNCH("resample");
     return STNERF_OK;

@@ -266,6 +266,7 @@ extern "C" int stnerf_sample_coarse(const float* rays, int64_t n, int ray_stride
     const int bs = 256;
     const int64_t tot = n * l * n1;
     STNERF_REQUIRE((tot + bs - 1) / bs < (1ll << 31), "sample_coarse: chunk too large");
+    LaunchTimer timer(PROF_SAMPLE_COARSE, 0, n, n1, (xyz ? 16ll : 4ll) * l * n1 + 4ll * ray_stride + l, as_stream(stream));
     const bool aligned = (n1 % 4 == 0) && ((uintptr_t)t % 16 == 0) && (!xyz || (uintptr_t)xyz % 16 == 0) &&
                          (!jitter || (uintptr_t)jitter % 16 == 0);
     if (aligned) {

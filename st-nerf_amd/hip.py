@@ -33,7 +33,29 @@ class CompositeParams(C.Structure):
                 ("sigma_scale", C.c_float * MAX_LAYERS), ("evaluated", C.c_int32 * MAX_LAYERS)]
 
 
+class Nets(C.Structure):
+    _fields_ = [("bkgd", C.c_void_p), ("bkgd_fine", C.c_void_p), ("space", C.c_void_p * MAX_LAYERS),
+                ("space_fine", C.c_void_p * MAX_LAYERS), ("motion", C.c_void_p * MAX_LAYERS)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("l", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32), ("ray_stride", C.c_int32),
+                ("retiming", C.c_int32), ("only_coarse", C.c_int32), ("use_deform_time", C.c_int32),
+                ("use_space_time", C.c_int32), ("precision", C.c_int32), ("has_edits", C.c_int32),
+                ("shown", C.c_int32 * MAX_LAYERS), ("border", C.c_float), ("near", C.c_float), ("alpha", C.c_float),
+                ("density_threshold", C.c_float), ("bkgd_density_threshold", C.c_float), ("seed", C.c_uint64),
+                ("ray_index_base", C.c_int64), ("edits_coarse", LayerEdit * MAX_LAYERS),
+                ("edits_fine", LayerEdit * MAX_LAYERS), ("pivot", C.c_float * 3)]
+
+
+class ProfileRecord(C.Structure):
+    _fields_ = [("kernel", C.c_int32), ("kind", C.c_int32), ("ns", C.c_int32), ("tag", C.c_int32),
+                ("n_rays", C.c_int64), ("bytes_per_ray", C.c_int64), ("ms", C.c_float), ("pad_", C.c_int32)]
+
+
 _PROTOS = {
+    "stnerf_profile_begin": (C.c_int, []),
+    "stnerf_profile_end": (C.c_int, [C.POINTER(ProfileRecord), C.c_int, C.POINTER(C.c_int)]),
     "stnerf_version": (C.c_char_p, []),
     "stnerf_last_error": (C.c_char_p, []),
     "stnerf_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
@@ -61,6 +83,9 @@ _PROTOS = {
     "stnerf_gen_weight": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "stnerf_composite": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_i64, C.c_int, C.c_int, C.POINTER(CompositeParams),
                                    c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
+    "stnerf_render_workspace_bytes": (c_i64, [c_i64, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "stnerf_render_rays": (C.c_int, [c_f32p, c_i64, c_f32p, c_i64, C.POINTER(Nets), C.POINTER(RenderParams), c_f32p, c_f32p,
+                                     C.c_void_p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
     "stnerf_resample": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_uint64, c_i64, c_f32p,
                                   C.c_int, C.POINTER(LayerEdit), C.POINTER(C.c_float), c_f32p, c_f32p, c_f32p,
                                   C.c_void_p, c_f32p, C.c_void_p]),

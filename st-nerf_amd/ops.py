@@ -99,11 +99,10 @@ def sample_coarse(rays: Tensor, boxes: Tensor, n1: int, jitter: Optional[Tensor]
     xyz = torch.empty(n, l, n1, 3, dtype=torch.float32, device=rays.device) if want_xyz else None
     mask = torch.empty(n, l, dtype=torch.uint8, device=rays.device)
     ed, pv = _edits(edits, pivot, l)
-    with _Observed("sample_coarse", 16 * l * n1 + 4 * rays.shape[1] + l, n, 1, None):   # kind = algorithmic bytes per ray
-        hip.check(hip.lib().stnerf_sample_coarse(hip.dptr(rays, name="rays"), n, rays.shape[1], bp, bstride, l, n1,
-                                                 hip.dptr(jitter, name="jitter"), seed, ray_index_base, ed, pv,
-                                                 hip.dptr(t), hip.dptr(xyz), hip.dptr(mask, torch.uint8),
-                                                 hip.stream_ptr()), "stnerf_sample_coarse")
+    hip.check(hip.lib().stnerf_sample_coarse(hip.dptr(rays, name="rays"), n, rays.shape[1], bp, bstride, l, n1,
+                                             hip.dptr(jitter, name="jitter"), seed, ray_index_base, ed, pv,
+                                             hip.dptr(t), hip.dptr(xyz), hip.dptr(mask, torch.uint8),
+                                             hip.stream_ptr()), "stnerf_sample_coarse")
     return t, xyz, mask
 
 
@@ -174,32 +173,24 @@ def pack_motionnet(state: dict, prefix: str, device="cuda", precision: str = "fp
     return pack_net(hip.NET_MOTION, ws, bs, device, precision)
 
 
-# Optional launch observer (bench.py): called as fn(name, kind, n_rays, ns, ray_count, start_evt, end_evt)
-# with torch events recorded on the launch stream around the kernel.  None in normal operation.
-# For the HBM-bound kernels (sample_coarse / composite / resample) `kind` carries the algorithmic bytes per ray.
-_observer = None
+PROFILE_KERNELS = ("spacenet", "motionnet", "composite", "resample", "sample_coarse")
 
 
-def set_launch_observer(fn):
-    global _observer
-    _observer = fn
+def profile_begin() -> None:
+    """Start the library's launch profiler (HIP events on the launch stream around every kernel launch)."""
+    hip.check(hip.lib().stnerf_profile_begin(), "stnerf_profile_begin")
 
 
-class _Observed:
-    def __init__(self, name, kind, n, ns, ray_count):
-        self.args = (name, kind, n, ns, ray_count)
-
-    def __enter__(self):
-        if _observer is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
-        return self
-
-    def __exit__(self, *exc):
-        if _observer is not None and exc[0] is None:
-            self.e1.record()
-            _observer(*self.args, self.e0, self.e1)
+def profile_end():
+    """Stop profiling; -> list of dicts (kernel name, kind, n_rays, ns, tag, bytes_per_ray, ms) in launch order."""
+    n = C.c_int(0)
+    hip.check(hip.lib().stnerf_profile_end(None, 0, C.byref(n)), "stnerf_profile_end")
+    if n.value == 0:
+        return []
+    buf = (hip.ProfileRecord * n.value)()
+    hip.check(hip.lib().stnerf_profile_end(buf, n.value, C.byref(n)), "stnerf_profile_end")
+    return [dict(kernel=PROFILE_KERNELS[r.kernel], kind=r.kind, n_rays=r.n_rays, ns=r.ns, tag=r.tag,
+                 bytes_per_ray=r.bytes_per_ray, ms=r.ms) for r in buf]
 
 
 def _worklist(ray_list, ray_count):
@@ -222,9 +213,8 @@ def spacenet_fwd(net: PackedNet, xyz: Tensor, dirs: Tensor, times: Optional[Tens
         tp, ts = C.c_void_p(0), 0
     lp, cp = _worklist(ray_list, ray_count)
     fwd = hip.lib().stnerf_spacenet_fwd_f16x3 if net.precision == "fp16x3" else hip.lib().stnerf_spacenet_fwd
-    with _Observed("spacenet", net.kind, n, ns, ray_count):
-        hip.check(fwd(net.kind, hip.dptr(net.blob), n, ns, lp, cp, xp, xs, dp, ds, tp, ts,
-                      rp, rs, hip.stream_ptr()), "stnerf_spacenet_fwd")
+    hip.check(fwd(net.kind, hip.dptr(net.blob), n, ns, lp, cp, xp, xs, dp, ds, tp, ts, rp, rs, hip.stream_ptr()),
+              "stnerf_spacenet_fwd")
     return raw
 
 
@@ -241,9 +231,8 @@ def motionnet_fwd(net: PackedNet, xyz: Tensor, times: Tensor, flow: Optional[Ten
         fp, fs = C.c_void_p(0), 0
     lp, cp = _worklist(ray_list, ray_count)
     fwd = hip.lib().stnerf_motionnet_fwd_f16x3 if net.precision == "fp16x3" else hip.lib().stnerf_motionnet_fwd
-    with _Observed("motionnet", net.kind, n, ns, ray_count):
-        hip.check(fwd(hip.dptr(net.blob), n, ns, lp, cp, xp, xs, tp, ts, fp, fs,
-                                                 1 if add_to_xyz else 0, hip.stream_ptr()), "stnerf_motionnet_fwd")
+    hip.check(fwd(hip.dptr(net.blob), n, ns, lp, cp, xp, xs, tp, ts, fp, fs, 1 if add_to_xyz else 0, hip.stream_ptr()),
+              "stnerf_motionnet_fwd")
     return flow
 
 
@@ -288,12 +277,10 @@ def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e
     mixed_out = torch.empty(n, 5, dtype=torch.float32, device=t.device)
     weights = torch.empty(n, l, S, dtype=torch.float32, device=t.device) if want_weights else None
     order = torch.empty(n, l * S, dtype=torch.int32, device=t.device) if want_order else None
-    bytes_per_ray = 20 * l * S + l + 20 * (l + 1) + (4 * l * S if want_weights else 0) + (4 * l * S if want_order else 0)
-    with _Observed("composite", bytes_per_ray, n, 1, None):
-        hip.check(hip.lib().stnerf_composite(hip.dptr(t, name="t"), hip.dptr(raw, name="raw"),
-                                             hip.dptr(mask, torch.uint8, "mask"), n, l, S, C.byref(p), hip.dptr(layer_out),
-                                             hip.dptr(mixed_out), hip.dptr(weights), hip.dptr(order, torch.int32),
-                                             hip.stream_ptr()), "stnerf_composite")
+    hip.check(hip.lib().stnerf_composite(hip.dptr(t, name="t"), hip.dptr(raw, name="raw"),
+                                         hip.dptr(mask, torch.uint8, "mask"), n, l, S, C.byref(p), hip.dptr(layer_out),
+                                         hip.dptr(mixed_out), hip.dptr(weights), hip.dptr(order, torch.int32),
+                                         hip.stream_ptr()), "stnerf_composite")
     return layer_out, mixed_out, weights, order
 
 
@@ -312,13 +299,59 @@ def resample(t: Tensor, weights: Tensor, n2: int, rays: Tensor, u: Optional[Tens
     inds = torch.empty(n, l, n2, dtype=torch.int32, device=dev) if debug else None
     cdf = torch.empty(n, l, n1 - 1, dtype=torch.float32, device=dev) if debug else None
     ed, pv = _edits(edits, pivot, l)
-    bytes_per_ray = l * (8 * n1 + (16 if want_xyz else 4) * (n1 + n2)) + 24
-    with _Observed("resample", bytes_per_ray, n, 1, None):
-        hip.check(hip.lib().stnerf_resample(hip.dptr(t, name="t"), hip.dptr(weights, name="weights"), n, l, n1, n2,
-                                            hip.dptr(u, name="u"), seed, ray_index_base, hip.dptr(rays, name="rays"),
-                                            rays.shape[1], ed, pv, hip.dptr(t_fine), hip.dptr(xyz), hip.dptr(z_new),
-                                            hip.dptr(inds, torch.int32), hip.dptr(cdf), hip.stream_ptr()),
-                  "stnerf_resample")
+    hip.check(hip.lib().stnerf_resample(hip.dptr(t, name="t"), hip.dptr(weights, name="weights"), n, l, n1, n2,
+                                        hip.dptr(u, name="u"), seed, ray_index_base, hip.dptr(rays, name="rays"),
+                                        rays.shape[1], ed, pv, hip.dptr(t_fine), hip.dptr(xyz), hip.dptr(z_new),
+                                        hip.dptr(inds, torch.int32), hip.dptr(cdf), hip.stream_ptr()),
+              "stnerf_resample")
     if debug:
         return t_fine, xyz, z_new, inds, cdf
     return t_fine, xyz
+
+
+# ---------------------------------------------------------------------------------------- whole pipeline
+def fill_edits(dst, edits, l):
+    """Copy per-layer (shift|None, scale|None) pairs into a LayerEdit array field of RenderParams."""
+    for i in range(l):
+        sh, sc = edits[i] if (edits is not None and i < len(edits)) else (None, None)
+        dst[i].has_shift, dst[i].has_scale, dst[i].scale = 0, 0, 1.0
+        if sh is not None:
+            v = torch.tensor(sh, dtype=torch.float32).tolist()   # fp32, as torch.tensor(shift[i]) in the reference
+            dst[i].shift[0], dst[i].shift[1], dst[i].shift[2] = v
+            dst[i].has_shift = 1
+        if sc is not None:
+            dst[i].scale, dst[i].has_scale = float(sc), 1
+
+
+def render_workspace_bytes(n: int, l: int, n1: int, n2: int, only_coarse: bool) -> int:
+    nb = hip.lib().stnerf_render_workspace_bytes(n, l, n1, n2, int(only_coarse))
+    if nb < 0:
+        hip.check(int(nb), "stnerf_render_workspace_bytes")
+    return int(nb)
+
+
+def render_rays(rays: Tensor, boxes: Tensor, nets: "hip.Nets", params: "hip.RenderParams", workspace: Tensor,
+                jitter: Optional[Tensor] = None, u: Optional[Tensor] = None):
+    """One call = the whole chunk pipeline (stnerf_render_rays).  Returns mixed_fine (n,5), mixed_coarse (n,5),
+    layer_fine (n,l,5), layer_coarse (n,l,5), mask (n,l) uint8 (fine outputs alias the coarse ones if only_coarse)."""
+    n, l = rays.shape[0], params.l
+    bp, bstride, lb = _boxes_arg(boxes, n)
+    if lb != l:
+        raise ValueError(f"boxes carry {lb} layers, params.l = {l}")
+    dev = rays.device
+    mix_c = torch.empty(n, 5, dtype=torch.float32, device=dev)
+    lo_c = torch.empty(n, l, 5, dtype=torch.float32, device=dev)
+    mask = torch.empty(n, l, dtype=torch.uint8, device=dev)
+    if params.only_coarse:
+        mix_f, lo_f = None, None
+    else:
+        mix_f = torch.empty(n, 5, dtype=torch.float32, device=dev)
+        lo_f = torch.empty(n, l, 5, dtype=torch.float32, device=dev)
+    hip.check(hip.lib().stnerf_render_rays(hip.dptr(rays, name="rays"), n, bp, bstride, C.byref(nets), C.byref(params),
+                                           hip.dptr(jitter, name="jitter"), hip.dptr(u, name="u"),
+                                           hip.dptr(workspace, torch.uint8, "workspace"), workspace.numel(),
+                                           hip.dptr(mix_f), hip.dptr(mix_c), hip.dptr(lo_f), hip.dptr(lo_c),
+                                           hip.dptr(mask, torch.uint8), hip.stream_ptr()), "stnerf_render_rays")
+    if params.only_coarse:
+        return mix_c, mix_c, lo_c, lo_c, mask
+    return mix_f, mix_c, lo_f, lo_c, mask

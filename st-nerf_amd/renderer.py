@@ -358,7 +358,9 @@ class LayeredRFRender(nn.Module):
         return (self.bkgd_spacenet_fine, self.spacenets_fine) if fine else (self.bkgd_spacenet, self.spacenets)
 
     def _stage(self, rays, xyz, raw, lst, cnt, times_col, fine):
-        """Deform + evaluate every layer's network on its (masked) rays.  :340-418 / :495-576."""
+        """Deform + evaluate every layer's network on its (masked) rays through the op-level entry points
+        (:340-418 / :495-576).  The render path itself runs this inside stnerf_render_rays; this op-level
+        composition is kept for stage-by-stage debugging (tools/debug_stages.py)."""
         l = self.layer_num + 1
         bk, nets = self._nets(fine)
         if self.use_deform_time:
@@ -376,38 +378,45 @@ class LayeredRFRender(nn.Module):
                              ray_count=cnt[i:i + 1])
 
     def _render_launch(self, rays, boxes, pivot, retiming, only_coarse, thr, bthr, index_base, replay):
-        """One kernel sequence over `rays` (n <= max_rays_per_launch).  boxes: (l,8,3) shared or (n,l,8,3)."""
+        """One kernel sequence over `rays` (n <= max_rays_per_launch) = ONE call into the C ABI
+        (stnerf_render_rays, csrc/pipeline.hip).  boxes: (l,8,3) shared or (n,l,8,3)."""
+        from stnerf_amd import hip
         n, l = rays.shape[0], self.layer_num + 1
-        N1, N2 = self.coarse_ray_sample, self.fine_ray_sample
-        dev = rays.device
-        times_col = (lambda i: 6 + i) if retiming else (lambda i: 6)
-        shown = [self.is_shown_layer(i) for i in range(l)]
-        pv = None if pivot is None else pivot.tolist()
-        jitter = replay["jitter"] if replay else None
-        t_c, xyz_c, mask = ops.sample_coarse(rays, boxes, N1, jitter=jitter, seed=self.seed, ray_index_base=index_base,
-                                             edits=self._point_edits(l, False), pivot=pv)
-        lst, cnt = ops.compact_rays(mask)
-        raw_c = torch.empty(n, l, N1, 4, dtype=torch.float32, device=dev)
-        self._stage(rays, xyz_c, raw_c, lst, cnt, times_col, False)
-        perf_thr = [None] + [thr if retiming else None] * (l - 1)
-        lo_c, mix_c, w_c, _ = ops.composite(t_c, raw_c, mask, border=self.boarder_weight, near=float(self.near),
-                                            fine=False, cut_negative_t=True, thresholds=perf_thr, evaluated=shown,
-                                            want_weights=not only_coarse)
-        if only_coarse:
-            return mix_c, mix_c, lo_c, lo_c, mask
-        u = replay["u"] if replay else None
-        t_f, xyz_f = ops.resample(t_c, w_c, N2, rays, u=u, seed=self.seed, ray_index_base=index_base,
-                                  edits=self._point_edits(l, True), pivot=pv)
-        del xyz_c, raw_c, w_c
-        raw_f = torch.empty(n, l, N1 + N2, 4, dtype=torch.float32, device=dev)
-        self._stage(rays, xyz_f, raw_f, lst, cnt, times_col, True)
-        fine_thr = [bthr if retiming else None] + [thr if retiming else None] * (l - 1)
-        scale = [1.0] * l
-        if l > 2:
-            scale[2] = float(self.alpha)                                    # :575-576
-        lo_f, mix_f, _, _ = ops.composite(t_f, raw_f, mask, border=self.boarder_weight, near=float(self.near),
-                                          fine=True, thresholds=fine_thr, sigma_scale=scale, evaluated=shown)
-        return mix_f, mix_c, lo_f, lo_c, mask
+        p = hip.RenderParams()
+        p.l, p.n1, p.n2, p.ray_stride = l, self.coarse_ray_sample, self.fine_ray_sample, rays.shape[1]
+        p.retiming, p.only_coarse = int(retiming), int(only_coarse)
+        p.use_deform_time, p.use_space_time = int(self.use_deform_time), int(self.use_space_time)
+        p.precision = ops.PRECISIONS.index(self.bkgd_spacenet.precision)
+        for i in range(l):
+            p.shown[i] = int(self.is_shown_layer(i))
+        p.border, p.near, p.alpha = float(self.boarder_weight), float(self.near), float(self.alpha)
+        p.density_threshold, p.bkgd_density_threshold = float(thr), float(bthr)
+        p.seed, p.ray_index_base = int(self.seed) & 0xFFFFFFFFFFFFFFFF, int(index_base)
+        ec, ef = self._point_edits(l, False), self._point_edits(l, True)
+        p.has_edits = int(ec is not None)
+        ops.fill_edits(p.edits_coarse, ec, l)
+        ops.fill_edits(p.edits_fine, ef, l)
+        if pivot is not None:
+            p.pivot[0], p.pivot[1], p.pivot[2] = pivot.tolist()
+        nets = hip.Nets()
+        keep = []                                                    # packed blobs must outlive the enqueue
+        def ptr(module):
+            pk = module._packed()
+            keep.append(pk)
+            return pk.blob.data_ptr()
+        nets.bkgd, nets.bkgd_fine = ptr(self.bkgd_spacenet), ptr(self.bkgd_spacenet_fine)
+        for i in range(1, l):
+            if not self.is_shown_layer(i):
+                continue
+            nets.space[i], nets.space_fine[i] = ptr(self.spacenets[i - 1]), ptr(self.spacenets_fine[i - 1])
+            if self.use_deform_time:
+                nets.motion[i] = ptr(self.time_deform_nets[i - 1])
+        need = ops.render_workspace_bytes(n, l, p.n1, p.n2, only_coarse)
+        ws = getattr(self, "_workspace", None)
+        if ws is None or ws.numel() < need or ws.device != rays.device:
+            self._workspace = ws = torch.empty(need, dtype=torch.uint8, device=rays.device)
+        return ops.render_rays(rays, boxes, nets, p, ws, jitter=replay["jitter"] if replay else None,
+                               u=(replay.get("u") if replay else None))
 
     def render_rays(self, rays, only_coarse=False, density_threshold=0.0001, bkgd_density_threshold=0.0,
                     ref_chunk: Optional[int] = None):

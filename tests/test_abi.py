@@ -101,3 +101,20 @@ def test_product_path_refuses_cpu_tensors():
         ops.intersect(torch.zeros(4, 9), torch.zeros(3, 8, 3))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.composite(torch.zeros(2, 1, 4), torch.zeros(2, 1, 4, 4), None)
+
+
+def test_render_structs_match_header_layout():
+    # stnerf_nets: 2 + 3*16 pointers; stnerf_render_params: 10 ints, 16 ints, 5 floats (+pad), u64, i64, 2*16 edits, 3 floats (+pad)
+    assert C.sizeof(hip.Nets) == 8 * (2 + 3 * hip.MAX_LAYERS)
+    assert C.sizeof(hip.RenderParams) == 40 + 64 + 20 + 4 + 8 + 8 + 2 * 16 * 24 + 12 + 4
+    assert C.sizeof(hip.ProfileRecord) == 40
+
+
+def test_render_workspace_query_and_argument_errors(lib):
+    nb = lib.stnerf_render_workspace_bytes(1000, 3, 64, 64, 0)
+    floats = 1000 * 3 * (64 * (1 + 3 + 4 + 1) + 128 * (1 + 3 + 4))
+    assert nb >= 4 * floats and nb < 4 * floats + 3 * 1000 * 4 + 8192
+    assert lib.stnerf_render_workspace_bytes(1000, 3, 64, 64, 1) < nb
+    assert lib.stnerf_render_workspace_bytes(10, 99, 64, 64, 0) == hip.EINVAL
+    null = C.c_void_p(0)
+    assert lib.stnerf_render_rays(null, 4, null, 0, None, None, null, null, null, 0, null, null, null, null, null, null) == hip.EINVAL
