@@ -185,10 +185,12 @@ def main():
     frame_ids = [1.0] + [2.5] * L
 
     def step(i, gather=True):
-        # novel-view sweep: every rank its own pose (weak scaling), a new pose every step
-        K, T = syn.camera(H, W, orbit_deg=10.0 + 7.0 * rank + 1.5 * i)
+        # novel-view sweep, a new pose every step.  Weak scaling: each GPU renders one whole view per step, and all
+        # ranks take the SAME camera for step i (distinct RNG streams), so the per-GPU work does not depend on N --
+        # a different pose per rank would change the performer coverage and with it the work of the slowest rank.
+        K, T = syn.camera(H, W, orbit_deg=10.0 + 1.5 * i)
         rays = ops.generate_rays(K, T, H, W, frame_ids=frame_ids, device=device)
-        model.seed = i
+        model.seed = i * world + rank
         with torch.no_grad():
             fine, coarse, fine_layers, _, masks = layered_batchify_ray(model, rays, None, None)
         tile = torch.cat(list(fine), dim=1).contiguous()      # (H*W, 5): colour, depth, acc of the final image
@@ -267,7 +269,8 @@ def main():
                        "coarse_samples": n1, "fine_samples": n2, "use_space_time": st, "use_deform_time": dt,
                        "rays_per_gpu_per_step": n_rays, "rays_per_launch": args.rays_per_launch,
                        "weights": "random, density head scaled (synthetic.make_state_dict seed 0)",
-                       "parallelism": f"ray tiles: 1 view per GPU x {world}, RCCL all-gather of tiles"},
+                       "parallelism": f"ray tiles: 1 view per GPU per step x {world} GPUs (same camera, own RNG stream), "
+                                      "one RCCL all-gather of the rendered tiles per step"},
             "ray_samples_per_s": evals_all / elapsed,
             "ray_samples_per_step_per_gpu": evals / args.steps,
             "mask_fraction": [float(m.float().mean()) for m in masks],
