@@ -12,47 +12,73 @@
 
 namespace stnerf {
 
+// ---- wave64 cross-lane primitives on DPP (gfx9 row_shr / row_bcast / wave_shr controls: one VALU op per
+// scan step, no LDS crossbar traffic; ds_bpermute-based __shfl_up costs ~5 instructions per step).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_move(float identity, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138;
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 
-__device__ __forceinline__ float wave_scan_mul(float v, int lane) {  // inclusive
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float u = __shfl_up(v, o);
-        if (lane >= o) v *= u;
-    }
+__device__ __forceinline__ float wave_scan_mul(float v) {  // inclusive
+    v *= dpp_move<DPP_ROW_SHR1>(1.f, v);
+    v *= dpp_move<DPP_ROW_SHR2>(1.f, v);
+    v *= dpp_move<DPP_ROW_SHR4>(1.f, v);
+    v *= dpp_move<DPP_ROW_SHR8>(1.f, v);
+    v *= dpp_move<DPP_ROW_BCAST15, 0xa>(1.f, v);
+    v *= dpp_move<DPP_ROW_BCAST31, 0xc>(1.f, v);
     return v;
 }
 
-__device__ __forceinline__ float wave_scan_add(float v, int lane) {  // inclusive
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float u = __shfl_up(v, o);
-        if (lane >= o) v += u;
-    }
+__device__ __forceinline__ float wave_scan_add(float v) {  // inclusive
+    v += dpp_move<DPP_ROW_SHR1>(0.f, v);
+    v += dpp_move<DPP_ROW_SHR2>(0.f, v);
+    v += dpp_move<DPP_ROW_SHR4>(0.f, v);
+    v += dpp_move<DPP_ROW_SHR8>(0.f, v);
+    v += dpp_move<DPP_ROW_BCAST15, 0xa>(0.f, v);
+    v += dpp_move<DPP_ROW_BCAST31, 0xc>(0.f, v);
     return v;
 }
 
-// #{x in a[0..n) : x < v}  /  #{x <= v}   for ascending a (LDS)
-__device__ __forceinline__ int lower_bound_lds(const float* a, int n, float v) {
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (a[mid] < v) lo = mid + 1; else hi = mid;
+// value of the previous lane (lane 0 gets `first`)
+__device__ __forceinline__ float wave_prev(float v, float first) { return dpp_move<DPP_WAVE_SHR1>(first, v); }
+__device__ __forceinline__ float wave_last(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+
+// Branch-free binary lifting over an ascending LDS array: #{x in a[0..n) : x < v} / #{x <= v}.
+// `p2` = largest power of two <= n (wave-uniform).
+__device__ __forceinline__ int lower_bound_lds(const float* a, int n, int p2, float v) {
+    int pos = 0;
+    for (int step = p2; step > 0; step >>= 1) {
+        const int np = pos + step;
+        const float x = a[(np < n ? np : n) - 1];
+        pos = (np <= n && x < v) ? np : pos;
     }
-    return lo;
+    return pos;
 }
-__device__ __forceinline__ int upper_bound_lds(const float* a, int n, float v) {
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (a[mid] <= v) lo = mid + 1; else hi = mid;
+__device__ __forceinline__ int upper_bound_lds(const float* a, int n, int p2, float v) {
+    int pos = 0;
+    for (int step = p2; step > 0; step >>= 1) {
+        const int np = pos + step;
+        const float x = a[(np < n ? np : n) - 1];
+        pos = (np <= n && x <= v) ? np : pos;
     }
-    return lo;
+    return pos;
 }
+__host__ __device__ __forceinline__ int floor_pow2(int n) {
+    int p = 1;
+    while (p * 2 <= n) p *= 2;
+    return p;
+}
+
+// torch.sigmoid: 1/(1+exp(-x)) with the accurate expf and a 1-ulp reciprocal
+__device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.f + expf(-x)); }
 
 // ---------------------------------------------------------------------------------------------
 // Alpha-composite `count` samples read through accessor functors, in index order.
@@ -63,10 +89,11 @@ __device__ __forceinline__ int upper_bound_lds(const float* a, int n, float v) {
 // the ray is staged and shared by the per-layer and the merged composite (3 of the 8 expf per sample saved).
 // ---------------------------------------------------------------------------------------------
 template <class TAt, class RawAt, class WOut>
-__device__ __forceinline__ void composite_run(int count, float border, int lane, TAt t_at, RawAt raw_at, WOut w_out,
+__device__ __forceinline__ bool composite_run(int count, float border, int lane, TAt t_at, RawAt raw_at, WOut w_out,
                                               float (&out)[5]) {
     float carry = 1.f;
     float cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
+    bool descending = false;  // some t_{k+1} < t_k: the list is not ascending
     for (int base = 0; base < count; base += 64) {
         const int k = base + lane;
         const bool ok = k < count;
@@ -75,15 +102,19 @@ __device__ __forceinline__ void composite_run(int count, float border, int lane,
         if (ok) {
             tk = t_at(k);
             rw = raw_at(k);
-            const float delta = (k + 1 < count) ? (t_at(k + 1) - tk) : border;
+            float delta = border;
+            if (k + 1 < count) {
+                const float tn = t_at(k + 1);
+                descending = descending || (tn < tk);
+                delta = tn - tk;
+            }
             alpha = 1.f - expf(-fmaxf(rw.w, 0.f) * delta);
             tr = (1.f - alpha) + 1e-10f;
         }
-        const float incl = wave_scan_mul(tr, lane);
-        float excl = __shfl_up(incl, 1);
-        if (lane == 0) excl = 1.f;
+        const float incl = wave_scan_mul(tr);
+        const float excl = wave_prev(incl, 1.f);
         const float w = alpha * (carry * excl);
-        carry = carry * __shfl(incl, 63);
+        carry = carry * wave_last(incl);
         if (ok) {
             w_out(k, w);
             cr += w * rw.x;  // rw.xyz = sigmoid(raw rgb), applied once when the ray is staged
@@ -93,11 +124,12 @@ __device__ __forceinline__ void composite_run(int count, float border, int lane,
             ca += w;
         }
     }
-    out[0] = wave_sum(cr);
-    out[1] = wave_sum(cg);
-    out[2] = wave_sum(cb);
-    out[3] = wave_sum(cd);
-    out[4] = wave_sum(ca);
+    out[0] = wave_last(wave_scan_add(cr));
+    out[1] = wave_last(wave_scan_add(cg));
+    out[2] = wave_last(wave_scan_add(cb));
+    out[3] = wave_last(wave_scan_add(cd));
+    out[4] = wave_last(wave_scan_add(ca));
+    return descending;
 }
 
 // gen_weight stand-alone: one wave per row.
@@ -114,11 +146,10 @@ __global__ void gen_weight_kernel(const float* __restrict__ sigma, const float* 
             alpha = 1.f - expf(-fmaxf(sigma[row * S + k], 0.f) * delta[row * S + k]);
             tr = (1.f - alpha) + 1e-10f;
         }
-        const float incl = wave_scan_mul(tr, lane);
-        float excl = __shfl_up(incl, 1);
-        if (lane == 0) excl = 1.f;
+        const float incl = wave_scan_mul(tr);
+        const float excl = wave_prev(incl, 1.f);
         if (k < S) weights[row * S + k] = alpha * (carry * excl);
-        carry = carry * __shfl(incl, 63);
+        carry = carry * wave_last(incl);
     }
 }
 
@@ -134,6 +165,7 @@ struct CompositeArgs {
     float* weights;
     int32_t* order;
     int waves_per_block;
+    int p2;  // floor_pow2(S)
 };
 
 __global__ void composite_kernel(CompositeArgs a) {
@@ -152,68 +184,76 @@ __global__ void composite_kernel(CompositeArgs a) {
     for (int64_t ray0 = (int64_t)blockIdx.x * a.waves_per_block; ray0 < a.n; ray0 += rays_per_iter) {
         const int64_t ray = ray0 + wave;
         const bool active = ray < a.n;
-        // ---- stage the ray, applying the post-network density edits (a10)
-        bool sorted_ok = true;
+        // ---- stage the ray, applying the post-network density edits (a10); layer-major so every edit
+        // switch is wave-uniform
         if (active) {
             const float* tsrc = a.t + ray * LS;
             const float4* rsrc = a.raw + ray * LS;
-            for (int e = lane; e < LS; e += 64) {
-                const int layer = e / a.S;
-                const float tv = tsrc[e];
+            for (int layer = 0; layer < a.l; ++layer) {
                 const bool have = a.p.evaluated[layer] && (!a.mask || a.mask[ray * a.l + layer]);
-                float4 rw = have ? rsrc[e] : make_float4(0.f, 0.f, 0.f, 0.f);  // zero tensors, :398-399
-                if (!a.p.fine && a.p.cut_negative_t && layer > 0 && tv < 0.f) rw.w = 0.f;       // :414
-                if (a.p.use_threshold[layer] && rw.w < a.p.threshold[layer]) rw.w = 0.f;       // :416-418, :538-547, :564-566
-                rw.w = rw.w * a.p.sigma_scale[layer];                                          // :575-576
-                if (!a.p.fine && layer == 0 && tv < a.p.near) rw.w = 0.f;                      // :422
-                rw.x = 1.f / (1.f + expf(-rw.x));  // torch.sigmoid(rgb), render_layer.py:47
-                rw.y = 1.f / (1.f + expf(-rw.y));
-                rw.z = 1.f / (1.f + expf(-rw.z));
-                ts[e] = tv;
-                raws[e] = rw;
+                const bool cut_neg = !a.p.fine && a.p.cut_negative_t && layer > 0;             // :414
+                const bool cut_near = !a.p.fine && layer == 0;                                 // :422
+                const bool use_thr = a.p.use_threshold[layer] != 0;                            // :416-418, :538-547, :564-566
+                const float thr = a.p.threshold[layer], sscale = a.p.sigma_scale[layer], nearv = a.p.near;
+                for (int k = lane; k < a.S; k += 64) {
+                    const int e = layer * a.S + k;
+                    const float tv = tsrc[e];
+                    float4 rw = have ? rsrc[e] : make_float4(0.f, 0.f, 0.f, 0.f);  // zero tensors, :398-399
+                    if (cut_neg && tv < 0.f) rw.w = 0.f;
+                    if (use_thr && rw.w < thr) rw.w = 0.f;
+                    rw.w = rw.w * sscale;                                          // :575-576
+                    if (cut_near && tv < nearv) rw.w = 0.f;
+                    rw.x = sigmoidf(rw.x);  // torch.sigmoid(rgb), render_layer.py:47
+                    rw.y = sigmoidf(rw.y);
+                    rw.z = sigmoidf(rw.z);
+                    ts[e] = tv;
+                    raws[e] = rw;
+                }
             }
         }
         __syncthreads();
         // ---- per-layer composites (:435-444 / :598-603)
         if (active) {
+            bool unsorted = false;  // a layer's list is ascending unless a box edit/miss made the bin width negative
             for (int layer = 0; layer < a.l; ++layer) {
                 const float* tl = ts + layer * a.S;
                 const float4* rl = raws + layer * a.S;
                 float* wdst = a.weights ? a.weights + (ray * a.l + layer) * a.S : nullptr;
                 float o5[5];
-                composite_run(a.S, a.p.border, lane, [&](int k) { return tl[k]; }, [&](int k) { return rl[k]; },
-                              [&](int k, float w) { if (wdst) wdst[k] = w; }, o5);
+                const bool desc = composite_run(a.S, a.p.border, lane, [&](int k) { return tl[k]; },
+                                                [&](int k) { return rl[k]; },
+                                                [&](int k, float w) { if (wdst) wdst[k] = w; }, o5);
+                unsorted = unsorted || desc;
                 if (a.layer_out && lane < 5) {
                     const float v = lane == 0 ? o5[0] : lane == 1 ? o5[1] : lane == 2 ? o5[2] : lane == 3 ? o5[3] : o5[4];
                     a.layer_out[(ray * a.l + layer) * 5 + lane] = v;
                 }
-                // is this layer's list ascending?  (it is, unless a box edit/miss made the bin width negative)
-                for (int k = lane; k + 1 < a.S; k += 64) sorted_ok = sorted_ok && !(tl[k + 1] < tl[k]);
             }
-            sorted_ok = __all(sorted_ok);
+            const bool sorted_ok = !__any(unsorted);
             // ---- cross-layer merge by depth (:425-429 / :587-592): rank of every sample in the union.
             // Stable: ties resolve by source index (layer-major), the order a stable sort of the
             // concatenation gives.
-            for (int e = lane; e < LS; e += 64) {
-                const int la = e / a.S;
-                const int k = e - la * a.S;
-                const float v = ts[e];
-                int rank;
-                if (sorted_ok) {
-                    rank = k;
-                    for (int lb = 0; lb < a.l; ++lb) {
-                        if (lb == la) continue;
-                        const float* tb = ts + lb * a.S;
-                        rank += (lb < la) ? upper_bound_lds(tb, a.S, v) : lower_bound_lds(tb, a.S, v);
+            if (sorted_ok) {
+                for (int la = 0; la < a.l; ++la) {
+                    for (int k = lane; k < a.S; k += 64) {
+                        const int e = la * a.S + k;
+                        const float v = ts[e];
+                        int rank = k;
+                        for (int lb = 0; lb < la; ++lb) rank += upper_bound_lds(ts + lb * a.S, a.S, a.p2, v);
+                        for (int lb = la + 1; lb < a.l; ++lb) rank += lower_bound_lds(ts + lb * a.S, a.S, a.p2, v);
+                        mord[rank] = (unsigned short)e;
                     }
-                } else {  // general O(n^2) fallback
-                    rank = 0;
+                }
+            } else {  // general O(n^2) fallback
+                for (int e = lane; e < LS; e += 64) {
+                    const float v = ts[e];
+                    int rank = 0;
                     for (int x = 0; x < LS; ++x) {
                         const float xv = ts[x];
                         rank += (xv < v || (xv == v && x < e)) ? 1 : 0;
                     }
+                    mord[rank] = (unsigned short)e;
                 }
-                mord[rank] = (unsigned short)e;
             }
         }
         __syncthreads();
@@ -273,11 +313,13 @@ __global__ void resample_kernel(ResampleArgs a) {
     float* bins = cdf + n1;    // [n1-1]
     float* zs = bins + n1;     // [n2]
     float* tf = zs + n2;       // [S]
+    const int p2_n1 = floor_pow2(n1), p2_nb = floor_pow2(nb), p2_n2 = floor_pow2(n2 > 0 ? n2 : 1);
     const int64_t pairs = a.n * a.l;
     const int64_t per_iter = (int64_t)gridDim.x * 4;
     for (int64_t p0 = (int64_t)blockIdx.x * 4; p0 < pairs; p0 += per_iter) {
         const int64_t pr = p0 + wave;
         const bool active = pr < pairs;
+        bool sorted_z = false;
         const int64_t ray = active ? pr / a.l : 0;
         const int layer = active ? (int)(pr - ray * a.l) : 0;
         // ---- pdf / cdf / bins   (sample_pdf.py:20-24; the caller passes w[..., 1:-1], layered_rfrender.py:460)
@@ -287,15 +329,15 @@ __global__ void resample_kernel(ResampleArgs a) {
             for (int k = lane; k < n1; k += 64) tc[k] = tsrc[k];
             float part = 0.f;
             for (int k = lane; k < n1 - 2; k += 64) part += wsrc[k + 1] + 1e-5f;
-            const float total = wave_sum(part);
+            const float total = wave_sum(part);  // butterfly: every lane holds the same bits
             float carry = 0.f;
             if (lane == 0) cdf[0] = 0.f;
             for (int base = 0; base < n1 - 2; base += 64) {
                 const int k = base + lane;
                 const float pdf = (k < n1 - 2) ? (wsrc[k + 1] + 1e-5f) / total : 0.f;
-                const float incl = wave_scan_add(pdf, lane);
+                const float incl = wave_scan_add(pdf);
                 if (k < n1 - 2) cdf[k + 1] = carry + incl;
-                carry = carry + __shfl(incl, 63);
+                carry = carry + wave_last(incl);
             }
         }
         __syncthreads();
@@ -311,7 +353,7 @@ __global__ void resample_kernel(ResampleArgs a) {
                 const float u = a.u ? a.u[((int64_t)layer * a.n + ray) * n2 + j]
                                     : philox_uniform(a.seed, (uint64_t)(a.ray_index_base + ray), (uint32_t)layer, 1u,
                                                      (uint32_t)j);
-                const int ind = upper_bound_lds(cdf, nb, u);          // searchsorted(right=True)
+                const int ind = upper_bound_lds(cdf, nb, p2_nb, u);   // searchsorted(right=True)
                 const int below = ind - 1 > 0 ? ind - 1 : 0;
                 const int above = ind < nb - 1 ? ind : nb - 1;
                 float den = cdf[above] - cdf[below];
@@ -325,30 +367,62 @@ __global__ void resample_kernel(ResampleArgs a) {
         }
         __syncthreads();
         // ---- sort(cat[t, z])  (layered_rfrender.py:462) by ranks == a stable sort with t before z on ties.
-        // The coarse list is ascending (unless a box edit made the bin width negative), so a t keeps its
-        // index and a z finds its place among the t by binary search; only the n2 new samples are counted.
+        // The coarse list is ascending (unless a box edit made the bin width negative), so a t keeps its index
+        // plus the number of smaller z, and a z its index among the sorted z plus the number of t <= z.  Up to 64
+        // new samples are sorted in registers (bitonic network over the wave's lanes); equal z are interchangeable
+        // because only values leave this kernel.
         if (active) {
-            bool asc = true;
-            for (int k = lane; k + 1 < n1; k += 64) asc = asc && !(tc[k + 1] < tc[k]);
-            asc = __all(asc);
-            for (int e = lane; e < S; e += 64) {
-                const bool is_t = e < n1;
-                const float v = is_t ? tc[e] : zs[e - n1];
-                int rank;
-                if (asc) {
-                    rank = is_t ? e : upper_bound_lds(tc, n1, v);
-                } else {
-                    rank = 0;
-                    for (int x = 0; x < n1; ++x) {
-                        const float xv = tc[x];
-                        rank += (xv < v || (xv == v && (!is_t || x < e))) ? 1 : 0;
+            bool desc = false;
+            for (int k = lane; k + 1 < n1; k += 64) desc = desc || (tc[k + 1] < tc[k]);
+            const bool asc = !__any(desc);
+            if (asc && n2 <= 64) {
+                float v = lane < n2 ? zs[lane] : __builtin_inff();
+#pragma unroll
+                for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+                    for (int j = kk >> 1; j > 0; j >>= 1) {
+                        const float pv = __shfl_xor(v, j);
+                        const bool keep_min = ((lane & j) == 0) == ((lane & kk) == 0);
+                        v = keep_min ? fminf(v, pv) : fmaxf(v, pv);
                     }
                 }
-                for (int x = 0; x < n2; ++x) {
-                    const float xv = zs[x];
-                    rank += (xv < v || (xv == v && !is_t && x < e - n1)) ? 1 : 0;
+                if (lane < n2) {
+                    zs[lane] = v;  // now ascending
+                    tf[lane + upper_bound_lds(tc, n1, p2_n1, v)] = v;
                 }
-                tf[rank] = v;
+            }
+            sorted_z = asc && n2 <= 64;
+        }
+        __syncthreads();
+        if (active) {
+            if (sorted_z) {
+                for (int k = lane; k < n1; k += 64) {
+                    const float v = tc[k];
+                    tf[k + (n2 > 0 ? lower_bound_lds(zs, n2, p2_n2, v) : 0)] = v;
+                }
+            } else {
+                bool desc = false;
+                for (int k = lane; k + 1 < n1; k += 64) desc = desc || (tc[k + 1] < tc[k]);
+                const bool asc = !__any(desc);
+                for (int e = lane; e < S; e += 64) {
+                    const bool is_t = e < n1;
+                    const float v = is_t ? tc[e] : zs[e - n1];
+                    int rank;
+                    if (asc) {
+                        rank = is_t ? e : upper_bound_lds(tc, n1, p2_n1, v);
+                    } else {
+                        rank = 0;
+                        for (int x = 0; x < n1; ++x) {
+                            const float xv = tc[x];
+                            rank += (xv < v || (xv == v && (!is_t || x < e))) ? 1 : 0;
+                        }
+                    }
+                    for (int x = 0; x < n2; ++x) {
+                        const float xv = zs[x];
+                        rank += (xv < v || (xv == v && !is_t && x < e - n1)) ? 1 : 0;
+                    }
+                    tf[rank] = v;
+                }
             }
         }
         __syncthreads();
@@ -411,7 +485,7 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
         lds_limit_set = lds;
     }
     CompositeArgs a{t, reinterpret_cast<const float4*>(raw), mask, n, l, S, *params_host, layer_out, mixed_out,
-                    weights, order, wpb};
+                    weights, order, wpb, floor_pow2(S)};
     int64_t blocks = (n + wpb - 1) / wpb;
     if (blocks > 256 * 16) blocks = 256 * 16;
     LaunchTimer timer(PROF_COMPOSITE, 0, n, S,
