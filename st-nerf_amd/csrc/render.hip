@@ -77,6 +77,14 @@ __host__ __device__ __forceinline__ int floor_pow2(int n) {
     return p;
 }
 
+// Every LDS region below is private to one wave, so phases only need ordering inside the wave: LDS operations of
+// a wave execute in issue order, the fences stop the compiler from moving accesses across the phase boundary.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // torch.sigmoid: 1/(1+exp(-x)) with the accurate expf and a 1-ulp reciprocal
 __device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.f + expf(-x)); }
 
@@ -168,7 +176,7 @@ struct CompositeArgs {
     int p2;  // floor_pow2(S)
 };
 
-__global__ void composite_kernel(CompositeArgs a) {
+__global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(CompositeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -211,7 +219,7 @@ __global__ void composite_kernel(CompositeArgs a) {
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         // ---- per-layer composites (:435-444 / :598-603)
         if (active) {
             bool unsorted = false;  // a layer's list is ascending unless a box edit/miss made the bin width negative
@@ -256,7 +264,7 @@ __global__ void composite_kernel(CompositeArgs a) {
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         // ---- merged composite (:448 / :605-606)
         if (active && (a.mixed_out || a.order)) {
             float o5[5];
@@ -277,7 +285,7 @@ __global__ void composite_kernel(CompositeArgs a) {
             if (a.order)
                 for (int m = lane; m < LS; m += 64) a.order[ray * LS + m] = mord[m];
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -302,7 +310,7 @@ struct ResampleArgs {
     float* cdf_out;
 };
 
-__global__ void resample_kernel(ResampleArgs a) {
+__global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) resample_kernel(ResampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -340,13 +348,13 @@ __global__ void resample_kernel(ResampleArgs a) {
                 carry = carry + wave_last(incl);
             }
         }
-        __syncthreads();
+        wave_sync();
         if (active) {
             for (int k = lane; k < nb; k += 64) bins[k] = 0.5f * (tc[k + 1] + tc[k]);
             if (a.cdf_out)
                 for (int k = lane; k < nb; k += 64) a.cdf_out[pr * nb + k] = cdf[k];
         }
-        __syncthreads();
+        wave_sync();
         // ---- invert the cdf (sample_pdf.py:44-61)
         if (active) {
             for (int j = lane; j < n2; j += 64) {
@@ -365,7 +373,7 @@ __global__ void resample_kernel(ResampleArgs a) {
                 if (a.inds) a.inds[pr * n2 + j] = ind;
             }
         }
-        __syncthreads();
+        wave_sync();
         // ---- sort(cat[t, z])  (layered_rfrender.py:462) by ranks == a stable sort with t before z on ties.
         // The coarse list is ascending (unless a box edit made the bin width negative), so a t keeps its index
         // plus the number of smaller z, and a z its index among the sorted z plus the number of t <= z.  Up to 64
@@ -393,7 +401,7 @@ __global__ void resample_kernel(ResampleArgs a) {
             }
             sorted_z = asc && n2 <= 64;
         }
-        __syncthreads();
+        wave_sync();
         if (active) {
             if (sorted_z) {
                 for (int k = lane; k < n1; k += 64) {
@@ -425,7 +433,7 @@ __global__ void resample_kernel(ResampleArgs a) {
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         if (active) {
             const float* r = a.rays + ray * a.ray_stride;
             const float o0 = r[0], o1 = r[1], o2 = r[2], d0 = r[3], d1 = r[4], d2 = r[5];
@@ -442,7 +450,7 @@ __global__ void resample_kernel(ResampleArgs a) {
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
