@@ -147,6 +147,34 @@ def cpu_baseline(workload, budget_rays):
                        f"{dt_s:.1f} s", seconds=dt_s)
 
 
+def eager_gpu_baseline(workload, n_rays, device):
+    """Informative only: the same restatement of the reference run op by op through eager
+    PyTorch-ROCm on the MI355X (rocBLAS GEMMs, one launch per elementwise op, activations through HBM) --
+    what pointing the reference's own code at the GPU would give.  Not part of the default run."""
+    from oracle import stnerf_oracle as O
+    H, W, L, n1, n2, st, dt = WORKLOADS[workload]
+    K, T = syn.camera(H, W, 10.0)
+    bk, per = syn.scene_boxes(L)
+    sd = {k: v.to(device) for k, v in syn.make_state_dict(L, st, dt, seed=0).items()}
+    m = O.OracleModel(layer_num=L, n_coarse=n1, n_fine=n2, params=sd, use_deform_time=dt, use_space_time=st,
+                      bkgd_bbox=bk.to(device), bboxes=per.to(device))
+    chunk = 3584
+    n = max(chunk, (n_rays // chunk) * chunk)
+    rays = ops.generate_rays(K, T, H, W, frame_ids=[1.0] + [2.5] * L, device=device)
+    r0 = (H * W - n) // 2
+    rays = rays[r0:r0 + n].contiguous()
+    torch.manual_seed(0)
+    with torch.no_grad(), torch.device(device):
+        O.layered_batchify_ray(m, rays[:chunk], chuncks=chunk)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        O.layered_batchify_ray(m, rays, chuncks=chunk)
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+    return dict(value=n / dt_s, unit="rays/s", kind="eager PyTorch-ROCm (oracle restatement on cuda:0)",
+                sample=f"{n} rays ({n // chunk} reference chunks of {chunk}) from the centre rows, {dt_s:.2f} s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +183,8 @@ def main():
     ap.add_argument("--workload", default="taekwondo-1080p-64+64", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-baseline-rays", type=int, default=7168, help="0 disables the CPU baseline leg")
     ap.add_argument("--rays-per-launch", type=int, default=1 << 19)
+    ap.add_argument("--eager-gpu-baseline-rays", type=int, default=0,
+                    help=">0: also time the oracle restatement through eager PyTorch-ROCm on this GPU (informative)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3"],
                     help="arithmetic of the headline run: exact f32 MFMA (default) or fp32-accurate split-fp16 MFMA")
     ap.add_argument("--no-second-precision", action="store_true",
@@ -308,6 +338,8 @@ def main():
                                 "algorithmic_tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12}
                             for k, d in other["ksum"].items() if "flop" in d},
             }
+        if world == 1 and args.eager_gpu_baseline_rays > 0:
+            rec["eager_gpu_baseline"] = eager_gpu_baseline(args.workload, args.eager_gpu_baseline_rays, device)
         if world == 1 and args.cpu_baseline_rays > 0:
             rec["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline_rays)
         else:

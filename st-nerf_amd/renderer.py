@@ -435,6 +435,8 @@ class LayeredRFRender(nn.Module):
             raise ValueError(f"undefined ray format in LayeredRFRender, ray dimension is {width}")
         if self.bkgd_bbox is None or self.bboxes is None:
             raise RuntimeError("set_bkgd_bbox / set_bboxes must be called before rendering")
+        if N == 0:  # the reference dereferences row 0 (rays_frame_id[0, i+1], layered_rfrender.py:200)
+            raise IndexError("empty ray batch: LayeredRFRender needs at least one ray")
         step = N if ref_chunk is None else ref_chunk
         groups = []  # (start, end, boxes, pivot)
         if retiming:

@@ -146,6 +146,61 @@ def test_chunking_and_launch_size_do_not_change_the_image():
         assert torch.equal(a1[2][i][0], a2[2][i][0])
 
 
+@pytest.mark.parametrize("n", [1, 31, 63])
+def test_ragged_ray_counts_match_the_reference_rows(n):
+    """Ray counts that fill neither a wave, a 128-row MLP tile nor a chunk: the first n rays of the
+    reference fixture rendered alone equal the fixture's first n rows (rays are independent, boxes come
+    from row 0 which is kept)."""
+    meta, a = load_golden("fwd_c3")
+    model = build_model(meta)
+    full = assemble_replay(meta, a, a["rays"].shape[0])
+    model.replay = {k: v[:, :n].contiguous() for k, v in full.items()}
+    with torch.no_grad():
+        got = flatten(model(a["rays"][:n].cuda(), None, None, **meta["call_kwargs"]))
+    for k, g in got.items():
+        ref = a[k][:n]
+        if k.startswith("mask"):
+            assert torch.equal(g.cpu(), ref), k
+        elif k.startswith("coarse"):
+            tol = DEPTH_ATOL if k.endswith("depth") else COLOR_ATOL
+            assert float((g.cpu() - ref).abs().max()) <= tol, k
+        else:
+            assert float((g.cpu() - ref).abs().max()) <= FINE_CAP * (10 if k.endswith("depth") else 1), k
+
+
+@pytest.mark.parametrize("n", [65, 130, 257])
+def test_ragged_ray_counts_above_a_wave_match_the_oracle(n):
+    """n rays that straddle wave (64) and MLP-tile (128 rows = 128/ns rays) boundaries, odd sample counts."""
+    from oracle import stnerf_oracle as O
+    meta = dict(L=2, n1=13, n2=7, space_time=True, deform_time=True, weight_seed=41, edit={}, H=36, W=64)
+    model = build_model(meta)
+    sd = syn.make_state_dict(2, True, True, 41)
+    K, T = syn.camera(36, 64, 12.0)
+    g = torch.Generator().manual_seed(n)
+    full = O.generate_rays(K, T, 36, 64)
+    pick = torch.randperm(full.shape[0], generator=g)[:n].sort()[0]
+    rays = torch.cat([full[pick], syn.frame_id_columns(n, 2)], -1)
+    jitter, u = torch.rand(3, n, 13, generator=g), torch.rand(3, n, 7, generator=g)
+    model.replay = {"jitter": jitter.cuda(), "u": u.cuda()}
+    with torch.no_grad():
+        out = model(rays.cuda(), None, None)
+        draws = iter(list(jitter) + list(u))
+        ref = O.render_chunk(_oracle_model(meta, sd), rays, rand=lambda shape: next(draws))
+    for i in range(3):
+        assert torch.equal(out[4][i].cpu(), ref[4][i])
+        assert float((out[3][i][0].cpu() - ref[3][i][0]).abs().max()) <= COLOR_ATOL
+    assert float((out[1][0].cpu() - ref[1][0]).abs().max()) <= COLOR_ATOL
+    per_ray = (out[0][0].cpu() - ref[0][0]).abs().max(-1)[0]
+    assert int((per_ray > COLOR_ATOL).sum()) <= max(2, n // 100) and float(per_ray.max()) <= FINE_CAP
+
+
+def test_empty_ray_batch_raises_like_the_reference():
+    meta, a = load_golden("fwd_c3")
+    model = build_model(meta)
+    with pytest.raises(IndexError):
+        model(a["rays"][:0].cuda(), None, None)
+
+
 def test_cpu_tensors_are_refused():
     meta, a = load_golden("fwd_c1")
     model = build_model(meta)
