@@ -153,8 +153,12 @@ int stnerf_motionnet_fwd_f16x3(const void* packed, int64_t n_rays, int ns, const
 
 /* a7 + a8: fused positional encoding (with the fractional-time lerp) + MotionNet MLP.
  * modeling/motion_net.py:34-71.  Same work list as above.  flow (may be NULL) gets the 3-vector at
- * flow + j*flow_ray_stride + 3k; if add_to_xyz the point is updated in place (xyz += flow), which
- * is what modeling/layered_rfrender.py:355-356,509-510 do. */
+ * flow + j*flow_ray_stride + 3k.  `add_to_xyz` is a set of STNERF_MOTION_* bits: ADD_TO_XYZ updates the
+ * point in place (xyz += flow), which is what modeling/layered_rfrender.py:355-356,509-510 do; PLAIN_TIME
+ * selects MotionNet(input_time=False) (motion_net.py:61-62: PE of [xyz, t] as given, no floor/ceil lerp),
+ * the flavour of bkgd_time_deform_net (layered_rfrender.py:92-93). */
+#define STNERF_MOTION_ADD_TO_XYZ 1
+#define STNERF_MOTION_PLAIN_TIME 2
 int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
                          const int32_t* ray_count, float* xyz, int64_t xyz_ray_stride,
                          const float* times, int64_t times_ray_stride, float* flow,
@@ -218,7 +222,8 @@ typedef struct stnerf_nets {
     const void* bkgd_fine;                      /* bkgd_spacenet_fine                                        */
     const void* space[STNERF_MAX_LAYERS];       /* [i] = spacenets[i-1], i >= 1 ([0] unused)                 */
     const void* space_fine[STNERF_MAX_LAYERS];  /* [i] = spacenets_fine[i-1]                                 */
-    const void* motion[STNERF_MAX_LAYERS];      /* [i] = time_deform_nets[i-1] (use_deform_time only)        */
+    const void* motion[STNERF_MAX_LAYERS];      /* [i] = time_deform_nets[i-1] (use_deform_time only);
+                                                   [0] = bkgd_time_deform_net (bkgd_use_deform_time only)    */
 } stnerf_nets;
 
 typedef struct stnerf_render_params {
@@ -229,6 +234,8 @@ typedef struct stnerf_render_params {
     int32_t use_deform_time, use_space_time;
     int32_t precision;            /* 0: exact f32 MFMA, 1: fp16x3                                            */
     int32_t has_edits;            /* edits_* / pivot are meaningful                                          */
+    int32_t bkgd_use_deform_time; /* BKGD_USE_DEFORM_TIME: nets.motion[0] warps the background samples (:358-367) */
+    int32_t bkgd_use_space_time;  /* BKGD_USE_SPACE_TIME: background SpaceNets take the frame id (needs use_space_time, :382-390) */
     int32_t shown[STNERF_MAX_LAYERS];                 /* display_layers (:99-112); [0] ignored               */
     float border, near, alpha;                        /* BOARDER_WEIGHT, model.near, model.alpha             */
     float density_threshold, bkgd_density_threshold;  /* applied in retiming mode only, as the reference     */

@@ -134,8 +134,9 @@ def _linear(params: Dict[str, Tensor], key: str, x: Tensor) -> Tensor:
     return F.linear(x, params[key + ".weight"], params[key + ".bias"])
 
 
-def motion_net(params: Dict[str, Tensor], prefix: str, xyzt: Tensor) -> Tensor:
-    """Scene flow of samples [x,y,z,t] (..., 4) -> (..., 3).
+def motion_net(params: Dict[str, Tensor], prefix: str, xyzt: Tensor, input_time: bool = True) -> Tensor:
+    """Scene flow of samples [x,y,z,t] (..., 4) -> (..., 3).  input_time=False (the flavour of
+    bkgd_time_deform_net, layered_rfrender.py:92-93) encodes [xyz, t] as given (:61-62).
 
     PE_10 of the 4-vector (84 wide); for fractional t the encoding is the lerp of the encodings
     at floor(t) and floor(t)+1 (:49-60) -- taken for the WHOLE batch if any t is fractional
@@ -146,7 +147,7 @@ def motion_net(params: Dict[str, Tensor], prefix: str, xyzt: Tensor) -> Tensor:
     x = xyzt.reshape(-1, 4)
     xyz, t = x[:, :3], x[:, 3:]
     lower = torch.floor(t)
-    if not torch.all(torch.eq(lower, t)):
+    if input_time and not torch.all(torch.eq(lower, t)):
         w = t - lower
         enc = (1 - w) * positional_encoding(torch.cat([xyz, lower], -1), 10) \
             + w * positional_encoding(torch.cat([xyz, lower + 1], -1), 10)
@@ -256,6 +257,8 @@ class OracleModel:
     params: Dict[str, Tensor]                 # reference state_dict key names
     use_deform_time: bool = True
     use_space_time: bool = True
+    bkgd_use_deform_time: bool = False        # :33, :92-93
+    bkgd_use_space_time: bool = False         # :34, :62 (only meaningful together with use_space_time)
     border: float = 1e10
     bkgd_bbox: Optional[Tensor] = None        # (1,8,3)  set_bkgd_bbox :114
     bboxes: Optional[Tensor] = None           # (F,L,8,3) set_bboxes :117
@@ -353,9 +356,12 @@ def render_chunk(m: OracleModel, rays: Tensor, only_coarse: bool = False,
 
     def deform(x, masks, ns):
         # :340-356 / :495-510: performers only, masked rays only, regardless of visibility
-        if not m.use_deform_time:
-            return
+        if m.bkgd_use_deform_time:  # :358-367 / :512-523: every ray, MotionNet(input_time=False)
+            tid = fid(0).view(-1, 1, 1).repeat(1, ns, 1)
+            x[0] = x[0] + motion_net(P, "bkgd_time_deform_net", torch.cat([x[0], tid], -1), input_time=False)
         for i in range(1, l):
+            if not m.use_deform_time:
+                break
             idx = masks[i]
             if torch.sum(idx) == 0:
                 continue
@@ -366,7 +372,10 @@ def render_chunk(m: OracleModel, rays: Tensor, only_coarse: bool = False,
     def run_nets(x, masks, ns, fine):
         sfx = "_fine" if fine else ""
         rgbs, sig = [], []
-        c0, s0 = space_net(P, "bkgd_spacenet" + sfx, x[0], d)            # :382-394 / :531-549
+        # :382-394 / :531-549: the frame id is handed over whenever use_space_time is on; the network uses it
+        # only if it was built with use_time (BKGD_USE_SPACE_TIME)
+        t0 = fid(0).reshape(-1, 1) if m.use_space_time else None
+        c0, s0 = space_net(P, "bkgd_spacenet" + sfx, x[0], d, t0)
         if fine and retiming:
             s0[s0 < bkgd_density_threshold] = 0                           # :538-547
         rgbs.append(c0)

@@ -153,7 +153,7 @@ struct MotionArgs {
     int64_t times_ray_stride;
     float* flow;
     int64_t flow_ray_stride;
-    int add_to_xyz;
+    int add_to_xyz;  // STNERF_MOTION_* flag bits
 };
 
 // Positional-encoding feature f of a tile sample lives at col[(f >> 2) * TM * 4 + (f & 3)], col = encf + s * 4.

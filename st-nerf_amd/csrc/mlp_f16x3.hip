@@ -570,7 +570,7 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_h
         {  // PE_10([x,y,z,t]) with the fractional-time lerp (modeling/motion_net.py:49-60), as in mlp.hip
             _Float16* eh = reinterpret_cast<_Float16*>(enc_hi);
             _Float16* el = reinterpret_cast<_Float16*>(enc_lo);
-            const float lo = floorf(tv);
+            const float lo = (a.add_to_xyz & STNERF_MOTION_PLAIN_TIME) ? tv : floorf(tv);  // input_time=False: PE(input) as is
             const float wgt = tv - lo;
             const bool frac = wgt != 0.f;
             const float om = 1.f - wgt;
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_h
                     dst[1] = fl[1];
                     dst[2] = fl[2];
                 }
-                if (a.add_to_xyz) {
+                if (a.add_to_xyz & STNERF_MOTION_ADD_TO_XYZ) {
                     float* dst = a.xyz + ray * a.xyz_ray_stride + 3 * k;
                     dst[0] = p[0] + fl[0];
                     dst[1] = p[1] + fl[1];
@@ -781,7 +781,7 @@ extern "C" int stnerf_motionnet_fwd_f16x3(const void* packed, int64_t n_rays, in
                                           const float* times, int64_t times_ray_stride, float* flow,
                                           int64_t flow_ray_stride, int add_to_xyz, stnerf_stream_t stream) {
     STNERF_REQUIRE(packed && xyz && times, "motionnet_fwd_f16x3: null pointer");
-    STNERF_REQUIRE(flow || add_to_xyz, "motionnet_fwd_f16x3: nothing to write");
+    STNERF_REQUIRE(flow || (add_to_xyz & STNERF_MOTION_ADD_TO_XYZ), "motionnet_fwd_f16x3: nothing to write");
     STNERF_REQUIRE(n_rays >= 0 && ns >= 1, "motionnet_fwd_f16x3: bad shape");
     STNERF_REQUIRE(((uintptr_t)packed & 15) == 0, "motionnet_fwd_f16x3: packed weights must be 16-byte aligned");
     if (n_rays == 0) return STNERF_OK;

@@ -68,6 +68,10 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
     STNERF_REQUIRE(rs >= (p->retiming ? 6 + l : 7), "render_rays: ray stride %d too small for the frame-id columns", rs);
     STNERF_REQUIRE(p->precision == 0 || p->precision == 1, "render_rays: unknown precision %d", p->precision);
     STNERF_REQUIRE(nets->bkgd && (p->only_coarse || nets->bkgd_fine), "render_rays: background network missing");
+    STNERF_REQUIRE(!p->bkgd_use_deform_time || nets->motion[0], "render_rays: bkgd_time_deform_net missing");
+    STNERF_REQUIRE(!p->bkgd_use_space_time || p->use_space_time,
+                   "render_rays: BKGD_USE_SPACE_TIME needs USE_SPACE_TIME (the reference passes the background its "
+                   "frame id only then, layered_rfrender.py:382-390)");
     for (int i = 1; i < l; ++i) {
         if (!p->shown[i]) continue;
         STNERF_REQUIRE(nets->space[i] && (p->only_coarse || nets->space_fine[i]), "render_rays: SpaceNet of layer %d missing", i);
@@ -106,22 +110,28 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
     // ---- one network stage: deform + evaluate every shown layer on its hit rays (:340-418 / :495-576)
     auto stage = [&](float* xyz, float* raw, int ns, bool fine) -> int {
         const int64_t xs = (int64_t)l * ns * 3, ws_ = (int64_t)l * ns * 4;
-        for (int i = 1; i < l && p->use_deform_time; ++i) {
-            if (!p->shown[i]) continue;  // a hidden layer's points are never consumed
+        for (int i = 0; i < l; ++i) {
+            if (i == 0 ? !p->bkgd_use_deform_time : !p->use_deform_time) continue;
+            if (i > 0 && !p->shown[i]) continue;  // a hidden layer's points are never consumed
             set_launch_tag(i);
+            // performers: time_deform_nets[i-1] on the hit rays, fractional frame ids lerp the encodings (:340-356);
+            // background: bkgd_time_deform_net on every ray, MotionNet(input_time=False) (:358-367)
             const float* times = rays + (p->retiming ? 6 + i : 6);
+            const int32_t* lst = i == 0 ? nullptr : ray_list + (int64_t)i * n;
+            const int32_t* cnt = i == 0 ? nullptr : ray_count + i;
+            const int flags = STNERF_MOTION_ADD_TO_XYZ | (i == 0 ? STNERF_MOTION_PLAIN_TIME : 0);
             const int r2 = p->precision == 1
-                               ? stnerf_motionnet_fwd_f16x3(nets->motion[i], n, ns, ray_list + (int64_t)i * n, ray_count + i,
-                                                            xyz + (int64_t)i * ns * 3, xs, times, rs, nullptr, 0, 1, stream)
-                               : stnerf_motionnet_fwd(nets->motion[i], n, ns, ray_list + (int64_t)i * n, ray_count + i,
-                                                      xyz + (int64_t)i * ns * 3, xs, times, rs, nullptr, 0, 1, stream);
+                               ? stnerf_motionnet_fwd_f16x3(nets->motion[i], n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs,
+                                                            times, rs, nullptr, 0, flags, stream)
+                               : stnerf_motionnet_fwd(nets->motion[i], n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs, times,
+                                                      rs, nullptr, 0, flags, stream);
             if (r2) return r2;
         }
         for (int i = 0; i < l; ++i) {
             if (i > 0 && !p->shown[i]) continue;
             set_launch_tag(i);
             const void* net = i == 0 ? (fine ? nets->bkgd_fine : nets->bkgd) : (fine ? nets->space_fine[i] : nets->space[i]);
-            const int kind = (i > 0 && p->use_space_time) ? STNERF_NET_SPACE_TIME : STNERF_NET_SPACE;
+            const int kind = ((i > 0 ? 1 : p->bkgd_use_space_time) && p->use_space_time) ? STNERF_NET_SPACE_TIME : STNERF_NET_SPACE;
             const float* times = kind == STNERF_NET_SPACE_TIME ? rays + (p->retiming ? 6 + i : 6) : nullptr;
             const int32_t* lst = i == 0 ? nullptr : ray_list + (int64_t)i * n;
             const int32_t* cnt = i == 0 ? nullptr : ray_count + i;

@@ -42,10 +42,14 @@ class RenderParams(C.Structure):
     _fields_ = [("l", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32), ("ray_stride", C.c_int32),
                 ("retiming", C.c_int32), ("only_coarse", C.c_int32), ("use_deform_time", C.c_int32),
                 ("use_space_time", C.c_int32), ("precision", C.c_int32), ("has_edits", C.c_int32),
+                ("bkgd_use_deform_time", C.c_int32), ("bkgd_use_space_time", C.c_int32),
                 ("shown", C.c_int32 * MAX_LAYERS), ("border", C.c_float), ("near", C.c_float), ("alpha", C.c_float),
                 ("density_threshold", C.c_float), ("bkgd_density_threshold", C.c_float), ("seed", C.c_uint64),
                 ("ray_index_base", C.c_int64), ("edits_coarse", LayerEdit * MAX_LAYERS),
                 ("edits_fine", LayerEdit * MAX_LAYERS), ("pivot", C.c_float * 3)]
+
+
+MOTION_ADD_TO_XYZ, MOTION_PLAIN_TIME = 1, 2   # STNERF_MOTION_* bits of stnerf_motionnet_fwd's add_to_xyz argument
 
 
 class ProfileRecord(C.Structure):

@@ -219,9 +219,11 @@ def spacenet_fwd(net: PackedNet, xyz: Tensor, dirs: Tensor, times: Optional[Tens
 
 
 def motionnet_fwd(net: PackedNet, xyz: Tensor, times: Tensor, flow: Optional[Tensor] = None,
-                  add_to_xyz: bool = True, ray_list: Optional[Tensor] = None, ray_count: Optional[Tensor] = None):
+                  add_to_xyz: bool = True, ray_list: Optional[Tensor] = None, ray_count: Optional[Tensor] = None,
+                  plain_time: bool = False):
     """xyz (n,ns,3) (updated in place if add_to_xyz), times (n,), flow (n,ns,3) out | None.
-    modeling/motion_net.py:34-71 + layered_rfrender.py:355-356."""
+    modeling/motion_net.py:34-71 + layered_rfrender.py:355-356.  plain_time = MotionNet(input_time=False):
+    the time column is encoded as given instead of lerping the encodings of floor(t) and floor(t)+1."""
     n, ns = xyz.shape[0], xyz.shape[1]
     xp, xs = _strided_view_ptr(xyz, (ns, 3), "xyz")
     tp, ts = _strided_view_ptr(times.reshape(n), (), "times")
@@ -231,7 +233,8 @@ def motionnet_fwd(net: PackedNet, xyz: Tensor, times: Tensor, flow: Optional[Ten
         fp, fs = C.c_void_p(0), 0
     lp, cp = _worklist(ray_list, ray_count)
     fwd = hip.lib().stnerf_motionnet_fwd_f16x3 if net.precision == "fp16x3" else hip.lib().stnerf_motionnet_fwd
-    hip.check(fwd(hip.dptr(net.blob), n, ns, lp, cp, xp, xs, tp, ts, fp, fs, 1 if add_to_xyz else 0, hip.stream_ptr()),
+    hip.check(fwd(hip.dptr(net.blob), n, ns, lp, cp, xp, xs, tp, ts, fp, fs,
+                  (hip.MOTION_ADD_TO_XYZ if add_to_xyz else 0) | (hip.MOTION_PLAIN_TIME if plain_time else 0), hip.stream_ptr()),
               "stnerf_motionnet_fwd")
     return flow
 

@@ -90,9 +90,9 @@ class MotionNet(nn.Module, _PackedMixin):
 
     def __init__(self, c_input=5, include_input=True, input_time=False):
         super().__init__()
-        if c_input != 4 or not include_input or not input_time:
-            raise NotImplementedError("HIP MotionNet supports c_input=4, include_input=True, input_time=True "
-                                      "(the time-deformation nets of the layered model)")
+        if c_input != 4 or not include_input:
+            raise NotImplementedError("HIP MotionNet supports c_input=4, include_input=True (the time-deformation "
+                                      "nets of the layered model; input_time selects the fractional-time lerp)")
         self.c_input, self.input_time, self.pos_dim = c_input, input_time, 84
         d = 128
         self.motion_net = nn.Sequential(nn.Linear(self.pos_dim, d), nn.ReLU(inplace=False), nn.Linear(d, d),
@@ -109,7 +109,8 @@ class MotionNet(nn.Module, _PackedMixin):
         x = input_0.reshape(-1, 1, 4)
         xyz = x[..., :3].contiguous()
         flow = torch.empty_like(xyz)
-        ops.motionnet_fwd(self._packed(), xyz, x[:, 0, 3].contiguous(), flow=flow, add_to_xyz=False)
+        ops.motionnet_fwd(self._packed(), xyz, x[:, 0, 3].contiguous(), flow=flow, add_to_xyz=False,
+                          plain_time=not self.input_time)
         return flow.reshape(*input_0.shape[:-1], 3) if bins else flow.reshape(-1, 3)
 
 
@@ -215,11 +216,13 @@ class LayeredRFRender(nn.Module):
         if M.SAMPLE_METHOD != "BBOX":
             raise NotImplementedError("only SAMPLE_METHOD 'BBOX' is on the render path (both shipped ymls)")
         unsupported = dict(POSE_REFINEMENT=M.POSE_REFINEMENT, USE_DEFORM_VIEW=M.USE_DEFORM_VIEW,
-                           BKGD_USE_DEFORM_TIME=M.BKGD_USE_DEFORM_TIME, BKGD_USE_SPACE_TIME=M.BKGD_USE_SPACE_TIME,
                            DEEP_RGB=(M.DEEP_RGB and M.USE_SPACE_TIME))
         bad = [k for k, v in unsupported.items() if v]
         if bad or not M.USE_DIR or not M.TKERNEL_INC_RAW:
             raise NotImplementedError(f"config flags outside the MI355X hot path: {bad or 'USE_DIR/TKERNEL_INC_RAW'}")
+        if M.BKGD_USE_SPACE_TIME and not M.USE_SPACE_TIME:
+            raise ValueError("BKGD_USE_SPACE_TIME needs USE_SPACE_TIME: the reference hands the background SpaceNet "
+                             "its frame id only then (layered_rfrender.py:382-390) and fails on the missing input")
         if not (M.USE_DEFORM_TIME or M.USE_SPACE_TIME):
             raise ValueError("one of USE_DEFORM_TIME / USE_SPACE_TIME must be on (the reference dereferences a "
                              "missing frame id otherwise, layered_rfrender.py:193)")
@@ -231,11 +234,12 @@ class LayeredRFRender(nn.Module):
         self.near, self.alpha = 0, 1
         self.pose_refinement = False
         self.layer_num, self.camera_num = layer_num, camera_num
-        self.use_deform_view, self.bkgd_use_deform_time = False, False
+        self.use_deform_view, self.bkgd_use_deform_time = False, bool(M.BKGD_USE_DEFORM_TIME)
         self.use_deform_time, self.use_space_time = M.USE_DEFORM_TIME, M.USE_SPACE_TIME
+        self.bkgd_use_space_time = bool(M.BKGD_USE_SPACE_TIME)
 
-        self.bkgd_spacenet = SpaceNet(use_time=False)
-        self.bkgd_spacenet_fine = SpaceNet(use_time=False)
+        self.bkgd_spacenet = SpaceNet(use_time=self.bkgd_use_space_time)
+        self.bkgd_spacenet_fine = SpaceNet(use_time=self.bkgd_use_space_time)
         self.spacenets, self.spacenets_fine = nn.ModuleList([]), nn.ModuleList([])
         for i in range(layer_num):
             self.spacenets.append(SpaceNet(use_time=self.use_space_time))
@@ -244,6 +248,8 @@ class LayeredRFRender(nn.Module):
         if self.use_deform_time:
             for i in range(layer_num):
                 self.time_deform_nets.append(MotionNet(c_input=4, input_time=True))
+        if self.bkgd_use_deform_time:                                  # :92-93 (input_time stays False)
+            self.bkgd_time_deform_net = MotionNet(c_input=4)
         # the reference initialises the fine / other-layer nets as deep copies (:63-74); keep that for a
         # freshly built model (a loaded checkpoint overwrites everything anyway)
         self.bkgd_spacenet_fine.load_state_dict(self.bkgd_spacenet.state_dict())
@@ -386,6 +392,7 @@ class LayeredRFRender(nn.Module):
         p.l, p.n1, p.n2, p.ray_stride = l, self.coarse_ray_sample, self.fine_ray_sample, rays.shape[1]
         p.retiming, p.only_coarse = int(retiming), int(only_coarse)
         p.use_deform_time, p.use_space_time = int(self.use_deform_time), int(self.use_space_time)
+        p.bkgd_use_deform_time, p.bkgd_use_space_time = int(self.bkgd_use_deform_time), int(self.bkgd_use_space_time)
         p.precision = ops.PRECISIONS.index(self.bkgd_spacenet.precision)
         for i in range(l):
             p.shown[i] = int(self.is_shown_layer(i))
@@ -405,6 +412,8 @@ class LayeredRFRender(nn.Module):
             keep.append(pk)
             return pk.blob.data_ptr()
         nets.bkgd, nets.bkgd_fine = ptr(self.bkgd_spacenet), ptr(self.bkgd_spacenet_fine)
+        if self.bkgd_use_deform_time:
+            nets.motion[0] = ptr(self.bkgd_time_deform_net)
         for i in range(1, l):
             if not self.is_shown_layer(i):
                 continue

@@ -61,18 +61,26 @@ def motionnet_state(prefix: str, rs: np.random.RandomState, flow_gain: float = 0
 
 
 def make_state_dict(layer_num: int, use_space_time: bool, use_deform_time: bool, seed: int = 0,
-                    sigma_gain: float = 60.0, sigma_bias: float = 0.5) -> Dict[str, torch.Tensor]:
-    """Full LayeredRFRender state_dict (key names of modeling/layered_rfrender.py:59-93)."""
+                    sigma_gain: float = 60.0, sigma_bias: float = 0.5, bkgd_use_space_time: bool = False,
+                    bkgd_use_deform_time: bool = False, same_spacenet: bool = False) -> Dict[str, torch.Tensor]:
+    """Full LayeredRFRender state_dict (key names of modeling/layered_rfrender.py:59-93).  With
+    ``same_spacenet`` the fine performer nets ARE the coarse ones (:70-71): both key sets, same tensors."""
     rs = np.random.RandomState(seed)
     sd: Dict[str, torch.Tensor] = {}
-    sd.update(spacenet_state("bkgd_spacenet", rs, False, sigma_gain, sigma_bias))
-    sd.update(spacenet_state("bkgd_spacenet_fine", rs, False, sigma_gain, sigma_bias))
+    sd.update(spacenet_state("bkgd_spacenet", rs, bkgd_use_space_time, sigma_gain, sigma_bias))
+    sd.update(spacenet_state("bkgd_spacenet_fine", rs, bkgd_use_space_time, sigma_gain, sigma_bias))
     for i in range(layer_num):
         sd.update(spacenet_state(f"spacenets.{i}", rs, use_space_time, sigma_gain, sigma_bias))
-        sd.update(spacenet_state(f"spacenets_fine.{i}", rs, use_space_time, sigma_gain, sigma_bias))
+        if same_spacenet:
+            sd.update({k.replace(f"spacenets.{i}.", f"spacenets_fine.{i}."): v for k, v in sd.items()
+                       if k.startswith(f"spacenets.{i}.")})
+        else:
+            sd.update(spacenet_state(f"spacenets_fine.{i}", rs, use_space_time, sigma_gain, sigma_bias))
     if use_deform_time:
         for i in range(layer_num):
             sd.update(motionnet_state(f"time_deform_nets.{i}", rs))
+    if bkgd_use_deform_time:
+        sd.update(motionnet_state("bkgd_time_deform_net", rs))
     return sd
 
 
@@ -103,8 +111,8 @@ def scene_boxes(layer_num: int, frames: int = 3) -> Tuple[torch.Tensor, torch.Te
     return bk, per
 
 
-def frame_id_columns(n: int, layer_num: int, frame: float = 2.5) -> torch.Tensor:
+def frame_id_columns(n: int, layer_num: int, frame: float = 2.5, bkgd_frame: float = 1.0) -> torch.Tensor:
     """Per-layer frame-id columns (data/datasets/ray_dataset.py:276-281); layer 0 gets frame 1."""
     cols = torch.full((n, layer_num + 1), float(frame), dtype=torch.float32)
-    cols[:, 0] = 1.0
+    cols[:, 0] = float(bkgd_frame)
     return cols

@@ -60,12 +60,15 @@ class RandRecorder:
         torch.rand = self._orig
 
 
-def make_cfg(layer_num, n1, n2, space_time, deform_time):
+def make_cfg(layer_num, n1, n2, space_time, deform_time, flags=None):
     m = types.SimpleNamespace(BOARDER_WEIGHT=1e10, SAMPLE_METHOD="BBOX", SAME_SPACENET=False,
                               TKERNEL_INC_RAW=True, POSE_REFINEMENT=False, USE_DIR=True,
                               USE_DEFORM_VIEW=False, USE_DEFORM_TIME=deform_time, USE_SPACE_TIME=space_time,
                               BKGD_USE_DEFORM_TIME=False, BKGD_USE_SPACE_TIME=False, DEEP_RGB=False,
                               COARSE_RAY_SAMPLING=n1, FINE_RAY_SAMPLING=n2)
+    for k, v in (flags or {}).items():   # SAME_SPACENET / BKGD_USE_DEFORM_TIME / BKGD_USE_SPACE_TIME
+        assert hasattr(m, k)
+        setattr(m, k, v)
     return types.SimpleNamespace(MODEL=m, DATASETS=types.SimpleNamespace(LAYER_NUM=layer_num))
 
 
@@ -76,13 +79,13 @@ def save(name, meta, **arrays):
     print(f"wrote {name}.npz  ({sum(a.nbytes for a in out.values())} B raw)")
 
 
-def view_rays(h, w, layer_num, orbit=20.0, frame=2.5, per_ray_frames=False):
+def view_rays(h, w, layer_num, orbit=20.0, frame=2.5, per_ray_frames=False, bkgd_frame=1.0):
     K, T = syn.camera(h, w, orbit)
     rays, _ = ref_utils.generate_rays(K, T, None, h, w)
     if per_ray_frames:
         fid = (torch.arange(rays.shape[0]) % 3 + 1).float().reshape(-1, 1)
         return torch.cat([rays, fid], -1)
-    return torch.cat([rays, syn.frame_id_columns(rays.shape[0], layer_num, frame)], -1)
+    return torch.cat([rays, syn.frame_id_columns(rays.shape[0], layer_num, frame, bkgd_frame)], -1)
 
 
 def flatten_out(out, prefix=""):
@@ -294,9 +297,12 @@ def g_path():
 
 
 # ----------------------------------------------------------------------------- whole-path fixtures
-def build_ref_model(L, n1, n2, st, dt, seed):
-    model = ref_modeling.build_layered_model(make_cfg(L, n1, n2, st, dt), camera_num=1).eval()
-    model.load_state_dict(syn.make_state_dict(L, st, dt, seed))
+def build_ref_model(L, n1, n2, st, dt, seed, flags=None):
+    flags = flags or {}
+    model = ref_modeling.build_layered_model(make_cfg(L, n1, n2, st, dt, flags), camera_num=1).eval()
+    model.load_state_dict(syn.make_state_dict(L, st, dt, seed, bkgd_use_space_time=flags.get("BKGD_USE_SPACE_TIME", False),
+                                              bkgd_use_deform_time=flags.get("BKGD_USE_DEFORM_TIME", False),
+                                              same_spacenet=flags.get("SAME_SPACENET", False)))
     bk, per = syn.scene_boxes(L)
     model.set_bkgd_bbox(bk)
     model.set_bboxes(per)
@@ -304,15 +310,15 @@ def build_ref_model(L, n1, n2, st, dt, seed):
 
 
 def g_forward(name, L, n1, n2, st, dt, seed, h, w, frame=2.5, per_ray_frames=False, edit=None,
-              call_kwargs=None, chunk=None, only_coarse=False):
-    model = build_ref_model(L, n1, n2, st, dt, seed)
+              call_kwargs=None, chunk=None, only_coarse=False, flags=None, bkgd_frame=1.0):
+    model = build_ref_model(L, n1, n2, st, dt, seed, flags)
     edit = edit or {}
     for k in ("scale", "shift", "alpha", "near"):
         if k in edit:
             setattr(model, k, edit[k])
     for i in edit.get("hide", []):
         model.hide_layer(i)
-    rays = view_rays(h, w, L, frame=frame, per_ray_frames=per_ray_frames)
+    rays = view_rays(h, w, L, frame=frame, per_ray_frames=per_ray_frames, bkgd_frame=bkgd_frame)
     n = rays.shape[0]
     labels, bb, nf = torch.zeros(n), torch.zeros(n, 8, 3), torch.zeros(n, 2)
     kw = dict(call_kwargs or {})
@@ -324,7 +330,7 @@ def g_forward(name, L, n1, n2, st, dt, seed, h, w, frame=2.5, per_ray_frames=Fal
             out = ref_utils.layered_batchify_ray(model, rays, labels, bb, chuncks=chunk, near_far=nf, **kw)
     meta = dict(L=L, n1=n1, n2=n2, space_time=st, deform_time=dt, weight_seed=seed, h=h, w=w,
                 edit={k: v for k, v in edit.items()}, call_kwargs=kw, chunk=chunk, only_coarse=only_coarse,
-                n_draws=len(rr.draws))
+                n_draws=len(rr.draws), flags=dict(flags or {}))
     arrays = flatten_out(out)
     for i, dr in enumerate(rr.draws):
         arrays[f"draw{i}"] = dr
@@ -332,6 +338,11 @@ def g_forward(name, L, n1, n2, st, dt, seed, h, w, frame=2.5, per_ray_frames=Fal
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--new-model-flags":   # add the two newest cases without touching the rest
+        g_forward("fwd_bkgd_time", 2, 12, 6, True, True, 29, 8, 8, bkgd_frame=1.25,
+                  flags=dict(BKGD_USE_DEFORM_TIME=True, BKGD_USE_SPACE_TIME=True))
+        g_forward("fwd_same_spacenet", 2, 12, 6, True, True, 32, 6, 8, flags=dict(SAME_SPACENET=True))
+        return
     g_generate_rays()
     g_sampler()
     g_encoding()
@@ -356,6 +367,12 @@ def main():
               call_kwargs=dict(density_threshold=0.05, bkgd_density_threshold=0.02))
     g_forward("batchify_small", 2, 12, 6, True, True, 28, 6, 8, chunk=3584,
               call_kwargs=dict(density_threshold=0.05, bkgd_density_threshold=0.02))
+    # the model flags both shipped ymls leave off: background deformation net (MotionNet(input_time=False), with a
+    # fractional background frame id so the plain-time encoding differs from the lerp) + background space-time,
+    # and fine performer nets shared with the coarse ones
+    g_forward("fwd_bkgd_time", 2, 12, 6, True, True, 29, 8, 8, bkgd_frame=1.25,
+              flags=dict(BKGD_USE_DEFORM_TIME=True, BKGD_USE_SPACE_TIME=True))
+    g_forward("fwd_same_spacenet", 2, 12, 6, True, True, 32, 6, 8, flags=dict(SAME_SPACENET=True))
 
 
 if __name__ == "__main__":

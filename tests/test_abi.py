@@ -106,8 +106,34 @@ def test_product_path_refuses_cpu_tensors():
 def test_render_structs_match_header_layout():
     # stnerf_nets: 2 + 3*16 pointers; stnerf_render_params: 10 ints, 16 ints, 5 floats (+pad), u64, i64, 2*16 edits, 3 floats (+pad)
     assert C.sizeof(hip.Nets) == 8 * (2 + 3 * hip.MAX_LAYERS)
-    assert C.sizeof(hip.RenderParams) == 40 + 64 + 20 + 4 + 8 + 8 + 2 * 16 * 24 + 12 + 4
+    assert C.sizeof(hip.RenderParams) == 48 + 64 + 20 + 4 + 8 + 8 + 2 * 16 * 24 + 12 + 4
     assert C.sizeof(hip.ProfileRecord) == 40
+
+
+def test_ctypes_structs_agree_with_the_c_compiler(tmp_path):
+    """include/stnerf.h compiled as plain C (gcc): sizeof and offsetof of every struct field == the ctypes mirror."""
+    import os, shutil, subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    pairs = {"stnerf_layer_edit": hip.LayerEdit, "stnerf_composite_params": hip.CompositeParams, "stnerf_nets": hip.Nets,
+             "stnerf_render_params": hip.RenderParams, "stnerf_profile_record": hip.ProfileRecord}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "stnerf.h"', 'int main(void){']
+    for cname, cls in pairs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append('return 0;}')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
 
 
 def test_render_workspace_query_and_argument_errors(lib):

@@ -22,24 +22,30 @@ from stnerf_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 FWD_CASES = ["fwd_c1", "fwd_c3", "fwd_edit", "fwd_hide", "fwd_nonretime", "fwd_only_coarse",
-             "batchify_chunked", "batchify_small"]
+             "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet"]
 COLOR_ATOL, DEPTH_ATOL = 5e-5, 5e-4
 FINE_CAP, FINE_FRACTION, FINE_PSNR = 2e-3, 0.99, 70.0
 
 
-def make_cfg(layer_num, n1, n2, space_time, deform_time):
+def make_cfg(layer_num, n1, n2, space_time, deform_time, flags=None):
     m = types.SimpleNamespace(BOARDER_WEIGHT=1e10, SAMPLE_METHOD="BBOX", SAME_SPACENET=False, TKERNEL_INC_RAW=True,
                               POSE_REFINEMENT=False, USE_DIR=True, USE_DEFORM_VIEW=False, USE_DEFORM_TIME=deform_time,
                               USE_SPACE_TIME=space_time, BKGD_USE_DEFORM_TIME=False, BKGD_USE_SPACE_TIME=False,
                               DEEP_RGB=False, COARSE_RAY_SAMPLING=n1, FINE_RAY_SAMPLING=n2)
+    for k, v in (flags or {}).items():
+        setattr(m, k, v)
     return types.SimpleNamespace(MODEL=m, DATASETS=types.SimpleNamespace(LAYER_NUM=layer_num))
 
 
 def build_model(meta):
     from stnerf_amd.modeling import build_layered_model
     L = meta["L"]
-    model = build_layered_model(make_cfg(L, meta["n1"], meta["n2"], meta["space_time"], meta["deform_time"]), camera_num=1)
-    model.load_state_dict(syn.make_state_dict(L, meta["space_time"], meta["deform_time"], meta["weight_seed"]))
+    fl = meta.get("flags", {})
+    model = build_layered_model(make_cfg(L, meta["n1"], meta["n2"], meta["space_time"], meta["deform_time"], fl), camera_num=1)
+    model.load_state_dict(syn.make_state_dict(L, meta["space_time"], meta["deform_time"], meta["weight_seed"],
+                                              bkgd_use_space_time=fl.get("BKGD_USE_SPACE_TIME", False),
+                                              bkgd_use_deform_time=fl.get("BKGD_USE_DEFORM_TIME", False),
+                                              same_spacenet=fl.get("SAME_SPACENET", False)))
     bk, per = syn.scene_boxes(L)
     model.set_bkgd_bbox(bk)
     model.set_bboxes(per)
