@@ -98,7 +98,9 @@ class KernelTimer:
                 call += 1                                          # every pipeline call starts with the sampler
             if name in ("spacenet", "motionnet"):
                 rays = r["n_rays"] if r["tag"] <= 0 else int(counts[call][r["tag"]])
-                flop = FLOP_MOTION if name == "motionnet" else (FLOP_SPACE_TIME if r["kind"] == 1 else FLOP_SPACE)
+                flop = FLOP_MOTION if name == "motionnet" else (FLOP_SPACE_TIME if r["kind"] in (1, 4) else FLOP_SPACE)
+                if name == "spacenet" and r["kind"] in (3, 4):     # deep_rgb: two more 128x128 layers
+                    flop += 2 * 2 * 128 * 128
                 d = out.setdefault(name, dict(launches=0, ms=0.0, evals=0, flop=0))
                 d["evals"] += rays * r["ns"]
                 d["flop"] += rays * r["ns"] * flop

@@ -108,13 +108,20 @@ int stnerf_compact_rays(const uint8_t* mask, int64_t n, int l, int32_t* ray_list
 /* Network weights ------------------------------------------------------------------------- */
 #define STNERF_NET_SPACE 0      /* SpaceNet(use_time=False)  modeling/spacenet.py:16-86  */
 #define STNERF_NET_SPACE_TIME 1 /* SpaceNet(use_time=True)                               */
-#define STNERF_NET_MOTION 2     /* MotionNet(c_input=4, input_time=True)  modeling/motion_net.py:7-32 */
+#define STNERF_NET_MOTION 2     /* MotionNet(c_input=4)  modeling/motion_net.py:7-32     */
+#define STNERF_NET_SPACE_DEEP 3      /* SpaceNet(use_time=False, deep_rgb=True)  modeling/spacenet.py:68-79 */
+#define STNERF_NET_SPACE_TIME_DEEP 4 /* SpaceNet(use_time=True,  deep_rgb=True)                             */
+#define STNERF_NET_IS_SPACE(kind) ((kind) == STNERF_NET_SPACE || (kind) == STNERF_NET_SPACE_TIME || \
+                                   (kind) == STNERF_NET_SPACE_DEEP || (kind) == STNERF_NET_SPACE_TIME_DEEP)
+#define STNERF_NET_USES_TIME(kind) ((kind) == STNERF_NET_SPACE_TIME || (kind) == STNERF_NET_SPACE_TIME_DEEP)
+#define STNERF_NET_IS_DEEP(kind) ((kind) == STNERF_NET_SPACE_DEEP || (kind) == STNERF_NET_SPACE_TIME_DEEP)
 
 /* Bytes of the packed (kernel-layout) weight blob of one network. */
 int64_t stnerf_packed_bytes(int kind);
 /* Repack reference-layout tensors (nn.Linear: weight (out,in) row-major, bias (out)) into the
  * kernel layout.  HOST -> HOST; the caller uploads `dst` to the device (any allocator).
- * SpaceNet order (10 tensors): stage1.{0,2,4,6}, stage2.{0,2,4}, density_net.0, rgb_net.{1,3}.
+ * SpaceNet order (10 tensors): stage1.{0,2,4,6}, stage2.{0,2,4}, density_net.0, rgb_net.{1,3};
+ * deep_rgb kinds (12 tensors): ..., density_net.0, rgb_net.{1,3,5,7}.
  * MotionNet order (6): motion_net.{0,2,4,6,8,10}.  Checkpoint key names: SURVEY.md section 5. */
 int stnerf_pack_net(int kind, const float* const* weights_host, const float* const* biases_host,
                     int n_tensors, void* dst_host, int64_t dst_bytes);
@@ -124,7 +131,7 @@ int stnerf_pack_net(int kind, const float* const* weights_host, const float* con
  * ray_count ? min(*ray_count, n_rays) : n_rays; every ray contributes ns samples.
  *   pos   of (j,k): xyz  + j*xyz_ray_stride  + 3k      (3 floats)
  *   dir   of  j   : dirs + j*dirs_ray_stride           (3 floats)
- *   time  of  j   : times + j*times_ray_stride         (1 float; STNERF_NET_SPACE_TIME only)
+ *   time  of  j   : times + j*times_ray_stride         (1 float; kinds with time only)
  *   out   of (j,k): raw  + j*raw_ray_stride  + 4k      = {r, g, b, sigma}, no activation
  * All strides in floats. */
 int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
@@ -236,6 +243,7 @@ typedef struct stnerf_render_params {
     int32_t has_edits;            /* edits_* / pivot are meaningful                                          */
     int32_t bkgd_use_deform_time; /* BKGD_USE_DEFORM_TIME: nets.motion[0] warps the background samples (:358-367) */
     int32_t bkgd_use_space_time;  /* BKGD_USE_SPACE_TIME: background SpaceNets take the frame id (needs use_space_time, :382-390) */
+    int32_t deep_rgb;             /* DEEP_RGB && USE_SPACE_TIME (:35): every SpaceNet blob is of a *_DEEP kind */
     int32_t shown[STNERF_MAX_LAYERS];                 /* display_layers (:99-112); [0] ignored               */
     float border, near, alpha;                        /* BOARDER_WEIGHT, model.near, model.alpha             */
     float density_threshold, bkgd_density_threshold;  /* applied in retiming mode only, as the reference     */

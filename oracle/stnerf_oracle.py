@@ -189,7 +189,12 @@ def space_net(params: Dict[str, Tensor], prefix: str, pos: Tensor, dirs: Tensor,
         feat.append(positional_encoding(times.reshape(n, 1, 1).repeat(1, s, 1).reshape(-1, 1), 10))
     x = F.relu(torch.cat(feat, dim=1))
     x = F.relu(_linear(params, f"{prefix}.rgb_net.1", x))
-    rgb = _linear(params, f"{prefix}.rgb_net.3", x)
+    if f"{prefix}.rgb_net.7.weight" in params:      # deep_rgb (:68-79): 128 -> 128 -> 128 -> 3
+        x = F.relu(_linear(params, f"{prefix}.rgb_net.3", x))
+        x = F.relu(_linear(params, f"{prefix}.rgb_net.5", x))
+        rgb = _linear(params, f"{prefix}.rgb_net.7", x)
+    else:
+        rgb = _linear(params, f"{prefix}.rgb_net.3", x)
     return rgb.reshape(n, s, 3), sigma.reshape(n, s, 1)
 
 

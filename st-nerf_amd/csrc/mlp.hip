@@ -263,7 +263,7 @@ __device__ __forceinline__ void head_partial(const float4* act, int s, int q_beg
         weight_lane_ptr(BASE_, NEXT_WOFF_, NN_, WaveSplit<TM_, NW_, NN_>::n0(wave), lane),                               \
         (BASE_) + (NEXT_BOFF_) + WaveSplit<TM_, NW_, NN_>::n0(wave) + 4 * (lane >> 5), WNEXT_ PH_ARGS)
 
-template <int TM, int NW, bool USE_TIME>
+template <int TM, int NW, bool USE_TIME, bool DEEP = false>
 __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_kernel(SpaceArgs a) {
     constexpr int NTHREADS = NW * 64;
     constexpr int NPARTS = NTHREADS / TM;  // threads cooperating on one sample in the VALU phases
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_ke
     float4* enc = smem + 64 * TM;   // [16][TM]
     float* encf = reinterpret_cast<float*>(enc);
     float* scratch = reinterpret_cast<float*>(enc + 12 * TM);  // quads 12..15: 16*TM floats
-    const SpaceLayout L = space_layout(USE_TIME);
+    const SpaceLayout L = space_layout(USE_TIME, DEEP);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_ke
     // step-0 weight fragments, prefetched one layer ahead (layer 0 of the first tile here, of every later
     // tile by the previous tile's last layer)
     WFrag<WaveSplit<TM, NW, 256>::NFB> wA, wB;
-    WFrag<WaveSplit<TM, NW, 128>::NFB> wR;
+    WFrag<WaveSplit<TM, NW, 128>::NFB> wR, wR2;
     load_wfrag(wA, weight_lane_ptr(a.net, L.w[0], 256, WaveSplit<TM, NW, 256>::n0(wave), lane),
                a.net + L.b[0] + WaveSplit<TM, NW, 256>::n0(wave) + 4 * (lane >> 5));
 
@@ -413,7 +413,15 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_ke
         PH(PH_HEAD);
         // ---- rgb_net: relu -> Linear(283|304,128) -> relu -> Linear(128,3)   (:80-86)
         // (h is already >= 0; the encodings were clamped when written)
-        DENSE(TM, NW, 128, 256, net, L.w_rgb1, L.b_rgb1, act, 64, enc, L.kq_rgb1 - 64, act, wR, L.w[0], L.b[0], wA);  // + next tile's layer 0
+        if constexpr (!DEEP) {
+            DENSE(TM, NW, 128, 256, net, L.w_rgb1, L.b_rgb1, act, 64, enc, L.kq_rgb1 - 64, act, wR, L.w[0], L.b[0], wA);  // + next tile's layer 0
+        } else {  // deep_rgb (:68-79): two more 128-wide hidden layers before the 3-wide output
+            DENSE(TM, NW, 128, 128, net, L.w_rgb1, L.b_rgb1, act, 64, enc, L.kq_rgb1 - 64, act, wR, L.w_deep[0], L.b_deep[0], wR2);
+            __syncthreads();
+            DENSE(TM, NW, 128, 128, net, L.w_deep[0], L.b_deep[0], act, 32, nullptr, 0, act, wR2, L.w_deep[1], L.b_deep[1], wR);
+            __syncthreads();
+            DENSE(TM, NW, 128, 256, net, L.w_deep[1], L.b_deep[1], act, 32, nullptr, 0, act, wR, L.w[0], L.b[0], wA);
+        }
         __syncthreads();
         {
             float ps[3];
@@ -675,6 +683,8 @@ extern "C" int64_t stnerf_packed_bytes(int kind) {
     switch (kind) {
         case STNERF_NET_SPACE: return space_layout(false).total * 4;
         case STNERF_NET_SPACE_TIME: return space_layout(true).total * 4;
+        case STNERF_NET_SPACE_DEEP: return space_layout(false, true).total * 4;
+        case STNERF_NET_SPACE_TIME_DEEP: return space_layout(true, true).total * 4;
         case STNERF_NET_MOTION: return motion_layout().total * 4;
         default: set_error("packed_bytes: unknown net kind %d", kind); return STNERF_EINVAL;
     }
@@ -684,12 +694,13 @@ extern "C" int stnerf_pack_net(int kind, const float* const* W, const float* con
                                int64_t dst_bytes) {
     STNERF_REQUIRE(W && B && dst_host, "pack_net: null pointer");
     float* dst = static_cast<float*>(dst_host);
-    if (kind == STNERF_NET_SPACE || kind == STNERF_NET_SPACE_TIME) {
-        const bool ut = kind == STNERF_NET_SPACE_TIME;
-        const SpaceLayout L = space_layout(ut);
-        STNERF_REQUIRE(n_tensors == 10, "pack_net: SpaceNet takes 10 tensors, got %d", n_tensors);
+    if (STNERF_NET_IS_SPACE(kind)) {
+        const bool ut = STNERF_NET_USES_TIME(kind), deep = STNERF_NET_IS_DEEP(kind);
+        const SpaceLayout L = space_layout(ut, deep);
+        const int nt = deep ? 12 : 10;
+        STNERF_REQUIRE(n_tensors == nt, "pack_net: this SpaceNet kind takes %d tensors, got %d", nt, n_tensors);
         STNERF_REQUIRE(dst_bytes >= L.total * 4, "pack_net: dst too small");
-        for (int i = 0; i < 10; ++i) STNERF_REQUIRE(W[i] && B[i], "pack_net: tensor %d is null", i);
+        for (int i = 0; i < nt; ++i) STNERF_REQUIRE(W[i] && B[i], "pack_net: tensor %d is null", i);
         memset(dst, 0, (size_t)L.total * 4);
         const int in_f[7] = {63, 256, 256, 256, 319, 256, 256};
         for (int i = 0; i < 7; ++i) {
@@ -700,8 +711,12 @@ extern "C" int stnerf_pack_net(int kind, const float* const* W, const float* con
         dst[L.b_sigma] = B[7][0];
         pack_linear(W[8], 128, 256 + 27 + (ut ? 21 : 0), L.kq_rgb1, dst + L.w_rgb1);
         memcpy(dst + L.b_rgb1, B[8], 128 * sizeof(float));
-        memcpy(dst + L.w_rgb2, W[9], 3 * 128 * sizeof(float));
-        memcpy(dst + L.b_rgb2, B[9], 3 * sizeof(float));
+        for (int i = 0; i < 2 && deep; ++i) {
+            pack_linear(W[9 + i], 128, 128, 32, dst + L.w_deep[i]);
+            memcpy(dst + L.b_deep[i], B[9 + i], 128 * sizeof(float));
+        }
+        memcpy(dst + L.w_rgb2, W[nt - 1], 3 * 128 * sizeof(float));
+        memcpy(dst + L.b_rgb2, B[nt - 1], 3 * sizeof(float));
         return STNERF_OK;
     }
     if (kind == STNERF_NET_MOTION) {
@@ -741,9 +756,9 @@ extern "C" int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays,
                                    const float* dirs, int64_t dirs_ray_stride, const float* times,
                                    int64_t times_ray_stride, float* raw, int64_t raw_ray_stride,
                                    stnerf_stream_t stream) {
-    STNERF_REQUIRE(kind == STNERF_NET_SPACE || kind == STNERF_NET_SPACE_TIME, "spacenet_fwd: bad kind %d", kind);
+    STNERF_REQUIRE(STNERF_NET_IS_SPACE(kind), "spacenet_fwd: bad kind %d", kind);
     STNERF_REQUIRE(packed && xyz && dirs && raw, "spacenet_fwd: null pointer");
-    STNERF_REQUIRE(kind == STNERF_NET_SPACE || times, "spacenet_fwd: net takes time but times is null");
+    STNERF_REQUIRE(!STNERF_NET_USES_TIME(kind) || times, "spacenet_fwd: net takes time but times is null");
     STNERF_REQUIRE(n_rays >= 0 && ns >= 1, "spacenet_fwd: bad shape n_rays=%lld ns=%d", (long long)n_rays, ns);
     STNERF_REQUIRE((raw_ray_stride & 3) == 0 && ((uintptr_t)raw & 15) == 0, "spacenet_fwd: raw must be 16-byte aligned");
     STNERF_REQUIRE(((uintptr_t)packed & 15) == 0, "spacenet_fwd: packed weights must be 16-byte aligned");
@@ -755,9 +770,15 @@ extern "C" int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays,
     const int tm = tc == TILE_64 ? 64 : 128;
     const int lds = (64 + 16) * tm * 16;
     const int grid = grid_for(n_rays, ns, tm);
-    const bool ut = kind == STNERF_NET_SPACE_TIME;
+    const bool ut = STNERF_NET_USES_TIME(kind);
     const char* what = "spacenet_fwd";
     const int PROF_KERNEL_ID = PROF_SPACENET, PROF_KIND_ID = kind;
+    if (STNERF_NET_IS_DEEP(kind)) {  // deep_rgb: the default tile configuration only
+        static bool opted_deep[2] = {false, false};
+        const int grid128 = grid_for(n_rays, ns, 128);
+        return ut ? launch_mlp(spacenet_kernel<128, 8, true, true>, &opted_deep[1], (64 + 16) * 128 * 16, grid128, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
+                  : launch_mlp(spacenet_kernel<128, 8, false, true>, &opted_deep[0], (64 + 16) * 128 * 16, grid128, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
+    }
     switch (tc) {
         case TILE_128:
             return ut ? launch_mlp(spacenet_kernel<128, 4, true>, &opted[0][1], lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)

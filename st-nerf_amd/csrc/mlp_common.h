@@ -32,13 +32,14 @@ struct SpaceLayout {
     int64_t w[7], b[7];        // backbone: stage1.{0,2,4,6}, stage2.{0,2,4};  W as [Kq][256][4]
     int64_t w_sigma, b_sigma;  // density_net.0: 256 + 1(4)
     int64_t w_rgb1, b_rgb1;    // rgb_net.1 as [Kq][128][4]
-    int64_t w_rgb2, b_rgb2;    // rgb_net.3 as [3][128] + 3(4)
+    int64_t w_deep[2], b_deep[2];  // deep_rgb only: rgb_net.{3,5} as [32][128][4]  (modeling/spacenet.py:68-79)
+    int64_t w_rgb2, b_rgb2;    // last rgb layer (rgb_net.3, or rgb_net.7 with deep_rgb) as [3][128] + 3(4)
     int64_t total;
     int kq[7];                 // K quads per backbone layer
     int kq_rgb1;               // 64 + 12 (time) | 64 + 8
 };
 
-__host__ __device__ inline SpaceLayout space_layout(bool use_time) {
+__host__ __device__ inline SpaceLayout space_layout(bool use_time, bool deep = false) {
     SpaceLayout L;
     const int kq[7] = {16, 64, 64, 64, 80, 64, 64};
     int64_t off = 0;
@@ -54,6 +55,10 @@ __host__ __device__ inline SpaceLayout space_layout(bool use_time) {
     L.kq_rgb1 = 64 + (use_time ? 12 : 8);
     L.w_rgb1 = off; off += (int64_t)L.kq_rgb1 * 128 * 4;
     L.b_rgb1 = off; off += 128;
+    for (int i = 0; i < 2; ++i) {
+        L.w_deep[i] = off; off += deep ? 32 * 128 * 4 : 0;
+        L.b_deep[i] = off; off += deep ? 128 : 0;
+    }
     L.w_rgb2 = off; off += 3 * 128;
     L.b_rgb2 = off; off += 4;
     L.total = off;

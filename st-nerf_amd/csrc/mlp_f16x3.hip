@@ -33,18 +33,19 @@ constexpr float WSCALE_INV = 1.0f / 256.0f;
 // ---------------------------------------------------------------------------------------------
 struct SpaceLayoutH {
     SpaceLayout f32;
-    int64_t whi[8], wlo[8];  // offsets in half8 units from the start of the fp16 region; [7] = rgb_net.1
-    int oct[8];              // K octets per layer (K padded to a multiple of 16)
+    int64_t whi[10], wlo[10];  // offsets in half8 units from the start of the fp16 region; [7] = rgb_net.1,
+                               // [8], [9] = rgb_net.{3,5} of the deep_rgb variant
+    int oct[10];               // K octets per layer (K padded to a multiple of 16)
     int64_t half_region_bytes;
     int64_t total_bytes;
 };
 
-__host__ __device__ inline SpaceLayoutH space_layout_h(bool use_time) {
+__host__ __device__ inline SpaceLayoutH space_layout_h(bool use_time, bool deep = false) {
     SpaceLayoutH L;
-    L.f32 = space_layout(use_time);
-    const int oct[8] = {8, 32, 32, 32, 40, 32, 32, 32 + (use_time ? 6 : 4)};
+    L.f32 = space_layout(use_time, deep);
+    const int oct[10] = {8, 32, 32, 32, 40, 32, 32, 32 + (use_time ? 6 : 4), deep ? 16 : 0, deep ? 16 : 0};
     int64_t off = 0;
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 10; ++i) {
         const int n = i < 7 ? 256 : 128;
         L.oct[i] = oct[i];
         L.whi[i] = off;
@@ -323,7 +324,7 @@ __device__ __forceinline__ void head_partial_h(const half8* act_hi, const half8*
 // ---------------------------------------------------------------------------------------------
 // SpaceNet
 // ---------------------------------------------------------------------------------------------
-template <int TM, int NW, bool USE_TIME>
+template <int TM, int NW, bool USE_TIME, bool DEEP = false>
 __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_h_kernel(SpaceArgs a) {
     constexpr int NTHREADS = NW * 64;
     constexpr int NPARTS = NTHREADS / TM;
@@ -336,8 +337,8 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_h_
     half8* const null_lo = nullptr;
     float* scratch_sigma = reinterpret_cast<float*>(enc_hi + 6 * TM);  // enc_hi octets 6..7: 1024 floats
     float* scratch_rgb = reinterpret_cast<float*>(act_hi + 16 * TM);   // act_hi octets 16..31 (free after rgb1)
-    const SpaceLayoutH L = space_layout_h(USE_TIME);
-#define BIAS_OFF(LI_) ((LI_) < 7 ? L.f32.b[(LI_) < 7 ? (LI_) : 0] : L.f32.b_rgb1)
+    const SpaceLayoutH L = space_layout_h(USE_TIME, DEEP);
+#define BIAS_OFF(LI_) ((LI_) < 7 ? L.f32.b[(LI_) < 7 ? (LI_) : 0] : (LI_) == 7 ? L.f32.b_rgb1 : L.f32.b_deep[(LI_) >= 8 ? (LI_) - 8 : 0])
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_h_
     PH_DECL
     const half8* hreg0 = reinterpret_cast<const half8*>(a.net + L.f32.total);
     HFrag<WaveSplit<TM, NW, 256>::NFB> wA, wB;
-    HFrag<WaveSplit<TM, NW, 128>::NFB> wR;
+    HFrag<WaveSplit<TM, NW, 128>::NFB> wR, wR2;
     load_hfrag(wA, hweight_lane_ptr(hreg0 + L.whi[0], 256, WaveSplit<TM, NW, 256>::n0(wave), lane),
                hweight_lane_ptr(hreg0 + L.wlo[0], 256, WaveSplit<TM, NW, 256>::n0(wave), lane),
                a.net + L.f32.b[0] + WaveSplit<TM, NW, 256>::n0(wave) + 4 * (lane >> 5));
@@ -470,7 +471,15 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_h_
             for (int pp = 0; pp < NPARTS; ++pp) sigma += scratch_sigma[pp * TM + s];
         }
         PH(PH_HEAD);
-        DENSE_H(TM, NW, 128, 256, 7, act, 32, enc, (USE_TIME ? 6 : 4), wR, 0, wA);  // + next tile's layer 0
+        if constexpr (!DEEP) {
+            DENSE_H(TM, NW, 128, 256, 7, act, 32, enc, (USE_TIME ? 6 : 4), wR, 0, wA);  // + next tile's layer 0
+        } else {  // deep_rgb (modeling/spacenet.py:68-79): two more 128-wide hidden layers
+            DENSE_H(TM, NW, 128, 128, 7, act, 32, enc, (USE_TIME ? 6 : 4), wR, 8, wR2);
+            __syncthreads();
+            DENSE_H(TM, NW, 128, 128, 8, act, 16, null, 0, wR2, 9, wR);
+            __syncthreads();
+            DENSE_H(TM, NW, 128, 256, 9, act, 16, null, 0, wR, 0, wA);
+        }
         __syncthreads();
         PH(PH_BAR2);
         {
@@ -690,6 +699,8 @@ extern "C" int64_t stnerf_packed_bytes_f16x3(int kind) {
     switch (kind) {
         case STNERF_NET_SPACE: return space_layout_h(false).total_bytes;
         case STNERF_NET_SPACE_TIME: return space_layout_h(true).total_bytes;
+        case STNERF_NET_SPACE_DEEP: return space_layout_h(false, true).total_bytes;
+        case STNERF_NET_SPACE_TIME_DEEP: return space_layout_h(true, true).total_bytes;
         case STNERF_NET_MOTION: return motion_layout_h().total_bytes;
         default: set_error("packed_bytes_f16x3: unknown net kind %d", kind); return STNERF_EINVAL;
     }
@@ -711,16 +722,16 @@ extern "C" int stnerf_pack_net_f16x3(int kind, const float* const* W, const floa
         }
         return STNERF_OK;
     }
-    STNERF_REQUIRE(kind == STNERF_NET_SPACE || kind == STNERF_NET_SPACE_TIME, "pack_net_f16x3: unknown kind %d", kind);
-    const bool ut = kind == STNERF_NET_SPACE_TIME;
-    const SpaceLayoutH L = space_layout_h(ut);
+    STNERF_REQUIRE(STNERF_NET_IS_SPACE(kind), "pack_net_f16x3: unknown kind %d", kind);
+    const bool ut = STNERF_NET_USES_TIME(kind), deep = STNERF_NET_IS_DEEP(kind);
+    const SpaceLayoutH L = space_layout_h(ut, deep);
     STNERF_REQUIRE(dst_host && dst_bytes >= L.total_bytes, "pack_net_f16x3: dst too small");
     const int rc = stnerf_pack_net(kind, W, B, n_tensors, dst_host, L.f32.total * 4);
     if (rc != STNERF_OK) return rc;
-    const int in_f[8] = {63, 256, 256, 256, 319, 256, 256, 256 + 27 + (ut ? 21 : 0)};
-    const int widx[8] = {0, 1, 2, 3, 4, 5, 6, 8};
+    const int in_f[10] = {63, 256, 256, 256, 319, 256, 256, 256 + 27 + (ut ? 21 : 0), 128, 128};
+    const int widx[10] = {0, 1, 2, 3, 4, 5, 6, 8, 9, 10};
     _Float16* hreg = reinterpret_cast<_Float16*>(static_cast<char*>(dst_host) + L.f32.total * 4);
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < (deep ? 10 : 8); ++i) {
         const int n = i < 7 ? 256 : 128;
         const float m = max_abs(W[widx[i]], (size_t)n * in_f[i]);
         STNERF_REQUIRE(m * WSCALE < 60000.f, "pack_net_f16x3: |weight| up to %g does not fit the fp16 split (use fp32)", m);
@@ -734,9 +745,9 @@ extern "C" int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n
                                          const float* dirs, int64_t dirs_ray_stride, const float* times,
                                          int64_t times_ray_stride, float* raw, int64_t raw_ray_stride,
                                          stnerf_stream_t stream) {
-    STNERF_REQUIRE(kind == STNERF_NET_SPACE || kind == STNERF_NET_SPACE_TIME, "spacenet_fwd_f16x3: bad kind %d", kind);
+    STNERF_REQUIRE(STNERF_NET_IS_SPACE(kind), "spacenet_fwd_f16x3: bad kind %d", kind);
     STNERF_REQUIRE(packed && xyz && dirs && raw, "spacenet_fwd_f16x3: null pointer");
-    STNERF_REQUIRE(kind == STNERF_NET_SPACE || times, "spacenet_fwd_f16x3: net takes time but times is null");
+    STNERF_REQUIRE(!STNERF_NET_USES_TIME(kind) || times, "spacenet_fwd_f16x3: net takes time but times is null");
     STNERF_REQUIRE(n_rays >= 0 && ns >= 1, "spacenet_fwd_f16x3: bad shape");
     STNERF_REQUIRE((raw_ray_stride & 3) == 0 && ((uintptr_t)raw & 15) == 0 && ((uintptr_t)packed & 15) == 0,
                    "spacenet_fwd_f16x3: raw / packed must be 16-byte aligned");
@@ -750,7 +761,7 @@ extern "C" int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n
     const int tm = small ? 64 : 128;
     const int lds = 80 * tm * 16;
     const int grid = grid_for_h(n_rays, ns, tm);
-    const bool ut = kind == STNERF_NET_SPACE_TIME;
+    const bool ut = STNERF_NET_USES_TIME(kind);
     auto launch = [&](auto kernel, bool* flag, int nthreads) -> int {
         if (!*flag) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -766,6 +777,15 @@ extern "C" int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n
         STNERF_CHECK_LAUNCH("spacenet_fwd_f16x3");
         return STNERF_OK;
     };
+    if (STNERF_NET_IS_DEEP(kind)) {  // deep_rgb: the default tile configuration only
+        static bool opted_deep[2] = {false, false};
+        if (tm != 128) {
+            set_error("spacenet_fwd_f16x3: deep_rgb nets run in the default tile configuration only (unset STNERF_TILE_H)");
+            return STNERF_EINVAL;
+        }
+        return ut ? launch(spacenet_h_kernel<128, 8, true, true>, &opted_deep[1], 512)
+                  : launch(spacenet_h_kernel<128, 8, false, true>, &opted_deep[0], 512);
+    }
     if (small)
         return ut ? launch(spacenet_h_kernel<64, 4, true>, &opted[2][1], 256)
                   : launch(spacenet_h_kernel<64, 4, false>, &opted[2][0], 256);

@@ -131,8 +131,10 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
             if (i > 0 && !p->shown[i]) continue;
             set_launch_tag(i);
             const void* net = i == 0 ? (fine ? nets->bkgd_fine : nets->bkgd) : (fine ? nets->space_fine[i] : nets->space[i]);
-            const int kind = ((i > 0 ? 1 : p->bkgd_use_space_time) && p->use_space_time) ? STNERF_NET_SPACE_TIME : STNERF_NET_SPACE;
-            const float* times = kind == STNERF_NET_SPACE_TIME ? rays + (p->retiming ? 6 + i : 6) : nullptr;
+            const bool timed = (i > 0 ? 1 : p->bkgd_use_space_time) && p->use_space_time;
+            const int kind = timed ? (p->deep_rgb ? STNERF_NET_SPACE_TIME_DEEP : STNERF_NET_SPACE_TIME)
+                                   : (p->deep_rgb ? STNERF_NET_SPACE_DEEP : STNERF_NET_SPACE);
+            const float* times = timed ? rays + (p->retiming ? 6 + i : 6) : nullptr;
             const int32_t* lst = i == 0 ? nullptr : ray_list + (int64_t)i * n;
             const int32_t* cnt = i == 0 ? nullptr : ray_count + i;
             const int r2 = p->precision == 1

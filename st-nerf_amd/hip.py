@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_PKG, "libstnerf_hip.so")
 
 OK, EINVAL, ELAUNCH, EARCH = 0, -1, -2, -3
 MAX_LAYERS = 16
-NET_SPACE, NET_SPACE_TIME, NET_MOTION = 0, 1, 2
+NET_SPACE, NET_SPACE_TIME, NET_MOTION, NET_SPACE_DEEP, NET_SPACE_TIME_DEEP = 0, 1, 2, 3, 4
 
 c_f32p = C.c_void_p  # device pointers travel as void*
 c_i64 = C.c_int64
@@ -42,7 +42,7 @@ class RenderParams(C.Structure):
     _fields_ = [("l", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32), ("ray_stride", C.c_int32),
                 ("retiming", C.c_int32), ("only_coarse", C.c_int32), ("use_deform_time", C.c_int32),
                 ("use_space_time", C.c_int32), ("precision", C.c_int32), ("has_edits", C.c_int32),
-                ("bkgd_use_deform_time", C.c_int32), ("bkgd_use_space_time", C.c_int32),
+                ("bkgd_use_deform_time", C.c_int32), ("bkgd_use_space_time", C.c_int32), ("deep_rgb", C.c_int32),
                 ("shown", C.c_int32 * MAX_LAYERS), ("border", C.c_float), ("near", C.c_float), ("alpha", C.c_float),
                 ("density_threshold", C.c_float), ("bkgd_density_threshold", C.c_float), ("seed", C.c_uint64),
                 ("ray_index_base", C.c_int64), ("edits_coarse", LayerEdit * MAX_LAYERS),

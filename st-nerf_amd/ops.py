@@ -134,7 +134,7 @@ class PackedNet:
 
     @property
     def use_time(self) -> bool:
-        return self.kind == hip.NET_SPACE_TIME
+        return self.kind in (hip.NET_SPACE_TIME, hip.NET_SPACE_TIME_DEEP)
 
 
 def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cuda", precision: str = "fp32") -> PackedNet:
@@ -159,12 +159,16 @@ def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cud
 
 def pack_spacenet(state: dict, prefix: str, device="cuda", precision: str = "fp32") -> PackedNet:
     """From reference state_dict keys ``{prefix}.stage1.0.weight`` ...."""
-    ws = [state[f"{prefix}.{k}.weight"] for k in SPACENET_KEYS]
-    bs = [state[f"{prefix}.{k}.bias"] for k in SPACENET_KEYS]
+    deep = f"{prefix}.rgb_net.7.weight" in state          # deep_rgb: rgb_net.{1,3,5,7} (modeling/spacenet.py:68-79)
+    keys = SPACENET_KEYS + (["rgb_net.5", "rgb_net.7"] if deep else [])
+    ws = [state[f"{prefix}.{k}.weight"] for k in keys]
+    bs = [state[f"{prefix}.{k}.bias"] for k in keys]
     in1 = ws[8].shape[1]
     if in1 not in (283, 304):
         raise ValueError(f"{prefix}.rgb_net.1 has in-width {in1}; only USE_DIR with/without time is supported")
-    return pack_net(hip.NET_SPACE_TIME if in1 == 304 else hip.NET_SPACE, ws, bs, device, precision)
+    kind = ((hip.NET_SPACE_TIME_DEEP if deep else hip.NET_SPACE_TIME) if in1 == 304
+            else (hip.NET_SPACE_DEEP if deep else hip.NET_SPACE))
+    return pack_net(kind, ws, bs, device, precision)
 
 
 def pack_motionnet(state: dict, prefix: str, device="cuda", precision: str = "fp32") -> PackedNet:

@@ -52,10 +52,9 @@ class SpaceNet(nn.Module, _PackedMixin):
 
     def __init__(self, c_pos=3, include_input=True, use_dir=True, use_time=False, deep_rgb=False):
         super().__init__()
-        if c_pos != 3 or not include_input or not use_dir or deep_rgb:
-            raise NotImplementedError("HIP SpaceNet supports c_pos=3, include_input=True, use_dir=True, "
-                                      "deep_rgb=False (the configuration of both shipped ymls)")
-        self.c_pos, self.use_dir, self.use_time = c_pos, use_dir, use_time
+        if c_pos != 3 or not include_input or not use_dir:
+            raise NotImplementedError("HIP SpaceNet supports c_pos=3, include_input=True, use_dir=True")
+        self.c_pos, self.use_dir, self.use_time, self.deep_rgb = c_pos, use_dir, use_time, deep_rgb
         self.pos_dim, self.dir_dim, self.time_dim = 63, 27, (21 if use_time else 0)
         bd, hd = 256, 128
         self.stage1 = nn.Sequential(nn.Linear(self.pos_dim, bd), nn.ReLU(inplace=True), nn.Linear(bd, bd),
@@ -64,8 +63,13 @@ class SpaceNet(nn.Module, _PackedMixin):
         self.stage2 = nn.Sequential(nn.Linear(bd + self.pos_dim, bd), nn.ReLU(inplace=True), nn.Linear(bd, bd),
                                     nn.ReLU(inplace=True), nn.Linear(bd, bd), nn.ReLU(inplace=True))
         self.density_net = nn.Sequential(nn.Linear(bd, 1))
-        self.rgb_net = nn.Sequential(nn.ReLU(inplace=True), nn.Linear(bd + self.dir_dim + self.time_dim, hd),
-                                     nn.ReLU(inplace=True), nn.Linear(hd, 3))
+        if deep_rgb:                                                        # modeling/spacenet.py:68-79
+            self.rgb_net = nn.Sequential(nn.ReLU(inplace=True), nn.Linear(bd + self.dir_dim + self.time_dim, hd),
+                                         nn.ReLU(inplace=True), nn.Linear(hd, hd), nn.ReLU(inplace=True),
+                                         nn.Linear(hd, hd), nn.ReLU(inplace=True), nn.Linear(hd, 3))
+        else:
+            self.rgb_net = nn.Sequential(nn.ReLU(inplace=True), nn.Linear(bd + self.dir_dim + self.time_dim, hd),
+                                         nn.ReLU(inplace=True), nn.Linear(hd, 3))
 
     def _pack(self, sd, dev):
         return ops.pack_spacenet({"net." + k: v for k, v in sd.items()}, "net", dev, self.precision)
@@ -215,8 +219,7 @@ class LayeredRFRender(nn.Module):
         M = cfg.MODEL
         if M.SAMPLE_METHOD != "BBOX":
             raise NotImplementedError("only SAMPLE_METHOD 'BBOX' is on the render path (both shipped ymls)")
-        unsupported = dict(POSE_REFINEMENT=M.POSE_REFINEMENT, USE_DEFORM_VIEW=M.USE_DEFORM_VIEW,
-                           DEEP_RGB=(M.DEEP_RGB and M.USE_SPACE_TIME))
+        unsupported = dict(POSE_REFINEMENT=M.POSE_REFINEMENT, USE_DEFORM_VIEW=M.USE_DEFORM_VIEW)
         bad = [k for k, v in unsupported.items() if v]
         if bad or not M.USE_DIR or not M.TKERNEL_INC_RAW:
             raise NotImplementedError(f"config flags outside the MI355X hot path: {bad or 'USE_DIR/TKERNEL_INC_RAW'}")
@@ -238,12 +241,14 @@ class LayeredRFRender(nn.Module):
         self.use_deform_time, self.use_space_time = M.USE_DEFORM_TIME, M.USE_SPACE_TIME
         self.bkgd_use_space_time = bool(M.BKGD_USE_SPACE_TIME)
 
-        self.bkgd_spacenet = SpaceNet(use_time=self.bkgd_use_space_time)
-        self.bkgd_spacenet_fine = SpaceNet(use_time=self.bkgd_use_space_time)
+        self.deep_rgb = deep = bool(M.DEEP_RGB and M.USE_SPACE_TIME)      # :35
+        self.bkgd_spacenet = SpaceNet(use_time=self.bkgd_use_space_time, deep_rgb=deep)
+        self.bkgd_spacenet_fine = SpaceNet(use_time=self.bkgd_use_space_time, deep_rgb=deep)
         self.spacenets, self.spacenets_fine = nn.ModuleList([]), nn.ModuleList([])
         for i in range(layer_num):
-            self.spacenets.append(SpaceNet(use_time=self.use_space_time))
-            self.spacenets_fine.append(self.spacenets[i] if M.SAME_SPACENET else SpaceNet(use_time=self.use_space_time))
+            self.spacenets.append(SpaceNet(use_time=self.use_space_time, deep_rgb=deep))
+            self.spacenets_fine.append(self.spacenets[i] if M.SAME_SPACENET
+                                       else SpaceNet(use_time=self.use_space_time, deep_rgb=deep))
         self.time_deform_nets = nn.ModuleList([])
         if self.use_deform_time:
             for i in range(layer_num):
@@ -393,6 +398,7 @@ class LayeredRFRender(nn.Module):
         p.retiming, p.only_coarse = int(retiming), int(only_coarse)
         p.use_deform_time, p.use_space_time = int(self.use_deform_time), int(self.use_space_time)
         p.bkgd_use_deform_time, p.bkgd_use_space_time = int(self.bkgd_use_deform_time), int(self.bkgd_use_space_time)
+        p.deep_rgb = int(self.deep_rgb)
         p.precision = ops.PRECISIONS.index(self.bkgd_spacenet.precision)
         for i in range(l):
             p.shown[i] = int(self.is_shown_layer(i))

@@ -38,7 +38,7 @@ def _linear(rs: np.random.RandomState, out_f: int, in_f: int, gain: float = 1.0,
 
 
 def spacenet_state(prefix: str, rs: np.random.RandomState, use_time: bool,
-                   sigma_gain: float = 60.0, sigma_bias: float = 0.5) -> Dict[str, torch.Tensor]:
+                   sigma_gain: float = 60.0, sigma_bias: float = 0.5, deep_rgb: bool = False) -> Dict[str, torch.Tensor]:
     """One SpaceNet (modeling/spacenet.py:45-86).  ``sigma_gain``/``sigma_bias`` make the density
     head 'trained-like' (random init gives sigma ~ 0 and a numerically trivial composite)."""
     sd = {}
@@ -47,7 +47,12 @@ def spacenet_state(prefix: str, rs: np.random.RandomState, use_time: bool,
         sd[f"{prefix}.{name}.weight"], sd[f"{prefix}.{name}.bias"] = _linear(rs, o, i, g, bs)
     rgb_in = 256 + 27 + (21 if use_time else 0)
     sd[f"{prefix}.rgb_net.1.weight"], sd[f"{prefix}.rgb_net.1.bias"] = _linear(rs, 128, rgb_in)
-    sd[f"{prefix}.rgb_net.3.weight"], sd[f"{prefix}.rgb_net.3.bias"] = _linear(rs, 3, 128, 4.0)
+    if deep_rgb:  # modeling/spacenet.py:68-79: two more 128-wide hidden layers
+        sd[f"{prefix}.rgb_net.3.weight"], sd[f"{prefix}.rgb_net.3.bias"] = _linear(rs, 128, 128)
+        sd[f"{prefix}.rgb_net.5.weight"], sd[f"{prefix}.rgb_net.5.bias"] = _linear(rs, 128, 128)
+        sd[f"{prefix}.rgb_net.7.weight"], sd[f"{prefix}.rgb_net.7.bias"] = _linear(rs, 3, 128, 4.0)
+    else:
+        sd[f"{prefix}.rgb_net.3.weight"], sd[f"{prefix}.rgb_net.3.bias"] = _linear(rs, 3, 128, 4.0)
     return sd
 
 
@@ -62,20 +67,22 @@ def motionnet_state(prefix: str, rs: np.random.RandomState, flow_gain: float = 0
 
 def make_state_dict(layer_num: int, use_space_time: bool, use_deform_time: bool, seed: int = 0,
                     sigma_gain: float = 60.0, sigma_bias: float = 0.5, bkgd_use_space_time: bool = False,
-                    bkgd_use_deform_time: bool = False, same_spacenet: bool = False) -> Dict[str, torch.Tensor]:
+                    bkgd_use_deform_time: bool = False, same_spacenet: bool = False,
+                    deep_rgb: bool = False) -> Dict[str, torch.Tensor]:
     """Full LayeredRFRender state_dict (key names of modeling/layered_rfrender.py:59-93).  With
     ``same_spacenet`` the fine performer nets ARE the coarse ones (:70-71): both key sets, same tensors."""
     rs = np.random.RandomState(seed)
     sd: Dict[str, torch.Tensor] = {}
-    sd.update(spacenet_state("bkgd_spacenet", rs, bkgd_use_space_time, sigma_gain, sigma_bias))
-    sd.update(spacenet_state("bkgd_spacenet_fine", rs, bkgd_use_space_time, sigma_gain, sigma_bias))
+    deep_rgb = deep_rgb and use_space_time                              # layered_rfrender.py:35
+    sd.update(spacenet_state("bkgd_spacenet", rs, bkgd_use_space_time, sigma_gain, sigma_bias, deep_rgb))
+    sd.update(spacenet_state("bkgd_spacenet_fine", rs, bkgd_use_space_time, sigma_gain, sigma_bias, deep_rgb))
     for i in range(layer_num):
-        sd.update(spacenet_state(f"spacenets.{i}", rs, use_space_time, sigma_gain, sigma_bias))
+        sd.update(spacenet_state(f"spacenets.{i}", rs, use_space_time, sigma_gain, sigma_bias, deep_rgb))
         if same_spacenet:
             sd.update({k.replace(f"spacenets.{i}.", f"spacenets_fine.{i}."): v for k, v in sd.items()
                        if k.startswith(f"spacenets.{i}.")})
         else:
-            sd.update(spacenet_state(f"spacenets_fine.{i}", rs, use_space_time, sigma_gain, sigma_bias))
+            sd.update(spacenet_state(f"spacenets_fine.{i}", rs, use_space_time, sigma_gain, sigma_bias, deep_rgb))
     if use_deform_time:
         for i in range(layer_num):
             sd.update(motionnet_state(f"time_deform_nets.{i}", rs))

@@ -302,7 +302,8 @@ def build_ref_model(L, n1, n2, st, dt, seed, flags=None):
     model = ref_modeling.build_layered_model(make_cfg(L, n1, n2, st, dt, flags), camera_num=1).eval()
     model.load_state_dict(syn.make_state_dict(L, st, dt, seed, bkgd_use_space_time=flags.get("BKGD_USE_SPACE_TIME", False),
                                               bkgd_use_deform_time=flags.get("BKGD_USE_DEFORM_TIME", False),
-                                              same_spacenet=flags.get("SAME_SPACENET", False)))
+                                              same_spacenet=flags.get("SAME_SPACENET", False),
+                                              deep_rgb=flags.get("DEEP_RGB", False)))
     bk, per = syn.scene_boxes(L)
     model.set_bkgd_bbox(bk)
     model.set_bboxes(per)
@@ -338,10 +339,11 @@ def g_forward(name, L, n1, n2, st, dt, seed, h, w, frame=2.5, per_ray_frames=Fal
 
 
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "--new-model-flags":   # add the two newest cases without touching the rest
+    if len(sys.argv) > 1 and sys.argv[1] == "--new-model-flags":   # add the newest cases without touching the rest
         g_forward("fwd_bkgd_time", 2, 12, 6, True, True, 29, 8, 8, bkgd_frame=1.25,
                   flags=dict(BKGD_USE_DEFORM_TIME=True, BKGD_USE_SPACE_TIME=True))
         g_forward("fwd_same_spacenet", 2, 12, 6, True, True, 32, 6, 8, flags=dict(SAME_SPACENET=True))
+        g_forward("fwd_deep_rgb", 2, 12, 6, True, True, 33, 6, 8, flags=dict(DEEP_RGB=True))
         return
     g_generate_rays()
     g_sampler()
@@ -373,6 +375,9 @@ def main():
     g_forward("fwd_bkgd_time", 2, 12, 6, True, True, 29, 8, 8, bkgd_frame=1.25,
               flags=dict(BKGD_USE_DEFORM_TIME=True, BKGD_USE_SPACE_TIME=True))
     g_forward("fwd_same_spacenet", 2, 12, 6, True, True, 32, 6, 8, flags=dict(SAME_SPACENET=True))
+    # config/defaults.py:39 has DEEP_RGB = True: any USE_SPACE_TIME config that does not switch it off gets the
+    # 4-layer colour head in every SpaceNet, background included (layered_rfrender.py:35,62)
+    g_forward("fwd_deep_rgb", 2, 12, 6, True, True, 33, 6, 8, flags=dict(DEEP_RGB=True))
 
 
 if __name__ == "__main__":

@@ -106,7 +106,7 @@ def test_product_path_refuses_cpu_tensors():
 def test_render_structs_match_header_layout():
     # stnerf_nets: 2 + 3*16 pointers; stnerf_render_params: 10 ints, 16 ints, 5 floats (+pad), u64, i64, 2*16 edits, 3 floats (+pad)
     assert C.sizeof(hip.Nets) == 8 * (2 + 3 * hip.MAX_LAYERS)
-    assert C.sizeof(hip.RenderParams) == 48 + 64 + 20 + 4 + 8 + 8 + 2 * 16 * 24 + 12 + 4
+    assert C.sizeof(hip.RenderParams) == 52 + 64 + 20 + 0 + 8 + 8 + 2 * 16 * 24 + 12 + 4
     assert C.sizeof(hip.ProfileRecord) == 40
 
 

@@ -17,11 +17,11 @@ def ops():
     return _ops
 
 
-@pytest.mark.parametrize("use_time", [False, True])
-def test_spacenet_f16x3_vs_fp64_oracle(ops, use_time):
+@pytest.mark.parametrize("use_time, deep", [(False, False), (True, False), (False, True), (True, True)])
+def test_spacenet_f16x3_vs_fp64_oracle(ops, use_time, deep):
     torch.manual_seed(11)
     rs = np.random.RandomState(5)
-    sd = syn.spacenet_state("net", rs, use_time)
+    sd = syn.spacenet_state("net", rs, use_time, deep_rgb=deep)
     n, s = 700, 13
     pos = (torch.rand(n, s, 3) - 0.5) * 6.0
     dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
@@ -100,7 +100,7 @@ def test_motionnet_f16x3_vs_fp64_oracle(ops):
 
 
 @pytest.mark.parametrize("name", ["fwd_c1", "fwd_c3", "fwd_edit", "fwd_hide", "fwd_nonretime", "fwd_only_coarse",
-                                  "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet"])
+                                  "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet", "fwd_deep_rgb"])
 def test_whole_path_fp16x3_matches_reference_fixtures(name):
     """The drop-in boundary in fp16x3 precision against the reference's own outputs: same tolerances as fp32."""
     import test_gpu_render as R

@@ -158,11 +158,11 @@ def test_nets_golden(ops):
         torch.testing.assert_close(x.cpu(), a["pos"] + a[key], rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("use_time", [False, True])
-def test_spacenet_vs_fp64_oracle(ops, use_time):
+@pytest.mark.parametrize("use_time, deep", [(False, False), (True, False), (False, True), (True, True)])
+def test_spacenet_vs_fp64_oracle(ops, use_time, deep):
     torch.manual_seed(11)
     rs = np.random.RandomState(5)
-    sd = syn.spacenet_state("net", rs, use_time)
+    sd = syn.spacenet_state("net", rs, use_time, deep_rgb=deep)
     n, s = 700, 13                       # 9100 rows: many tiles, ragged tail, rays straddling tiles
     pos = (torch.rand(n, s, 3) - 0.5) * 6.0
     dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
