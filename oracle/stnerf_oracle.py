@@ -146,13 +146,14 @@ def motion_net(params: Dict[str, Tensor], prefix: str, xyzt: Tensor, input_time:
     shape = xyzt.shape
     x = xyzt.reshape(-1, 4)
     xyz, t = x[:, :3], x[:, 3:]
+    inc = params[f"{prefix}.motion_net.0.weight"].shape[1] == 84   # include_input (TKERNEL_INC_RAW), else 80
     lower = torch.floor(t)
     if input_time and not torch.all(torch.eq(lower, t)):
         w = t - lower
-        enc = (1 - w) * positional_encoding(torch.cat([xyz, lower], -1), 10) \
-            + w * positional_encoding(torch.cat([xyz, lower + 1], -1), 10)
+        enc = (1 - w) * positional_encoding(torch.cat([xyz, lower], -1), 10, inc) \
+            + w * positional_encoding(torch.cat([xyz, lower + 1], -1), 10, inc)
     else:
-        enc = positional_encoding(x, 10)
+        enc = positional_encoding(x, 10, inc)
     h = enc
     for j in (0, 2, 4, 6, 8):
         h = F.relu(_linear(params, f"{prefix}.motion_net.{j}", h))
@@ -174,8 +175,13 @@ def space_net(params: Dict[str, Tensor], prefix: str, pos: Tensor, dirs: Tensor,
     Whether the net takes time is decided by its first rgb layer's width (304 vs 283).
     """
     n, s = pos.shape[0], pos.shape[1]
-    use_time = params[f"{prefix}.rgb_net.1.weight"].shape[1] == 304
-    p = positional_encoding(pos.reshape(-1, 3), 10)
+    # the flavour (include_input / use_dir / use_time, :16-44) is read off the tensor shapes
+    inc = params[f"{prefix}.stage1.0.weight"].shape[1] == 63
+    dir_w, time_w = (27, 21) if inc else (24, 20)
+    extra = params[f"{prefix}.rgb_net.1.weight"].shape[1] - 256
+    use_dir, use_time = {dir_w + time_w: (True, True), dir_w: (True, False), time_w: (False, True),
+                         0: (False, False)}[extra]
+    p = positional_encoding(pos.reshape(-1, 3), 10, inc)
     h = p
     for j in (0, 2, 4, 6):
         h = F.relu(_linear(params, f"{prefix}.stage1.{j}", h))
@@ -183,10 +189,11 @@ def space_net(params: Dict[str, Tensor], prefix: str, pos: Tensor, dirs: Tensor,
     for j in (0, 2, 4):
         h = F.relu(_linear(params, f"{prefix}.stage2.{j}", h))
     sigma = _linear(params, f"{prefix}.density_net.0", h)
-    d = positional_encoding(dirs.unsqueeze(1).repeat(1, s, 1).reshape(-1, 3), 4)
-    feat = [h, d]
+    feat = [h]
+    if use_dir:
+        feat.append(positional_encoding(dirs.unsqueeze(1).repeat(1, s, 1).reshape(-1, 3), 4, inc))
     if use_time:
-        feat.append(positional_encoding(times.reshape(n, 1, 1).repeat(1, s, 1).reshape(-1, 1), 10))
+        feat.append(positional_encoding(times.reshape(n, 1, 1).repeat(1, s, 1).reshape(-1, 1), 10, inc))
     x = F.relu(torch.cat(feat, dim=1))
     x = F.relu(_linear(params, f"{prefix}.rgb_net.1", x))
     if f"{prefix}.rgb_net.7.weight" in params:      # deep_rgb (:68-79): 128 -> 128 -> 128 -> 3

@@ -157,23 +157,56 @@ def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cud
     return PackedNet(kind, host.to(device), precision)
 
 
+def _pe_columns(w: Tensor, dim: int, n_freq: int, include_input: bool, present: bool = True) -> Tensor:
+    """Columns of a Linear weight that multiply one positional-encoding block, widened to the kernels' layout
+    [x, sin, cos, ...] (dim*(1+2L) columns).  The kernels always build that block; an encoding without the raw
+    input (TKERNEL_INC_RAW=False, utils/dimension_kernel.py:12-14) or an absent direction encoding (USE_DIR=False,
+    modeling/spacenet.py:22-31) gets ZERO weight columns there, which leaves every output bit-identical."""
+    full = dim * (1 + 2 * n_freq)
+    if not present:
+        return w.new_zeros(w.shape[0], full)
+    if include_input:
+        assert w.shape[1] == full
+        return w
+    assert w.shape[1] == full - dim
+    return torch.cat([w.new_zeros(w.shape[0], dim), w], 1)
+
+
 def pack_spacenet(state: dict, prefix: str, device="cuda", precision: str = "fp32") -> PackedNet:
-    """From reference state_dict keys ``{prefix}.stage1.0.weight`` ...."""
+    """From reference state_dict keys ``{prefix}.stage1.0.weight`` ....  The SpaceNet flavour
+    (use_time, use_dir, include_input, deep_rgb: modeling/spacenet.py:16-86) is read off the tensor shapes."""
     deep = f"{prefix}.rgb_net.7.weight" in state          # deep_rgb: rgb_net.{1,3,5,7} (modeling/spacenet.py:68-79)
     keys = SPACENET_KEYS + (["rgb_net.5", "rgb_net.7"] if deep else [])
-    ws = [state[f"{prefix}.{k}.weight"] for k in keys]
+    ws = [state[f"{prefix}.{k}.weight"].detach().float().cpu() for k in keys]
     bs = [state[f"{prefix}.{k}.bias"] for k in keys]
-    in1 = ws[8].shape[1]
-    if in1 not in (283, 304):
-        raise ValueError(f"{prefix}.rgb_net.1 has in-width {in1}; only USE_DIR with/without time is supported")
-    kind = ((hip.NET_SPACE_TIME_DEEP if deep else hip.NET_SPACE_TIME) if in1 == 304
+    pos_w = ws[0].shape[1]
+    if pos_w not in (63, 60):
+        raise ValueError(f"{prefix}.stage1.0 has in-width {pos_w}: only c_pos=3 with PE_10 is supported")
+    inc = pos_w == 63
+    dir_w, time_w = (27, 21) if inc else (24, 20)
+    extra = ws[8].shape[1] - 256
+    flavours = {dir_w + time_w: (True, True), dir_w: (True, False), time_w: (False, True), 0: (False, False)}
+    if extra not in flavours:
+        raise ValueError(f"{prefix}.rgb_net.1 has in-width {ws[8].shape[1]}: not a SpaceNet colour head")
+    use_dir, use_time = flavours[extra]
+    ws[0] = _pe_columns(ws[0], 3, 10, inc)
+    ws[4] = torch.cat([ws[4][:, :256], _pe_columns(ws[4][:, 256:], 3, 10, inc)], 1)
+    r = ws[8]
+    parts = [r[:, :256], _pe_columns(r[:, 256:256 + (dir_w if use_dir else 0)], 3, 4, inc, use_dir)]
+    if use_time:
+        parts.append(_pe_columns(r[:, 256 + (dir_w if use_dir else 0):], 1, 10, inc))
+    ws[8] = torch.cat(parts, 1)
+    kind = ((hip.NET_SPACE_TIME_DEEP if deep else hip.NET_SPACE_TIME) if use_time
             else (hip.NET_SPACE_DEEP if deep else hip.NET_SPACE))
     return pack_net(kind, ws, bs, device, precision)
 
 
 def pack_motionnet(state: dict, prefix: str, device="cuda", precision: str = "fp32") -> PackedNet:
-    ws = [state[f"{prefix}.{k}.weight"] for k in MOTIONNET_KEYS]
+    ws = [state[f"{prefix}.{k}.weight"].detach().float().cpu() for k in MOTIONNET_KEYS]
     bs = [state[f"{prefix}.{k}.bias"] for k in MOTIONNET_KEYS]
+    if ws[0].shape[1] not in (84, 80):
+        raise ValueError(f"{prefix}.motion_net.0 has in-width {ws[0].shape[1]}: only c_input=4 with PE_10 is supported")
+    ws[0] = _pe_columns(ws[0], 4, 10, ws[0].shape[1] == 84)
     return pack_net(hip.NET_MOTION, ws, bs, device, precision)
 
 

@@ -52,10 +52,14 @@ class SpaceNet(nn.Module, _PackedMixin):
 
     def __init__(self, c_pos=3, include_input=True, use_dir=True, use_time=False, deep_rgb=False):
         super().__init__()
-        if c_pos != 3 or not include_input or not use_dir:
-            raise NotImplementedError("HIP SpaceNet supports c_pos=3, include_input=True, use_dir=True")
+        if c_pos != 3:
+            raise NotImplementedError("HIP SpaceNet supports c_pos=3")
         self.c_pos, self.use_dir, self.use_time, self.deep_rgb = c_pos, use_dir, use_time, deep_rgb
-        self.pos_dim, self.dir_dim, self.time_dim = 63, 27, (21 if use_time else 0)
+        self.include_input = include_input
+        raw = int(include_input)             # encodings without the raw input lose d columns (dimension_kernel.py:12-14)
+        self.pos_dim = 3 * (raw + 20)
+        self.dir_dim = 3 * (raw + 8) if use_dir else 0
+        self.time_dim = (raw + 20) if use_time else 0
         bd, hd = 256, 128
         self.stage1 = nn.Sequential(nn.Linear(self.pos_dim, bd), nn.ReLU(inplace=True), nn.Linear(bd, bd),
                                     nn.ReLU(inplace=True), nn.Linear(bd, bd), nn.ReLU(inplace=True),
@@ -94,10 +98,10 @@ class MotionNet(nn.Module, _PackedMixin):
 
     def __init__(self, c_input=5, include_input=True, input_time=False):
         super().__init__()
-        if c_input != 4 or not include_input:
-            raise NotImplementedError("HIP MotionNet supports c_input=4, include_input=True (the time-deformation "
-                                      "nets of the layered model; input_time selects the fractional-time lerp)")
-        self.c_input, self.input_time, self.pos_dim = c_input, input_time, 84
+        if c_input != 4:
+            raise NotImplementedError("HIP MotionNet supports c_input=4 (the time-deformation nets of the layered "
+                                      "model; input_time selects the fractional-time lerp)")
+        self.c_input, self.input_time, self.pos_dim = c_input, input_time, 4 * (int(include_input) + 20)
         d = 128
         self.motion_net = nn.Sequential(nn.Linear(self.pos_dim, d), nn.ReLU(inplace=False), nn.Linear(d, d),
                                         nn.ReLU(inplace=True), nn.Linear(d, d), nn.ReLU(inplace=True),
@@ -221,8 +225,8 @@ class LayeredRFRender(nn.Module):
             raise NotImplementedError("only SAMPLE_METHOD 'BBOX' is on the render path (both shipped ymls)")
         unsupported = dict(POSE_REFINEMENT=M.POSE_REFINEMENT, USE_DEFORM_VIEW=M.USE_DEFORM_VIEW)
         bad = [k for k, v in unsupported.items() if v]
-        if bad or not M.USE_DIR or not M.TKERNEL_INC_RAW:
-            raise NotImplementedError(f"config flags outside the MI355X hot path: {bad or 'USE_DIR/TKERNEL_INC_RAW'}")
+        if bad:
+            raise NotImplementedError(f"config flags outside the MI355X hot path (training-time features): {bad}")
         if M.BKGD_USE_SPACE_TIME and not M.USE_SPACE_TIME:
             raise ValueError("BKGD_USE_SPACE_TIME needs USE_SPACE_TIME: the reference hands the background SpaceNet "
                              "its frame id only then (layered_rfrender.py:382-390) and fails on the missing input")
@@ -242,19 +246,21 @@ class LayeredRFRender(nn.Module):
         self.bkgd_use_space_time = bool(M.BKGD_USE_SPACE_TIME)
 
         self.deep_rgb = deep = bool(M.DEEP_RGB and M.USE_SPACE_TIME)      # :35
-        self.bkgd_spacenet = SpaceNet(use_time=self.bkgd_use_space_time, deep_rgb=deep)
-        self.bkgd_spacenet_fine = SpaceNet(use_time=self.bkgd_use_space_time, deep_rgb=deep)
+        inc, use_dir = bool(M.TKERNEL_INC_RAW), bool(M.USE_DIR)          # :27-29
+        common = dict(include_input=inc, use_dir=use_dir, deep_rgb=deep)
+        self.bkgd_spacenet = SpaceNet(use_time=self.bkgd_use_space_time, **common)
+        self.bkgd_spacenet_fine = SpaceNet(use_time=self.bkgd_use_space_time, **common)
         self.spacenets, self.spacenets_fine = nn.ModuleList([]), nn.ModuleList([])
         for i in range(layer_num):
-            self.spacenets.append(SpaceNet(use_time=self.use_space_time, deep_rgb=deep))
+            self.spacenets.append(SpaceNet(use_time=self.use_space_time, **common))
             self.spacenets_fine.append(self.spacenets[i] if M.SAME_SPACENET
-                                       else SpaceNet(use_time=self.use_space_time, deep_rgb=deep))
+                                       else SpaceNet(use_time=self.use_space_time, **common))
         self.time_deform_nets = nn.ModuleList([])
         if self.use_deform_time:
             for i in range(layer_num):
-                self.time_deform_nets.append(MotionNet(c_input=4, input_time=True))
+                self.time_deform_nets.append(MotionNet(c_input=4, include_input=inc, input_time=True))
         if self.bkgd_use_deform_time:                                  # :92-93 (input_time stays False)
-            self.bkgd_time_deform_net = MotionNet(c_input=4)
+            self.bkgd_time_deform_net = MotionNet(c_input=4, include_input=inc)
         # the reference initialises the fine / other-layer nets as deep copies (:63-74); keep that for a
         # freshly built model (a loaded checkpoint overwrites everything anyway)
         self.bkgd_spacenet_fine.load_state_dict(self.bkgd_spacenet.state_dict())

@@ -38,14 +38,17 @@ def _linear(rs: np.random.RandomState, out_f: int, in_f: int, gain: float = 1.0,
 
 
 def spacenet_state(prefix: str, rs: np.random.RandomState, use_time: bool,
-                   sigma_gain: float = 60.0, sigma_bias: float = 0.5, deep_rgb: bool = False) -> Dict[str, torch.Tensor]:
+                   sigma_gain: float = 60.0, sigma_bias: float = 0.5, deep_rgb: bool = False,
+                   include_input: bool = True, use_dir: bool = True) -> Dict[str, torch.Tensor]:
     """One SpaceNet (modeling/spacenet.py:45-86).  ``sigma_gain``/``sigma_bias`` make the density
     head 'trained-like' (random init gives sigma ~ 0 and a numerically trivial composite)."""
     sd = {}
+    drop = 0 if include_input else 3     # TKERNEL_INC_RAW=False: the encodings lose their raw-input block
     for name, o, i in _SPACENET_LAYERS:
         g, bs = (sigma_gain, sigma_bias) if name == "density_net.0" else (1.0, 0.0)
+        i = i - drop if name in ("stage1.0", "stage2.0") else i
         sd[f"{prefix}.{name}.weight"], sd[f"{prefix}.{name}.bias"] = _linear(rs, o, i, g, bs)
-    rgb_in = 256 + 27 + (21 if use_time else 0)
+    rgb_in = 256 + ((27 - drop) if use_dir else 0) + ((21 - (0 if include_input else 1)) if use_time else 0)
     sd[f"{prefix}.rgb_net.1.weight"], sd[f"{prefix}.rgb_net.1.bias"] = _linear(rs, 128, rgb_in)
     if deep_rgb:  # modeling/spacenet.py:68-79: two more 128-wide hidden layers
         sd[f"{prefix}.rgb_net.3.weight"], sd[f"{prefix}.rgb_net.3.bias"] = _linear(rs, 128, 128)
@@ -56,11 +59,13 @@ def spacenet_state(prefix: str, rs: np.random.RandomState, use_time: bool,
     return sd
 
 
-def motionnet_state(prefix: str, rs: np.random.RandomState, flow_gain: float = 0.25) -> Dict[str, torch.Tensor]:
+def motionnet_state(prefix: str, rs: np.random.RandomState, flow_gain: float = 0.25,
+                    include_input: bool = True) -> Dict[str, torch.Tensor]:
     """One MotionNet (modeling/motion_net.py:20-32)."""
     sd = {}
     for name, o, i in _MOTION_LAYERS:
         g = flow_gain if name == "motion_net.10" else 1.0
+        i = i - 4 if (name == "motion_net.0" and not include_input) else i
         sd[f"{prefix}.{name}.weight"], sd[f"{prefix}.{name}.bias"] = _linear(rs, o, i, g)
     return sd
 
@@ -68,27 +73,38 @@ def motionnet_state(prefix: str, rs: np.random.RandomState, flow_gain: float = 0
 def make_state_dict(layer_num: int, use_space_time: bool, use_deform_time: bool, seed: int = 0,
                     sigma_gain: float = 60.0, sigma_bias: float = 0.5, bkgd_use_space_time: bool = False,
                     bkgd_use_deform_time: bool = False, same_spacenet: bool = False,
-                    deep_rgb: bool = False) -> Dict[str, torch.Tensor]:
+                    deep_rgb: bool = False, include_input: bool = True, use_dir: bool = True) -> Dict[str, torch.Tensor]:
     """Full LayeredRFRender state_dict (key names of modeling/layered_rfrender.py:59-93).  With
     ``same_spacenet`` the fine performer nets ARE the coarse ones (:70-71): both key sets, same tensors."""
     rs = np.random.RandomState(seed)
     sd: Dict[str, torch.Tensor] = {}
     deep_rgb = deep_rgb and use_space_time                              # layered_rfrender.py:35
-    sd.update(spacenet_state("bkgd_spacenet", rs, bkgd_use_space_time, sigma_gain, sigma_bias, deep_rgb))
-    sd.update(spacenet_state("bkgd_spacenet_fine", rs, bkgd_use_space_time, sigma_gain, sigma_bias, deep_rgb))
+    kw = dict(deep_rgb=deep_rgb, include_input=include_input, use_dir=use_dir)
+    sd.update(spacenet_state("bkgd_spacenet", rs, bkgd_use_space_time, sigma_gain, sigma_bias, **kw))
+    sd.update(spacenet_state("bkgd_spacenet_fine", rs, bkgd_use_space_time, sigma_gain, sigma_bias, **kw))
     for i in range(layer_num):
-        sd.update(spacenet_state(f"spacenets.{i}", rs, use_space_time, sigma_gain, sigma_bias, deep_rgb))
+        sd.update(spacenet_state(f"spacenets.{i}", rs, use_space_time, sigma_gain, sigma_bias, **kw))
         if same_spacenet:
             sd.update({k.replace(f"spacenets.{i}.", f"spacenets_fine.{i}."): v for k, v in sd.items()
                        if k.startswith(f"spacenets.{i}.")})
         else:
-            sd.update(spacenet_state(f"spacenets_fine.{i}", rs, use_space_time, sigma_gain, sigma_bias, deep_rgb))
+            sd.update(spacenet_state(f"spacenets_fine.{i}", rs, use_space_time, sigma_gain, sigma_bias, **kw))
     if use_deform_time:
         for i in range(layer_num):
-            sd.update(motionnet_state(f"time_deform_nets.{i}", rs))
+            sd.update(motionnet_state(f"time_deform_nets.{i}", rs, include_input=include_input))
     if bkgd_use_deform_time:
-        sd.update(motionnet_state("bkgd_time_deform_net", rs))
+        sd.update(motionnet_state("bkgd_time_deform_net", rs, include_input=include_input))
     return sd
+
+
+def state_dict_for_flags(layer_num: int, use_space_time: bool, use_deform_time: bool, seed: int, flags=None):
+    """make_state_dict with the optional cfg.MODEL flags of a test case ({"DEEP_RGB": True, ...})."""
+    f = flags or {}
+    return make_state_dict(layer_num, use_space_time, use_deform_time, seed,
+                           bkgd_use_space_time=f.get("BKGD_USE_SPACE_TIME", False),
+                           bkgd_use_deform_time=f.get("BKGD_USE_DEFORM_TIME", False),
+                           same_spacenet=f.get("SAME_SPACENET", False), deep_rgb=f.get("DEEP_RGB", False),
+                           include_input=f.get("TKERNEL_INC_RAW", True), use_dir=f.get("USE_DIR", True))
 
 
 def camera(h: int, w: int, orbit_deg: float = 0.0, dist: float = 4.0) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -300,10 +300,7 @@ def g_path():
 def build_ref_model(L, n1, n2, st, dt, seed, flags=None):
     flags = flags or {}
     model = ref_modeling.build_layered_model(make_cfg(L, n1, n2, st, dt, flags), camera_num=1).eval()
-    model.load_state_dict(syn.make_state_dict(L, st, dt, seed, bkgd_use_space_time=flags.get("BKGD_USE_SPACE_TIME", False),
-                                              bkgd_use_deform_time=flags.get("BKGD_USE_DEFORM_TIME", False),
-                                              same_spacenet=flags.get("SAME_SPACENET", False),
-                                              deep_rgb=flags.get("DEEP_RGB", False)))
+    model.load_state_dict(syn.state_dict_for_flags(L, st, dt, seed, flags))
     bk, per = syn.scene_boxes(L)
     model.set_bkgd_bbox(bk)
     model.set_bboxes(per)
@@ -338,12 +335,24 @@ def g_forward(name, L, n1, n2, st, dt, seed, h, w, frame=2.5, per_ray_frames=Fal
     save(name, meta, rays=rays, **arrays)
 
 
+def g_model_flag_cases():
+    """The model flags both shipped ymls leave off."""
+    # background deformation net (MotionNet(input_time=False), with a fractional background frame id so that the
+    # plain-time encoding differs from the lerp) + background space-time
+    g_forward("fwd_bkgd_time", 2, 12, 6, True, True, 29, 8, 8, bkgd_frame=1.25,
+              flags=dict(BKGD_USE_DEFORM_TIME=True, BKGD_USE_SPACE_TIME=True))
+    # fine performer nets shared with the coarse ones
+    g_forward("fwd_same_spacenet", 2, 12, 6, True, True, 32, 6, 8, flags=dict(SAME_SPACENET=True))
+    # config/defaults.py:39 has DEEP_RGB = True: any USE_SPACE_TIME config that does not switch it off gets the
+    # 4-layer colour head in every SpaceNet, background included (layered_rfrender.py:35,62)
+    g_forward("fwd_deep_rgb", 2, 12, 6, True, True, 33, 6, 8, flags=dict(DEEP_RGB=True))
+    # encodings without their raw-input block and no view dependence (TKERNEL_INC_RAW / USE_DIR off)
+    g_forward("fwd_no_raw_no_dir", 2, 12, 6, True, True, 34, 6, 8, flags=dict(TKERNEL_INC_RAW=False, USE_DIR=False))
+
+
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "--new-model-flags":   # add the newest cases without touching the rest
-        g_forward("fwd_bkgd_time", 2, 12, 6, True, True, 29, 8, 8, bkgd_frame=1.25,
-                  flags=dict(BKGD_USE_DEFORM_TIME=True, BKGD_USE_SPACE_TIME=True))
-        g_forward("fwd_same_spacenet", 2, 12, 6, True, True, 32, 6, 8, flags=dict(SAME_SPACENET=True))
-        g_forward("fwd_deep_rgb", 2, 12, 6, True, True, 33, 6, 8, flags=dict(DEEP_RGB=True))
+    if len(sys.argv) > 1 and sys.argv[1] == "--model-flags":   # (re)generate these cases without touching the rest
+        g_model_flag_cases()
         return
     g_generate_rays()
     g_sampler()
@@ -369,15 +378,7 @@ def main():
               call_kwargs=dict(density_threshold=0.05, bkgd_density_threshold=0.02))
     g_forward("batchify_small", 2, 12, 6, True, True, 28, 6, 8, chunk=3584,
               call_kwargs=dict(density_threshold=0.05, bkgd_density_threshold=0.02))
-    # the model flags both shipped ymls leave off: background deformation net (MotionNet(input_time=False), with a
-    # fractional background frame id so the plain-time encoding differs from the lerp) + background space-time,
-    # and fine performer nets shared with the coarse ones
-    g_forward("fwd_bkgd_time", 2, 12, 6, True, True, 29, 8, 8, bkgd_frame=1.25,
-              flags=dict(BKGD_USE_DEFORM_TIME=True, BKGD_USE_SPACE_TIME=True))
-    g_forward("fwd_same_spacenet", 2, 12, 6, True, True, 32, 6, 8, flags=dict(SAME_SPACENET=True))
-    # config/defaults.py:39 has DEEP_RGB = True: any USE_SPACE_TIME config that does not switch it off gets the
-    # 4-layer colour head in every SpaceNet, background included (layered_rfrender.py:35,62)
-    g_forward("fwd_deep_rgb", 2, 12, 6, True, True, 33, 6, 8, flags=dict(DEEP_RGB=True))
+    g_model_flag_cases()
 
 
 if __name__ == "__main__":

@@ -181,6 +181,39 @@ def test_spacenet_vs_fp64_oracle(ops, use_time, deep):
     assert e_gpu <= 4 * e_cpu + 1e-6, (e_gpu, e_cpu)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+@pytest.mark.parametrize("include_input, use_dir, use_time", [(False, True, True), (True, False, True), (False, False, False)])
+def test_spacenet_flavours_without_raw_input_or_direction(ops, precision, include_input, use_dir, use_time):
+    """TKERNEL_INC_RAW=False / USE_DIR=False are packed as zero weight columns (ops._pe_columns): same kernels."""
+    torch.manual_seed(12)
+    sd = syn.spacenet_state("net", np.random.RandomState(6), use_time, include_input=include_input, use_dir=use_dir)
+    n, s = 300, 9
+    pos = (torch.rand(n, s, 3) - 0.5) * 6.0
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
+    times = torch.rand(n) * 50 + 1
+    net = ops.pack_spacenet(sd, "net", precision=precision)
+    assert net.use_time == use_time
+    raw = torch.full((n, s, 4), float("nan"), device="cuda")
+    ops.spacenet_fwd(net, dev(pos), dev(dirs), dev(times) if use_time else None, raw)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    rgb64, sig64 = O.space_net(sd64, "net", pos.double(), dirs.double(), times.double().reshape(-1, 1) if use_time else None)
+    _net_close(raw[..., :3].cpu(), rgb64, 4.0, "rgb")
+    _net_close(raw[..., 3:].cpu(), sig64, 60.0, "sigma")
+
+
+def test_motionnet_without_raw_input(ops):
+    sd = syn.motionnet_state("net", np.random.RandomState(8), include_input=False)
+    torch.manual_seed(13)
+    n, s = 200, 7
+    xyz = (torch.rand(n, s, 3) - 0.5) * 4.0
+    times = torch.rand(n) * 20 + 1
+    flow = torch.empty(n, s, 3, device="cuda")
+    ops.motionnet_fwd(ops.pack_motionnet(sd, "net"), dev(xyz), dev(times), flow=flow, add_to_xyz=False)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    ref = O.motion_net(sd64, "net", torch.cat([xyz.double(), times.double().view(n, 1, 1).repeat(1, s, 1)], -1))
+    _net_close(flow.cpu(), ref, 1.0, "flow")
+
+
 def test_spacenet_worklist_and_strided_views(ops):
     """Masked evaluation through (ray_list, ray_count) into ray-major strided buffers."""
     torch.manual_seed(12)

@@ -22,7 +22,7 @@ from stnerf_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 FWD_CASES = ["fwd_c1", "fwd_c3", "fwd_edit", "fwd_hide", "fwd_nonretime", "fwd_only_coarse",
-             "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet", "fwd_deep_rgb"]
+             "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet", "fwd_deep_rgb", "fwd_no_raw_no_dir"]
 COLOR_ATOL, DEPTH_ATOL = 5e-5, 5e-4
 FINE_CAP, FINE_FRACTION, FINE_PSNR = 2e-3, 0.99, 70.0
 
@@ -42,11 +42,7 @@ def build_model(meta):
     L = meta["L"]
     fl = meta.get("flags", {})
     model = build_layered_model(make_cfg(L, meta["n1"], meta["n2"], meta["space_time"], meta["deform_time"], fl), camera_num=1)
-    model.load_state_dict(syn.make_state_dict(L, meta["space_time"], meta["deform_time"], meta["weight_seed"],
-                                              bkgd_use_space_time=fl.get("BKGD_USE_SPACE_TIME", False),
-                                              bkgd_use_deform_time=fl.get("BKGD_USE_DEFORM_TIME", False),
-                                              same_spacenet=fl.get("SAME_SPACENET", False),
-                                              deep_rgb=fl.get("DEEP_RGB", False)))
+    model.load_state_dict(syn.state_dict_for_flags(L, meta["space_time"], meta["deform_time"], meta["weight_seed"], fl))
     bk, per = syn.scene_boxes(L)
     model.set_bkgd_bbox(bk)
     model.set_bboxes(per)

@@ -9,7 +9,7 @@ from oracle import stnerf_oracle as O
 from stnerf_amd import synthetic as syn
 
 FWD_CASES = ["fwd_c1", "fwd_c3", "fwd_edit", "fwd_hide", "fwd_nonretime", "fwd_only_coarse",
-             "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet", "fwd_deep_rgb"]
+             "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet", "fwd_deep_rgb", "fwd_no_raw_no_dir"]
 
 
 def test_generate_rays():
@@ -86,10 +86,7 @@ def _model_from_meta(meta):
     L = meta["L"]
     bk, per = syn.scene_boxes(L)
     fl = meta.get("flags", {})
-    sd = syn.make_state_dict(L, meta["space_time"], meta["deform_time"], meta["weight_seed"],
-                             bkgd_use_space_time=fl.get("BKGD_USE_SPACE_TIME", False),
-                             bkgd_use_deform_time=fl.get("BKGD_USE_DEFORM_TIME", False),
-                             same_spacenet=fl.get("SAME_SPACENET", False), deep_rgb=fl.get("DEEP_RGB", False))
+    sd = syn.state_dict_for_flags(L, meta["space_time"], meta["deform_time"], meta["weight_seed"], fl)
     m = O.OracleModel(layer_num=L, n_coarse=meta["n1"], n_fine=meta["n2"], params=sd,
                       use_deform_time=meta["deform_time"], use_space_time=meta["space_time"],
                       bkgd_use_deform_time=fl.get("BKGD_USE_DEFORM_TIME", False),
