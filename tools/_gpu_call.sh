@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/r01m
-timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/r01m/pytest.log 2>&1; echo rc=$? >> gpurun_out/r01m/pytest.log
+mkdir -p gpurun_out/r01o
+tools/power_trace.sh gpurun_out/r01o/power_micro.csv tools/micro/mfma_rate sustained > gpurun_out/r01o/micro.log 2>&1
