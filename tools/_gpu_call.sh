@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/r01o
-tools/power_trace.sh gpurun_out/r01o/power_micro.csv tools/micro/mfma_rate sustained > gpurun_out/r01o/micro.log 2>&1
+mkdir -p gpurun_out/r01p
+tools/power_trace.sh gpurun_out/r01p/power_dual.csv tools/micro/dual_issue > gpurun_out/r01p/dual.log 2>&1
