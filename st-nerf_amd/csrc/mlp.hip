@@ -210,10 +210,10 @@ __device__ __forceinline__ void dense_layer(const float* __restrict__ base, int6
                 v.z = acc[fb][sb][4 * q + 2];
                 v.w = acc[fb][sb][4 * q + 3];
                 if (RELU) {
-                    v.x = fmaxf(v.x, 0.f);
-                    v.y = fmaxf(v.y, 0.f);
-                    v.z = fmaxf(v.z, 0.f);
-                    v.w = fmaxf(v.w, 0.f);
+                    v.x = relu_bits(v.x);
+                    v.y = relu_bits(v.y);
+                    v.z = relu_bits(v.z);
+                    v.w = relu_bits(v.w);
                 }
                 out[(f >> 2) * TM + sb * 32 + s0] = v;
             }
@@ -371,8 +371,8 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_ke
                     float sn, cs;
                     sincos_pe(dv[dmn] * freq, sn, cs);
                     const int fs = 3 + fq * 6 + dmn, fc = fs + 3;
-                    ENC_AT(col, fs) = fmaxf(sn, 0.f);
-                    ENC_AT(col, fc) = fmaxf(cs, 0.f);
+                    ENC_AT(col, fs) = relu_bits(sn);
+                    ENC_AT(col, fc) = relu_bits(cs);
                 }
             }
             if (USE_TIME) {
@@ -382,8 +382,8 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_ke
                     float sn, cs;
                     sincos_pe(tv * (float)(1 << fq), sn, cs);
                     const int fs = 28 + 2 * fq, fc = fs + 1;
-                    ENC_AT(col, fs) = fmaxf(sn, 0.f);
-                    ENC_AT(col, fc) = fmaxf(cs, 0.f);
+                    ENC_AT(col, fs) = relu_bits(sn);
+                    ENC_AT(col, fc) = relu_bits(cs);
                 }
             } else if (part == NPARTS - 1) {
 #pragma unroll

@@ -90,6 +90,14 @@ __host__ __device__ inline MotionLayout motion_layout() {
 }
 
 
+// ReLU as ONE VALU instruction (v_max_i32 on the bit pattern: negative floats are negative integers).  fmaxf(x, 0)
+// costs two (a canonicalising v_max_f32 first), and on gfx950 every VALU instruction displaces f32 MFMA work
+// (profiles/r01_dual_issue_microbench.md).  Differs from fmaxf only for NaNs with the sign bit set.
+__device__ __forceinline__ float relu_bits(float x) {
+    const int b = __float_as_int(x);
+    return __int_as_float(b > 0 ? b : 0);
+}
+
 // sin and cos of one fp32 argument, |x| up to a few thousand (positional-encoding arguments are
 // 2^f * coordinate, f <= 9).  Cody-Waite reduction by pi/2 in three fma steps (fdlibm's 17-bit splits of
 // pi/2: the first step is exact, the total reduction error is < 1 ulp of the reduced argument), then

@@ -271,7 +271,7 @@ __device__ __forceinline__ void dense_layer_h(const half8* __restrict__ whi, con
                 half4 vh, vl;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = fmaxf(acc[fb][sb][4 * q + r], 0.f) * WSCALE_INV;
+                    const float v = relu_bits(acc[fb][sb][4 * q + r]) * WSCALE_INV;
                     _Float16 a_, b_;
                     split_f16(v, a_, b_);
                     vh[r] = a_;
@@ -431,8 +431,8 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_h_
                 for (int dmn = 0; dmn < 3; ++dmn) {
                     float sn, cs;
                     sincos_pe(dv[dmn] * freq, sn, cs);
-                    put_feature<TM>(eh, el, s, 3 + fq * 6 + dmn, fmaxf(sn, 0.f));
-                    put_feature<TM>(eh, el, s, 6 + fq * 6 + dmn, fmaxf(cs, 0.f));
+                    put_feature<TM>(eh, el, s, 3 + fq * 6 + dmn, relu_bits(sn));
+                    put_feature<TM>(eh, el, s, 6 + fq * 6 + dmn, relu_bits(cs));
                 }
             }
             if (USE_TIME) {
@@ -441,8 +441,8 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_h_
                 for (int fq = NPARTS - 1 - part; fq < 10; fq += NPARTS) {
                     float sn, cs;
                     sincos_pe(tv * (float)(1 << fq), sn, cs);
-                    put_feature<TM>(eh, el, s, 28 + 2 * fq, fmaxf(sn, 0.f));
-                    put_feature<TM>(eh, el, s, 29 + 2 * fq, fmaxf(cs, 0.f));
+                    put_feature<TM>(eh, el, s, 28 + 2 * fq, relu_bits(sn));
+                    put_feature<TM>(eh, el, s, 29 + 2 * fq, relu_bits(cs));
                 }
             } else if (part == NPARTS - 1) {
 #pragma unroll
