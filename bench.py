@@ -31,7 +31,7 @@ sys.path.insert(0, REPO)
 from stnerf_amd import ops, synthetic as syn          # noqa: E402
 from stnerf_amd.modeling import build_layered_model   # noqa: E402
 from stnerf_amd.utils import layered_batchify_ray     # noqa: E402
-from stnerf_amd.parallel import gather_tiles          # noqa: E402
+from stnerf_amd.parallel import gather_tiles, make_row_renderer, render_view_striped  # noqa: E402
 
 # Algorithmic work per network evaluation: 2 * MACs of every nn.Linear.
 FLOP_SPACE, FLOP_SPACE_TIME, FLOP_MOTION = 924_672, 930_048, 153_344
@@ -185,6 +185,9 @@ def main():
     ap.add_argument("--workload", default="taekwondo-1080p-64+64", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-baseline-rays", type=int, default=7168, help="0 disables the CPU baseline leg")
     ap.add_argument("--rays-per-launch", type=int, default=1 << 19)
+    ap.add_argument("--partition", default="views", choices=["views", "stripes"],
+                    help="N>1: 'views' = one whole view per GPU per step (weak scaling, the default the driver runs); "
+                         "'stripes' = ONE view per step, interleaved 8-row stripes over the GPUs (strong scaling)")
     ap.add_argument("--eager-gpu-baseline-rays", type=int, default=0,
                     help=">0: also time the oracle restatement through eager PyTorch-ROCm on this GPU (informative)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3"],
@@ -216,7 +219,17 @@ def main():
     n_rays = H * W
     frame_ids = [1.0] + [2.5] * L
 
+    def step_striped(i):
+        # strong scaling: all ranks share ONE view; rank r renders stripes r, r+N, ... of 8 image rows
+        K, T = syn.camera(H, W, orbit_deg=10.0 + 1.5 * i)
+        model.seed = i
+        rows = make_row_renderer(model, K, T, H, W, frame_ids, device=device)
+        tile = render_view_striped(rows, n_rays, 8 * W)
+        return tile, [torch.ones(1, device=device)] * l   # (per-layer hit masks are not gathered in this mode)
+
     def step(i, gather=True):
+        if args.partition == "stripes":
+            return step_striped(i)
         # novel-view sweep, a new pose every step.  Weak scaling: each GPU renders one whole view per step, and all
         # ranks take the SAME camera for step i (distinct RNG streams), so the per-GPU work does not depend on N --
         # a different pose per rank would change the performer coverage and with it the work of the slowest rank.
@@ -290,19 +303,21 @@ def main():
                 traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_pmc_spacenet_traffic.json"
         rec = {
             "metric": "rendered rays/s (and ray-samples/s) per GPU, 1080p x 128-sample layered render",
-            "value": world * n_rays * args.steps / elapsed,
+            "value": (1 if args.partition == "stripes" else world) * n_rays * args.steps / elapsed,
             "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.partition == "stripes" else "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "f32-accurate products as 3 fp16 MFMA terms (22-bit split operands), f32 accumulate",
             "data": "synthetic",
             "config": {"workload": args.workload, "precision": args.precision, "height": H, "width": W, "performer_layers": L,
                        "coarse_samples": n1, "fine_samples": n2, "use_space_time": st, "use_deform_time": dt,
                        "rays_per_gpu_per_step": n_rays, "rays_per_launch": args.rays_per_launch,
                        "weights": "random, density head scaled (synthetic.make_state_dict seed 0)",
-                       "parallelism": f"ray tiles: 1 view per GPU per step x {world} GPUs (same camera, own RNG stream), "
-                                      "one RCCL all-gather of the rendered tiles per step"},
+                       "parallelism": (f"1 view per step in interleaved 8-row stripes over {world} GPUs, one RCCL all-gather per step"
+                                       if args.partition == "stripes" else
+                                       f"ray tiles: 1 view per GPU per step x {world} GPUs (same camera, own RNG stream), "
+                                       "one RCCL all-gather of the rendered tiles per step")},
             "ray_samples_per_s": evals_all / elapsed,
             "ray_samples_per_step_per_gpu": evals / args.steps,
             "mask_fraction": [float(m.float().mean()) for m in masks],
@@ -331,7 +346,7 @@ def main():
                 "note": "same workload and poses, measured after the headline run; fp16x3 = every product a*b evaluated as "
                         "ah*bh + ah*bl + al*bh on the fp16 MFMA pipe with f32 accumulation: passes the same parity tests "
                         "and tolerances as the exact-f32 kernels (tests/test_gpu_f16x3.py)",
-                "value": world * n_rays * other["steps"] / other["elapsed"], "unit": "rays/s",
+                "value": (1 if args.partition == "stripes" else world) * n_rays * other["steps"] / other["elapsed"], "unit": "rays/s",
                 "ms_per_step": 1e3 * other["elapsed"] / other["steps"], "steps": other["steps"],
                 "ray_samples_per_s": other["evals_all"] / other["elapsed"],
                 "roofline": {"bound": "mfma", "algorithmic_tflops": o_ach, "executed_mfma_tflops": mult * o_ach,

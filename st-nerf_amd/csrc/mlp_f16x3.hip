@@ -757,7 +757,7 @@ extern "C" int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n
                 dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride};
     const char* e = getenv("STNERF_TILE_H");
     const bool four = e && !strcmp(e, "128");
-    const bool small = e && !strcmp(e, "64");
+    const bool small = e && !strcmp(e, "64") && !STNERF_NET_IS_DEEP(kind);
     const int tm = small ? 64 : 128;
     const int lds = 80 * tm * 16;
     const int grid = grid_for_h(n_rays, ns, tm);
@@ -777,12 +777,8 @@ extern "C" int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n
         STNERF_CHECK_LAUNCH("spacenet_fwd_f16x3");
         return STNERF_OK;
     };
-    if (STNERF_NET_IS_DEEP(kind)) {  // deep_rgb: the default tile configuration only
+    if (STNERF_NET_IS_DEEP(kind)) {  // deep_rgb: compiled for the default tile configuration only (the knob is ignored)
         static bool opted_deep[2] = {false, false};
-        if (tm != 128) {
-            set_error("spacenet_fwd_f16x3: deep_rgb nets run in the default tile configuration only (unset STNERF_TILE_H)");
-            return STNERF_EINVAL;
-        }
         return ut ? launch(spacenet_h_kernel<128, 8, true, true>, &opted_deep[1], 512)
                   : launch(spacenet_h_kernel<128, 8, false, true>, &opted_deep[0], 512);
     }

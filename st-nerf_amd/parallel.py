@@ -5,12 +5,17 @@ replicated weights, then ONE all-gather of the rendered tiles (20 B per ray per 
 the frame on every rank.  There is no other collective on the path.  The on-device RNG is keyed by the
 global ray index, so a sharded render is bitwise identical to the single-GPU render.
 
+Two partitions are offered: contiguous tiles (``render_view_sharded``: fewest launches, right when every
+rank renders its own view or the view's cost is uniform) and interleaved stripes (``render_view_striped``:
+rank r takes stripes r, r+G, r+2G, ... of the image; the performers cover only part of the picture, so
+contiguous tiles of ONE view differ in cost by ~2x between its centre and its border, stripes do not).
+
 The helpers are device-agnostic (they run under gloo on CPU tensors in tests/test_parallel_cpu.py);
 only the ``render_rows`` callable passed in touches the GPU.
 """
 from __future__ import annotations
 
-from typing import Callable, Tuple
+from typing import Callable, List, Tuple
 
 import torch
 import torch.distributed as dist
@@ -59,21 +64,70 @@ def render_view_sharded(render_rows: Callable[[int, int], torch.Tensor], n_rays:
     return gather_tiles(tile, n_rays, group) if gather else tile
 
 
+def stripe_spans(n: int, stripe: int, rank: int, world: int) -> List[Tuple[int, int]]:
+    """Ray ranges [start, end) of the stripes owned by ``rank``: stripe k = rays [k*stripe, (k+1)*stripe) and
+    belongs to rank k % world (the last stripe may be short)."""
+    if stripe < 1:
+        raise ValueError("stripe must be >= 1 ray")
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    n_stripes = (n + stripe - 1) // stripe
+    return [(k * stripe, min((k + 1) * stripe, n)) for k in range(rank, n_stripes, world)]
+
+
+def render_view_striped(render_rows: Callable[[int, int], torch.Tensor], n_rays: int, stripe: int, group=None):
+    """Like render_view_sharded with interleaved stripes of ``stripe`` rays (use a multiple of the image
+    width): every rank renders its stripes (one ``render_rows`` call each), ONE all-gather of the
+    concatenated stripes (padded to the largest rank), then the stripes are put back in image order."""
+    if not dist.is_available() or not dist.is_initialized():
+        return render_rows(0, n_rays)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    spans = [stripe_spans(n_rays, stripe, r, world) for r in range(world)]
+    mine = [render_rows(s, e - s) for s, e in spans[rank]]
+    sizes = [sum(e - s for s, e in sp) for sp in spans]
+    m = max(sizes)
+    if mine:
+        local = torch.cat(mine, 0)
+    else:  # more ranks than stripes: this rank only takes part in the collective
+        probe = render_rows(0, 0)
+        local = probe.new_zeros((0,) + tuple(probe.shape[1:]))
+    padded = local.new_zeros((m,) + tuple(local.shape[1:]))
+    padded[: local.shape[0]] = local
+    gathered = local.new_empty((world * m,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(gathered, padded.contiguous(), group=group)
+    out = local.new_empty((n_rays,) + tuple(local.shape[1:]))
+    for r in range(world):
+        off = r * m
+        for s, e in spans[r]:
+            out[s:e] = gathered[off:off + (e - s)]
+            off += e - s
+    return out
+
+
 def make_row_renderer(model, K, T, h: int, w: int, frame_ids, density_threshold: float = 0.0,
                       bkgd_density_threshold: float = 0.0, chuncks: int = 512 * 7, device="cuda"):
     """The GPU ``render_rows`` for a LayeredRFRender view: device ray generation for the row window,
-    layered_batchify_ray semantics, final image packed as (n, 5) = colour, depth, acc."""
+    layered_batchify_ray semantics OF THE WHOLE VIEW (a view of at least ``chuncks`` rays is rendered with the
+    thresholds whatever the size of the piece a rank renders; the reference drops them only when the whole
+    call has fewer rays than one chunk, utils/batchify_rays.py:52-54), final image packed as (n, 5) =
+    colour, depth, acc."""
     from stnerf_amd import ops
     from stnerf_amd.renderer import layered_batchify_ray
 
     def render_rows(first: int, n: int) -> torch.Tensor:
+        if n == 0:
+            return torch.empty(0, 5, dtype=torch.float32, device=device)
         rays = ops.generate_rays(K, T, h, w, frame_ids=frame_ids, first_ray=first, n=n, device=device)
         model.ray_index_base = first
         try:
             with torch.no_grad():
-                fine = layered_batchify_ray(model, rays, None, None, chuncks=chuncks,
-                                            density_threshold=density_threshold,
-                                            bkgd_density_threshold=bkgd_density_threshold)[0]
+                if h * w < chuncks:
+                    fine = layered_batchify_ray(model, rays, None, None, chuncks=chuncks,
+                                                density_threshold=density_threshold,
+                                                bkgd_density_threshold=bkgd_density_threshold)[0]
+                else:
+                    fine = model.render_rays(rays, False, density_threshold, bkgd_density_threshold,
+                                             ref_chunk=chuncks)[0]
         finally:
             model.ray_index_base = 0
         return torch.cat(list(fine), dim=1)

@@ -214,17 +214,24 @@ def test_cpu_tensors_are_refused():
 def test_sharded_render_is_bitwise_the_single_gpu_render():
     """Ray-tile sharding (stnerf_amd.parallel): shards rendered separately (as ranks would) and
     concatenated == the whole view rendered at once, bit for bit (RNG keyed by global ray index)."""
-    from stnerf_amd.parallel import make_row_renderer, shard_range
+    from stnerf_amd.parallel import make_row_renderer, shard_range, stripe_spans
     meta, _ = load_golden("fwd_c3")
     model = build_model(meta)
     model.seed = 11
     h, w = 48, 80
     K, T = syn.camera(h, w, -12.0)
-    render_rows = make_row_renderer(model, K, T, h, w, [1.0, 2.5, 2.5], chuncks=512)
+    render_rows = make_row_renderer(model, K, T, h, w, [1.0, 2.5, 2.5], density_threshold=0.05, chuncks=512)
     whole = render_rows(0, h * w)
     for world in (2, 3):
         parts = [render_rows(*(lambda s, e: (s, e - s))(*shard_range(h * w, r, world))) for r in range(world)]
         assert torch.equal(torch.cat(parts, 0), whole)
+    # interleaved stripes of 2 image rows (160 rays < one 512-ray chunk: the thresholds must still apply)
+    for world in (2, 5):
+        out = torch.empty_like(whole)
+        for r in range(world):
+            for s, e in stripe_spans(h * w, 2 * w, r, world):
+                out[s:e] = render_rows(s, e - s)
+        assert torch.equal(out, whole)
     assert bool(torch.isfinite(whole).all()) and float(whole[:, 4].max()) > 0.5
 
 

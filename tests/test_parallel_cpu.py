@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from stnerf_amd.parallel import gather_tiles, render_view_sharded, shard_range
+from stnerf_amd.parallel import gather_tiles, render_view_sharded, render_view_striped, shard_range, stripe_spans
 
 
 def test_shard_range_partitions_exactly():
@@ -22,6 +22,19 @@ def test_shard_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(10, 2, 2)
+
+
+def test_stripe_spans_cover_every_ray_once():
+    for n in (0, 5, 64, 101, 2073600):
+        for world in (1, 2, 3, 8):
+            for stripe in (1, 8, 1920 * 8):
+                got = sorted(sp for r in range(world) for sp in stripe_spans(n, stripe, r, world))
+                assert sum(e - s for s, e in got) == n
+                assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
+                if n:
+                    assert got[0][0] == 0 and got[-1][1] == n
+    with pytest.raises(ValueError):
+        stripe_spans(10, 0, 0, 2)
 
 
 def _fake_render(first, n):
@@ -38,6 +51,8 @@ def _worker(rank, world, port, n_rays, q):
         tile = render_view_sharded(_fake_render, n_rays, gather=False)
         s, e = shard_range(n_rays, rank, world)
         ok = torch.equal(img, _fake_render(0, n_rays)) and torch.equal(tile, _fake_render(s, e - s))
+        for stripe in (8, 16, 1000):   # interleaved stripes incl. a short last stripe and "more ranks than stripes"
+            ok = ok and torch.equal(render_view_striped(_fake_render, n_rays, stripe), _fake_render(0, n_rays))
         # wrong tile size is an error on every rank, not a hang
         try:
             gather_tiles(torch.zeros(3, 5), n_rays)
@@ -72,3 +87,4 @@ def test_two_rank_gloo_render_and_gather(n_rays):
 
 def test_single_process_path_needs_no_process_group():
     assert torch.equal(render_view_sharded(_fake_render, 33), _fake_render(0, 33))
+    assert torch.equal(render_view_striped(_fake_render, 33, 8), _fake_render(0, 33))
