@@ -443,7 +443,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) resample_kernel(Resam
                 if (a.xyz_fine) {
                     float x = z * d0 + o0, y = z * d1 + o1, w = z * d2 + o2;  // :465
                     if (a.ed.any) unedit_point(x, y, w, a.ed.e[layer], a.ed.pivot);
-                    float* dst = a.xyz_fine + (pr * S + m) * 3;
+                    float* dst = a.xyz_fine + (pr * S + m) * 3;  // (staging these through LDS for 16-B stores measured slower)
                     dst[0] = x;
                     dst[1] = y;
                     dst[2] = w;

@@ -138,10 +138,12 @@ __global__ void sample_coarse_kernel_x4(const float* __restrict__ rays, int64_t 
                                         const float* __restrict__ jitter, uint64_t seed, int64_t ray_index_base,
                                         EditArgs ed, float* __restrict__ t_out, float* __restrict__ xyz_out,
                                         uint8_t* __restrict__ mask_out) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 samples
+    __shared__ float4 xyz_stage[4 * 192];                              // 4 waves x 64 groups x 3 float4
+    const int64_t g_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 samples
     const int gpl = n1 >> 2;                                           // groups per (ray, layer)
     const int64_t per_ray = (int64_t)l * gpl;
-    if (g >= n * per_ray) return;
+    const bool valid = g_raw < n * per_ray;      // lanes past the end keep running: they help with the stores below
+    const int64_t g = valid ? g_raw : n * per_ray - 1;
     const int64_t ray = g / per_ray;
     const int rem = (int)(g - ray * per_ray);
     const int layer = rem / gpl;
@@ -175,14 +177,32 @@ __global__ void sample_coarse_kernel_x4(const float* __restrict__ rays, int64_t 
         px[3 * j + 2] = z;
     }
     const int64_t e = (ray * l + layer) * n1 + k0;
-    *reinterpret_cast<float4*>(t_out + e) = make_float4(tv[0], tv[1], tv[2], tv[3]);
-    if (xyz_out) {
-        float4* dst = reinterpret_cast<float4*>(xyz_out + e * 3);
-        dst[0] = make_float4(px[0], px[1], px[2], px[3]);
-        dst[1] = make_float4(px[4], px[5], px[6], px[7]);
-        dst[2] = make_float4(px[8], px[9], px[10], px[11]);
+    if (valid) {
+        *reinterpret_cast<float4*>(t_out + e) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+        if (k0 == 0) mask_out[ray * l + layer] = fabsf(width) > 1e-5f ? 1 : 0;
     }
-    if (k0 == 0) mask_out[ray * l + layer] = fabsf(width) > 1e-5f ? 1 : 0;
+    if (xyz_out) {
+        // A wave's 64 groups are consecutive, so its points are 3 KB of contiguous output.  Written straight from the
+        // registers every store instruction would touch 64 x 16 B at a 48-B stride; transposed through LDS each of the
+        // three store instructions writes 1 KB contiguous.
+        float4* stage = xyz_stage + (threadIdx.x >> 6) * 192;
+        const int lane = threadIdx.x & 63;
+        stage[lane * 3 + 0] = make_float4(px[0], px[1], px[2], px[3]);
+        stage[lane * 3 + 1] = make_float4(px[4], px[5], px[6], px[7]);
+        stage[lane * 3 + 2] = make_float4(px[8], px[9], px[10], px[11]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int64_t g0 = g_raw - lane;                           // first group of this wave
+        const int64_t live = n * per_ray - g0;                     // groups of this wave that exist (>= 1)
+        const int nq = (int)(live < 64 ? live : 64) * 3;           // float4s to write
+        float4* dst = reinterpret_cast<float4*>(xyz_out) + g0 * 3;
+#pragma unroll
+        for (int rnd = 0; rnd < 3; ++rnd) {
+            const int q = rnd * 64 + lane;
+            if (q < nq) dst[q] = stage[q];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------- compaction
