@@ -192,8 +192,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
     for (int64_t ray0 = (int64_t)blockIdx.x * a.waves_per_block; ray0 < a.n; ray0 += rays_per_iter) {
         const int64_t ray = ray0 + wave;
         const bool active = ray < a.n;
+        int n_merged = 0;
         // ---- stage the ray, applying the post-network density edits (a10); layer-major so every edit
-        // switch is wave-uniform
+        // switch is wave-uniform.
+        // A layer the ray misses altogether (not evaluated, every t == -1000: bin width 0 from start = end = -1000,
+        // layers/RaySamplePoint.py:53-62,98-102) is dropped from everything below: its samples have sigma = 0, so
+        // alpha = 0, w = 0 and the transmittance factor fl(1 - 0 + 1e-10) is exactly 1; they sort in front of every
+        // real sample, so they are nobody's successor and change no delta.  Results are bit-identical, and with
+        // performers covering a fraction of the image most rays carry one or two live layers instead of l.
+        // (A not-evaluated layer with real depths -- hidden, or a grazing hit -- still takes part: its depths
+        // shape its neighbours' deltas.)
+        unsigned live = 0;  // bit i: layer i takes part
         if (active) {
             const float* tsrc = a.t + ray * LS;
             const float4* rsrc = a.raw + ray * LS;
@@ -203,30 +212,43 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
                 const bool cut_near = !a.p.fine && layer == 0;                                 // :422
                 const bool use_thr = a.p.use_threshold[layer] != 0;                            // :416-418, :538-547, :564-566
                 const float thr = a.p.threshold[layer], sscale = a.p.sigma_scale[layer], nearv = a.p.near;
+                bool missed = true;
                 for (int k = lane; k < a.S; k += 64) {
                     const int e = layer * a.S + k;
                     const float tv = tsrc[e];
-                    float4 rw = have ? rsrc[e] : make_float4(0.f, 0.f, 0.f, 0.f);  // zero tensors, :398-399
-                    if (cut_neg && tv < 0.f) rw.w = 0.f;
-                    if (use_thr && rw.w < thr) rw.w = 0.f;
-                    rw.w = rw.w * sscale;                                          // :575-576
-                    if (cut_near && tv < nearv) rw.w = 0.f;
-                    rw.x = sigmoidf(rw.x);  // torch.sigmoid(rgb), render_layer.py:47
-                    rw.y = sigmoidf(rw.y);
-                    rw.z = sigmoidf(rw.z);
                     ts[e] = tv;
-                    raws[e] = rw;
+                    missed = missed && tv == -1000.f;
+                    if (have) {
+                        float4 rw = rsrc[e];
+                        if (cut_neg && tv < 0.f) rw.w = 0.f;
+                        if (use_thr && rw.w < thr) rw.w = 0.f;
+                        rw.w = rw.w * sscale;                                      // :575-576
+                        if (cut_near && tv < nearv) rw.w = 0.f;
+                        rw.x = sigmoidf(rw.x);  // torch.sigmoid(rgb), render_layer.py:47
+                        rw.y = sigmoidf(rw.y);
+                        rw.z = sigmoidf(rw.z);
+                        raws[e] = rw;
+                    } else {
+                        raws[e] = make_float4(0.f, 0.f, 0.f, 0.f);  // zero tensors (:398-399); sigma = 0 makes the colour moot
+                    }
                 }
+                if (have || a.order || !__all(missed)) live |= 1u << layer;
             }
         }
         wave_sync();
         // ---- per-layer composites (:435-444 / :598-603)
         if (active) {
-            bool unsorted = false;  // a layer's list is ascending unless a box edit/miss made the bin width negative
+            bool unsorted = false;  // a layer's list is ascending unless a box edit made the bin width negative
             for (int layer = 0; layer < a.l; ++layer) {
+                float* wdst = a.weights ? a.weights + (ray * a.l + layer) * a.S : nullptr;
+                if (!(live >> layer & 1u)) {  // missed: every weight and every composite output is zero
+                    if (wdst)
+                        for (int k = lane; k < a.S; k += 64) wdst[k] = 0.f;
+                    if (a.layer_out && lane < 5) a.layer_out[(ray * a.l + layer) * 5 + lane] = 0.f;
+                    continue;
+                }
                 const float* tl = ts + layer * a.S;
                 const float4* rl = raws + layer * a.S;
-                float* wdst = a.weights ? a.weights + (ray * a.l + layer) * a.S : nullptr;
                 float o5[5];
                 const bool desc = composite_run(a.S, a.p.border, lane, [&](int k) { return tl[k]; },
                                                 [&](int k) { return rl[k]; },
@@ -238,21 +260,27 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
                 }
             }
             const bool sorted_ok = !__any(unsorted);
-            // ---- cross-layer merge by depth (:425-429 / :587-592): rank of every sample in the union.
+            // ---- cross-layer merge by depth (:425-429 / :587-592): rank of every live sample in the union.
             // Stable: ties resolve by source index (layer-major), the order a stable sort of the
             // concatenation gives.
             if (sorted_ok) {
+                int before = 0;  // live samples of the layers in front of `la`
                 for (int la = 0; la < a.l; ++la) {
+                    if (!(live >> la & 1u)) continue;
                     for (int k = lane; k < a.S; k += 64) {
                         const int e = la * a.S + k;
                         const float v = ts[e];
                         int rank = k;
-                        for (int lb = 0; lb < la; ++lb) rank += upper_bound_lds(ts + lb * a.S, a.S, a.p2, v);
-                        for (int lb = la + 1; lb < a.l; ++lb) rank += lower_bound_lds(ts + lb * a.S, a.S, a.p2, v);
+                        for (int lb = 0; lb < la; ++lb)
+                            if (live >> lb & 1u) rank += upper_bound_lds(ts + lb * a.S, a.S, a.p2, v);
+                        for (int lb = la + 1; lb < a.l; ++lb)
+                            if (live >> lb & 1u) rank += lower_bound_lds(ts + lb * a.S, a.S, a.p2, v);
                         mord[rank] = (unsigned short)e;
                     }
+                    before += a.S;
                 }
-            } else {  // general O(n^2) fallback
+                n_merged = before;
+            } else {  // general O(n^2) fallback over every sample (missed layers included: they sort first, weight 0)
                 for (int e = lane; e < LS; e += 64) {
                     const float v = ts[e];
                     int rank = 0;
@@ -262,6 +290,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
                     }
                     mord[rank] = (unsigned short)e;
                 }
+                n_merged = LS;
             }
         }
         wave_sync();
@@ -270,7 +299,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
             float o5[5];
             const bool cut_near = a.p.fine != 0;
             const float nearv = a.p.near;
-            composite_run(LS, a.p.border, lane, [&](int m) { return ts[mord[m]]; },
+            composite_run(n_merged, a.p.border, lane, [&](int m) { return ts[mord[m]]; },
                           [&](int m) {
                               const int src = mord[m];
                               float4 rw = raws[src];
