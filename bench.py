@@ -44,6 +44,7 @@ WORKLOADS = {
     "taekwondo-1080p-90+30": (1080, 1920, 2, 90, 30, True, True),
     "single-512-64+64": (512, 512, 1, 64, 64, True, False),
     "walking-1080p-L4-64+64": (1080, 1920, 4, 64, 64, False, True),
+    "synthetic-4k-L8-128+64": (2160, 3840, 8, 128, 64, False, True),   # BASELINE configs[4] on one GPU (use --rays-per-launch 131072)
     "tiny-64-32+0": (64, 64, 1, 32, 0, True, False),
 }
 
