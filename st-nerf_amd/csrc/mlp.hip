@@ -456,7 +456,7 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_ke
 // MotionNet
 // ---------------------------------------------------------------------------------------------
 template <int TM, int NW>
-constexpr int motion_lds_bytes() { return (32 + 22) * TM * 16 + 3 * NW * 64 * 4; }
+constexpr int motion_lds_bytes() { return 32 * TM * 16 + 3 * NW * 64 * 4; }
 
 template <int TM, int NW>
 __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_kernel(MotionArgs a) {
@@ -464,9 +464,11 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_k
     constexpr int NPARTS = NTHREADS / TM;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float4* act = smem;            // [32][TM]
-    float4* enc = smem + 32 * TM;  // [22][TM]: 84 features + 4 zero pads
+    float4* enc = smem;            // [22][TM]: 84 features + 4 zero pads.  ALIASES act: layer 0 is the only reader of enc and
+                                   // every wave passes dense_layer's barrier before the first output quad is written, so
+                                   // the tile needs 32 KiB (TM = 64) and four workgroups share a CU instead of two
     float* encf = reinterpret_cast<float*>(enc);
-    float* scratch = reinterpret_cast<float*>(enc + 22 * TM);  // 3*NPARTS*TM floats
+    float* scratch = reinterpret_cast<float*>(smem + 32 * TM);  // 3*NPARTS*TM floats
     const MotionLayout L = motion_layout();
     const int tid = threadIdx.x;
     const int lane = tid & 63;

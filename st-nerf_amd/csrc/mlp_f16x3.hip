@@ -516,7 +516,7 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_h_
 // MotionNet
 // ---------------------------------------------------------------------------------------------
 template <int TM, int NW>
-constexpr int motion_h_lds_bytes() { return (16 + 12) * 2 * TM * 16 + 3 * NW * 64 * 4; }
+constexpr int motion_h_lds_bytes() { return 16 * 2 * TM * 16 + 3 * NW * 64 * 4; }
 
 #define DENSE_HM(TM_, NW_, LI_, INA_, OCTA_, WFIRST_, LNEXT_, WNEXT_)                                                   \
     dense_layer_h<TM_, WaveSplit<TM_, NW_, 128>::NFB, WaveSplit<TM_, NW_, 128>::NSB, WaveSplit<TM_, NW_, 128>::NFB>(    \
@@ -533,11 +533,11 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_h
     extern __shared__ __attribute__((aligned(16))) half8 smem_h[];
     half8* act_hi = smem_h;             // [16][TM]
     half8* act_lo = smem_h + 16 * TM;   // [16][TM]
-    half8* enc_hi = smem_h + 32 * TM;   // [12][TM]: 84 features + 12 zero pads
-    half8* enc_lo = smem_h + 44 * TM;
+    half8* enc_hi = smem_h;             // [12][TM]: 84 features + 12 zero pads; ALIAS the activation planes (layer 0 is
+    half8* enc_lo = smem_h + 16 * TM;   // their only reader and the layer's barrier precedes its first output write)
     half8* const null_hi = nullptr;
     half8* const null_lo = nullptr;
-    float* scratch = reinterpret_cast<float*>(smem_h + 56 * TM);  // 3*NTHREADS floats
+    float* scratch = reinterpret_cast<float*>(smem_h + 32 * TM);  // 3*NTHREADS floats
     const MotionLayoutH L = motion_layout_h();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
