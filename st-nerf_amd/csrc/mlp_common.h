@@ -173,8 +173,8 @@ struct MotionArgs {
 #define ENC_AT(col, f) (col)[((f) >> 2) * TM * 4 + ((f) & 3)]
 
 // Wave -> (feature block, sample blocks) decomposition of a layer with N outputs on a TM-sample tile, NW waves.
-//   N = 256: NW = 4 -> 64 features x all samples per wave;  NW = 8 -> 32 features x all samples
-//   N = 128: NW = 4 -> 32 features x all samples;           NW = 8 -> 32 features x half the samples
+//   N = 256: NW = 4 -> 64 features x all samples per wave;  NW = 8 -> 32 features x all samples;  NW = 16 -> 32 x half
+//   N = 128: NW = 4 -> 32 features x all samples;           NW = 8 -> 32 features x half the samples;  NW = 16 -> 32 x quarter
 // STNERF_WS_SQUARE (experiment): with 8 waves give a 256-wide layer 64 features x half the samples per wave
 // (2 x 2 blocks: 4 global + 4 LDS operand loads per step instead of 2 + 8).
 #ifndef STNERF_WS_SQUARE
@@ -182,11 +182,14 @@ struct MotionArgs {
 #endif
 template <int TM, int NW, int N>
 struct WaveSplit {
-    static constexpr bool HALF = (NW == 8) && (N == 128 || STNERF_WS_SQUARE);   // wave owns half the samples
-    static constexpr int NFB = (N == 256 && (NW == 4 || STNERF_WS_SQUARE)) ? 2 : 1;
-    static constexpr int NSB = HALF ? TM / 64 : TM / 32;
-    __device__ static __forceinline__ int n0(int wave) { return HALF ? (wave & 3) * NFB * 32 : wave * NFB * 32; }
-    __device__ static __forceinline__ int sb0(int wave) { return HALF ? (wave >> 2) * NSB : 0; }
+    // FS feature slices x SG sample groups = NW waves
+    static constexpr int NFB = (N == 256 && (NW == 4 || (STNERF_WS_SQUARE && NW == 8))) ? 2 : 1;
+    static constexpr int FS = N / (32 * NFB);
+    static constexpr int SG = NW / FS;
+    static constexpr int NSB = (TM / 32) / SG;
+    static_assert(FS * SG == NW && NSB >= 1 && NSB * SG * 32 == TM, "unsupported tile / wave decomposition");
+    __device__ static __forceinline__ int n0(int wave) { return (wave % FS) * NFB * 32; }
+    __device__ static __forceinline__ int sb0(int wave) { return (wave / FS) * NSB; }
 };
 
 
