@@ -335,6 +335,13 @@ def g_forward(name, L, n1, n2, st, dt, seed, h, w, frame=2.5, per_ray_frames=Fal
     save(name, meta, rays=rays, **arrays)
 
 
+def g_more_layers():
+    """BASELINE C4 / C5 shapes at fixture size: 4 performers with deformation only (configs/config_walking.yml has
+    USE_SPACE_TIME off), 8 performers; rays hit 0-2 of the side-by-side performer slabs."""
+    g_forward("fwd_c4", 4, 10, 6, False, True, 35, 6, 12)
+    g_forward("fwd_c5", 8, 12, 4, False, True, 36, 4, 16, call_kwargs=dict(density_threshold=0.05))
+
+
 def g_model_flag_cases():
     """The model flags both shipped ymls leave off."""
     # background deformation net (MotionNet(input_time=False), with a fractional background frame id so that the
@@ -353,6 +360,9 @@ def g_model_flag_cases():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--model-flags":   # (re)generate these cases without touching the rest
         g_model_flag_cases()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--more-layers":
+        g_more_layers()
         return
     g_generate_rays()
     g_sampler()
@@ -379,6 +389,7 @@ def main():
     g_forward("batchify_small", 2, 12, 6, True, True, 28, 6, 8, chunk=3584,
               call_kwargs=dict(density_threshold=0.05, bkgd_density_threshold=0.02))
     g_model_flag_cases()
+    g_more_layers()
 
 
 if __name__ == "__main__":

@@ -100,7 +100,7 @@ def test_motionnet_f16x3_vs_fp64_oracle(ops):
 
 
 @pytest.mark.parametrize("name", ["fwd_c1", "fwd_c3", "fwd_edit", "fwd_hide", "fwd_nonretime", "fwd_only_coarse",
-                                  "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet", "fwd_deep_rgb", "fwd_no_raw_no_dir"])
+                                  "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet", "fwd_deep_rgb", "fwd_no_raw_no_dir", "fwd_c4", "fwd_c5"])
 def test_whole_path_fp16x3_matches_reference_fixtures(name):
     """The drop-in boundary in fp16x3 precision against the reference's own outputs: same tolerances as fp32."""
     import test_gpu_render as R

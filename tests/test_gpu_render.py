@@ -22,7 +22,7 @@ from stnerf_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 FWD_CASES = ["fwd_c1", "fwd_c3", "fwd_edit", "fwd_hide", "fwd_nonretime", "fwd_only_coarse",
-             "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet", "fwd_deep_rgb", "fwd_no_raw_no_dir"]
+             "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet", "fwd_deep_rgb", "fwd_no_raw_no_dir", "fwd_c4", "fwd_c5"]
 COLOR_ATOL, DEPTH_ATOL = 5e-5, 5e-4
 FINE_CAP, FINE_FRACTION, FINE_PSNR = 2e-3, 0.99, 70.0
 
