@@ -13,4 +13,6 @@ CMD="python bench.py --steps 1 --warmup 0 --cpu-baseline-rays 0"
 rocprofv3 --kernel-trace --stats -d $out/trace -o p -- $CMD > $out/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o p -- $CMD --no-second-precision > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $out/write -o p -- $CMD --no-second-precision > $out/write.log 2>&1
+rocprofv3 --pmc MfmaUtil -d $out/mfma -o p -- $CMD > $out/mfma.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS -d $out/lds -o p -- $CMD --no-second-precision > $out/lds.log 2>&1
 ls -R $out | head -40
