@@ -237,8 +237,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
         }
         wave_sync();
         // ---- per-layer composites (:435-444 / :598-603)
+        bool merged_done = false;
         if (active) {
             bool unsorted = false;  // a layer's list is ascending unless a box edit made the bin width negative
+            const bool single = __popc(live) == 1 && !a.order;  // one live layer: the union IS that layer
+            float single5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
             for (int layer = 0; layer < a.l; ++layer) {
                 float* wdst = a.weights ? a.weights + (ray * a.l + layer) * a.S : nullptr;
                 if (!(live >> layer & 1u)) {  // missed: every weight and every composite output is zero
@@ -258,12 +261,25 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
                     const float v = lane == 0 ? o5[0] : lane == 1 ? o5[1] : lane == 2 ? o5[2] : lane == 3 ? o5[3] : o5[4];
                     a.layer_out[(ray * a.l + layer) * 5 + lane] = v;
                 }
+                if (single) {
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) single5[c] = o5[c];
+                    // the merged composite differs from the layer's own only by the fine stage's `t < near` cut (:605)
+                    merged_done = !a.p.fine || !(tl[0] < a.p.near);
+                }
             }
             const bool sorted_ok = !__any(unsorted);
-            // ---- cross-layer merge by depth (:425-429 / :587-592): rank of every live sample in the union.
-            // Stable: ties resolve by source index (layer-major), the order a stable sort of the
-            // concatenation gives.
-            if (sorted_ok) {
+            merged_done = merged_done && sorted_ok;
+            if (merged_done) {  // same samples, same deltas, same arithmetic: the layer's composite is the mix
+                if (a.mixed_out && lane < 5) {
+                    const float v = lane == 0 ? single5[0] : lane == 1 ? single5[1] : lane == 2 ? single5[2]
+                                  : lane == 3 ? single5[3] : single5[4];
+                    a.mixed_out[ray * 5 + lane] = v;
+                }
+            } else if (sorted_ok) {
+                // ---- cross-layer merge by depth (:425-429 / :587-592): rank of every live sample in the union.
+                // Stable: ties resolve by source index (layer-major), the order a stable sort of the
+                // concatenation gives.
                 int before = 0;  // live samples of the layers in front of `la`
                 for (int la = 0; la < a.l; ++la) {
                     if (!(live >> la & 1u)) continue;
@@ -295,7 +311,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
         }
         wave_sync();
         // ---- merged composite (:448 / :605-606)
-        if (active && (a.mixed_out || a.order)) {
+        if (active && !merged_done && (a.mixed_out || a.order)) {
             float o5[5];
             const bool cut_near = a.p.fine != 0;
             const float nearv = a.p.near;
