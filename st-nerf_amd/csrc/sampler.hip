@@ -131,23 +131,25 @@ __global__ void sample_coarse_kernel(const float* __restrict__ rays, int64_t n, 
     if (k == 0) mask_out[ray * l + layer] = fabsf(width) > 1e-5f ? 1 : 0;  // :105
 }
 
-// Same arithmetic, four consecutive samples of one (ray, layer) per thread: one slab test per four samples and
-// 16-byte stores (t: 1 x float4, xyz: 3 x float4).  Used when n1 % 4 == 0 (then every group is 16-B aligned).
-__global__ void sample_coarse_kernel_x4(const float* __restrict__ rays, int64_t n, int ray_stride,
+// Same arithmetic, G = 4 or 2 consecutive samples of one (ray, layer) per thread: one slab test per group, vector
+// stores for t and points that leave as contiguous 16-byte stores.  Used when n1 % G == 0 (every group is then
+// 4G-byte aligned): G = 4 for the usual 64 / 128 samples, G = 2 for the 90 of configs/config_taekwondo.yml.
+template <int G>
+__global__ void sample_coarse_kernel_xg(const float* __restrict__ rays, int64_t n, int ray_stride,
                                         const float* __restrict__ boxes, int64_t box_ray_stride, int l, int n1,
                                         const float* __restrict__ jitter, uint64_t seed, int64_t ray_index_base,
                                         EditArgs ed, float* __restrict__ t_out, float* __restrict__ xyz_out,
                                         uint8_t* __restrict__ mask_out) {
-    __shared__ float4 xyz_stage[4 * 192];                              // 4 waves x 64 groups x 3 float4
-    const int64_t g_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 samples
-    const int gpl = n1 >> 2;                                           // groups per (ray, layer)
+    __shared__ __attribute__((aligned(16))) float xyz_stage[4 * 64 * 3 * G];  // 4 waves x 64 groups x 3G floats
+    const int64_t g_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // group of G samples
+    const int gpl = n1 / G;                                            // groups per (ray, layer)
     const int64_t per_ray = (int64_t)l * gpl;
     const bool valid = g_raw < n * per_ray;      // lanes past the end keep running: they help with the stores below
     const int64_t g = valid ? g_raw : n * per_ray - 1;
     const int64_t ray = g / per_ray;
     const int rem = (int)(g - ray * per_ray);
     const int layer = rem / gpl;
-    const int k0 = (rem - layer * gpl) * 4;
+    const int k0 = (rem - layer * gpl) * G;
     const float* r = rays + ray * ray_stride;
     const float o[3] = {r[0], r[1], r[2]};
     const float d[3] = {r[3], r[4], r[5]};
@@ -156,18 +158,24 @@ __global__ void sample_coarse_kernel_x4(const float* __restrict__ rays, int64_t 
     float start = near_t;
     if (layer == 0 && start <= 0.f) start = 0.f;
     const float width = (far_t - start) / (float)n1;
-    float xi[4];
+    float xi[G];
     if (jitter) {
-        const float4 j4 = *reinterpret_cast<const float4*>(jitter + ((int64_t)layer * n + ray) * n1 + k0);
-        xi[0] = j4.x; xi[1] = j4.y; xi[2] = j4.z; xi[3] = j4.w;
+        const float* jp = jitter + ((int64_t)layer * n + ray) * n1 + k0;
+        if (G == 4) {
+            const float4 j4 = *reinterpret_cast<const float4*>(jp);
+            xi[0] = j4.x; xi[1] = j4.y; xi[G - 2] = j4.z; xi[G - 1] = j4.w;
+        } else {
+            const float2 j2 = *reinterpret_cast<const float2*>(jp);
+            xi[0] = j2.x; xi[1] = j2.y;
+        }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < G; ++j)
             xi[j] = philox_uniform(seed, (uint64_t)(ray_index_base + ray), (uint32_t)layer, 0u, (uint32_t)(k0 + j));
     }
-    float tv[4], px[12];
+    float tv[G], px[3 * G];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < G; ++j) {
         const float t = ((float)(k0 + j) + xi[j]) * width + start;
         tv[j] = t;
         float x = t * d[0] + o[0], y = t * d[1] + o[1], z = t * d[2] + o[2];
@@ -178,30 +186,30 @@ __global__ void sample_coarse_kernel_x4(const float* __restrict__ rays, int64_t 
     }
     const int64_t e = (ray * l + layer) * n1 + k0;
     if (valid) {
-        *reinterpret_cast<float4*>(t_out + e) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+        if (G == 4) *reinterpret_cast<float4*>(t_out + e) = make_float4(tv[0], tv[1], tv[G - 2], tv[G - 1]);
+        else *reinterpret_cast<float2*>(t_out + e) = make_float2(tv[0], tv[1]);
         if (k0 == 0) mask_out[ray * l + layer] = fabsf(width) > 1e-5f ? 1 : 0;
     }
     if (xyz_out) {
-        // A wave's 64 groups are consecutive, so its points are 3 KB of contiguous output.  Written straight from the
-        // registers every store instruction would touch 64 x 16 B at a 48-B stride; transposed through LDS each of the
-        // three store instructions writes 1 KB contiguous.
-        float4* stage = xyz_stage + (threadIdx.x >> 6) * 192;
+        // A wave's 64 groups are consecutive, so its points are 768 G bytes of contiguous output.  Written straight from
+        // the registers every store instruction would touch 64 pieces at a 12 G-byte stride; transposed through LDS every
+        // store instruction writes 1 KB contiguous.
         const int lane = threadIdx.x & 63;
-        stage[lane * 3 + 0] = make_float4(px[0], px[1], px[2], px[3]);
-        stage[lane * 3 + 1] = make_float4(px[4], px[5], px[6], px[7]);
-        stage[lane * 3 + 2] = make_float4(px[8], px[9], px[10], px[11]);
+        float* stage = xyz_stage + (threadIdx.x >> 6) * (64 * 3 * G);
+#pragma unroll
+        for (int j = 0; j < 3 * G; j += 2)
+            *reinterpret_cast<float2*>(stage + lane * 3 * G + j) = make_float2(px[j], px[j + 1]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int64_t g0 = g_raw - lane;                           // first group of this wave
-        const int64_t live = n * per_ray - g0;                     // groups of this wave that exist (>= 1)
-        const int nq = (int)(live < 64 ? live : 64) * 3;           // float4s to write
-        float4* dst = reinterpret_cast<float4*>(xyz_out) + g0 * 3;
-#pragma unroll
-        for (int rnd = 0; rnd < 3; ++rnd) {
-            const int q = rnd * 64 + lane;
-            if (q < nq) dst[q] = stage[q];
-        }
+        const int64_t live = n * per_ray - g0;                     // groups of this wave that exist (<= 0: none)
+        const int nf = (int)(live < 64 ? (live > 0 ? live : 0) : 64) * 3 * G;   // floats to write
+        float* dstf = xyz_out + g0 * 3 * G;                        // 16-byte aligned: g0 is a multiple of 64
+        float4* dst = reinterpret_cast<float4*>(dstf);
+        const float4* src = reinterpret_cast<const float4*>(stage);
+        for (int q = lane; q < nf / 4; q += 64) dst[q] = src[q];
+        if (lane < (nf & 3)) dstf[(nf & ~3) + lane] = stage[(nf & ~3) + lane];   // odd tail of the very last wave
     }
 }
 
@@ -287,13 +295,19 @@ extern "C" int stnerf_sample_coarse(const float* rays, int64_t n, int ray_stride
     const int64_t tot = n * l * n1;
     STNERF_REQUIRE((tot + bs - 1) / bs < (1ll << 31), "sample_coarse: chunk too large");
     LaunchTimer timer(PROF_SAMPLE_COARSE, 0, n, n1, (xyz ? 16ll : 4ll) * l * n1 + 4ll * ray_stride + l, as_stream(stream));
-    const bool aligned = (n1 % 4 == 0) && ((uintptr_t)t % 16 == 0) && (!xyz || (uintptr_t)xyz % 16 == 0) &&
-                         (!jitter || (uintptr_t)jitter % 16 == 0);
+    const int G = n1 % 4 == 0 ? 4 : n1 % 2 == 0 ? 2 : 1;
+    const uintptr_t am = (uintptr_t)(4 * G - 1);   // vector loads / stores of one group
+    const bool aligned = G > 1 && ((uintptr_t)t & am) == 0 && (!xyz || ((uintptr_t)xyz & 15) == 0) &&
+                         (!jitter || ((uintptr_t)jitter & am) == 0);
     if (aligned) {
-        const int64_t groups = tot / 4;
-        hipLaunchKernelGGL(sample_coarse_kernel_x4, dim3((unsigned)((groups + bs - 1) / bs)), dim3(bs), 0,
-                           as_stream(stream), rays, n, ray_stride, boxes, box_ray_stride, l, n1, jitter, seed,
-                           ray_index_base, ed, t, xyz, mask);
+        const int64_t groups = tot / G;
+        const dim3 grid((unsigned)((groups + bs - 1) / bs));
+        if (G == 4)
+            hipLaunchKernelGGL(sample_coarse_kernel_xg<4>, grid, dim3(bs), 0, as_stream(stream), rays, n, ray_stride, boxes,
+                               box_ray_stride, l, n1, jitter, seed, ray_index_base, ed, t, xyz, mask);
+        else
+            hipLaunchKernelGGL(sample_coarse_kernel_xg<2>, grid, dim3(bs), 0, as_stream(stream), rays, n, ray_stride, boxes,
+                               box_ray_stride, l, n1, jitter, seed, ray_index_base, ed, t, xyz, mask);
         STNERF_CHECK_LAUNCH("sample_coarse");
         return STNERF_OK;
     }

@@ -65,10 +65,11 @@ def test_sampler_golden_bit_exact(ops):
     assert torch.equal(mask.cpu().bool(), a["mask"].permute(1, 0))
 
 
+@pytest.mark.parametrize("n1", [24, 90, 13])   # 4, 2 and 1 samples per thread (sampler.hip)
 @pytest.mark.parametrize("edit", [False, True])
-def test_sampler_random_bit_exact(ops, edit):
+def test_sampler_random_bit_exact(ops, edit, n1):
     torch.manual_seed(7)
-    n, L, n1 = 6000, 3, 24
+    n, L = 6000, 3
     K, T = syn.camera(60, 100, -25.0)
     rays = torch.cat([O.generate_rays(K, T, 60, 100), syn.frame_id_columns(n, L)], -1)
     bk, per = syn.scene_boxes(L)
@@ -99,7 +100,7 @@ def test_sampler_random_bit_exact(ops, edit):
 
 
 def test_device_rng_statistics_and_chunk_invariance(ops):
-    n, L, n1 = 4096, 1, 32
+    n, L, n1 = 4096, 1, 30   # 30: the two-samples-per-thread variant of the sampler
     K, T = syn.camera(64, 64, 5.0)
     rays = dev(torch.cat([O.generate_rays(K, T, 64, 64), syn.frame_id_columns(n, L)], -1))
     bk, per = syn.scene_boxes(L)
