@@ -136,6 +136,44 @@ def test_ctypes_structs_agree_with_the_c_compiler(tmp_path):
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
 
 
+def test_plain_c_program_links_and_calls_the_library(tmp_path):
+    """The boundary is a C ABI: a C99 translation unit including only include/stnerf.h links against
+    libstnerf_hip.so and calls the entry points that need no GPU (sizes, argument errors, error string)."""
+    import os, shutil, subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "st-nerf_amd")
+    if not os.path.exists(os.path.join(libdir, "libstnerf_hip.so")):
+        pytest.skip("library not built")
+    src = tmp_path / "client.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <string.h>
+#include "stnerf.h"
+int main(void) {
+    printf("version %s\n", stnerf_version());
+    printf("space %lld time %lld motion %lld deep %lld\n", (long long)stnerf_packed_bytes(STNERF_NET_SPACE),
+           (long long)stnerf_packed_bytes(STNERF_NET_SPACE_TIME), (long long)stnerf_packed_bytes(STNERF_NET_MOTION),
+           (long long)stnerf_packed_bytes(STNERF_NET_SPACE_TIME_DEEP));
+    printf("workspace %lld\n", (long long)stnerf_render_workspace_bytes(3584, 3, 90, 30, 0));
+    int rc = stnerf_composite(NULL, NULL, NULL, 8, 3, 64, NULL, NULL, NULL, NULL, NULL, NULL);
+    printf("rc %d err %s\n", rc, stnerf_last_error());
+    return rc == STNERF_EINVAL && strlen(stnerf_last_error()) > 0 ? 0 : 1;
+}
+""")
+    exe = tmp_path / "client"
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-lstnerf_hip", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath-link,{torch_lib}",
+                    f"-Wl,-rpath,{torch_lib}"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert "version stnerf-hip" in out and "rc -1" in out
+    sizes = dict(zip(("space", "time", "motion", "deep"), map(int, out.splitlines()[1].split()[1::2])))
+    assert sizes["space"] == hip.lib().stnerf_packed_bytes(hip.NET_SPACE) and sizes["deep"] > sizes["time"] > sizes["space"] > sizes["motion"]
+
+
 def test_render_workspace_query_and_argument_errors(lib):
     nb = lib.stnerf_render_workspace_bytes(1000, 3, 64, 64, 0)
     floats = 1000 * 3 * (64 * (1 + 3 + 4 + 1) + 128 * (1 + 3 + 4))
