@@ -519,6 +519,19 @@ def layered_batchify_ray(model, rays, labels, bboxes, chuncks=512 * 7, near_far=
     return model.render_rays(rays, False, density_threshold, bkgd_density_threshold, ref_chunk=chuncks)
 
 
-def psnr(image_pred, image_gt):
-    """utils/metrics.py:16-17."""
-    return -10 * torch.log10(torch.mean((image_pred - image_gt) ** 2))
+def mse(image_pred, image_gt, valid_mask=None, reduction="mean"):
+    """utils/metrics.py:4-10."""
+    value = (image_pred - image_gt) ** 2
+    if valid_mask is not None:
+        value = value[valid_mask]
+    return torch.mean(value) if reduction == "mean" else value
+
+
+def mae(image_pred, image_gt):
+    """utils/metrics.py:12-14."""
+    return torch.mean(torch.abs(image_pred - image_gt))
+
+
+def psnr(image_pred, image_gt, valid_mask=None, reduction="mean"):
+    """utils/metrics.py:16-17.  (ssim, :19-24, needs kornia and is not mirrored.)"""
+    return -10 * torch.log10(mse(image_pred, image_gt, valid_mask, reduction))

@@ -4,6 +4,7 @@ CPU only: no kernel is launched (rendering itself is covered by the GPU tests)."
 import types
 
 import numpy as np
+import torch
 import pytest
 
 from conftest import load_golden
@@ -84,3 +85,16 @@ def test_constructor_needs_explicit_scene():
     from stnerf_amd.render import LayeredNeuralRenderer
     with pytest.raises(NotImplementedError, match="pass model="):
         LayeredNeuralRenderer(types.SimpleNamespace())
+
+
+def test_metrics_mirror():
+    """utils/metrics.py:4-17 (mse / mae / psnr with the optional mask and reduction)."""
+    from stnerf_amd.utils import mae, mse, psnr
+    torch.manual_seed(0)
+    a, b = torch.rand(3, 8, 8), torch.rand(3, 8, 8)
+    m = torch.rand(3, 8, 8) > 0.5
+    assert torch.allclose(mse(a, b), ((a - b) ** 2).mean())
+    assert torch.allclose(mse(a, b, m), ((a - b) ** 2)[m].mean())
+    assert mse(a, b, reduction="none").shape == a.shape
+    assert torch.allclose(mae(a, b), (a - b).abs().mean())
+    assert torch.allclose(psnr(a, b, m), -10 * torch.log10(((a - b) ** 2)[m].mean()))
