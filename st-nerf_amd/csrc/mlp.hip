@@ -45,6 +45,23 @@ __device__ __forceinline__ const float4* weight_lane_ptr(const float* base, int6
     return reinterpret_cast<const float4*>(base + w_off) + ((int64_t)(lane >> 5) * n_total + n0 + (lane & 31));
 }
 
+// K-loop weight loads are BUFFER loads: resource descriptor of the packed blob (4 SGPRs) + wave-uniform byte offset
+// (soffset, advanced on the scalar ALU) + per-lane byte offset in one VGPR that never changes.  With a per-lane 64-bit
+// pointer (global_load) every step costs 64-bit VALU adds, and on gfx950 every VALU instruction displaces f32 MFMA
+// work (profiles/r01_dual_issue_microbench.md; stubbing the weight loads out of the K loop was worth +1.9 % on
+// SpaceNet and +5.6 % on MotionNet).
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const float* blob) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blob), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ uint32_t weight_lane_bytes(int n_total, int lane) {
+    return (uint32_t)((lane >> 5) * n_total + (lane & 31)) * 16u;
+}
+__device__ __forceinline__ float4 load_weight(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_bytes, uint32_t wave_bytes) {
+    const i32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, wave_bytes, 0);
+    return make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+}
+
 // lane_bias = bias + n0 + 4*(lane>>5): register 4q+r of block fb <-> feature n0 + fb*32 + 8q + 4h + r
 template <int NFB>
 __device__ __forceinline__ void load_wfrag(WFrag<NFB>& f, const float4* __restrict__ lane_ptr,
@@ -88,11 +105,12 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[NFB][NSB], const float4 (
 // epilogue); requires steps >= 2.
 template <int TM, int NFB, int NSB, bool FIRST>
 __device__ __forceinline__ void mma_segment(f32x16 (&acc)[NFB][NSB], const float4 (&wfirst)[NFB],
-                                            const f32x16 (&cinit)[NFB], const float4* __restrict__ wp, int n_total,
-                                            const float4* in, int steps) {
-    // wp / in point at this lane's first quad row of the segment; one step = 2 quad rows = 8 k values.
+                                            const f32x16 (&cinit)[NFB], __amdgpu_buffer_rsrc_t rsrc, uint32_t wwave,
+                                            uint32_t wlane, int n_total, const float4* in, int steps) {
+    // rsrc + wwave (wave-uniform byte offset) + wlane (this lane's byte offset) / in point at the first quad row of the
+    // segment; one step = 2 quad rows = 8 k values.
     float4 w0[NFB], a0[NSB], w1[NFB], a1[NSB];
-    const int64_t wstep = 2 * (int64_t)n_total;
+    const uint32_t wstep = 2u * (uint32_t)n_total * 16u;  // bytes per step
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb) w0[fb] = wfirst[fb];
 #pragma unroll
@@ -123,7 +141,7 @@ __device__ __forceinline__ void mma_segment(f32x16 (&acc)[NFB][NSB], const float
 #if defined(STNERF_EXP_NOGLOBAL)   /* development experiments only: wrong results, isolates a stall source */
 #define STNERF_LOAD_W(W, STEP) _Pragma("unroll") for (int fb = 0; fb < NFB; ++fb) asm volatile("" : "+v"(W[fb].x), "+v"(W[fb].y), "+v"(W[fb].z), "+v"(W[fb].w));
 #else
-#define STNERF_LOAD_W(W, STEP) _Pragma("unroll") for (int fb = 0; fb < NFB; ++fb) W[fb] = wp[(STEP) * wstep + fb * 32];
+#define STNERF_LOAD_W(W, STEP) _Pragma("unroll") for (int fb = 0; fb < NFB; ++fb) W[fb] = load_weight(rsrc, wlane + fb * 512u, wwave + (uint32_t)(STEP) * wstep);
 #endif
 #if defined(STNERF_EXP_NOLDS)
 #define STNERF_LOAD_A(A, STEP) _Pragma("unroll") for (int sb = 0; sb < NSB; ++sb) asm volatile("" : "+v"(A[sb].x), "+v"(A[sb].y), "+v"(A[sb].z), "+v"(A[sb].w));
@@ -183,14 +201,16 @@ __device__ __forceinline__ void dense_layer(const float* __restrict__ base, int6
             cinit[fb][4 * q + 3] = wfirst.b[fb][q].w;
         }
     f32x16 acc[NFB][NSB];
-    const float4* wp = weight_lane_ptr(base, w_off, n_total, n0, lane);
-    mma_segment<TM, NFB, NSB, true>(acc, wfirst.w, cinit, wp, n_total, inA + h * TM + s0, kqA / 2);
+    const __amdgpu_buffer_rsrc_t rsrc = weight_rsrc(base);
+    const uint32_t wwave = (uint32_t)(w_off * 4) + (uint32_t)n0 * 16u;
+    const uint32_t wlane = weight_lane_bytes(n_total, lane);
+    mma_segment<TM, NFB, NSB, true>(acc, wfirst.w, cinit, rsrc, wwave, wlane, n_total, inA + h * TM + s0, kqA / 2);
     if (kqB > 0) {
+        const uint32_t wwave2 = wwave + (uint32_t)kqA * (uint32_t)n_total * 16u;
         float4 wseg[NFB];
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) wseg[fb] = (wp + (int64_t)kqA * n_total)[fb * 32];
-        mma_segment<TM, NFB, NSB, false>(acc, wseg, cinit, wp + (int64_t)kqA * n_total, n_total, inB + h * TM + s0,
-                                         kqB / 2);
+        for (int fb = 0; fb < NFB; ++fb) wseg[fb] = load_weight(rsrc, wlane + fb * 512u, wwave2);
+        mma_segment<TM, NFB, NSB, false>(acc, wseg, cinit, rsrc, wwave2, wlane, n_total, inB + h * TM + s0, kqB / 2);
     }
     load_wfrag<NFB_NEXT>(wnext, next_lane_ptr, next_lane_bias);
     PH(PH_MMA);
