@@ -1,15 +1,9 @@
-"""Host-side mirror of the reference's call surface for the layered ray-march path.
+"""The layered model with the reference's constructor, attributes and forward signature
+(modeling/layered_rfrender.py:19-741).
 
-Same names, argument meaning and return structure as the reference:
-``LayeredRFRender`` (modeling/layered_rfrender.py:19-741), ``build_layered_model``
-(modeling/__init__.py:5), ``layered_batchify_ray`` (utils/batchify_rays.py:51-140), and the op-level
-modules ``SpaceNet``, ``MotionNet``, ``RaySamplePoint``, ``VolumeRenderer``, ``sample_pdf``.
-
-Everything numeric runs in the HIP library through ``stnerf_amd.ops``; this file only does what the
-reference does on the host: config, per-frame box interpolation/edit on l x 8 x 3 numbers, chunk
-bookkeeping and output packing.  Parameters are ordinary ``nn.Linear`` modules under the
-reference's attribute names, so ``state_dict()`` / ``load_state_dict()`` speak the reference's
-checkpoint keys; the kernel-layout copy of the weights is rebuilt lazily when they change.
+Everything numeric runs in the HIP library through ``stnerf_amd.ops`` (ONE call into the C ABI per launch
+sequence, ``stnerf_render_rays``); this file only does what the reference does on the host: config, per-frame box
+interpolation/edit on l x 8 x 3 numbers, chunk bookkeeping and output packing.
 """
 from __future__ import annotations
 
@@ -20,201 +14,12 @@ import torch
 from torch import nn
 
 from stnerf_amd import ops
+from stnerf_amd.modeling.motion_net import MotionNet
+from stnerf_amd.modeling.spacenet import SpaceNet
 
 Tensor = torch.Tensor
 
 
-# ------------------------------------------------------------------------------------ networks
-def _params_fingerprint(module: nn.Module):
-    return tuple((p.data_ptr(), p._version, str(p.device)) for p in module.parameters())
-
-
-class _PackedMixin:
-    """Lazily (re)packs a module's nn.Linear weights into the kernel layout."""
-
-    precision = "fp32"   # "fp32": exact f32 MFMA;  "fp16x3": fp32-accurate split-fp16 MFMA (ops.PRECISIONS)
-
-    def _packed(self):
-        fp = _params_fingerprint(self) + (self.precision,)
-        if getattr(self, "_pack_fp", None) != fp:
-            dev = next(self.parameters()).device
-            if dev.type != "cuda":
-                raise RuntimeError("this network lives on %s: call .cuda() first -- the render path runs on the "
-                                   "MI355X only (no CPU fallback)" % dev)
-            sd = {k: v for k, v in self.state_dict().items()}
-            self._pack_net = self._pack(sd, dev)
-            self._pack_fp = fp
-        return self._pack_net
-
-
-class SpaceNet(nn.Module, _PackedMixin):
-    """Radiance MLP, modeling/spacenet.py:13-160 (same constructor, attribute names and forward)."""
-
-    def __init__(self, c_pos=3, include_input=True, use_dir=True, use_time=False, deep_rgb=False):
-        super().__init__()
-        if c_pos != 3:
-            raise NotImplementedError("HIP SpaceNet supports c_pos=3")
-        self.c_pos, self.use_dir, self.use_time, self.deep_rgb = c_pos, use_dir, use_time, deep_rgb
-        self.include_input = include_input
-        raw = int(include_input)             # encodings without the raw input lose d columns (dimension_kernel.py:12-14)
-        self.pos_dim = 3 * (raw + 20)
-        self.dir_dim = 3 * (raw + 8) if use_dir else 0
-        self.time_dim = (raw + 20) if use_time else 0
-        bd, hd = 256, 128
-        self.stage1 = nn.Sequential(nn.Linear(self.pos_dim, bd), nn.ReLU(inplace=True), nn.Linear(bd, bd),
-                                    nn.ReLU(inplace=True), nn.Linear(bd, bd), nn.ReLU(inplace=True),
-                                    nn.Linear(bd, bd), nn.ReLU(inplace=True))
-        self.stage2 = nn.Sequential(nn.Linear(bd + self.pos_dim, bd), nn.ReLU(inplace=True), nn.Linear(bd, bd),
-                                    nn.ReLU(inplace=True), nn.Linear(bd, bd), nn.ReLU(inplace=True))
-        self.density_net = nn.Sequential(nn.Linear(bd, 1))
-        if deep_rgb:                                                        # modeling/spacenet.py:68-79
-            self.rgb_net = nn.Sequential(nn.ReLU(inplace=True), nn.Linear(bd + self.dir_dim + self.time_dim, hd),
-                                         nn.ReLU(inplace=True), nn.Linear(hd, hd), nn.ReLU(inplace=True),
-                                         nn.Linear(hd, hd), nn.ReLU(inplace=True), nn.Linear(hd, 3))
-        else:
-            self.rgb_net = nn.Sequential(nn.ReLU(inplace=True), nn.Linear(bd + self.dir_dim + self.time_dim, hd),
-                                         nn.ReLU(inplace=True), nn.Linear(hd, 3))
-
-    def _pack(self, sd, dev):
-        return ops.pack_spacenet({"net." + k: v for k, v in sd.items()}, "net", dev, self.precision)
-
-    def forward(self, pos, rays, times=None, maxs=None, mins=None):
-        """pos (N,L,3) or (N,3); rays (N,>=6); times (N,1) -> rgbs (N,L,3)|(N,3), density (N,L,1)|(N,1)."""
-        if maxs is not None:
-            raise NotImplementedError("maxs/mins normalisation is unused by the reference (always None)")
-        bins = pos.dim() > 2
-        x = pos if bins else pos.unsqueeze(1)
-        n, s = x.shape[0], x.shape[1]
-        x = x.contiguous()
-        raw = torch.empty(n, s, 4, dtype=torch.float32, device=x.device)
-        tm = times.reshape(n).contiguous() if (self.use_time and times is not None) else None
-        ops.spacenet_fwd(self._packed(), x, rays[:, 3:6], tm, raw)
-        rgb, sig = raw[..., :3], raw[..., 3:]
-        return (rgb, sig) if bins else (rgb[:, 0], sig[:, 0])
-
-
-class MotionNet(nn.Module, _PackedMixin):
-    """Deformation MLP, modeling/motion_net.py:5-71."""
-
-    def __init__(self, c_input=5, include_input=True, input_time=False):
-        super().__init__()
-        if c_input != 4:
-            raise NotImplementedError("HIP MotionNet supports c_input=4 (the time-deformation nets of the layered "
-                                      "model; input_time selects the fractional-time lerp)")
-        self.c_input, self.input_time, self.pos_dim = c_input, input_time, 4 * (int(include_input) + 20)
-        d = 128
-        self.motion_net = nn.Sequential(nn.Linear(self.pos_dim, d), nn.ReLU(inplace=False), nn.Linear(d, d),
-                                        nn.ReLU(inplace=True), nn.Linear(d, d), nn.ReLU(inplace=True),
-                                        nn.Linear(d, d), nn.ReLU(inplace=True), nn.Linear(d, d),
-                                        nn.ReLU(inplace=True), nn.Linear(d, 3))
-
-    def _pack(self, sd, dev):
-        return ops.pack_motionnet({"net." + k: v for k, v in sd.items()}, "net", dev, self.precision)
-
-    def forward(self, input_0):
-        """input_0 (N,L,4) or (N,4) = [x,y,z,t] -> flow (N,L,3) or (N,3).  The time may differ per sample."""
-        bins = input_0.dim() > 2
-        x = input_0.reshape(-1, 1, 4)
-        xyz = x[..., :3].contiguous()
-        flow = torch.empty_like(xyz)
-        ops.motionnet_fwd(self._packed(), xyz, x[:, 0, 3].contiguous(), flow=flow, add_to_xyz=False,
-                          plain_time=not self.input_time)
-        return flow.reshape(*input_0.shape[:-1], 3) if bins else flow.reshape(-1, 3)
-
-
-class Trigonometric_kernel:
-    """Positional encoding, utils/dimension_kernel.py:54-73 (same constructor, __call__ and calc_dim)."""
-
-    def __init__(self, L=10, input_dim=3, include_input=True):
-        self.L, self.input_dim, self.include_input = L, input_dim, include_input
-        self.out_ch = input_dim * (int(include_input) + 2 * L)
-
-    def __call__(self, x):
-        return ops.encode(x, self.L, self.include_input)
-
-    def calc_dim(self, dims=0):
-        return self.out_ch
-
-
-def gen_weight(sigma, delta, act_fn=None):
-    """layers/render_layer.py:8-17 (act_fn is relu, as everywhere in the reference)."""
-    if act_fn is not None and act_fn is not torch.nn.functional.relu:
-        raise NotImplementedError("gen_weight: only the relu activation of the reference is implemented")
-    return ops.gen_weight(sigma.squeeze(-1) if sigma.dim() == delta.dim() + 1 else sigma, delta)
-
-
-def load_reference_checkpoint(model, path, map_location="cuda"):
-    """Load a reference ``layered_rfnr_checkpoint_N.pt`` ({'model': state_dict, ...}); keys the checkpoint
-    lacks keep the model's current values, as render/layered_neural_renderer.py:110-117 does."""
-    ckpt = torch.load(path, map_location=map_location)
-    sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
-    own = model.state_dict()
-    for k, v in own.items():
-        if k not in sd:
-            sd[k] = v
-    model.load_state_dict({k: v for k, v in sd.items() if k in own})
-    return model
-
-
-# ------------------------------------------------------------------------------------ op-level layers
-class RaySamplePoint(nn.Module):
-    """layers/RaySamplePoint.py:64-107.  ``jitter`` (l,n,N) replays given uniform draws; otherwise the
-    device Philox stream (``seed``) is used -- the reference draws fresh torch.rand numbers (:98)."""
-
-    def __init__(self, coarse_num=64):
-        super().__init__()
-        self.coarse_num = coarse_num
-        self.seed = 0
-
-    def forward(self, rays, bbox, pdf=None, method="coarse", jitter=None):
-        t, xyz, mask = ops.sample_coarse(rays.contiguous(), bbox.contiguous(), self.coarse_num, jitter=jitter,
-                                         seed=self.seed)
-        l = t.shape[1]
-        return ([t[:, i].unsqueeze(-1) for i in range(l)], [xyz[:, i] for i in range(l)],
-                [mask[:, i].bool() for i in range(l)])
-
-
-def intersection(rays, bbox):
-    """layers/RaySamplePoint.py:8-62: rays (n,>=6), bbox (n,8,3) -> (n,2) = (far, near)."""
-    return ops.intersect(rays.contiguous(), bbox.unsqueeze(1).contiguous())[:, 0]
-
-
-class VolumeRenderer(nn.Module):
-    """layers/render_layer.py:19-58."""
-
-    def __init__(self, use_mask=False, boarder_weight=1e10):
-        super().__init__()
-        if use_mask:
-            raise NotImplementedError("use_mask is False everywhere in the reference")
-        self.boarder_weight, self.use_mask = boarder_weight, use_mask
-
-    def forward(self, depth, rgb, sigma, noise=0):
-        if noise > 0.:
-            raise NotImplementedError("density noise is a training-time feature")
-        n, s = depth.shape[0], depth.shape[1]
-        raw = torch.cat([rgb, sigma], -1).reshape(n, 1, s, 4).contiguous()
-        lo, _, w, _ = ops.composite(depth.reshape(n, 1, s).contiguous(), raw, None, border=self.boarder_weight,
-                                    want_weights=True)
-        return lo[:, 0, 0:3], lo[:, 0, 3:4], lo[:, 0, 4:5], w[:, 0].unsqueeze(-1)
-
-
-def sample_pdf(z_vals, weights, N_samples, det=False, pytest=False, u=None, seed=0):
-    """utils/sample_pdf.py:18-63: z_vals (n,N1), weights (n,N1-2) -> new samples (n,N_samples).
-    ``u`` (n,N_samples) replays uniform draws; default is the device Philox stream."""
-    if det or pytest:
-        n = z_vals.shape[0]
-        u = torch.linspace(0., 1., steps=N_samples, device=z_vals.device).expand(n, N_samples).contiguous()
-    n, n1 = z_vals.shape
-    pad = torch.zeros(n, 1, device=z_vals.device)
-    wfull = torch.cat([pad, weights, pad], -1).reshape(n, 1, n1).contiguous()
-    rays = torch.zeros(n, 6, device=z_vals.device)
-    out = ops.resample(z_vals.reshape(n, 1, n1).contiguous(), wfull, N_samples, rays,
-                       u=None if u is None else u.reshape(1, n, N_samples).contiguous(), seed=seed,
-                       want_xyz=False, debug=True)
-    return out[2][:, 0]
-
-
-# ------------------------------------------------------------------------------------ the layered model
 class LayeredRFRender(nn.Module):
     """modeling/layered_rfrender.py:19-741 -- same constructor, attributes and forward signature."""
 
@@ -500,38 +305,3 @@ class LayeredRFRender(nn.Module):
         (color (N,3), depth (N,1), acc (N,1)) triple.  layered_rfrender.py:141-734.
         labels / bboxes / near_far / near_far_points are accepted and ignored, as in the BBOX path."""
         return self.render_rays(rays, only_coarse, density_threshold, bkgd_density_threshold, ref_chunk=None)
-
-
-def build_layered_model(cfg, camera_num=0, scale=None, shift=None):
-    """modeling/__init__.py:5."""
-    return LayeredRFRender(cfg, camera_num=camera_num, scale=scale, shift=shift)
-
-
-def layered_batchify_ray(model, rays, labels, bboxes, chuncks=512 * 7, near_far=None, near_far_points=[],
-                         density_threshold=0, bkgd_density_threshold=0):
-    """utils/batchify_rays.py:51-140.  Fewer rays than one chunk: the model is called WITHOUT the
-    thresholds (its defaults 1e-4 / 0 apply, :52-54).  Otherwise the reference loops over
-    ``chuncks``-ray pieces on the host; here the pieces only define which row supplies the per-chunk
-    boxes, and the kernels run over up to ``model.max_rays_per_launch`` rays at a time."""
-    N = rays.size(0)
-    if N < chuncks:
-        return model(rays, labels, bboxes, near_far=near_far, near_far_points=near_far_points)
-    return model.render_rays(rays, False, density_threshold, bkgd_density_threshold, ref_chunk=chuncks)
-
-
-def mse(image_pred, image_gt, valid_mask=None, reduction="mean"):
-    """utils/metrics.py:4-10."""
-    value = (image_pred - image_gt) ** 2
-    if valid_mask is not None:
-        value = value[valid_mask]
-    return torch.mean(value) if reduction == "mean" else value
-
-
-def mae(image_pred, image_gt):
-    """utils/metrics.py:12-14."""
-    return torch.mean(torch.abs(image_pred - image_gt))
-
-
-def psnr(image_pred, image_gt, valid_mask=None, reduction="mean"):
-    """utils/metrics.py:16-17.  (ssim, :19-24, needs kornia and is not mirrored.)"""
-    return -10 * torch.log10(mse(image_pred, image_gt, valid_mask, reduction))

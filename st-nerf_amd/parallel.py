@@ -112,7 +112,7 @@ def make_row_renderer(model, K, T, h: int, w: int, frame_ids, density_threshold:
     call has fewer rays than one chunk, utils/batchify_rays.py:52-54), final image packed as (n, 5) =
     colour, depth, acc."""
     from stnerf_amd import ops
-    from stnerf_amd.renderer import layered_batchify_ray
+    from stnerf_amd.utils.batchify_rays import layered_batchify_ray
 
     def render_rows(first: int, n: int) -> torch.Tensor:
         if n == 0:

@@ -11,7 +11,7 @@ demos use (demo/taekwondo_demo.py:46-53): same method names, argument meaning an
   checkpoint half (reference key names);
 * rays are generated on the device and images stay there until the caller asks for them
   (``render_path`` returns them; writing jpg/png/mp4 is left to ``on_frame`` -- imageio is absent here);
-* per-frame rendering is ``stnerf_amd.render_pose.render_pose`` (HIP kernels).
+* per-frame rendering is ``stnerf_amd.render.render_pose.render_pose`` (HIP kernels).
 
 The host logic below is pinned against fixtures produced by the reference's own methods
 (tests/golden/make_golden.py: ``g_path``).
@@ -26,7 +26,7 @@ from scipy.interpolate import splev, splprep
 from scipy.spatial.transform import Rotation as R
 from scipy.spatial.transform import Slerp
 
-from stnerf_amd.render_pose import render_pose as _render_pose
+from stnerf_amd.render.render_pose import render_pose as _render_pose
 
 
 class LayeredNeuralRenderer:

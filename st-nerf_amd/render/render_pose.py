@@ -11,7 +11,7 @@ from typing import Sequence, Tuple
 import torch
 
 from stnerf_amd import ops
-from stnerf_amd.renderer import layered_batchify_ray
+from stnerf_amd.utils.batchify_rays import layered_batchify_ray
 
 
 def render_pose(model, pose, K, height: int, width: int, layer_frame_pair: Sequence[Tuple[int, float]], far: float,

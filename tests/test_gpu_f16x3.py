@@ -110,7 +110,7 @@ def test_whole_path_fp16x3_matches_reference_fixtures(name):
 def test_c2_full_view_fp16x3_agrees_with_fp32():
     """C2 (512x512, 64+64) rendered in both arithmetic modes with the same device RNG stream."""
     import test_gpu_render as R
-    from stnerf_amd.render_pose import render_pose
+    from stnerf_amd.render.render_pose import render_pose
     meta = dict(L=1, n1=64, n2=64, space_time=True, deform_time=False, weight_seed=40, edit={})
     model = R.build_model(meta)
     K, T = syn.camera(512, 512, 8.0)

@@ -278,7 +278,7 @@ def test_full_sample_counts_on_a_ray_subset_match_the_oracle(cfg_name, meta):
 
 def test_c2_full_view_properties_and_determinism():
     """C2 at its full size (262,144 rays, device RNG): size-independent properties."""
-    from stnerf_amd.render_pose import render_pose, to_uint8
+    from stnerf_amd.render.render_pose import render_pose, to_uint8
     meta = dict(L=1, n1=64, n2=64, space_time=True, deform_time=False, weight_seed=40, edit={})
     model = build_model(meta)
     K, T = syn.camera(512, 512, 8.0)
