@@ -8,8 +8,14 @@
 A "step" = one pass of the hot path over one synthetic 1080p view per GPU: device ray generation
 (a1/a2) -> coarse sampler -> mask compaction -> MotionNet/SpaceNet (fp32 MFMA) -> composite + merge ->
 inverse-CDF resample -> fine MotionNet/SpaceNet -> composite + merge, followed (N > 1) by the RCCL
-all-gather of the rendered tiles.  Weak scaling: every rank renders its own full view of a novel-view
-sweep; value = total rays of all ranks / max-over-ranks time.
+all-gather of the rendered tiles.
+
+N > 1 (the split BASELINE.json configs[3]/[4] describe): ONE view per step is cut into interleaved single-row
+stripes over the N ranks (the performers cover only part of the picture; contiguous tiles would differ ~2x in
+cost), every rank renders its 1/N of the rows as one launch sequence (striped ray window), one RCCL all-gather
+rebuilds the frame on every rank: `scaling` = "strong", value = rays of the view x steps / max-over-ranks time.
+A short secondary leg (`weak_scaling_views`) renders one whole view per rank per step.  `--partition views`
+makes that the headline instead.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): Taekwondo-shaped
 scene, 2 performer layers + background, 1920x1080, 64 coarse + 64 fine samples (128/ray/layer),
@@ -32,6 +38,10 @@ from stnerf_amd import ops, synthetic as syn          # noqa: E402
 from stnerf_amd.modeling import build_layered_model   # noqa: E402
 from stnerf_amd.utils import layered_batchify_ray     # noqa: E402
 from stnerf_amd.parallel import gather_tiles, make_row_renderer, render_view_striped  # noqa: E402
+
+PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+MEASURED_HBM_JSON = os.path.join(REPO, "profiles", "r02_hbm_copy_microbench.json")   # tools/micro/hbm_copy on the GPU box
+PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r02_pmc_hbm_traffic.json")         # tools/pmc_traffic.py
 
 # Algorithmic work per network evaluation: 2 * MACs of every nn.Linear.
 FLOP_SPACE, FLOP_SPACE_TIME, FLOP_MOTION = 924_672, 930_048, 153_344
@@ -72,9 +82,10 @@ class KernelTimer:
     kernel launch, stnerf_profile_begin/_end) joined with the hit masks of each stnerf_render_rays call, which
     give the number of rows a masked performer launch really processed."""
 
-    def __init__(self):
+    def __init__(self, n1=64):
         self.masks = []
         self._orig = None
+        self.n1 = n1
 
     def start(self):
         self._orig = ops.render_rays
@@ -106,17 +117,46 @@ class KernelTimer:
                 d["evals"] += rays * r["ns"]
                 d["flop"] += rays * r["ns"] * flop
             else:                                                  # HBM-bound kernels: algorithmic bytes per ray
-                d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
-                d["bytes"] += r["bytes_per_ray"] * r["n_rays"]
+                d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0, bytes_dense=0))
+                d["bytes_dense"] += r["bytes_per_ray"] * r["n_rays"]
+                if name == "composite":
+                    # bytes the kernel HAS to move: t + raw (20 B/sample) only of the layers a ray hits (the background:
+                    # every ray), the mask, the outputs, and the per-layer weights of the coarse stage (all layers: the
+                    # resampler reads them).  The library's own figure (bytes_dense) charges every layer.
+                    l = len(counts[call])
+                    hits = r["n_rays"] + sum(int(c) for c in counts[call][1:])
+                    dense = r["bytes_per_ray"]
+                    weights = dense - (20 * l * r["ns"] + l + 20 * (l + 1))       # 4*l*S if weights were written
+                    d["bytes"] += 20 * r["ns"] * hits + (l + 20 * (l + 1) + weights) * r["n_rays"]
+                elif name == "resample":
+                    # 8 B per coarse sample read and 16 B per fine sample written for hit layers; a missed
+                    # (ray, layer) pair only gets its constant fill written (16 B per fine sample), no weights read
+                    l = len(counts[call])
+                    hits = r["n_rays"] + sum(int(c) for c in counts[call][1:])
+                    n1 = self.n1
+                    d["bytes"] += 8 * n1 * hits + 16 * r["ns"] * l * r["n_rays"] + 24 * r["n_rays"]
+                else:
+                    d["bytes"] += r["bytes_per_ray"] * r["n_rays"]
             d["launches"] += 1
             d["ms"] += r["ms"]
         return out
 
 
+def _oracle_ray_window(O, K, T, H, W, first, n):
+    """Rays [first, first + n) of the H x W view from the oracle's ray generator (on the image rows they lie in)."""
+    rows0, rows1 = first // W, (first + n + W - 1) // W
+    Kc = K.clone()
+    Kc[1, 2] -= rows0                                    # v = row - rows0 in the crop: same K^-1 [u, row, 1]
+    part = O.generate_rays(Kc, T, rows1 - rows0, W)
+    return part[first - rows0 * W: first - rows0 * W + n]
+
+
 def cpu_baseline(workload, budget_rays):
-    """The CPU oracle (a restatement of the reference algorithm, oracle/stnerf_oracle.py) timed on this
-    box's host cores on a bounded sample of the same workload: whole 3584-ray reference chunks taken
-    from the centre rows of the view (where rays hit the performers)."""
+    """The CPU oracle (a restatement of the reference algorithm, oracle/stnerf_oracle.py) timed on this box's host
+    cores on a bounded sample of the same workload: whole 3584-ray reference chunks spread
+    evenly over the image height -- border rows see the background only, centre rows hit the performers -- each
+    timed on its own; `value` = rays of all chunks / their total time = the whole-frame rate they extrapolate to."""
+    import platform
     from oracle import stnerf_oracle as O
     H, W, L, n1, n2, st, dt = WORKLOADS[workload]
     K, T = syn.camera(H, W, 10.0)
@@ -124,30 +164,63 @@ def cpu_baseline(workload, budget_rays):
     m = O.OracleModel(layer_num=L, n_coarse=n1, n_fine=n2, params=syn.make_state_dict(L, st, dt, seed=0),
                       use_deform_time=dt, use_space_time=st, bkgd_bbox=bk, bboxes=per)
     chunk = 3584
-    n = max(chunk, (budget_rays // chunk) * chunk)
-    n = min(n, H * W)
-    full = O.generate_rays(K, T, H, W) if H * W <= 1 << 19 else None
-    if full is None:  # rows around the image centre only (generate the window analytically via the oracle on a crop)
-        r0 = (H // 2) * W - n // 2
-        rows0, rows1 = r0 // W, (r0 + n + W - 1) // W
-        Kc = K.clone()
-        Kc[1, 2] -= rows0
-        part = O.generate_rays(Kc, T, rows1 - rows0, W)
-        rays = part[r0 - rows0 * W: r0 - rows0 * W + n]
-    else:
-        r0 = max(0, (H * W - n) // 2)
-        rays = full[r0:r0 + n]
-    rays = torch.cat([rays, syn.frame_id_columns(rays.shape[0], L)], -1)
+    n_chunks = max(1, min(budget_rays // chunk, (H * W) // chunk))
     torch.manual_seed(0)
+    per_chunk, evals = [], 0
     with torch.no_grad():
-        O.render_chunk(m, rays[:256])  # warm the allocator / thread pool
-        t0 = time.perf_counter()
-        O.layered_batchify_ray(m, rays, chuncks=chunk)
-        dt_s = time.perf_counter() - t0
-    return dict(value=rays.shape[0] / dt_s, unit="rays/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{rays.shape[0]} rays ({rays.shape[0] // chunk} reference chunks of {chunk}) from the centre "
-                       f"rows of the {W}x{H} view, oracle/stnerf_oracle.py on torch {torch.__version__} CPU fp32, "
-                       f"{dt_s:.1f} s", seconds=dt_s)
+        O.render_chunk(m, torch.cat([_oracle_ray_window(O, K, T, H, W, (H // 2) * W, 256),
+                                     syn.frame_id_columns(256, L)], -1))            # warm the allocator / thread pool
+        for i in range(n_chunks):
+            first = min(H * W - chunk, max(0, int((i + 0.5) / n_chunks * H * W) - chunk // 2))
+            rays = torch.cat([_oracle_ray_window(O, K, T, H, W, first, chunk), syn.frame_id_columns(chunk, L)], -1)
+            t0 = time.perf_counter()
+            out = O.layered_batchify_ray(m, rays, chuncks=chunk)
+            sec = time.perf_counter() - t0
+            hits = chunk + sum(int(mk.sum()) for mk in out[4][1:])
+            evals += hits * (2 * n1 + n2)
+            per_chunk.append(dict(first_row=first // W, seconds=round(sec, 3), rays_per_s=round(chunk / sec, 1),
+                                  performer_hit_fraction=round((hits - chunk) / (chunk * max(L, 1)), 3)))
+    total = sum(c["seconds"] for c in per_chunk)
+    rate = n_chunks * chunk / total
+    cpu = platform.processor() or ""
+    try:
+        cpu = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+    except Exception:
+        pass
+    return dict(value=rate, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n_chunks} reference chunks of {chunk} rays spread evenly over the rows of the {W}x{H} view "
+                       f"(border rows: background only; centre rows: performers), oracle/stnerf_oracle.py on torch "
+                       f"{torch.__version__} CPU fp32, {total:.1f} s",
+                seconds=total, ray_samples_per_s=evals / total, extrapolated_frame_seconds=H * W / rate,
+                host=dict(nproc=os.cpu_count(), torch_threads=torch.get_num_threads(), cpu=cpu), chunks=per_chunk)
+
+
+def psnr_vs_reference(model_unused, device):
+    """PSNR parity of the production (device Philox) RNG mode with the reference: tests/golden/psnr_view.npz holds the
+    REFERENCE rendered with two torch seeds on a 128 x 128 view of this scene (64+64, seed-0 weights; written by
+    tests/golden/make_golden.py from /root/reference).  PSNR(reference B, reference A) is its own run-to-run spread;
+    the HIP render must land on it."""
+    import numpy as np
+    path = os.path.join(REPO, "tests", "golden", "psnr_view.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    meta = json.loads(bytes(z["meta"]).decode())
+    A, B = torch.from_numpy(z["color_a"]).float(), torch.from_numpy(z["color_b"]).float()
+    model = build_layered_model(make_cfg(meta["L"], meta["n1"], meta["n2"], True, True), camera_num=1)
+    model.load_state_dict(syn.make_state_dict(meta["L"], True, True, seed=meta["weight_seed"]))
+    bk, per = syn.scene_boxes(meta["L"])
+    model.set_bkgd_bbox(bk)
+    model.set_bboxes(per)
+    model = model.to(device).eval()
+    K, T = syn.camera(meta["h"], meta["w"], meta["orbit"])
+    rays = ops.generate_rays(K, T, meta["h"], meta["w"], frame_ids=[1.0] + [meta["frame"]] * meta["L"], device=device)
+    psnr = lambda a, b: float(-10 * torch.log10(torch.mean((a - b) ** 2)))
+    model.seed = 5
+    with torch.no_grad():
+        img = layered_batchify_ray(model, rays, None, None)[0][0].cpu()
+    return {"hip_device_rng_vs_reference_seed_a_dB": psnr(img, A), "reference_seed_b_vs_seed_a_dB": psnr(B, A),
+            "view": f"{meta['w']}x{meta['h']}, L={meta['L']}, {meta['n1']}+{meta['n2']}", "fixture": "tests/golden/psnr_view.npz"}
 
 
 def eager_gpu_baseline(workload, n_rays, device):
@@ -184,11 +257,19 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="taekwondo-1080p-64+64", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-baseline-rays", type=int, default=7168, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-baseline-rays", type=int, default=8 * 3584,
+                    help="0 disables the CPU baseline leg; default = 8 reference chunks spread over the image (BASELINE.md 3.3)")
     ap.add_argument("--rays-per-launch", type=int, default=1 << 19)
-    ap.add_argument("--partition", default="views", choices=["views", "stripes"],
-                    help="N>1: 'views' = one whole view per GPU per step (weak scaling, the default the driver runs); "
-                         "'stripes' = ONE view per step, interleaved 8-row stripes over the GPUs (strong scaling)")
+    ap.add_argument("--partition", default=None, choices=["views", "stripes"],
+                    help="N>1 headline: 'stripes' (default) = ONE view per step in interleaved row stripes over the GPUs "
+                         "(strong scaling, the split BASELINE configs[3]/[4] describe); 'views' = one whole view per GPU "
+                         "per step (weak scaling)")
+    ap.add_argument("--stripe-rows", type=int, default=1, help="image rows per stripe of the striped partition")
+    ap.add_argument("--debug-single-device", action="store_true",
+                    help="N>1 with every rank on cuda:0 over gloo: exercises the multi-rank code path on a 1-GPU box (not a measurement)")
+    ap.add_argument("--no-weak-leg", action="store_true", help="N>1: skip the secondary weak-scaling leg")
+    ap.add_argument("--no-psnr-check", action="store_true",
+                    help="skip the PSNR-vs-reference check of the device RNG mode (a 128x128 view, ~0.1 s)")
     ap.add_argument("--eager-gpu-baseline-rays", type=int, default=0,
                     help=">0: also time the oracle restatement through eager PyTorch-ROCm on this GPU (informative)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3"],
@@ -204,13 +285,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the render path has no CPU fallback)")
+    if args.debug_single_device:
+        local_rank = 0                  # every rank on cuda:0 (validates the N > 1 logic on a 1-GPU box; gloo, not RCCL)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
+        if args.debug_single_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
 
     from stnerf_amd import hip
     info = hip.device_info()
@@ -220,29 +306,46 @@ def main():
     n_rays = H * W
     frame_ids = [1.0] + [2.5] * L
 
-    def step_striped(i):
-        # strong scaling: all ranks share ONE view; rank r renders stripes r, r+N, ... of 8 image rows
-        K, T = syn.camera(H, W, orbit_deg=10.0 + 1.5 * i)
-        model.seed = i
-        rows = make_row_renderer(model, K, T, H, W, frame_ids, device=device)
-        tile = render_view_striped(rows, n_rays, 8 * W)
-        return tile, [torch.ones(1, device=device)] * l   # (per-layer hit masks are not gathered in this mode)
+    mode = args.partition or ("stripes" if world > 1 else "views")
+    stripe = W * args.stripe_rows                     # rays per stripe: whole image rows
 
-    def step(i, gather=True):
-        if args.partition == "stripes":
-            return step_striped(i)
-        # novel-view sweep, a new pose every step.  Weak scaling: each GPU renders one whole view per step, and all
-        # ranks take the SAME camera for step i (distinct RNG streams), so the per-GPU work does not depend on N --
-        # a different pose per rank would change the performer coverage and with it the work of the slowest rank.
+    def step(i, mode):
+        """-> (image tile (n_rays [x world if views], 5), this rank's per-layer hit masks, this rank's compute seconds).
+        Novel-view sweep, a new pose every step; every rank uses the same camera for step i."""
         K, T = syn.camera(H, W, orbit_deg=10.0 + 1.5 * i)
+        t0 = time.perf_counter()
+        if mode == "stripes":
+            # strong scaling: ONE view per step; rank r renders image rows r, r+N, r+2N, ... (x stripe_rows) as one
+            # launch sequence over a striped ray window, then one RCCL all-gather of the stripes
+            model.seed = i
+            rows = make_row_renderer(model, K, T, H, W, frame_ids, device=device)
+            holder = {}
+
+            def timed_rows(first, n):
+                out = rows(first, n)
+                torch.cuda.synchronize()
+                holder["t"] = time.perf_counter() - t0
+                return out
+
+            def timed_striped(first, n, st_, period):
+                out = rows.striped(first, n, st_, period)
+                torch.cuda.synchronize()
+                holder["t"] = time.perf_counter() - t0
+                return out
+            timed_rows.striped = timed_striped
+            tile = render_view_striped(timed_rows, n_rays, stripe)
+            return tile, rows.last_masks, holder.get("t", 0.0)
+        # weak scaling: one whole view per GPU per step (distinct RNG streams), tiles all-gathered
         rays = ops.generate_rays(K, T, H, W, frame_ids=frame_ids, device=device)
         model.seed = i * world + rank
         with torch.no_grad():
             fine, coarse, fine_layers, _, masks = layered_batchify_ray(model, rays, None, None)
         tile = torch.cat(list(fine), dim=1).contiguous()      # (H*W, 5): colour, depth, acc of the final image
-        if world > 1 and gather:
+        torch.cuda.synchronize()
+        compute = time.perf_counter() - t0
+        if world > 1:
             tile = gather_tiles(tile, world * n_rays)          # ONE RCCL all-gather of the rendered tiles
-        return tile, masks
+        return tile, masks, compute
 
     def fence():
         torch.cuda.synchronize()
@@ -250,42 +353,58 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(precision, steps, warmup):
+    def measure(precision, steps, warmup, mode):
         """K timed steps (barrier + synchronize on both sides, MAX over ranks) in one precision mode."""
         model.set_precision(precision)
         for i in range(warmup):
-            step(-1 - i)
-        timer = KernelTimer()
+            step(-1 - i, mode)
+        timer = KernelTimer(n1)
         timer.start()
         fence()
         t0 = time.perf_counter()
+        compute = 0.0
         for i in range(steps):
-            tile, masks = step(i)
+            tile, masks, c = step(i, mode)
+            compute += c
         fence()
         elapsed = time.perf_counter() - t0
         timer.stop()
+        per_rank = [compute]
         if world > 1:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
+            allc = torch.zeros(world, dtype=torch.float64, device=device)
+            allc[rank] = compute
+            dist.all_reduce(allc)
+            per_rank = allc.tolist()
         ksum = timer.summarise()  # this rank's launches over the timed steps
         evals = sum(d["evals"] for name, d in ksum.items() if name == "spacenet")
+        hit = torch.stack([m.float().mean() for m in masks]).double() if masks is not None else torch.zeros(l, dtype=torch.float64, device=device)
         if world > 1:
             ev = torch.tensor([evals], dtype=torch.float64, device=device)
             dist.all_reduce(ev)
             evals_all = float(ev.item())
+            dist.all_reduce(hit)
+            hit = hit / world
         else:
             evals_all = float(evals)
         assert bool(torch.isfinite(tile).all()), "non-finite pixels in the rendered tile"
-        return elapsed, ksum, evals, evals_all, tile, masks
+        return dict(elapsed=elapsed, ksum=ksum, evals=evals, evals_all=evals_all, tile=tile, mask_fraction=hit.tolist(),
+                    per_rank_compute_s=per_rank, steps=steps, mode=mode,
+                    rays=(n_rays if mode == "stripes" else world * n_rays) * steps)
 
-    elapsed, ksum, evals, evals_all, tile, masks = measure(args.precision, args.steps, args.warmup)
+    head = measure(args.precision, args.steps, args.warmup, mode)
+    elapsed, ksum, evals, evals_all = head["elapsed"], head["ksum"], head["evals"], head["evals_all"]
     other = None
     if not args.no_second_precision:
         op = "fp16x3" if args.precision == "fp32" else "fp32"
-        o_el, o_ks, o_ev, o_eva, o_tile, _ = measure(op, max(1, min(args.steps, 2)), 1)
-        # same poses / seeds as the headline run's first steps: image agreement between the two arithmetic modes
-        other = dict(precision=op, steps=max(1, min(args.steps, 2)), elapsed=o_el, ksum=o_ks, evals_all=o_eva)
+        other = measure(op, max(1, min(args.steps, 2)), 1, mode)
+        other["precision"] = op
+    weak = None
+    if world > 1 and mode == "stripes" and not args.no_weak_leg:
+        weak = measure(args.precision, max(1, min(args.steps, 2)), 1, "views")
+    psnr_check = psnr_vs_reference(model, device) if (rank == 0 and not args.no_psnr_check) else None
 
     if rank == 0:
         sp = ksum["spacenet"]
@@ -296,45 +415,69 @@ def main():
             peak_used = PEAK_F32_MFMA_TFLOPS
         # HBM traffic cannot be counted inside this process: it comes from the committed rocprofv3 PMC passes
         # of the same command (profiles/), per launch, with the gfx950 FETCH_SIZE correction applied.
-        traffic, traffic_src = None, None
-        pmc_path = os.path.join(REPO, "profiles", "r01_pmc_spacenet_traffic.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            if pmc.get("workload") == args.workload:
-                traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_pmc_spacenet_traffic.json"
+        pmc = json.load(open(PMC_TRAFFIC_JSON)) if os.path.exists(PMC_TRAFFIC_JSON) else {}
+        pmc_ok = pmc.get("workload") == args.workload and world == 1
+        traffic = pmc["kernels"]["spacenet"]["hbm_bytes_per_launch"] if pmc_ok and "spacenet" in pmc.get("kernels", {}) else None
+        measured = json.load(open(MEASURED_HBM_JSON)) if os.path.exists(MEASURED_HBM_JSON) else {}
+        hbm_meas = {"composite": measured.get("read_GBps"), "resample": measured.get("copy_GBps"),
+                    "sample_coarse": measured.get("write_GBps")}
+
+        def hbm_entry(k, d):
+            sec = d["ms"] * 1e-3
+            e = {"launches": d["launches"], "ms_per_step": d["ms"] / head["steps"],
+                 "algorithmic_GBps": d["bytes"] / sec / 1e9, "peak_GBps": PEAK_HBM_GBPS, "frac": d["bytes"] / sec / (PEAK_HBM_GBPS * 1e9),
+                 "algorithmic_bytes_per_step": d["bytes"] / head["steps"],
+                 "dense_bytes_per_step": d["bytes_dense"] / head["steps"],
+                 "bytes_note": "algorithmic = bytes the kernel has to move (t, raw and weights only of the layers a ray hits); "
+                               "dense = every layer charged (round-1 accounting)"}
+            if hbm_meas.get(k):
+                e["measured_peak_GBps"] = hbm_meas[k]
+                e["frac_of_measured_peak"] = d["bytes"] / sec / (hbm_meas[k] * 1e9)
+            if pmc_ok and k in pmc.get("kernels", {}):
+                cb = pmc["kernels"][k]["hbm_bytes_per_step"]
+                e["counter_bytes_per_step"] = cb
+                e["counter_GBps"] = cb / (d["ms"] / head["steps"] * 1e-3) / 1e9
+                e["counter_source"] = "profiles/" + os.path.basename(PMC_TRAFFIC_JSON)
+            return e
+
+        per_rank = head["per_rank_compute_s"]
         rec = {
             "metric": "rendered rays/s (and ray-samples/s) per GPU, 1080p x 128-sample layered render",
-            "value": (1 if args.partition == "stripes" else world) * n_rays * args.steps / elapsed,
+            "value": head["rays"] / elapsed,
             "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong" if args.partition == "stripes" else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if mode == "stripes" else "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "f32-accurate products as 3 fp16 MFMA terms (22-bit split operands), f32 accumulate",
             "data": "synthetic",
             "config": {"workload": args.workload, "precision": args.precision, "height": H, "width": W, "performer_layers": L,
                        "coarse_samples": n1, "fine_samples": n2, "use_space_time": st, "use_deform_time": dt,
-                       "rays_per_gpu_per_step": n_rays, "rays_per_launch": args.rays_per_launch,
+                       "rays_per_view": n_rays, "rays_per_launch": args.rays_per_launch,
                        "weights": "random, density head scaled (synthetic.make_state_dict seed 0)",
-                       "parallelism": (f"1 view per step in interleaved 8-row stripes over {world} GPUs, one RCCL all-gather per step"
-                                       if args.partition == "stripes" else
+                       "parallelism": (f"ONE view per step in interleaved {args.stripe_rows}-row stripes over {world} GPUs (each rank: "
+                                       f"one launch sequence over its striped ray window), one RCCL all-gather per step"
+                                       if mode == "stripes" else
                                        f"ray tiles: 1 view per GPU per step x {world} GPUs (same camera, own RNG stream), "
                                        "one RCCL all-gather of the rendered tiles per step")},
             "ray_samples_per_s": evals_all / elapsed,
-            "ray_samples_per_step_per_gpu": evals / args.steps,
-            "mask_fraction": [float(m.float().mean()) for m in masks],
+            "ray_samples_per_step_rank0": evals / args.steps,
+            "mask_fraction": head["mask_fraction"],
+            "per_rank_compute_s": {"min": min(per_rank), "mean": sum(per_rank) / len(per_rank), "max": max(per_rank),
+                                   "all": per_rank, "note": "render time of each rank's share over the timed steps, before the all-gather"},
             "roofline": {"kernel": "stnerf::spacenet_kernel (fused PE + 9-layer MLP, v_mfma_f32_32x32x2_f32)",
                          "bound": "mfma", "achieved": achieved, "peak": peak_used, "unit": "TFLOP/s",
-                         "frac": achieved / peak_used, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / peak_used, "traffic": traffic,
+                         "traffic_source": ("profiles/" + os.path.basename(PMC_TRAFFIC_JSON)) if traffic else None,
                          "algorithmic_bytes_per_launch": 28 * sp["evals"] / sp["launches"],
                          "launches": sp["launches"], "avg_launch_ms": sp["ms"] / sp["launches"],
                          "algorithmic_flop_per_launch": sp["flop"] / sp["launches"],
                          "note": "algorithmic FLOPs = network evaluations x 924,672 (930,048 with time), "
-                                 "HIP events recorded by the library on the launch stream around every launch of the timed steps"},
+                                 "HIP events recorded by the library on the launch stream around every launch of the timed steps (rank 0)"},
             "kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / args.steps,
                             "tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12} for k, d in ksum.items() if "flop" in d},
-            "hbm_kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / args.steps,
-                                "algorithmic_GBps": d["bytes"] / (d["ms"] * 1e-3) / 1e9, "peak_GBps": 8000.0,
-                                "frac": d["bytes"] / (d["ms"] * 1e-3) / 8e12} for k, d in ksum.items() if "bytes" in d},
+            "hbm_kernels": {k: hbm_entry(k, d) for k, d in ksum.items() if "bytes" in d},
+            "hbm_microbench": measured or None,
+            "psnr_vs_reference": psnr_check,
             "device": info,
         }
         if other is not None:
@@ -346,8 +489,8 @@ def main():
                 "precision": other["precision"],
                 "note": "same workload and poses, measured after the headline run; fp16x3 = every product a*b evaluated as "
                         "ah*bh + ah*bl + al*bh on the fp16 MFMA pipe with f32 accumulation: passes the same parity tests "
-                        "and tolerances as the exact-f32 kernels (tests/test_gpu_f16x3.py)",
-                "value": (1 if args.partition == "stripes" else world) * n_rays * other["steps"] / other["elapsed"], "unit": "rays/s",
+                        "as the exact-f32 kernels (tests/test_gpu_f16x3.py); opt-in, not the headline",
+                "value": other["rays"] / other["elapsed"], "unit": "rays/s",
                 "ms_per_step": 1e3 * other["elapsed"] / other["steps"], "steps": other["steps"],
                 "ray_samples_per_s": other["evals_all"] / other["elapsed"],
                 "roofline": {"bound": "mfma", "algorithmic_tflops": o_ach, "executed_mfma_tflops": mult * o_ach,
@@ -356,6 +499,13 @@ def main():
                                 "algorithmic_tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12}
                             for k, d in other["ksum"].items() if "flop" in d},
             }
+        if weak is not None:
+            wr = weak["per_rank_compute_s"]
+            rec["weak_scaling_views"] = {
+                "note": "secondary leg: one whole view per GPU per step (same camera, own RNG stream), tiles all-gathered",
+                "value": weak["rays"] / weak["elapsed"], "unit": "rays/s", "steps": weak["steps"],
+                "ms_per_step": 1e3 * weak["elapsed"] / weak["steps"],
+                "per_rank_compute_s": {"min": min(wr), "mean": sum(wr) / len(wr), "max": max(wr)}}
         if world == 1 and args.eager_gpu_baseline_rays > 0:
             rec["eager_gpu_baseline"] = eager_gpu_baseline(args.workload, args.eager_gpu_baseline_rays, device)
         if world == 1 and args.cpu_baseline_rays > 0:

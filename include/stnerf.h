@@ -71,14 +71,24 @@ typedef struct stnerf_layer_edit {
     int32_t has_scale;
 } stnerf_layer_edit;
 
-/* a1 + a2: pinhole rays of rows [first_ray, first_ray+n) of an h x w view, row-major over
+/* Which rays of a view a call works on.  Local ray i of a call is GLOBAL ray
+ *     first + i                                    (stripe == 0: one contiguous window)
+ *     first + (i / stripe) * period + i % stripe   (stripe  > 0: stripes of `stripe` rays, one every `period` rays --
+ *                                                   what rank r of G takes of a view split into interleaved stripes:
+ *                                                   first = r * stripe, period = G * stripe)
+ * The global index selects the pixel (stnerf_generate_rays) and keys the device RNG (stnerf_sample_coarse,
+ * stnerf_resample, stnerf_render_rays), so an image does not depend on how its rays are cut into launches, chunks
+ * or GPU shards.  The three numbers travel as (first_ray | ray_index_base, ray_index_stripe, ray_index_period). */
+
+/* a1 + a2: pinhole rays of the n rays of the window (first_ray, stripe, period) of an h x w view, row-major over
  * (row, col), written as [origin(3), dir(3), frame_ids(n_frame_cols)] with `ray_stride` floats per
  * ray.  Replaces utils/render_helpers.py:42-128 (generate_rays), utils/ray_sampling.py:22-72 and
  * data/datasets/ray_dataset.py:276-281.  Kinv = inverse intrinsics (host, 9 floats, row-major),
  * T = camera-to-world (host, 16 floats), frame_ids host array of n_frame_cols floats (or NULL). */
 int stnerf_generate_rays(const float* Kinv_host, const float* T_host, int h, int w, int64_t first_ray,
-                         int64_t n, const float* frame_ids_host, int n_frame_cols, float* rays,
-                         int ray_stride, stnerf_stream_t stream);
+                         int64_t ray_index_stripe, int64_t ray_index_period, int64_t n,
+                         const float* frame_ids_host, int n_frame_cols, float* rays, int ray_stride,
+                         stnerf_stream_t stream);
 
 /* a5: ray / 8-corner-box slab test.  layers/RaySamplePoint.py:8-62 (intersection).
  * boxes: [l][8][3] shared by all rays (box_ray_stride = 0) or per ray (box_ray_stride = l*24).
@@ -89,14 +99,14 @@ int stnerf_intersect(const float* rays, int64_t n, int ray_stride, const float* 
 /* a5 + a6 (+ the point un-edit of a4): stratified jittered coarse samples of every layer.
  * layers/RaySamplePoint.py:70-107 (RaySamplePoint.forward).
  * jitter: [l][n][n1] uniform draws to REPLAY (the reference's torch.rand tensors), or NULL to draw
- * on the device: Philox4x32-10 keyed by (seed, ray_index_base + ray, layer, sample) -- independent
- * of chunking.  edits: host array of l entries or NULL; pivot: host, 3 floats.
+ * on the device: Philox4x32-10 keyed by (seed, global ray index, layer, sample) -- independent
+ * of chunking (global index: see the ray-window note above).  edits: host array of l entries or NULL; pivot: host, 3 floats.
  * Outputs: t[n][l][n1], xyz[n][l][n1][3] (may be NULL), mask[n][l] (|bin width| > 1e-5). */
 int stnerf_sample_coarse(const float* rays, int64_t n, int ray_stride, const float* boxes,
                          int64_t box_ray_stride, int l, int n1, const float* jitter, uint64_t seed,
-                         int64_t ray_index_base, const stnerf_layer_edit* edits_host,
-                         const float* pivot_host, float* t, float* xyz, uint8_t* mask,
-                         stnerf_stream_t stream);
+                         int64_t ray_index_base, int64_t ray_index_stripe, int64_t ray_index_period,
+                         const stnerf_layer_edit* edits_host, const float* pivot_host, float* t, float* xyz,
+                         uint8_t* mask, stnerf_stream_t stream);
 
 /* Ragged work: list of rays whose mask[ray][layer] is set.  Replaces the boolean-mask indexing
  * (and its host sync) at modeling/layered_rfrender.py:344-353,400-413,497-510,555-563.
@@ -194,7 +204,11 @@ typedef struct stnerf_composite_params {
     float threshold[STNERF_MAX_LAYERS];        /* sigma < threshold -> 0 (retiming)        */
     int32_t use_threshold[STNERF_MAX_LAYERS];
     float sigma_scale[STNERF_MAX_LAYERS];      /* fine: layer 2 *= alpha (:575-576), else 1 */
-    int32_t evaluated[STNERF_MAX_LAYERS];      /* 0: layer's nets were skipped (hidden): raw is not read */
+    int32_t evaluated[STNERF_MAX_LAYERS];      /* 0: layer's nets were skipped (hidden): raw is not read;
+                                                * 1: evaluated on the rays `mask` marks (performers, :397-413);
+                                                * 2: evaluated on EVERY ray, `mask` is not consulted (the background:
+                                                *    bkgd_spacenet runs on all rays, :382-392, and is composited even
+                                                *    where ray_mask[0] is False -- a ray through an edge of its box) */
 } stnerf_composite_params;
 
 /* t[n][l][S], raw[n][l][S][4], mask[n][l] (NULL = all set; a clear bit means "not evaluated":
@@ -209,12 +223,16 @@ int stnerf_composite(const float* t, const float* raw, const uint8_t* mask, int6
 /* a13 (+ the sort/merge and point generation of layered_rfrender.py:459-475): inverse-CDF
  * resampling of every layer.  utils/sample_pdf.py:18-63.
  * t[n][l][n1] coarse depths, weights[n][l][n1] coarse per-layer weights (interior [1:-1] used),
- * u: [l][n][n2] uniform draws to replay, or NULL -> device Philox (seed, ray_index_base, stream 1).
+ * u: [l][n][n2] uniform draws to replay, or NULL -> device Philox (seed, global ray index, stream 1).
  * Outputs: t_fine[n][l][n1+n2] ascending; xyz_fine[n][l][n1+n2][3] (may be NULL) = un-edited points;
  * optional debug/parity outputs z_new[n][l][n2] (unsorted new samples), inds[n][l][n2] int32
- * (searchsorted index), cdf[n][l][n1-1]. */
+ * (searchsorted index), cdf[n][l][n1-1].
+ * Exactness: pdf = (w + 1e-5) / torch.sum(w + 1e-5) with the sum in ATen's CPU reduction order (8-float vectors x 4
+ * interleaved accumulators), cdf = torch.cumsum accumulated in fp64 and rounded per prefix as ATen's CPU kernel does:
+ * cdf, inds and z_new are bit-equal to the reference's CPU evaluation of utils/sample_pdf.py on the same (t, w, u). */
 int stnerf_resample(const float* t, const float* weights, int64_t n, int l, int n1, int n2,
-                    const float* u, uint64_t seed, int64_t ray_index_base, const float* rays,
+                    const float* u, uint64_t seed, int64_t ray_index_base, int64_t ray_index_stripe,
+                    int64_t ray_index_period, const float* rays,
                     int ray_stride, const stnerf_layer_edit* edits_host, const float* pivot_host,
                     float* t_fine, float* xyz_fine, float* z_new, int32_t* inds, float* cdf,
                     stnerf_stream_t stream);
@@ -248,7 +266,7 @@ typedef struct stnerf_render_params {
     float border, near, alpha;                        /* BOARDER_WEIGHT, model.near, model.alpha             */
     float density_threshold, bkgd_density_threshold;  /* applied in retiming mode only, as the reference     */
     uint64_t seed;                                    /* device RNG (used where jitter / u are NULL)         */
-    int64_t ray_index_base;
+    int64_t ray_index_base, ray_index_stripe, ray_index_period;  /* ray window of rays[0..n) (see above)     */
     stnerf_layer_edit edits_coarse[STNERF_MAX_LAYERS]; /* :293-303 */
     stnerf_layer_edit edits_fine[STNERF_MAX_LAYERS];   /* :467-475 */
     float pivot[3];

@@ -257,6 +257,56 @@ def sample_pdf(z_vals: Tensor, weights: Tensor, u: Tensor, return_aux: bool = Fa
     return z
 
 
+def aten_cpu_row_sum(x) -> "numpy.float32":
+    """What ``torch.sum(w, -1)`` (utils/sample_pdf.py:22) returns for one contiguous fp32 row on a CPU, restated in
+    numpy: the order ATen's reduction kernel uses (aten/src/ATen/native/cpu/SumKernel.cpp -- dispatched with 8-float
+    vectors at every x86 capability level).  Rows of >= 8 elements: ``vectorized_inner_sum`` = ``row_sum`` over the full
+    8-float vectors (4 interleaved accumulators, folded ((a0+a1)+a2)+a3; a cascade level folds the accumulators away
+    every 16 rows), then a scalar chain over the leftover elements followed by the 8 vector lanes in order.  Shorter
+    rows: the scalar ``row_sum``.  The HIP resampler reproduces exactly this (csrc/render.hip); the oracle itself just
+    calls torch.sum -- tests/test_host_cpu.py::test_aten_sum_order checks that the two agree on the running host."""
+    import numpy as np
+    f32 = np.float32
+    x = np.asarray(x, dtype=f32)
+    n = x.shape[0]
+
+    def row_sum(get, size, zero):
+        rows = size // 4
+        a = [zero.copy() for _ in range(4)]
+        b = [zero.copy() for _ in range(4)]
+        i = 0
+        while i + 16 <= rows:
+            for _ in range(16):
+                for k in range(4):
+                    a[k] = (a[k] + get(4 * i + k)).astype(f32)
+                i += 1
+            for k in range(4):
+                b[k] = (b[k] + a[k]).astype(f32)
+                a[k] = zero.copy()
+        while i < rows:
+            for k in range(4):
+                a[k] = (a[k] + get(4 * i + k)).astype(f32)
+            i += 1
+        for k in range(4):
+            a[k] = (a[k] + b[k]).astype(f32)
+        for j in range(rows * 4, size):
+            a[0] = (a[0] + get(j)).astype(f32)
+        for k in range(1, 4):
+            a[0] = (a[0] + a[k]).astype(f32)
+        return a[0]
+
+    if n >= 8:
+        nv = n // 8
+        lanes = row_sum(lambda i: x[8 * i:8 * i + 8], nv, np.zeros(8, dtype=f32))
+        fin = f32(0)
+        for k in range(nv * 8, n):
+            fin = f32(fin + x[k])
+        for j in range(8):
+            fin = f32(fin + lanes[j])
+        return fin
+    return f32(row_sum(lambda i: x[i:i + 1], n, np.zeros(1, dtype=f32))[0])
+
+
 # --------------------------------------------------------------------------------------
 # a4 + a10 + a11 + a14: one chunk                          modeling/layered_rfrender.py:141-734
 # --------------------------------------------------------------------------------------

@@ -10,6 +10,11 @@ void set_error(const char* fmt, ...);
 
 static inline hipStream_t as_stream(stnerf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Opt a kernel into `bytes` of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize; needed above 64 KiB).  The
+// attribute belongs to the (device, function) pair: the cache is keyed by the calling thread's current device and is
+// guarded by a mutex, so a process that renders on several GPUs (or from several host threads) opts in on each.
+int reserve_dynamic_lds(const void* kernel, int bytes, const char* what);
+
 // Optional launch profiler (stnerf_profile_begin / _end): while enabled, every kernel launch of the op-level
 // entry points is bracketed by a HIP event pair recorded on the launch stream.
 enum ProfKernel { PROF_SPACENET = 0, PROF_MOTIONNET = 1, PROF_COMPOSITE = 2, PROF_RESAMPLE = 3, PROF_SAMPLE_COARSE = 4 };
@@ -38,6 +43,19 @@ struct LaunchTimer {            // RAII: records start on construction, stop + b
             return STNERF_ELAUNCH;                                                       \
         }                                                                                \
     } while (0)
+
+// Ray window (include/stnerf.h): local ray i of a call -> global ray index of the view.
+struct RayWindow {
+    int64_t first, stripe, period;
+};
+__host__ __device__ inline int64_t global_ray(const RayWindow& w, int64_t i) {
+    if (w.stripe <= 0) return w.first + i;
+    const int64_t s = i / w.stripe;
+    return w.first + s * w.period + (i - s * w.stripe);
+}
+#define STNERF_REQUIRE_WINDOW(what, stripe, period)                                                              \
+    STNERF_REQUIRE((stripe) >= 0 && ((stripe) == 0 || (period) >= (stripe)), what ": bad ray window (stripe %lld, period %lld)", \
+                   (long long)(stripe), (long long)(period))
 
 // Scene constants passed by value to kernels (small, wave-uniform -> SGPRs).
 struct EditArgs {

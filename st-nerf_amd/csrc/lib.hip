@@ -16,8 +16,35 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace stnerf
 
-// ------------------------------------------------------------------------------------------ launch profiler
+// ------------------------------------------------------------------------------------------ LDS opt-in
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
+namespace stnerf {
+int reserve_dynamic_lds(const void* kernel, int bytes, const char* what) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, int> reserved;  // (device, kernel) -> bytes opted in so far
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("%s: no current HIP device", what);
+        return STNERF_ELAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    int& have = reserved[std::make_pair(dev, kernel)];
+    if (bytes <= have) return STNERF_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("%s: cannot reserve %d B of LDS on device %d", what, bytes, dev);
+        return STNERF_ELAUNCH;
+    }
+    have = bytes;
+    return STNERF_OK;
+}
+}  // namespace stnerf
+
+// ------------------------------------------------------------------------------------------ launch profiler
 namespace stnerf {
 namespace {
 struct ProfRec {

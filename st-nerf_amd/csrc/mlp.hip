@@ -667,19 +667,11 @@ static TileCfg tile_config(TileCfg dflt) {
     return cfg < 0 ? dflt : (TileCfg)cfg;
 }
 
-// One-time LDS opt-in + launch.  `slot` identifies the instantiation (static flags per kernel).
+// LDS opt-in (per device, see reserve_dynamic_lds) + launch.
 template <class Args>
-static int launch_mlp(void (*kernel)(Args), bool* opted_in, int lds, int grid, int nthreads, stnerf_stream_t stream,
+static int launch_mlp(void (*kernel)(Args), int lds, int grid, int nthreads, stnerf_stream_t stream,
                       const Args& a, const char* what, int prof_kernel, int prof_kind) {
-    if (!*opted_in) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("%s: cannot reserve %d B of LDS", what, lds);
-            return STNERF_ELAUNCH;
-        }
-        *opted_in = true;
-    }
+    if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(kernel), lds, what)) return rc;
     LaunchTimer timer(prof_kernel, prof_kind, a.wl.n_rays, a.wl.ns, 0, as_stream(stream));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(nthreads), lds, as_stream(stream), a);
     STNERF_CHECK_LAUNCH(what);
@@ -785,7 +777,6 @@ extern "C" int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays,
     STNERF_REQUIRE((raw_ray_stride & 3) == 0 && ((uintptr_t)raw & 15) == 0, "spacenet_fwd: raw must be 16-byte aligned");
     STNERF_REQUIRE(((uintptr_t)packed & 15) == 0, "spacenet_fwd: packed weights must be 16-byte aligned");
     if (n_rays == 0) return STNERF_OK;
-    static bool opted[3][2] = {{false, false}, {false, false}, {false, false}};
     SpaceArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, dirs,
                 dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride};
     const TileCfg tc = tile_config(TILE_128X8);
@@ -796,21 +787,20 @@ extern "C" int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays,
     const char* what = "spacenet_fwd";
     const int PROF_KERNEL_ID = PROF_SPACENET, PROF_KIND_ID = kind;
     if (STNERF_NET_IS_DEEP(kind)) {  // deep_rgb: the default tile configuration only
-        static bool opted_deep[2] = {false, false};
         const int grid128 = grid_for(n_rays, ns, 128);
-        return ut ? launch_mlp(spacenet_kernel<128, 8, true, true>, &opted_deep[1], (64 + 16) * 128 * 16, grid128, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
-                  : launch_mlp(spacenet_kernel<128, 8, false, true>, &opted_deep[0], (64 + 16) * 128 * 16, grid128, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
+        return ut ? launch_mlp(spacenet_kernel<128, 8, true, true>, (64 + 16) * 128 * 16, grid128, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
+                  : launch_mlp(spacenet_kernel<128, 8, false, true>, (64 + 16) * 128 * 16, grid128, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
     }
     switch (tc) {
         case TILE_128:
-            return ut ? launch_mlp(spacenet_kernel<128, 4, true>, &opted[0][1], lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
-                      : launch_mlp(spacenet_kernel<128, 4, false>, &opted[0][0], lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
+            return ut ? launch_mlp(spacenet_kernel<128, 4, true>, lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
+                      : launch_mlp(spacenet_kernel<128, 4, false>, lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
         case TILE_128X8:
-            return ut ? launch_mlp(spacenet_kernel<128, 8, true>, &opted[1][1], lds, grid, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
-                      : launch_mlp(spacenet_kernel<128, 8, false>, &opted[1][0], lds, grid, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
+            return ut ? launch_mlp(spacenet_kernel<128, 8, true>, lds, grid, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
+                      : launch_mlp(spacenet_kernel<128, 8, false>, lds, grid, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
         default:
-            return ut ? launch_mlp(spacenet_kernel<64, 4, true>, &opted[2][1], lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
-                      : launch_mlp(spacenet_kernel<64, 4, false>, &opted[2][0], lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
+            return ut ? launch_mlp(spacenet_kernel<64, 4, true>, lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
+                      : launch_mlp(spacenet_kernel<64, 4, false>, lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
     }
 }
 
@@ -823,7 +813,6 @@ extern "C" int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, 
     STNERF_REQUIRE(n_rays >= 0 && ns >= 1, "motionnet_fwd: bad shape");
     STNERF_REQUIRE(((uintptr_t)packed & 15) == 0, "motionnet_fwd: packed weights must be 16-byte aligned");
     if (n_rays == 0) return STNERF_OK;
-    static bool opted[3] = {false, false, false};
     MotionArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, times,
                  times_ray_stride, flow, flow_ray_stride, add_to_xyz};
     const TileCfg tc = tile_config(TILE_64);
@@ -832,10 +821,10 @@ extern "C" int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, 
     const int PROF_KERNEL_ID = PROF_MOTIONNET, PROF_KIND_ID = STNERF_NET_MOTION;
     switch (tc) {
         case TILE_128:
-            return launch_mlp(motionnet_kernel<128, 4>, &opted[0], motion_lds_bytes<128, 4>(), grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
+            return launch_mlp(motionnet_kernel<128, 4>, motion_lds_bytes<128, 4>(), grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
         case TILE_128X8:
-            return launch_mlp(motionnet_kernel<128, 8>, &opted[1], motion_lds_bytes<128, 8>(), grid, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
+            return launch_mlp(motionnet_kernel<128, 8>, motion_lds_bytes<128, 8>(), grid, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
         default:
-            return launch_mlp(motionnet_kernel<64, 4>, &opted[2], motion_lds_bytes<64, 4>(), grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
+            return launch_mlp(motionnet_kernel<64, 4>, motion_lds_bytes<64, 4>(), grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
     }
 }

@@ -752,7 +752,6 @@ extern "C" int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n
     STNERF_REQUIRE((raw_ray_stride & 3) == 0 && ((uintptr_t)raw & 15) == 0 && ((uintptr_t)packed & 15) == 0,
                    "spacenet_fwd_f16x3: raw / packed must be 16-byte aligned");
     if (n_rays == 0) return STNERF_OK;
-    static bool opted[3][2] = {{false, false}, {false, false}, {false, false}};
     SpaceArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, dirs,
                 dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride};
     const char* e = getenv("STNERF_TILE_H");
@@ -762,34 +761,25 @@ extern "C" int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n
     const int lds = 80 * tm * 16;
     const int grid = grid_for_h(n_rays, ns, tm);
     const bool ut = STNERF_NET_USES_TIME(kind);
-    auto launch = [&](auto kernel, bool* flag, int nthreads) -> int {
-        if (!*flag) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    lds) != hipSuccess) {
-                (void)hipGetLastError();
-                set_error("spacenet_fwd_f16x3: cannot reserve %d B of LDS", lds);
-                return STNERF_ELAUNCH;
-            }
-            *flag = true;
-        }
+    auto launch = [&](auto kernel, int nthreads) -> int {
+        if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(kernel), lds, "spacenet_fwd_f16x3")) return rc;
         LaunchTimer timer(PROF_SPACENET, kind, n_rays, ns, 0, as_stream(stream));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(nthreads), lds, as_stream(stream), a);
         STNERF_CHECK_LAUNCH("spacenet_fwd_f16x3");
         return STNERF_OK;
     };
     if (STNERF_NET_IS_DEEP(kind)) {  // deep_rgb: compiled for the default tile configuration only (the knob is ignored)
-        static bool opted_deep[2] = {false, false};
-        return ut ? launch(spacenet_h_kernel<128, 8, true, true>, &opted_deep[1], 512)
-                  : launch(spacenet_h_kernel<128, 8, false, true>, &opted_deep[0], 512);
+        return ut ? launch(spacenet_h_kernel<128, 8, true, true>, 512)
+                  : launch(spacenet_h_kernel<128, 8, false, true>, 512);
     }
     if (small)
-        return ut ? launch(spacenet_h_kernel<64, 4, true>, &opted[2][1], 256)
-                  : launch(spacenet_h_kernel<64, 4, false>, &opted[2][0], 256);
+        return ut ? launch(spacenet_h_kernel<64, 4, true>, 256)
+                  : launch(spacenet_h_kernel<64, 4, false>, 256);
     if (four)
-        return ut ? launch(spacenet_h_kernel<128, 4, true>, &opted[0][1], 256)
-                  : launch(spacenet_h_kernel<128, 4, false>, &opted[0][0], 256);
-    return ut ? launch(spacenet_h_kernel<128, 8, true>, &opted[1][1], 512)
-              : launch(spacenet_h_kernel<128, 8, false>, &opted[1][0], 512);
+        return ut ? launch(spacenet_h_kernel<128, 4, true>, 256)
+                  : launch(spacenet_h_kernel<128, 4, false>, 256);
+    return ut ? launch(spacenet_h_kernel<128, 8, true>, 512)
+              : launch(spacenet_h_kernel<128, 8, false>, 512);
 }
 
 extern "C" int stnerf_motionnet_fwd_f16x3(const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
@@ -801,28 +791,19 @@ extern "C" int stnerf_motionnet_fwd_f16x3(const void* packed, int64_t n_rays, in
     STNERF_REQUIRE(n_rays >= 0 && ns >= 1, "motionnet_fwd_f16x3: bad shape");
     STNERF_REQUIRE(((uintptr_t)packed & 15) == 0, "motionnet_fwd_f16x3: packed weights must be 16-byte aligned");
     if (n_rays == 0) return STNERF_OK;
-    static bool opted[2] = {false, false};
     MotionArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, times,
                  times_ray_stride, flow, flow_ray_stride, add_to_xyz};
     const char* e = getenv("STNERF_TILE_HM");
     const bool big = e && !strcmp(e, "128x8");
-    auto launch = [&](auto kernel, bool* flag, int lds, int nthreads, int tm) -> int {
-        if (!*flag) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    lds) != hipSuccess) {
-                (void)hipGetLastError();
-                set_error("motionnet_fwd_f16x3: cannot reserve %d B of LDS", lds);
-                return STNERF_ELAUNCH;
-            }
-            *flag = true;
-        }
+    auto launch = [&](auto kernel, int lds, int nthreads, int tm) -> int {
+        if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(kernel), lds, "motionnet_fwd_f16x3")) return rc;
         LaunchTimer timer(PROF_MOTIONNET, STNERF_NET_MOTION, n_rays, ns, 0, as_stream(stream));
         hipLaunchKernelGGL(kernel, dim3(grid_for_h(n_rays, ns, tm)), dim3(nthreads), lds, as_stream(stream), a);
         STNERF_CHECK_LAUNCH("motionnet_fwd_f16x3");
         return STNERF_OK;
     };
-    if (big) return launch(motionnet_h_kernel<128, 8>, &opted[0], motion_h_lds_bytes<128, 8>(), 512, 128);
-    return launch(motionnet_h_kernel<64, 4>, &opted[1], motion_h_lds_bytes<64, 4>(), 256, 64);
+    if (big) return launch(motionnet_h_kernel<128, 8>, motion_h_lds_bytes<128, 8>(), 512, 128);
+    return launch(motionnet_h_kernel<64, 4>, motion_h_lds_bytes<64, 4>(), 256, 64);
 }
 
 #ifdef STNERF_PHASE_PROF

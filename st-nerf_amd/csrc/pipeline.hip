@@ -98,6 +98,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
 
     // ---- coarse samples + hit masks (+ un-edit), then the per-layer lists of hit rays
     rc = stnerf_sample_coarse(rays, n, rs, boxes, box_ray_stride, l, n1, jitter, p->seed, p->ray_index_base,
+                              p->ray_index_stripe, p->ray_index_period,
                               p->has_edits ? p->edits_coarse : nullptr, p->pivot, t_c, xyz_c, mask, stream);
     if (rc) return rc;
     if (hipMemsetAsync(ray_count, 0, sizeof(int32_t) * STNERF_MAX_LAYERS, st) != hipSuccess) {
@@ -159,7 +160,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
     cp.cut_negative_t = 1;
     for (int i = 0; i < STNERF_MAX_LAYERS; ++i) {
         cp.sigma_scale[i] = 1.f;
-        cp.evaluated[i] = i < l ? (i == 0 ? 1 : p->shown[i]) : 1;
+        cp.evaluated[i] = i < l ? (i == 0 ? 2 : p->shown[i]) : 1;  // background: every ray, mask or not (:382-392)
         cp.use_threshold[i] = (p->retiming && i >= 1) ? 1 : 0;  // :416-418 (performers, retiming only)
         cp.threshold[i] = p->density_threshold;
     }
@@ -168,7 +169,8 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
     if (rc || p->only_coarse) return rc;
 
     // ---- resample + fine points (:459-475), fine networks, fine composite (:538-606)
-    rc = stnerf_resample(t_c, w_c, n, l, n1, n2, u, p->seed, p->ray_index_base, rays, rs,
+    rc = stnerf_resample(t_c, w_c, n, l, n1, n2, u, p->seed, p->ray_index_base, p->ray_index_stripe, p->ray_index_period,
+                         rays, rs,
                          p->has_edits ? p->edits_fine : nullptr, p->pivot, t_f, xyz_f, nullptr, nullptr, nullptr, stream);
     if (rc) return rc;
     rc = stage(xyz_f, raw_f, S, true);

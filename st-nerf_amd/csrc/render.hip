@@ -21,12 +21,6 @@ __device__ __forceinline__ float dpp_move(float identity, float v) {
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
 constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138;
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
 __device__ __forceinline__ float wave_scan_mul(float v) {  // inclusive
     v *= dpp_move<DPP_ROW_SHR1>(1.f, v);
     v *= dpp_move<DPP_ROW_SHR2>(1.f, v);
@@ -45,6 +39,66 @@ __device__ __forceinline__ float wave_scan_add(float v) {  // inclusive
     v += dpp_move<DPP_ROW_BCAST15, 0xa>(0.f, v);
     v += dpp_move<DPP_ROW_BCAST31, 0xc>(0.f, v);
     return v;
+}
+
+// Inclusive add-scan in fp64 (cdf accumulation of the resampler, see resample_kernel).
+__device__ __forceinline__ double wave_scan_add_f64(double v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(v, o);
+        if (lane >= o) v += up;
+    }
+    return v;
+}
+
+// torch.sum(x, -1) of one contiguous fp32 row, bit for bit as ATen computes it on a CPU: the reference's
+// `torch.sum(weights, -1, keepdim=True)` (utils/sample_pdf.py:22) is an fp32 reduction whose rounding depends on the
+// order, so "the reference's value" is defined by ATen's kernel (aten/src/ATen/native/cpu/SumKernel.cpp, dispatched
+// with 8-float vectors on every x86 capability level -- DEFAULT, AVX2 and AVX512 alike, checked against torch 2.10 in
+// tests/test_oracle_golden.py::test_aten_sum_order): rows of >= 8 elements go through vectorized_inner_sum = 8 vector
+// lanes x 4 interleaved accumulators over the full vectors (row_sum / multi_row_sum, with its 16-row cascade level),
+// the accumulators folded ((a0+a1)+a2)+a3, then a scalar chain over the < 8 leftover elements followed by the 8
+// lanes in order; shorter rows take the scalar row_sum.  x lives in (wave-private) LDS; every lane returns the sum.
+__device__ __forceinline__ float aten_cpu_row_sum(const float* x, int n, int lane) {
+    if (n < 8) {
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        const int rows = n >> 2;
+        for (int i = 0; i < rows; ++i) {
+            p0 += x[4 * i + 0];
+            p1 += x[4 * i + 1];
+            p2 += x[4 * i + 2];
+            p3 += x[4 * i + 3];
+        }
+        for (int j = rows * 4; j < n; ++j) p0 += x[j];
+        return ((p0 + p1) + p2) + p3;
+    }
+    const int nv = n >> 3, rows = nv >> 2, j = lane & 7;  // lanes 8.. repeat column lane & 7 (uniform control flow)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    int i = 0;
+    for (; i + 16 <= rows;) {  // cascade level 1: every 16 rows the running accumulators are folded away
+        for (int r = 0; r < 16; ++r, ++i) {
+            a0 += x[(4 * i + 0) * 8 + j];
+            a1 += x[(4 * i + 1) * 8 + j];
+            a2 += x[(4 * i + 2) * 8 + j];
+            a3 += x[(4 * i + 3) * 8 + j];
+        }
+        b0 += a0; b1 += a1; b2 += a2; b3 += a3;
+        a0 = a1 = a2 = a3 = 0.f;
+    }
+    for (; i < rows; ++i) {
+        a0 += x[(4 * i + 0) * 8 + j];
+        a1 += x[(4 * i + 1) * 8 + j];
+        a2 += x[(4 * i + 2) * 8 + j];
+        a3 += x[(4 * i + 3) * 8 + j];
+    }
+    a0 += b0; a1 += b1; a2 += b2; a3 += b3;  // (levels 2 and 3 stay zero below 256 rows = 8192 elements)
+    for (int v = rows * 4; v < nv; ++v) a0 += x[v * 8 + j];
+    const float col = ((a0 + a1) + a2) + a3;
+    float fin = 0.f;
+    for (int k = nv * 8; k < n; ++k) fin += x[k];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) fin += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col), jj));
+    return fin;
 }
 
 // value of the previous lane (lane 0 gets `first`)
@@ -67,6 +121,25 @@ __device__ __forceinline__ int upper_bound_lds(const float* a, int n, int p2, fl
     for (int step = p2; step > 0; step >>= 1) {
         const int np = pos + step;
         const float x = a[(np < n ? np : n) - 1];
+        pos = (np <= n && x <= v) ? np : pos;
+    }
+    return pos;
+}
+// The same two counts over a strictly DESCENDING array, read back to front (a[n-1-i] is ascending).
+__device__ __forceinline__ int lower_bound_lds_rev(const float* a, int n, int p2, float v) {
+    int pos = 0;
+    for (int step = p2; step > 0; step >>= 1) {
+        const int np = pos + step;
+        const float x = a[n - (np < n ? np : n)];
+        pos = (np <= n && x < v) ? np : pos;
+    }
+    return pos;
+}
+__device__ __forceinline__ int upper_bound_lds_rev(const float* a, int n, int p2, float v) {
+    int pos = 0;
+    for (int step = p2; step > 0; step >>= 1) {
+        const int np = pos + step;
+        const float x = a[n - (np < n ? np : n)];
         pos = (np <= n && x <= v) ? np : pos;
     }
     return pos;
@@ -96,12 +169,14 @@ __device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcp
 // raw_at(k) returns {sigmoid(r), sigmoid(g), sigmoid(b), sigma}: the sigmoid is evaluated once per sample when
 // the ray is staged and shared by the per-layer and the merged composite (3 of the 8 expf per sample saved).
 // ---------------------------------------------------------------------------------------------
+// Returns bit 0: some t_{k+1} < t_k (the list is not ascending); bit 1: some t_{k+1} >= t_k (it is not strictly
+// descending) -- per lane, the caller reduces over the wave.
 template <class TAt, class RawAt, class WOut>
-__device__ __forceinline__ bool composite_run(int count, float border, int lane, TAt t_at, RawAt raw_at, WOut w_out,
-                                              float (&out)[5]) {
+__device__ __forceinline__ int composite_run(int count, float border, int lane, TAt t_at, RawAt raw_at, WOut w_out,
+                                             float (&out)[5]) {
     float carry = 1.f;
     float cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
-    bool descending = false;  // some t_{k+1} < t_k: the list is not ascending
+    bool descending = false, not_descending = false;
     for (int base = 0; base < count; base += 64) {
         const int k = base + lane;
         const bool ok = k < count;
@@ -114,6 +189,7 @@ __device__ __forceinline__ bool composite_run(int count, float border, int lane,
             if (k + 1 < count) {
                 const float tn = t_at(k + 1);
                 descending = descending || (tn < tk);
+                not_descending = not_descending || !(tn < tk);
                 delta = tn - tk;
             }
             alpha = 1.f - expf(-fmaxf(rw.w, 0.f) * delta);
@@ -137,7 +213,7 @@ __device__ __forceinline__ bool composite_run(int count, float border, int lane,
     out[2] = wave_last(wave_scan_add(cb));
     out[3] = wave_last(wave_scan_add(cd));
     out[4] = wave_last(wave_scan_add(ca));
-    return descending;
+    return (descending ? 1 : 0) | (not_descending ? 2 : 0);
 }
 
 // gen_weight stand-alone: one wave per row.
@@ -198,8 +274,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
         // A layer the ray misses altogether (not evaluated, every t == -1000: bin width 0 from start = end = -1000,
         // layers/RaySamplePoint.py:53-62,98-102) is dropped from everything below: its samples have sigma = 0, so
         // alpha = 0, w = 0 and the transmittance factor fl(1 - 0 + 1e-10) is exactly 1; they sort in front of every
-        // real sample, so they are nobody's successor and change no delta.  Results are bit-identical, and with
-        // performers covering a fraction of the image most rays carry one or two live layers instead of l.
+        // real sample, so they are nobody's successor and change no delta.  The composites are the same numbers (the
+        // dropped factors are exact ones; only the association order of the parallel transmittance scan moves with the
+        // lane a sample lands in, i.e. fp32 rounding), and with performers covering a fraction of the image most rays
+        // carry one or two live layers instead of l.  The `order` parity output does not change what is composited
+        // (tests/test_gpu_ops.py::test_composite_production_shortcuts_are_bitwise_neutral).
         // (A not-evaluated layer with real depths -- hidden, or a grazing hit -- still takes part: its depths
         // shape its neighbours' deltas.)
         unsigned live = 0;  // bit i: layer i takes part
@@ -207,7 +286,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
             const float* tsrc = a.t + ray * LS;
             const float4* rsrc = a.raw + ray * LS;
             for (int layer = 0; layer < a.l; ++layer) {
-                const bool have = a.p.evaluated[layer] && (!a.mask || a.mask[ray * a.l + layer]);
+                // evaluated: 0 = no network output for this layer (hidden), 1 = on the rays its hit mask marks,
+                // 2 = on every ray whatever the mask says -- the background: bkgd_spacenet runs on all rays and its
+                // output is composited even where ray_mask[0] is False (a ray through an edge of the background
+                // box: start == end, bin width 0; layered_rfrender.py:382-392,435-444, fixture fwd_grazing)
+                const int ev = a.p.evaluated[layer];
+                const bool have = ev == 2 || (ev != 0 && (!a.mask || a.mask[ray * a.l + layer]));
                 const bool cut_neg = !a.p.fine && a.p.cut_negative_t && layer > 0;             // :414
                 const bool cut_near = !a.p.fine && layer == 0;                                 // :422
                 const bool use_thr = a.p.use_threshold[layer] != 0;                            // :416-418, :538-547, :564-566
@@ -232,15 +316,21 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
                         raws[e] = make_float4(0.f, 0.f, 0.f, 0.f);  // zero tensors (:398-399); sigma = 0 makes the colour moot
                     }
                 }
-                if (have || a.order || !__all(missed)) live |= 1u << layer;
+                if (have || !__all(missed)) live |= 1u << layer;
             }
         }
         wave_sync();
         // ---- per-layer composites (:435-444 / :598-603)
-        bool merged_done = false;
+        bool merged_done = false, unsorted_any = false;
+        unsigned reversed_all = 0;
         if (active) {
-            bool unsorted = false;  // a layer's list is ascending unless a box edit made the bin width negative
-            const bool single = __popc(live) == 1 && !a.order;  // one live layer: the union IS that layer
+            // a layer's list is ascending, unless its bin width is negative: a box edit, or a ray that misses the
+            // background box (far = -1000, start clamped to 0: depths run from 0 down to -1000).  Such a list is strictly
+            // descending and is merged through a reversed view; anything else (ties inside a descending list) takes
+            // the general rank.
+            bool unsorted = false;
+            unsigned reversed = 0;  // bit i: layer i is strictly descending
+            const bool single = __popc(live) == 1;  // one live layer: the union IS that layer
             float single5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
             for (int layer = 0; layer < a.l; ++layer) {
                 float* wdst = a.weights ? a.weights + (ray * a.l + layer) * a.S : nullptr;
@@ -253,10 +343,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
                 const float* tl = ts + layer * a.S;
                 const float4* rl = raws + layer * a.S;
                 float o5[5];
-                const bool desc = composite_run(a.S, a.p.border, lane, [&](int k) { return tl[k]; },
-                                                [&](int k) { return rl[k]; },
-                                                [&](int k, float w) { if (wdst) wdst[k] = w; }, o5);
-                unsorted = unsorted || desc;
+                const int dir = composite_run(a.S, a.p.border, lane, [&](int k) { return tl[k]; },
+                                              [&](int k) { return rl[k]; },
+                                              [&](int k, float w) { if (wdst) wdst[k] = w; }, o5);
+                const bool some_desc = __any(dir & 1), some_asc = __any(dir & 2);
+                if (some_desc && !some_asc) reversed |= 1u << layer;
+                unsorted = unsorted || (some_desc && some_asc);
                 if (a.layer_out && lane < 5) {
                     const float v = lane == 0 ? o5[0] : lane == 1 ? o5[1] : lane == 2 ? o5[2] : lane == 3 ? o5[3] : o5[4];
                     a.layer_out[(ray * a.l + layer) * 5 + lane] = v;
@@ -268,8 +360,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
                     merged_done = !a.p.fine || !(tl[0] < a.p.near);
                 }
             }
-            const bool sorted_ok = !__any(unsorted);
-            merged_done = merged_done && sorted_ok;
+            const bool sorted_ok = !unsorted;  // (wave-uniform)
+            unsorted_any = unsorted;
+            reversed_all = reversed;
+            merged_done = merged_done && sorted_ok && reversed == 0;
             if (merged_done) {  // same samples, same deltas, same arithmetic: the layer's composite is the mix
                 if (a.mixed_out && lane < 5) {
                     const float v = lane == 0 ? single5[0] : lane == 1 ? single5[1] : lane == 2 ? single5[2]
@@ -286,11 +380,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
                     for (int k = lane; k < a.S; k += 64) {
                         const int e = la * a.S + k;
                         const float v = ts[e];
-                        int rank = k;
+                        int rank = (reversed >> la & 1u) ? a.S - 1 - k : k;
                         for (int lb = 0; lb < la; ++lb)
-                            if (live >> lb & 1u) rank += upper_bound_lds(ts + lb * a.S, a.S, a.p2, v);
+                            if (live >> lb & 1u)
+                                rank += (reversed >> lb & 1u) ? upper_bound_lds_rev(ts + lb * a.S, a.S, a.p2, v)
+                                                              : upper_bound_lds(ts + lb * a.S, a.S, a.p2, v);
                         for (int lb = la + 1; lb < a.l; ++lb)
-                            if (live >> lb & 1u) rank += lower_bound_lds(ts + lb * a.S, a.S, a.p2, v);
+                            if (live >> lb & 1u)
+                                rank += (reversed >> lb & 1u) ? lower_bound_lds_rev(ts + lb * a.S, a.S, a.p2, v)
+                                                              : lower_bound_lds(ts + lb * a.S, a.S, a.p2, v);
                         mord[rank] = (unsigned short)e;
                     }
                     before += a.S;
@@ -311,7 +409,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
         }
         wave_sync();
         // ---- merged composite (:448 / :605-606)
-        if (active && !merged_done && (a.mixed_out || a.order)) {
+        if (active && !merged_done && a.mixed_out) {
             float o5[5];
             const bool cut_near = a.p.fine != 0;
             const float nearv = a.p.near;
@@ -327,8 +425,37 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
                 const float v = lane == 0 ? o5[0] : lane == 1 ? o5[1] : lane == 2 ? o5[2] : lane == 3 ? o5[3] : o5[4];
                 a.mixed_out[ray * 5 + lane] = v;
             }
-            if (a.order)
-                for (int m = lane; m < LS; m += 64) a.order[ray * LS + m] = mord[m];
+        }
+        // ---- optional parity output: torch.sort's index over ALL l * S samples (the composites above leave the
+        // layers a ray misses out; their samples, t = -1000, sort in front of everything and carry no weight)
+        if (active && a.order) {
+            int32_t* od = a.order + ray * LS;
+            if (!unsorted_any) {
+                for (int la = 0; la < a.l; ++la) {
+                    for (int k = lane; k < a.S; k += 64) {
+                        const int e = la * a.S + k;
+                        const float v = ts[e];
+                        int rank = (reversed_all >> la & 1u) ? a.S - 1 - k : k;
+                        for (int lb = 0; lb < la; ++lb)
+                            rank += (reversed_all >> lb & 1u) ? upper_bound_lds_rev(ts + lb * a.S, a.S, a.p2, v)
+                                                              : upper_bound_lds(ts + lb * a.S, a.S, a.p2, v);
+                        for (int lb = la + 1; lb < a.l; ++lb)
+                            rank += (reversed_all >> lb & 1u) ? lower_bound_lds_rev(ts + lb * a.S, a.S, a.p2, v)
+                                                              : lower_bound_lds(ts + lb * a.S, a.S, a.p2, v);
+                        od[rank] = e;
+                    }
+                }
+            } else {
+                for (int e = lane; e < LS; e += 64) {
+                    const float v = ts[e];
+                    int rank = 0;
+                    for (int x = 0; x < LS; ++x) {
+                        const float xv = ts[x];
+                        rank += (xv < v || (xv == v && x < e)) ? 1 : 0;
+                    }
+                    od[rank] = e;
+                }
+            }
         }
         wave_sync();
     }
@@ -344,7 +471,7 @@ struct ResampleArgs {
     int l, n1, n2;
     const float* u;
     uint64_t seed;
-    int64_t ray_index_base;
+    RayWindow win;
     const float* rays;
     int ray_stride;
     EditArgs ed;
@@ -360,11 +487,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) resample_kernel(Resam
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n1 = a.n1, n2 = a.n2, S = n1 + n2, nb = n1 - 1;  // nb = #bins = len(cdf)
-    float* mine = reinterpret_cast<float*>(smem_raw) + (size_t)wave * (3 * n1 + n2 + S);
+    float* mine = reinterpret_cast<float*>(smem_raw) + (size_t)wave * (4 * n1 + n2 + S);
     float* tc = mine;          // [n1]  coarse depths
     float* cdf = tc + n1;      // [n1-1]
     float* bins = cdf + n1;    // [n1-1]
-    float* zs = bins + n1;     // [n2]
+    float* wv = bins + n1;     // [n1-2] pdf numerators w + 1e-5
+    float* zs = wv + n1;       // [n2]
     float* tf = zs + n2;       // [S]
     const int p2_n1 = floor_pow2(n1), p2_nb = floor_pow2(nb), p2_n2 = floor_pow2(n2 > 0 ? n2 : 1);
     const int64_t pairs = a.n * a.l;
@@ -403,17 +531,24 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) resample_kernel(Resam
             const float* tsrc = a.t + pr * n1;
             const float* wsrc = a.weights + pr * n1;
             for (int k = lane; k < n1; k += 64) tc[k] = tsrc[k];
-            float part = 0.f;
-            for (int k = lane; k < n1 - 2; k += 64) part += wsrc[k + 1] + 1e-5f;
-            const float total = wave_sum(part);  // butterfly: every lane holds the same bits
-            float carry = 0.f;
+            for (int k = lane; k < n1 - 2; k += 64) wv[k] = wsrc[k + 1] + 1e-5f;  // weights + 1e-5 (sample_pdf.py:21)
+        }
+        wave_sync();
+        if (active) {
+            // pdf = w / torch.sum(w) in ATen's CPU summation order; cdf = torch.cumsum(pdf): ATen's CPU cumsum
+            // accumulates fp32 rows in DOUBLE and rounds every prefix to fp32 (cumsum_cpu_kernel: at::acc_type<float,
+            // false>).  The pdf values are fp32 numbers in [2^-17, 1], so every fp64 partial sum is exact and the
+            // parallel scan below yields the sequential loop's bits: cdf, and with it inds and z, are bit-equal to the
+            // reference's CPU evaluation for the same (t, w, u).
+            const float total = aten_cpu_row_sum(wv, n1 - 2, lane);
+            double carry = 0.0;
             if (lane == 0) cdf[0] = 0.f;
             for (int base = 0; base < n1 - 2; base += 64) {
                 const int k = base + lane;
-                const float pdf = (k < n1 - 2) ? (wsrc[k + 1] + 1e-5f) / total : 0.f;
-                const float incl = wave_scan_add(pdf);
-                if (k < n1 - 2) cdf[k + 1] = carry + incl;
-                carry = carry + wave_last(incl);
+                const double pdf = (k < n1 - 2) ? (double)(wv[k] / total) : 0.0;
+                const double incl = wave_scan_add_f64(pdf, lane);
+                if (k < n1 - 2) cdf[k + 1] = (float)(carry + incl);
+                carry = carry + __shfl(incl, 63);
             }
         }
         wave_sync();
@@ -427,7 +562,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) resample_kernel(Resam
         if (active) {
             for (int j = lane; j < n2; j += 64) {
                 const float u = a.u ? a.u[((int64_t)layer * a.n + ray) * n2 + j]
-                                    : philox_uniform(a.seed, (uint64_t)(a.ray_index_base + ray), (uint32_t)layer, 1u,
+                                    : philox_uniform(a.seed, (uint64_t)global_ray(a.win, ray), (uint32_t)layer, 1u,
                                                      (uint32_t)j);
                 const int ind = upper_bound_lds(cdf, nb, p2_nb, u);   // searchsorted(right=True)
                 const int below = ind - 1 > 0 ? ind - 1 : 0;
@@ -448,9 +583,24 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) resample_kernel(Resam
         // new samples are sorted in registers (bitonic network over the wave's lanes); equal z are interchangeable
         // because only values leave this kernel.
         if (active) {
-            bool desc = false;
-            for (int k = lane; k + 1 < n1; k += 64) desc = desc || (tc[k + 1] < tc[k]);
-            const bool asc = !__any(desc);
+            bool desc = false, ndesc = false;
+            for (int k = lane; k + 1 < n1; k += 64) {
+                desc = desc || (tc[k + 1] < tc[k]);
+                ndesc = ndesc || !(tc[k + 1] < tc[k]);
+            }
+            bool asc = !__any(desc);
+            if (!asc && !__any(ndesc)) {
+                // strictly descending coarse list (negative bin width: a ray that misses the background box, or an
+                // edited box): only the sorted VALUES leave this kernel and bins / cdf are done with, so turn the
+                // list round in place and take the sorted path
+                for (int k = lane; k < n1 / 2; k += 64) {
+                    const float lo = tc[k], hi = tc[n1 - 1 - k];
+                    tc[k] = hi;
+                    tc[n1 - 1 - k] = lo;
+                }
+                wave_sync();
+                asc = true;
+            }
             if (asc && n2 <= 64) {
                 float v = lane < n2 ? zs[lane] : __builtin_inff();
 #pragma unroll
@@ -550,16 +700,9 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
     int wpb = (int)((150 * 1024) / per_wave);
     STNERF_REQUIRE(wpb >= 1, "composite: %d samples per ray do not fit the 160 KiB LDS", l * S);
     if (wpb > 4) wpb = 4;
-    static int lds_limit_set = 0;
     const int lds = (int)(per_wave * wpb);
-    if (lds > 64 * 1024 && lds > lds_limit_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(composite_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            set_error("composite: cannot reserve %d B of LDS", lds);
-            return STNERF_ELAUNCH;
-        }
-        lds_limit_set = lds;
-    }
+    if (lds > 64 * 1024)
+        if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(composite_kernel), lds, "composite")) return rc;
     CompositeArgs a{t, reinterpret_cast<const float4*>(raw), mask, n, l, S, *params_host, layer_out, mixed_out,
                     weights, order, wpb, floor_pow2(S)};
     int64_t blocks = (n + wpb - 1) / wpb;
@@ -573,19 +716,21 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
 }
 
 extern "C" int stnerf_resample(const float* t, const float* weights, int64_t n, int l, int n1, int n2, const float* u,
-                               uint64_t seed, int64_t ray_index_base, const float* rays, int ray_stride,
+                               uint64_t seed, int64_t ray_index_base, int64_t ray_index_stripe, int64_t ray_index_period,
+                               const float* rays, int ray_stride,
                                const stnerf_layer_edit* edits_host, const float* pivot_host, float* t_fine,
                                float* xyz_fine, float* z_new, int32_t* inds, float* cdf, stnerf_stream_t stream) {
     STNERF_REQUIRE(t && weights && rays && t_fine, "resample: null pointer");
     STNERF_REQUIRE(n >= 0 && l >= 1 && l <= STNERF_MAX_LAYERS && n1 >= 3 && n2 >= 0 && ray_stride >= 6,
                    "resample: bad shape n=%lld l=%d n1=%d n2=%d", (long long)n, l, n1, n2);
+    STNERF_REQUIRE_WINDOW("resample", ray_index_stripe, ray_index_period);
     if (n == 0) return STNERF_OK;
     ResampleArgs a;
     a.t = t; a.weights = weights; a.n = n; a.l = l; a.n1 = n1; a.n2 = n2; a.u = u; a.seed = seed;
-    a.ray_index_base = ray_index_base; a.rays = rays; a.ray_stride = ray_stride;
+    a.win = RayWindow{ray_index_base, ray_index_stripe, ray_index_period}; a.rays = rays; a.ray_stride = ray_stride;
     fill_edit_args(a.ed, edits_host, pivot_host, l);
     a.t_fine = t_fine; a.xyz_fine = xyz_fine; a.z_new = z_new; a.inds = inds; a.cdf_out = cdf;
-    const int lds = 4 * (3 * n1 + n2 + n1 + n2) * (int)sizeof(float);
+    const int lds = 4 * (4 * n1 + n2 + n1 + n2) * (int)sizeof(float);
     STNERF_REQUIRE(lds <= 64 * 1024, "resample: %d+%d samples per ray exceed the LDS budget", n1, n2);
     int64_t blocks = (n * l + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;

@@ -17,11 +17,11 @@ struct RayGenArgs {
     float frame_ids[STNERF_MAX_LAYERS + 1];
 };
 
-__global__ void generate_rays_kernel(RayGenArgs a, int w, int64_t first_ray, int64_t n, int n_frame_cols,
+__global__ void generate_rays_kernel(RayGenArgs a, int w, RayWindow win, int64_t n, int n_frame_cols,
                                      float* __restrict__ rays, int ray_stride) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int64_t pix = first_ray + i;
+    const int64_t pix = global_ray(win, i);
     const float u = (float)(pix % w);  // column: integer pixel centre, render_helpers.py:96-102
     const float v = (float)(pix / w);  // row
     // K^-1 [u, v, 1]  (:105), normalised (:108)
@@ -99,7 +99,7 @@ __global__ void intersect_kernel(const float* __restrict__ rays, int64_t n, int 
 // One thread per (ray, layer, sample): consecutive threads write consecutive t / xyz elements.
 __global__ void sample_coarse_kernel(const float* __restrict__ rays, int64_t n, int ray_stride,
                                      const float* __restrict__ boxes, int64_t box_ray_stride, int l, int n1,
-                                     const float* __restrict__ jitter, uint64_t seed, int64_t ray_index_base,
+                                     const float* __restrict__ jitter, uint64_t seed, RayWindow win,
                                      EditArgs ed, float* __restrict__ t_out, float* __restrict__ xyz_out,
                                      uint8_t* __restrict__ mask_out) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -118,7 +118,7 @@ __global__ void sample_coarse_kernel(const float* __restrict__ rays, int64_t n, 
     if (layer == 0 && start <= 0.f) start = 0.f;  // RaySamplePoint.py:93-95
     const float width = (far_t - start) / (float)n1;  // :100
     const float xi = jitter ? jitter[((int64_t)layer * n + ray) * n1 + k]
-                            : philox_uniform(seed, (uint64_t)(ray_index_base + ray), (uint32_t)layer, 0u, (uint32_t)k);
+                            : philox_uniform(seed, (uint64_t)global_ray(win, ray), (uint32_t)layer, 0u, (uint32_t)k);
     const float t = ((float)k + xi) * width + start;  // :102
     t_out[e] = t;
     if (xyz_out) {
@@ -137,7 +137,7 @@ __global__ void sample_coarse_kernel(const float* __restrict__ rays, int64_t n, 
 template <int G>
 __global__ void sample_coarse_kernel_xg(const float* __restrict__ rays, int64_t n, int ray_stride,
                                         const float* __restrict__ boxes, int64_t box_ray_stride, int l, int n1,
-                                        const float* __restrict__ jitter, uint64_t seed, int64_t ray_index_base,
+                                        const float* __restrict__ jitter, uint64_t seed, RayWindow win,
                                         EditArgs ed, float* __restrict__ t_out, float* __restrict__ xyz_out,
                                         uint8_t* __restrict__ mask_out) {
     __shared__ __attribute__((aligned(16))) float xyz_stage[4 * 64 * 3 * G];  // 4 waves x 64 groups x 3G floats
@@ -169,9 +169,9 @@ __global__ void sample_coarse_kernel_xg(const float* __restrict__ rays, int64_t 
             xi[0] = j2.x; xi[1] = j2.y;
         }
     } else {
+        const uint64_t gray = (uint64_t)global_ray(win, ray);
 #pragma unroll
-        for (int j = 0; j < G; ++j)
-            xi[j] = philox_uniform(seed, (uint64_t)(ray_index_base + ray), (uint32_t)layer, 0u, (uint32_t)(k0 + j));
+        for (int j = 0; j < G; ++j) xi[j] = philox_uniform(seed, gray, (uint32_t)layer, 0u, (uint32_t)(k0 + j));
     }
     float tv[G], px[3 * G];
 #pragma unroll
@@ -245,11 +245,15 @@ __global__ void compact_rays_kernel(const uint8_t* __restrict__ mask, int64_t n,
 using namespace stnerf;
 
 extern "C" int stnerf_generate_rays(const float* Kinv_host, const float* T_host, int h, int w, int64_t first_ray,
-                                    int64_t n, const float* frame_ids_host, int n_frame_cols, float* rays,
-                                    int ray_stride, stnerf_stream_t stream) {
+                                    int64_t ray_index_stripe, int64_t ray_index_period, int64_t n,
+                                    const float* frame_ids_host, int n_frame_cols, float* rays, int ray_stride,
+                                    stnerf_stream_t stream) {
     STNERF_REQUIRE(Kinv_host && T_host && rays, "generate_rays: null pointer");
-    STNERF_REQUIRE(h > 0 && w > 0 && n >= 0 && first_ray >= 0 && first_ray + n <= (int64_t)h * w,
-                   "generate_rays: rows [%lld,+%lld) outside a %dx%d view", (long long)first_ray, (long long)n, h, w);
+    STNERF_REQUIRE_WINDOW("generate_rays", ray_index_stripe, ray_index_period);
+    const int64_t last = n > 0 ? global_ray(RayWindow{first_ray, ray_index_stripe, ray_index_period}, n - 1) : first_ray;
+    STNERF_REQUIRE(h > 0 && w > 0 && n >= 0 && first_ray >= 0 && last < (int64_t)h * w,
+                   "generate_rays: rays [%lld .. %lld] (%lld of them) outside a %dx%d view", (long long)first_ray,
+                   (long long)last, (long long)n, h, w);
     STNERF_REQUIRE(n_frame_cols >= 0 && n_frame_cols <= STNERF_MAX_LAYERS + 1 && ray_stride >= 6 + n_frame_cols,
                    "generate_rays: bad frame-id columns %d / stride %d", n_frame_cols, ray_stride);
     STNERF_REQUIRE(n_frame_cols == 0 || frame_ids_host, "generate_rays: frame_ids is null");
@@ -260,7 +264,7 @@ extern "C" int stnerf_generate_rays(const float* Kinv_host, const float* T_host,
     for (int i = 0; i < STNERF_MAX_LAYERS + 1; ++i) a.frame_ids[i] = i < n_frame_cols ? frame_ids_host[i] : 0.f;
     const int bs = 256;
     hipLaunchKernelGGL(generate_rays_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, as_stream(stream), a, w,
-                       first_ray, n, n_frame_cols, rays, ray_stride);
+                       RayWindow{first_ray, ray_index_stripe, ray_index_period}, n, n_frame_cols, rays, ray_stride);
     STNERF_CHECK_LAUNCH("generate_rays");
     return STNERF_OK;
 }
@@ -281,14 +285,17 @@ extern "C" int stnerf_intersect(const float* rays, int64_t n, int ray_stride, co
 
 extern "C" int stnerf_sample_coarse(const float* rays, int64_t n, int ray_stride, const float* boxes,
                                     int64_t box_ray_stride, int l, int n1, const float* jitter, uint64_t seed,
-                                    int64_t ray_index_base, const stnerf_layer_edit* edits_host,
+                                    int64_t ray_index_base, int64_t ray_index_stripe, int64_t ray_index_period,
+                                    const stnerf_layer_edit* edits_host,
                                     const float* pivot_host, float* t, float* xyz, uint8_t* mask,
                                     stnerf_stream_t stream) {
     STNERF_REQUIRE(rays && boxes && t && mask, "sample_coarse: null pointer");
     STNERF_REQUIRE(n >= 0 && ray_stride >= 6 && l >= 1 && l <= STNERF_MAX_LAYERS && n1 >= 1,
                    "sample_coarse: bad shape n=%lld stride=%d l=%d n1=%d", (long long)n, ray_stride, l, n1);
     STNERF_REQUIRE(box_ray_stride == 0 || box_ray_stride >= (int64_t)l * 24, "sample_coarse: bad box stride");
+    STNERF_REQUIRE_WINDOW("sample_coarse", ray_index_stripe, ray_index_period);
     if (n == 0) return STNERF_OK;
+    const RayWindow win{ray_index_base, ray_index_stripe, ray_index_period};
     EditArgs ed;
     fill_edit_args(ed, edits_host, pivot_host, l);
     const int bs = 256;
@@ -304,15 +311,15 @@ extern "C" int stnerf_sample_coarse(const float* rays, int64_t n, int ray_stride
         const dim3 grid((unsigned)((groups + bs - 1) / bs));
         if (G == 4)
             hipLaunchKernelGGL(sample_coarse_kernel_xg<4>, grid, dim3(bs), 0, as_stream(stream), rays, n, ray_stride, boxes,
-                               box_ray_stride, l, n1, jitter, seed, ray_index_base, ed, t, xyz, mask);
+                               box_ray_stride, l, n1, jitter, seed, win, ed, t, xyz, mask);
         else
             hipLaunchKernelGGL(sample_coarse_kernel_xg<2>, grid, dim3(bs), 0, as_stream(stream), rays, n, ray_stride, boxes,
-                               box_ray_stride, l, n1, jitter, seed, ray_index_base, ed, t, xyz, mask);
+                               box_ray_stride, l, n1, jitter, seed, win, ed, t, xyz, mask);
         STNERF_CHECK_LAUNCH("sample_coarse");
         return STNERF_OK;
     }
     hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((tot + bs - 1) / bs)), dim3(bs), 0, as_stream(stream), rays,
-                       n, ray_stride, boxes, box_ray_stride, l, n1, jitter, seed, ray_index_base, ed, t, xyz, mask);
+                       n, ray_stride, boxes, box_ray_stride, l, n1, jitter, seed, win, ed, t, xyz, mask);
     STNERF_CHECK_LAUNCH("sample_coarse");
     return STNERF_OK;
 }

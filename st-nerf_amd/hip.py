@@ -45,7 +45,8 @@ class RenderParams(C.Structure):
                 ("bkgd_use_deform_time", C.c_int32), ("bkgd_use_space_time", C.c_int32), ("deep_rgb", C.c_int32),
                 ("shown", C.c_int32 * MAX_LAYERS), ("border", C.c_float), ("near", C.c_float), ("alpha", C.c_float),
                 ("density_threshold", C.c_float), ("bkgd_density_threshold", C.c_float), ("seed", C.c_uint64),
-                ("ray_index_base", C.c_int64), ("edits_coarse", LayerEdit * MAX_LAYERS),
+                ("ray_index_base", C.c_int64), ("ray_index_stripe", C.c_int64), ("ray_index_period", C.c_int64),
+                ("edits_coarse", LayerEdit * MAX_LAYERS),
                 ("edits_fine", LayerEdit * MAX_LAYERS), ("pivot", C.c_float * 3)]
 
 
@@ -63,12 +64,12 @@ _PROTOS = {
     "stnerf_version": (C.c_char_p, []),
     "stnerf_last_error": (C.c_char_p, []),
     "stnerf_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
-    "stnerf_generate_rays": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, c_i64, c_i64,
-                                       C.POINTER(C.c_float), C.c_int, c_f32p, C.c_int, C.c_void_p]),
+    "stnerf_generate_rays": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, c_i64, c_i64, c_i64,
+                                       c_i64, C.POINTER(C.c_float), C.c_int, c_f32p, C.c_int, C.c_void_p]),
     "stnerf_intersect": (C.c_int, [c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "stnerf_sample_coarse": (C.c_int, [c_f32p, c_i64, C.c_int, c_f32p, c_i64, C.c_int, C.c_int, c_f32p, C.c_uint64,
-                                       c_i64, C.POINTER(LayerEdit), C.POINTER(C.c_float), c_f32p, c_f32p, C.c_void_p,
-                                       C.c_void_p]),
+                                       c_i64, c_i64, c_i64, C.POINTER(LayerEdit), C.POINTER(C.c_float), c_f32p, c_f32p,
+                                       C.c_void_p, C.c_void_p]),
     "stnerf_compact_rays": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "stnerf_packed_bytes": (c_i64, [C.c_int]),
     "stnerf_pack_net": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, c_i64]),
@@ -90,7 +91,7 @@ _PROTOS = {
     "stnerf_render_workspace_bytes": (c_i64, [c_i64, C.c_int, C.c_int, C.c_int, C.c_int]),
     "stnerf_render_rays": (C.c_int, [c_f32p, c_i64, c_f32p, c_i64, C.POINTER(Nets), C.POINTER(RenderParams), c_f32p, c_f32p,
                                      C.c_void_p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
-    "stnerf_resample": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_uint64, c_i64, c_f32p,
+    "stnerf_resample": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_uint64, c_i64, c_i64, c_i64, c_f32p,
                                   C.c_int, C.POINTER(LayerEdit), C.POINTER(C.c_float), c_f32p, c_f32p, c_f32p,
                                   C.c_void_p, c_f32p, C.c_void_p]),
 }

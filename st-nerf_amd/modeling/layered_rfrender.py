@@ -80,7 +80,8 @@ class LayeredRFRender(nn.Module):
         self.seed = 0                      # Philox seed of the on-device jitter / resampling draws
         self.max_rays_per_launch = 1 << 19 # rays per kernel sequence (workspace bound ~20 KB/ray, not a semantic chunk)
         self.replay = None                 # {"jitter": (l,N,N1), "u": (l,N,N2)} to replay recorded uniforms
-        self.ray_index_base = 0            # global index of rays[0] (multi-GPU sharding keeps the RNG stream)
+        self.ray_window = (0, 0, 0)        # (first, stripe, period): which rays of the view `rays` are (include/stnerf.h);
+                                           # keeps the RNG stream of a view under multi-GPU sharding
 
     def set_precision(self, precision: str):
         """"fp32" (default: exact f32 MFMA) or "fp16x3" (fp32-accurate 3-term split-fp16 MFMA, ~2.8x faster)."""
@@ -199,7 +200,7 @@ class LayeredRFRender(nn.Module):
             ops.spacenet_fwd(nets[i - 1]._packed(), xyz[:, i], rays[:, 3:6], tm, raw[:, i], ray_list=lst[i],
                              ray_count=cnt[i:i + 1])
 
-    def _render_launch(self, rays, boxes, pivot, retiming, only_coarse, thr, bthr, index_base, replay):
+    def _render_launch(self, rays, boxes, pivot, retiming, only_coarse, thr, bthr, window, replay):
         """One kernel sequence over `rays` (n <= max_rays_per_launch) = ONE call into the C ABI
         (stnerf_render_rays, csrc/pipeline.hip).  boxes: (l,8,3) shared or (n,l,8,3)."""
         from stnerf_amd import hip
@@ -215,7 +216,8 @@ class LayeredRFRender(nn.Module):
             p.shown[i] = int(self.is_shown_layer(i))
         p.border, p.near, p.alpha = float(self.boarder_weight), float(self.near), float(self.alpha)
         p.density_threshold, p.bkgd_density_threshold = float(thr), float(bthr)
-        p.seed, p.ray_index_base = int(self.seed) & 0xFFFFFFFFFFFFFFFF, int(index_base)
+        p.seed = int(self.seed) & 0xFFFFFFFFFFFFFFFF
+        p.ray_index_base, p.ray_index_stripe, p.ray_index_period = (int(x) for x in window)
         ec, ef = self._point_edits(l, False), self._point_edits(l, True)
         p.has_edits = int(ec is not None)
         ops.fill_edits(p.edits_coarse, ec, l)
@@ -281,6 +283,13 @@ class LayeredRFRender(nn.Module):
             groups.append((0, N, boxes, pivot))
         outs = []
         cap = self.max_rays_per_launch
+        first, stripe, period = self.ray_window
+        if stripe > 0:                     # launch pieces must start on a stripe boundary
+            cap = max(stripe, cap // stripe * stripe)
+            if any(g0 % stripe for (g0, _, _, _) in groups):
+                raise ValueError("a striped ray window needs chunk groups that start on a stripe boundary "
+                                 "(frame ids that change inside the view: render it unstriped)")
+        window_at = (lambda s: (first + s, 0, 0)) if stripe <= 0 else (lambda s: (first + s // stripe * period, stripe, period))
         for (g0, g1, boxes, pivot) in groups:
             for s in range(g0, g1, cap):
                 e = min(s + cap, g1)
@@ -289,7 +298,7 @@ class LayeredRFRender(nn.Module):
                 if self.replay is not None:
                     rp = {k: v[:, s:e].contiguous() for k, v in self.replay.items()}
                 outs.append(self._render_launch(rays[s:e], bx, pivot, retiming, only_coarse, density_threshold,
-                                                bkgd_density_threshold, self.ray_index_base + s, rp))
+                                                bkgd_density_threshold, window_at(s), rp))
         cat = (lambda j: outs[0][j]) if len(outs) == 1 else (lambda j: torch.cat([o[j] for o in outs], 0))
         mix_f, mix_c, lo_f, lo_c, mask = (cat(j) for j in range(5))
         l = L + 1

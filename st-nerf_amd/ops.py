@@ -60,11 +60,22 @@ def _boxes_arg(boxes: Tensor, n: int):
 
 
 # ---------------------------------------------------------------------------------------- a1/a2
+def window_size(total: int, first: int, stripe: int, period: int) -> int:
+    """Number of rays of a `total`-ray view inside the window (first, stripe, period) of include/stnerf.h."""
+    if stripe <= 0:
+        return max(0, total - first)
+    if first >= total:
+        return 0
+    full, rem = divmod(total - first, period)
+    return full * stripe + min(rem, stripe)
+
+
 def generate_rays(K: Tensor, T: Tensor, h: int, w: int, frame_ids: Optional[Sequence[float]] = None,
-                  first_ray: int = 0, n: Optional[int] = None, device="cuda") -> Tensor:
-    """Rays of a view, generated on the device: (n, 6 + len(frame_ids)).
+                  first_ray: int = 0, n: Optional[int] = None, device="cuda", stripe: int = 0, period: int = 0) -> Tensor:
+    """Rays of a view, generated on the device: (n, 6 + len(frame_ids)).  (first_ray, stripe, period) = the ray
+    window of include/stnerf.h: a contiguous piece of the view (stripe = 0) or interleaved stripes.
     utils/render_helpers.py:42-128 + data/datasets/ray_dataset.py:276-281."""
-    n = h * w - first_ray if n is None else n
+    n = window_size(h * w, first_ray, stripe, period) if n is None else n
     kinv = torch.inverse(K.detach().to("cpu", torch.float32)).contiguous()  # :103 (torch.inverse on the host)
     Tm = torch.as_tensor(T, dtype=torch.float32).detach().cpu().contiguous()
     fids = [float(x) for x in (frame_ids or [])]
@@ -72,7 +83,7 @@ def generate_rays(K: Tensor, T: Tensor, h: int, w: int, frame_ids: Optional[Sequ
     kin = (C.c_float * 9)(*kinv.reshape(-1).tolist())
     tin = (C.c_float * 16)(*Tm.reshape(-1).tolist())
     fin = (C.c_float * max(len(fids), 1))(*(fids or [0.0]))
-    hip.check(hip.lib().stnerf_generate_rays(kin, tin, h, w, first_ray, n, fin if fids else None, len(fids),
+    hip.check(hip.lib().stnerf_generate_rays(kin, tin, h, w, first_ray, stripe, period, n, fin if fids else None, len(fids),
                                              hip.dptr(rays), rays.shape[1], hip.stream_ptr()), "stnerf_generate_rays")
     return rays
 
@@ -89,7 +100,8 @@ def intersect(rays: Tensor, boxes: Tensor) -> Tensor:
 
 
 def sample_coarse(rays: Tensor, boxes: Tensor, n1: int, jitter: Optional[Tensor] = None, seed: int = 0,
-                  ray_index_base: int = 0, edits=None, pivot=None, want_xyz: bool = True):
+                  ray_index_base: int = 0, edits=None, pivot=None, want_xyz: bool = True, ray_index_stripe: int = 0,
+                  ray_index_period: int = 0):
     """-> t (n,l,n1), xyz (n,l,n1,3) | None, mask (n,l) uint8.  layers/RaySamplePoint.py:70-107."""
     n = rays.shape[0]
     bp, bstride, l = _boxes_arg(boxes, n)
@@ -100,7 +112,8 @@ def sample_coarse(rays: Tensor, boxes: Tensor, n1: int, jitter: Optional[Tensor]
     mask = torch.empty(n, l, dtype=torch.uint8, device=rays.device)
     ed, pv = _edits(edits, pivot, l)
     hip.check(hip.lib().stnerf_sample_coarse(hip.dptr(rays, name="rays"), n, rays.shape[1], bp, bstride, l, n1,
-                                             hip.dptr(jitter, name="jitter"), seed, ray_index_base, ed, pv,
+                                             hip.dptr(jitter, name="jitter"), seed, ray_index_base, ray_index_stripe,
+                                             ray_index_period, ed, pv,
                                              hip.dptr(t), hip.dptr(xyz), hip.dptr(mask, torch.uint8),
                                              hip.stream_ptr()), "stnerf_sample_coarse")
     return t, xyz, mask
@@ -299,11 +312,12 @@ def gen_weight(sigma: Tensor, delta: Tensor) -> Tensor:
 # ---------------------------------------------------------------------------------------- a10-a13
 def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e10, near: float = 0.0,
               fine: bool = False, cut_negative_t: bool = False, thresholds: Optional[Sequence[Optional[float]]] = None,
-              sigma_scale: Optional[Sequence[float]] = None, evaluated: Optional[Sequence[bool]] = None,
+              sigma_scale: Optional[Sequence[float]] = None, evaluated: Optional[Sequence[int]] = None,
               want_weights: bool = False, want_order: bool = False):
     """t (n,l,S), raw (n,l,S,4), mask (n,l) uint8 | None ->
     layer_out (n,l,5), mixed_out (n,5), weights (n,l,S) | None, order (n,l*S) int32 | None.
-    layers/render_layer.py:8-58 + modeling/layered_rfrender.py:414-448 / :538-606."""
+    layers/render_layer.py:8-58 + modeling/layered_rfrender.py:414-448 / :538-606.
+    evaluated[i]: 0 = hidden layer, 1 = evaluated where mask is set, 2 = evaluated on every ray (the background)."""
     n, l, S = t.shape
     p = hip.CompositeParams()
     p.border, p.near, p.fine, p.cut_negative_t = border, near, int(fine), int(cut_negative_t)
@@ -325,7 +339,8 @@ def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e
 
 
 def resample(t: Tensor, weights: Tensor, n2: int, rays: Tensor, u: Optional[Tensor] = None, seed: int = 0,
-             ray_index_base: int = 0, edits=None, pivot=None, want_xyz: bool = True, debug: bool = False):
+             ray_index_base: int = 0, edits=None, pivot=None, want_xyz: bool = True, debug: bool = False,
+             ray_index_stripe: int = 0, ray_index_period: int = 0):
     """t (n,l,n1), weights (n,l,n1) -> t_fine (n,l,n1+n2) ascending, xyz_fine (n,l,n1+n2,3) | None
     [, z_new (n,l,n2), inds (n,l,n2) int32, cdf (n,l,n1-1) if debug].
     utils/sample_pdf.py:18-63 + modeling/layered_rfrender.py:459-475."""
@@ -340,7 +355,8 @@ def resample(t: Tensor, weights: Tensor, n2: int, rays: Tensor, u: Optional[Tens
     cdf = torch.empty(n, l, n1 - 1, dtype=torch.float32, device=dev) if debug else None
     ed, pv = _edits(edits, pivot, l)
     hip.check(hip.lib().stnerf_resample(hip.dptr(t, name="t"), hip.dptr(weights, name="weights"), n, l, n1, n2,
-                                        hip.dptr(u, name="u"), seed, ray_index_base, hip.dptr(rays, name="rays"),
+                                        hip.dptr(u, name="u"), seed, ray_index_base, ray_index_stripe, ray_index_period,
+                                        hip.dptr(rays, name="rays"),
                                         rays.shape[1], ed, pv, hip.dptr(t_fine), hip.dptr(xyz), hip.dptr(z_new),
                                         hip.dptr(inds, torch.int32), hip.dptr(cdf), hip.stream_ptr()),
               "stnerf_resample")

@@ -77,17 +77,20 @@ def stripe_spans(n: int, stripe: int, rank: int, world: int) -> List[Tuple[int, 
 
 def render_view_striped(render_rows: Callable[[int, int], torch.Tensor], n_rays: int, stripe: int, group=None):
     """Like render_view_sharded with interleaved stripes of ``stripe`` rays (use a multiple of the image
-    width): every rank renders its stripes (one ``render_rows`` call each), ONE all-gather of the
-    concatenated stripes (padded to the largest rank), then the stripes are put back in image order."""
+    width): rank r renders stripes r, r+G, r+2G, ... -- in ONE call if ``render_rows`` offers
+    ``render_rows.striped(first, n, stripe, period)`` (the GPU renderer does: one launch sequence over the rank's
+    rays, ray window = include/stnerf.h), else one ``render_rows`` call per stripe -- then ONE all-gather of the
+    concatenated stripes (padded to the largest rank) and the stripes are put back in image order."""
     if not dist.is_available() or not dist.is_initialized():
         return render_rows(0, n_rays)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     spans = [stripe_spans(n_rays, stripe, r, world) for r in range(world)]
-    mine = [render_rows(s, e - s) for s, e in spans[rank]]
     sizes = [sum(e - s for s, e in sp) for sp in spans]
     m = max(sizes)
-    if mine:
-        local = torch.cat(mine, 0)
+    if spans[rank] and hasattr(render_rows, "striped"):
+        local = render_rows.striped(rank * stripe, sizes[rank], stripe, world * stripe)
+    elif spans[rank]:
+        local = torch.cat([render_rows(s, e - s) for s, e in spans[rank]], 0)
     else:  # more ranks than stripes: this rank only takes part in the collective
         probe = render_rows(0, 0)
         local = probe.new_zeros((0,) + tuple(probe.shape[1:]))
@@ -95,12 +98,23 @@ def render_view_striped(render_rows: Callable[[int, int], torch.Tensor], n_rays:
     padded[: local.shape[0]] = local
     gathered = local.new_empty((world * m,) + tuple(local.shape[1:]))
     dist.all_gather_into_tensor(gathered, padded.contiguous(), group=group)
-    out = local.new_empty((n_rays,) + tuple(local.shape[1:]))
-    for r in range(world):
-        off = r * m
-        for s, e in spans[r]:
-            out[s:e] = gathered[off:off + (e - s)]
-            off += e - s
+    return unstripe(gathered, n_rays, stripe, world, m)
+
+
+def unstripe(gathered: torch.Tensor, n_rays: int, stripe: int, world: int, per_rank: int) -> torch.Tensor:
+    """(world * per_rank, C) = every rank's stripes back to back (padded to per_rank rows) -> (n_rays, C) in image
+    order.  Full stripes move as ONE strided copy; only a short last stripe is handled on its own."""
+    C = tuple(gathered.shape[1:])
+    out = gathered.new_empty((n_rays,) + C)
+    n_full = n_rays // stripe                       # stripes of full length
+    rounds = n_full // world                        # rounds in which every rank owns a full stripe
+    if rounds:
+        src = gathered.reshape((world, per_rank) + C)[:, : rounds * stripe].reshape((world, rounds, stripe) + C)
+        out[: rounds * world * stripe].reshape((rounds, world, stripe) + C).copy_(src.transpose(0, 1))
+    for k in range(rounds * world, (n_rays + stripe - 1) // stripe):   # the last, incomplete round (< world stripes)
+        r, j = k % world, k // world
+        s, e = k * stripe, min((k + 1) * stripe, n_rays)
+        out[s:e] = gathered[r * per_rank + j * stripe: r * per_rank + j * stripe + (e - s)]
     return out
 
 
@@ -114,11 +128,12 @@ def make_row_renderer(model, K, T, h: int, w: int, frame_ids, density_threshold:
     from stnerf_amd import ops
     from stnerf_amd.utils.batchify_rays import layered_batchify_ray
 
-    def render_rows(first: int, n: int) -> torch.Tensor:
+    def render_window(first: int, n: int, stripe: int, period: int) -> torch.Tensor:
         if n == 0:
             return torch.empty(0, 5, dtype=torch.float32, device=device)
-        rays = ops.generate_rays(K, T, h, w, frame_ids=frame_ids, first_ray=first, n=n, device=device)
-        model.ray_index_base = first
+        rays = ops.generate_rays(K, T, h, w, frame_ids=frame_ids, first_ray=first, n=n, device=device, stripe=stripe,
+                                 period=period)
+        model.ray_window = (first, stripe, period)
         try:
             with torch.no_grad():
                 if h * w < chuncks:
@@ -126,10 +141,16 @@ def make_row_renderer(model, K, T, h: int, w: int, frame_ids, density_threshold:
                                                 density_threshold=density_threshold,
                                                 bkgd_density_threshold=bkgd_density_threshold)[0]
                 else:
-                    fine = model.render_rays(rays, False, density_threshold, bkgd_density_threshold,
-                                             ref_chunk=chuncks)[0]
+                    out = model.render_rays(rays, False, density_threshold, bkgd_density_threshold, ref_chunk=chuncks)
+                    fine = out[0]
+                    render_rows.last_masks = out[4]
         finally:
-            model.ray_index_base = 0
+            model.ray_window = (0, 0, 0)
         return torch.cat(list(fine), dim=1)
 
+    def render_rows(first: int, n: int) -> torch.Tensor:
+        return render_window(first, n, 0, 0)
+
+    render_rows.striped = render_window     # (first, n, stripe, period): all of a rank's stripes in one launch sequence
+    render_rows.last_masks = None           # per-layer hit masks of the latest call (bench.py counts evaluations)
     return render_rows

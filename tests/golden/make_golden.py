@@ -308,7 +308,7 @@ def build_ref_model(L, n1, n2, st, dt, seed, flags=None):
 
 
 def g_forward(name, L, n1, n2, st, dt, seed, h, w, frame=2.5, per_ray_frames=False, edit=None,
-              call_kwargs=None, chunk=None, only_coarse=False, flags=None, bkgd_frame=1.0):
+              call_kwargs=None, chunk=None, only_coarse=False, flags=None, bkgd_frame=1.0, extra_rays=None):
     model = build_ref_model(L, n1, n2, st, dt, seed, flags)
     edit = edit or {}
     for k in ("scale", "shift", "alpha", "near"):
@@ -317,6 +317,9 @@ def g_forward(name, L, n1, n2, st, dt, seed, h, w, frame=2.5, per_ray_frames=Fal
     for i in edit.get("hide", []):
         model.hide_layer(i)
     rays = view_rays(h, w, L, frame=frame, per_ray_frames=per_ray_frames, bkgd_frame=bkgd_frame)
+    if extra_rays is not None:      # hand-made (origin, direction) rows appended to the view
+        ex = torch.tensor(extra_rays, dtype=torch.float32)
+        rays = torch.cat([rays, torch.cat([ex, syn.frame_id_columns(ex.shape[0], L, frame, bkgd_frame)], -1)], 0)
     n = rays.shape[0]
     labels, bb, nf = torch.zeros(n), torch.zeros(n, 8, 3), torch.zeros(n, 2)
     kw = dict(call_kwargs or {})
@@ -357,7 +360,87 @@ def g_model_flag_cases():
     g_forward("fwd_no_raw_no_dir", 2, 12, 6, True, True, 34, 6, 8, flags=dict(TKERNEL_INC_RAW=False, USE_DIR=False))
 
 
+def g_round2():
+    """Round-2 additions (VERDICT r01 items 2a / ADVICE): the shipped yml's sample counts, full 64-lane blocks,
+    rays that graze / miss the background box, a wider sample_pdf case, the reference's checkpoint key names."""
+    # configs/config_taekwondo.yml: 90 coarse + 30 fine = a ragged second 64-lane block in every scan, and n2 = 30
+    # (padded bitonic sort); thresholds as the demos pass them (demo/taekwondo_demo.py: density_threshold, bkgd 0.8 ...)
+    g_forward("fwd_c3_90_30", 2, 90, 30, True, True, 41, 8, 8, chunk=3584,
+              call_kwargs=dict(density_threshold=0.05, bkgd_density_threshold=0.02))
+    g_forward("fwd_c3_90_30_chunked", 2, 90, 30, True, True, 42, 8, 9, chunk=40,
+              call_kwargs=dict(density_threshold=0.05, bkgd_density_threshold=0.02))
+    # the metric's 64 + 64 (two full 64-lane blocks)
+    g_forward("fwd_c3_64_64", 2, 64, 64, True, True, 43, 6, 8)
+    # background-box corner cases (layers/RaySamplePoint.py:8-107 with layer 0): a ray through the box EDGE
+    # x=-3,z=3 (both slab hits at t=1 exactly: start == end, bin width 0, ray_mask[0] False, yet the reference still
+    # evaluates and composites the background, layered_rfrender.py:382-392); the same through a CORNER; a ray that
+    # misses the background box altogether (far = -1000, start clamped to 0: descending depths, mask True); a ray
+    # starting inside a performer box; an axis-parallel ray along a face of the background box
+    g_forward("fwd_grazing", 2, 12, 6, True, True, 44, 4, 6,
+              extra_rays=[[-4.0, 0.0, 2.0, 1.0, 0.0, 1.0], [-4.0, -4.0, 2.0, 1.0, 1.0, 1.0],
+                          [5.0, 5.0, 5.0, 1.0, 0.0, 0.0], [0.0, 9.0, 0.0, 0.0, 1.0, 0.0],
+                          [-0.5, 0.1, 0.0, 0.6, 0.0, 0.8], [-5.0, 0.0, 3.0, 1.0, 0.0, 0.0]])
+    # sample_pdf at the yml's counts on peaky weights (what a trained density gives): pins the cdf bit pattern
+    torch.manual_seed(6)
+    n, n1, n2 = 96, 90, 30
+    t = torch.sort(torch.rand(n, n1) * 6.0, -1)[0]
+    w = torch.rand(n, n1 - 2) ** 12
+    w = w / w.sum(-1, keepdim=True) * torch.rand(n, 1)
+    w[0] = 0.0
+    w[1] = 0.0
+    w[1, 40] = 0.97
+    with RandRecorder() as rr:
+        z = ref_utils.sample_pdf(t, w, n2)
+    save("sample_pdf_90_30", dict(n2=n2), t=t, w=w, u=rr.draws[0], z=z)
+    n, n1, n2 = 64, 128, 64
+    t = torch.sort(torch.rand(n, n1) * 6.0, -1)[0]
+    w = torch.rand(n, n1 - 2) ** 12
+    w = w / w.sum(-1, keepdim=True) * torch.rand(n, 1)
+    with RandRecorder() as rr:
+        z = ref_utils.sample_pdf(t, w, n2)
+    save("sample_pdf_128_64", dict(n2=n2), t=t, w=w, u=rr.draws[0], z=z)
+    # checkpoint key names and shapes of the reference model for the shipped configurations
+    # (render/layered_neural_renderer.py:110-117 loads dict_0['model'] into exactly these)
+    keys = {}
+    for tag, (L, st, dt, flags) in dict(taekwondo=(2, True, True, {}), walking=(2, False, True, {}),
+                                        deep=(2, True, True, dict(DEEP_RGB=True)),
+                                        bkgd_time=(1, True, True, dict(BKGD_USE_DEFORM_TIME=True, BKGD_USE_SPACE_TIME=True)),
+                                        same=(2, True, True, dict(SAME_SPACENET=True))).items():
+        m = ref_modeling.build_layered_model(make_cfg(L, 8, 4, st, dt, flags), camera_num=1)
+        keys[tag] = dict(L=L, space_time=st, deform_time=dt, flags=flags,
+                         state_dict={k: list(v.shape) for k, v in m.state_dict().items()})
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+    print("wrote state_dict_keys.json")
+
+
+def g_psnr_view():
+    """PSNR parity of a renderer that draws its own random numbers (last row): the reference rendered twice
+    with two torch seeds on a 128 x 128 view of the benchmark scene (bench.py: L=2, 64+64, space-time + deform,
+    make_state_dict seed 0, batchify defaults).  PSNR(B, A) is the reference's own run-to-run spread; a device-RNG
+    render must land within 1 dB of it against A."""
+    L, n1, n2, H, W = 2, 64, 64, 128, 128
+    model = build_ref_model(L, n1, n2, True, True, 0)
+    rays = view_rays(H, W, L, orbit=10.0)
+    n = rays.shape[0]
+    imgs = {}
+    for tag, seed in (("a", 1), ("b", 2)):
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            out = ref_utils.layered_batchify_ray(model, rays, torch.zeros(n), torch.zeros(n, 8, 3), chuncks=3584,
+                                                 near_far=torch.zeros(n, 2))
+        imgs[f"color_{tag}"] = out[0][0].half()       # fp16 storage: 6e-4 abs, far below the ~35 dB sampling noise
+        imgs[f"acc_{tag}"] = out[0][2].half()
+    save("psnr_view", dict(L=L, n1=n1, n2=n2, h=H, w=W, orbit=10.0, weight_seed=0, frame=2.5, seeds=[1, 2]), **imgs)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--psnr-view":
+        g_psnr_view()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--round2":
+        g_round2()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--model-flags":   # (re)generate these cases without touching the rest
         g_model_flag_cases()
         return
@@ -390,6 +473,8 @@ def main():
               call_kwargs=dict(density_threshold=0.05, bkgd_density_threshold=0.02))
     g_model_flag_cases()
     g_more_layers()
+    g_round2()
+    g_psnr_view()
 
 
 if __name__ == "__main__":

@@ -89,7 +89,7 @@ def test_pack_spacenet_layout(lib):
 
 def test_argument_errors_before_any_launch(lib):
     null = C.c_void_p(0)
-    assert lib.stnerf_sample_coarse(null, 4, 9, null, 0, 3, 8, null, 0, 0, None, None, null, null, null, null) == hip.EINVAL
+    assert lib.stnerf_sample_coarse(null, 4, 9, null, 0, 3, 8, null, 0, 0, 0, 0, None, None, null, null, null, null) == hip.EINVAL
     assert lib.stnerf_spacenet_fwd(7, null, 1, 1, null, null, null, 0, null, 0, null, 0, null, 0, null) == hip.EINVAL
     assert "bad kind" in hip.last_error()
 
@@ -104,9 +104,9 @@ def test_product_path_refuses_cpu_tensors():
 
 
 def test_render_structs_match_header_layout():
-    # stnerf_nets: 2 + 3*16 pointers; stnerf_render_params: 10 ints, 16 ints, 5 floats (+pad), u64, i64, 2*16 edits, 3 floats (+pad)
+    # stnerf_nets: 2 + 3*16 pointers; stnerf_render_params: 13 ints, 16 ints, 5 floats, u64, 3 x i64 (ray window), 2*16 edits, 3 floats (+pad)
     assert C.sizeof(hip.Nets) == 8 * (2 + 3 * hip.MAX_LAYERS)
-    assert C.sizeof(hip.RenderParams) == 52 + 64 + 20 + 0 + 8 + 8 + 2 * 16 * 24 + 12 + 4
+    assert C.sizeof(hip.RenderParams) == 52 + 64 + 20 + 0 + 8 + 3 * 8 + 2 * 16 * 24 + 12 + 4
     assert C.sizeof(hip.ProfileRecord) == 40
 
 

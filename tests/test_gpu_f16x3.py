@@ -124,4 +124,4 @@ def test_c2_full_view_fp16x3_agrees_with_fp32():
     frac = float((per_pix <= R.COLOR_ATOL).float().mean())
     quality = float(-10 * torch.log10(torch.mean((a - b) ** 2)))
     print(f"fp16x3 vs fp32 at C2: {100 * frac:.3f} % of pixels within {R.COLOR_ATOL}, PSNR {quality:.1f} dB, max {float(per_pix.max()):.2e}")
-    assert frac >= R.FINE_FRACTION and quality >= R.FINE_PSNR
+    assert frac >= 0.99 and quality >= 70.0     # two fp32-accurate evaluations of one view (mostly background rays)

@@ -325,15 +325,77 @@ def test_composite_merge_vs_oracle(ops, fine):
     torch.testing.assert_close(mo[:, 4:5].cpu(), mix[2], rtol=1e-5, atol=2e-6)
 
 
-def test_composite_unsorted_layer_falls_back_to_general_sort(ops):
+def test_composite_descending_and_unsorted_layers(ops):
+    """A strictly descending layer (negative bin width: an edited box, or a ray that misses the background box) is merged
+    through a reversed view; a layer that is neither ascending nor strictly descending takes the general rank.  Both give
+    the order of a stable sort of the concatenation, and the composites follow."""
     torch.manual_seed(23)
-    n, l, S = 50, 2, 17
+    n, l, S = 60, 3, 17
     t = torch.sort(torch.rand(n, l, S) * 4.0, -1)[0]
-    t[:, 0] = t[:, 0].flip(-1)                                    # descending layer (negative bin width)
+    t[:20, 0] = t[:20, 0].flip(-1)                                # strictly descending background
+    t[10:30, 2] = t[10:30, 2].flip(-1)                            # ... and / or a descending performer
+    t[40:50, 1] = t[40:50, 1][:, torch.randperm(S)]               # unsorted
+    t[50:, 1] = t[50:, 1].flip(-1)
+    t[50:, 1, 3] = t[50:, 1, 2]                                   # a tie inside a descending list: general rank
     raw = torch.randn(n, l, S, 4)
-    _, _, _, od = ops.composite(dev(t), dev(raw), None, want_order=True)
+    lo, mo, _, od = ops.composite(dev(t), dev(raw), None, want_order=True)
     _, order = torch.sort(t.reshape(n, l * S), dim=-1, stable=True)
     assert torch.equal(od.cpu().long(), order)
+    ts = [t[:, i].unsqueeze(-1) for i in range(l)]
+    t_mix = torch.cat(ts, -2).gather(1, order.unsqueeze(-1))
+    rgb_mix = raw[..., :3].reshape(n, l * S, 3).gather(1, order.unsqueeze(-1).repeat(1, 1, 3))
+    sig_mix = raw[..., 3:].reshape(n, l * S, 1).gather(1, order.unsqueeze(-1))
+    mix = O.composite(t_mix, rgb_mix, sig_mix)
+    torch.testing.assert_close(mo[:, :3].cpu(), mix[0], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(mo[:, 4:5].cpu(), mix[2], rtol=1e-5, atol=2e-6)
+    # the production call (no order output) takes the same branches: bitwise the same images
+    lo2, mo2, _, _ = ops.composite(dev(t), dev(raw), None)
+    assert torch.equal(lo, lo2) and torch.equal(mo, mo2)
+
+
+@pytest.mark.parametrize("fine", [False, True])
+def test_composite_production_shortcuts_are_bitwise_neutral(ops, fine):
+    """Without the `order` output the kernel drops layers a ray misses and reuses a single live layer's composite as the
+    mix (render.hip); with `order` it merges everything.  Same inputs -> bit-identical images and weights."""
+    torch.manual_seed(29 + fine)
+    n, l, S = 4000, 3, 96
+    t = torch.sort(torch.rand(n, l, S) * 6.0 - 0.3, -1)[0]
+    miss1, miss2 = torch.rand(n) < 0.5, torch.rand(n) < 0.6
+    t[:, 1][miss1] = -1000.0                                      # missed performers (most rays: one live layer)
+    t[:, 2][miss2] = -1000.0
+    bk_miss = torch.rand(n) < 0.1                                 # rays that miss the background box: 0 .. -1000, descending
+    t[bk_miss, 0] = -(torch.arange(S).float() + torch.rand(int(bk_miss.sum()), S)) * (1000.0 / S)
+    raw = torch.randn(n, l, S, 4) * torch.tensor([2.0, 2.0, 2.0, 4.0])
+    mask = torch.stack([torch.rand(n) < 0.97, ~miss1, ~miss2], 1).to(torch.uint8)   # a few grazing background rays
+    kw = dict(near=0.4, fine=fine, cut_negative_t=not fine, thresholds=[0.3 if fine else None, 0.5, 0.5],
+              sigma_scale=[1.0, 1.0, 0.4 if fine else 1.0], evaluated=[2, 1, 1], want_weights=True)
+    lo_a, mo_a, w_a, _ = ops.composite(dev(t), dev(raw), dev(mask), want_order=False, **kw)
+    lo_b, mo_b, w_b, od = ops.composite(dev(t), dev(raw), dev(mask), want_order=True, **kw)
+    bits = lambda x: x.contiguous().view(torch.int32)      # bit patterns: a descending fine-stage background has negative
+    assert torch.equal(bits(lo_a), bits(lo_b))             # deltas, i.e. inf / NaN composites in the reference as well
+    assert torch.equal(bits(mo_a), bits(mo_b)) and torch.equal(bits(w_a), bits(w_b))
+    assert float(torch.nan_to_num(mo_a[:, 4], nan=0.0, posinf=0.0, neginf=0.0).max()) > 0.5 and int(((~miss1) & (~miss2)).sum()) > 100 and int((miss1 & miss2).sum()) > 100
+    _, order = torch.sort(t.reshape(n, l * S), dim=-1, stable=True)
+    assert torch.equal(od.cpu().long(), order)
+
+
+def test_composite_background_is_composited_where_its_mask_is_clear(ops):
+    """evaluated = 2: the layer's network output is used on every ray (bkgd_spacenet runs on all rays and is composited even
+    where ray_mask[0] is False, layered_rfrender.py:382-392); evaluated = 1 zeroes it where the mask is clear."""
+    torch.manual_seed(33)
+    n, S = 64, 20
+    t = torch.sort(torch.rand(n, 1, S) * 3.0, -1)[0]
+    t[:8] = t[:8, :, :1]                                          # grazing rays: all samples at the same depth
+    raw = torch.randn(n, 1, S, 4) + torch.tensor([0.0, 0.0, 0.0, 2.0])
+    mask = torch.ones(n, 1, dtype=torch.uint8)
+    mask[:8] = 0
+    lo2, mo2, _, _ = ops.composite(dev(t), dev(raw), dev(mask), evaluated=[2])
+    lo1, _, _, _ = ops.composite(dev(t), dev(raw), dev(mask), evaluated=[1])
+    ref = O.composite(t[:, 0].unsqueeze(-1), raw[:, 0, :, :3], raw[:, 0, :, 3:])
+    torch.testing.assert_close(lo2[:, 0, :3].cpu(), ref[0], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(mo2[:, 4:5].cpu(), ref[2], rtol=1e-5, atol=2e-6)
+    assert float(lo2[:8, 0, 4].min()) > 0.0 and float(lo1[:8, 0, 4].abs().max()) == 0.0
+    assert torch.equal(lo1[8:], lo2[8:])
 
 
 def test_resample_golden(ops):
@@ -346,11 +408,9 @@ def test_resample_golden(ops):
     tf, xyz, z, inds, cdf = ops.resample(dev(a["t"].unsqueeze(1)), dev(wfull.unsqueeze(1)), n2, dev(rays),
                                          u=dev(a["u"].unsqueeze(0)), debug=True)
     z_ref, cdf_ref, inds_ref = O.sample_pdf(a["t"], a["w"], a["u"], return_aux=True)
-    torch.testing.assert_close(cdf[:, 0].cpu(), cdf_ref, rtol=0, atol=5e-7)
-    # index contract: bit-exact given identical cdf and u
-    assert torch.equal(inds[:, 0].cpu().long(), torch.searchsorted(cdf[:, 0].cpu(), a["u"], right=True))
-    assert torch.equal(inds[:, 0].cpu().long(), inds_ref)         # (no u within 1 ulp of a cdf knot in this fixture)
-    torch.testing.assert_close(z[:, 0].cpu(), a["z"], rtol=1e-5, atol=1e-5)
+    assert torch.equal(cdf[:, 0].cpu(), cdf_ref)                  # ATen-order sum + fp64 cumsum: bit-equal
+    assert torch.equal(inds[:, 0].cpu().long(), inds_ref)
+    assert torch.equal(z[:, 0].cpu(), a["z"]) and torch.equal(z_ref, a["z"])    # ... down to the reference's own z
     ref_sorted = torch.sort(torch.cat([a["t"], z[:, 0].cpu()], -1), -1)[0]
     assert torch.equal(tf[:, 0].cpu(), ref_sorted)                # sort/merge: bit-exact
     assert torch.equal(xyz[:, 0].cpu(), ref_sorted.unsqueeze(-1) * rays[:, None, 3:6] + rays[:, None, 0:3])
@@ -371,21 +431,9 @@ def test_resample_random_layers_edits_and_device_rng(ops):
     tf, xyz, z, inds, cdf = ops.resample(dev(t), dev(w), n2, dev(rays), u=dev(u), edits=edits, pivot=pivot, debug=True)
     for i in range(l):
         z_ref, cdf_ref, inds_ref = O.sample_pdf(t[:, i], w[:, i, 1:-1], u[i], return_aux=True)
-        torch.testing.assert_close(cdf[:, i].cpu(), cdf_ref, rtol=0, atol=1e-6)
-        assert torch.equal(inds[:, i].cpu().long(), torch.searchsorted(cdf[:, i].cpu().contiguous(), u[i], right=True))
-        agree = inds[:, i].cpu().long() == inds_ref              # knots may differ in the last ulp of the cdf
-        assert agree.float().mean() > 0.999
-        # inversion: exact given the kernel's own cdf (same IEEE ops, contraction off) ...
-        kc, ki = cdf[:, i].cpu(), inds[:, i].cpu().long()
-        bins = 0.5 * (t[:, i, 1:] + t[:, i, :-1])
-        below, above = (ki - 1).clamp(min=0), ki.clamp(max=n1 - 2)
-        den = kc.gather(1, above) - kc.gather(1, below)
-        den = torch.where(den < 1e-5, torch.ones_like(den), den)
-        z_inv = bins.gather(1, below) + (u[i] - kc.gather(1, below)) / den * (bins.gather(1, above) - bins.gather(1, below))
-        assert torch.equal(z[:, i].cpu(), z_inv)
-        # ... and within the conditioning of the inverse (|dz| ~ bin * cdf_err / den) of the oracle's z
-        bound = 1e-5 + (bins.gather(1, above) - bins.gather(1, below)).abs() * 4e-7 / den
-        assert bool(((z[:, i].cpu() - z_ref).abs()[agree] <= bound[agree]).all())
+        assert torch.equal(cdf[:, i].cpu(), cdf_ref)              # bit-exact: cdf, searchsorted indices, new depths
+        assert torch.equal(inds[:, i].cpu().long(), inds_ref)
+        assert torch.equal(z[:, i].cpu(), z_ref)
         srt = torch.sort(torch.cat([t[:, i], z[:, i].cpu()], -1), -1)[0]
         assert torch.equal(tf[:, i].cpu(), srt)
         p = srt.unsqueeze(-1) * rays[:, None, 3:6] + rays[:, None, 0:3]
@@ -400,6 +448,60 @@ def test_resample_random_layers_edits_and_device_rng(ops):
     tb, _ = ops.resample(dev(t[100:300]), dev(w[100:300]), n2, dev(rays[100:300]), seed=99, ray_index_base=100)
     assert torch.equal(ta[100:300], tb)
     assert bool((ta[..., 1:] >= ta[..., :-1]).all())
+
+
+@pytest.mark.parametrize("n1, n2", [(3, 2), (5, 4), (8, 4), (9, 5), (10, 64), (12, 6), (16, 8), (18, 7), (64, 64),
+                                    (90, 30), (128, 64), (200, 40)])
+def test_resample_bit_exact_vs_oracle_on_random_inputs(ops, n1, n2):
+    """utils/sample_pdf.py on the CPU = torch.sum (ATen's fp32 reduction order) + torch.cumsum (fp64 accumulator);
+    the kernel reproduces both orders, so cdf, inds and z are bit-equal for every row shape: rows shorter than one
+    8-float vector (scalar path), with and without leftover elements, one and two 64-lane blocks."""
+    torch.manual_seed(1000 + n1)
+    n, l = 700, 2
+    t = torch.sort(torch.rand(n, l, n1) * 5.0, -1)[0]
+    w = torch.rand(n, l, n1) ** 10                                # peaky, as a trained density gives
+    w = w / w.sum(-1, keepdim=True) * torch.rand(n, l, 1)
+    w[:5] = 0.0                                                   # flat pdf rows
+    w[5:10] = 0.0
+    w[5:10, :, n1 // 2] = 0.9                                     # one spike: den < 1e-5 bins all around it
+    u = torch.rand(l, n, n2)
+    u[:, :, 0] = 0.0
+    rays = torch.cat([torch.rand(n, 3), torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)], -1)
+    tf, _, z, inds, cdf = ops.resample(dev(t), dev(w), n2, dev(rays), u=dev(u), debug=True)
+    for i in range(l):
+        z_ref, cdf_ref, inds_ref = O.sample_pdf(t[:, i], w[:, i, 1:-1], u[i], return_aux=True)
+        assert torch.equal(cdf[:, i].cpu(), cdf_ref), f"cdf differs in {int((cdf[:, i].cpu() != cdf_ref).sum())} places"
+        assert torch.equal(inds[:, i].cpu().long(), inds_ref)
+        assert torch.equal(z[:, i].cpu(), z_ref)
+        assert torch.equal(tf[:, i].cpu(), torch.sort(torch.cat([t[:, i], z_ref], -1), -1)[0])
+
+
+@pytest.mark.parametrize("name", ["sample_pdf_90_30", "sample_pdf_128_64"])
+def test_resample_reference_fixtures_at_production_sample_counts(ops, name):
+    meta, a = load_golden(name)
+    n, n1 = a["t"].shape
+    wfull = torch.cat([torch.zeros(n, 1), a["w"], torch.zeros(n, 1)], -1)
+    rays = torch.zeros(n, 6)
+    _, _, z, _, _ = ops.resample(dev(a["t"].unsqueeze(1)), dev(wfull.unsqueeze(1)), meta["n2"], dev(rays),
+                                 u=dev(a["u"].unsqueeze(0)), debug=True)
+    assert torch.equal(z[:, 0].cpu(), a["z"])                     # the reference's own output, bit for bit
+
+
+def test_resample_descending_coarse_list(ops):
+    """A ray that misses the background box has start = 0, far = -1000: the coarse depths DEscend.  Only the sorted values
+    leave the kernel; they must equal torch.sort(cat[t, z])."""
+    torch.manual_seed(37)
+    n, n1, n2 = 300, 64, 64
+    t = -(torch.arange(n1).float() + torch.rand(n, n1)) * (1000.0 / n1)
+    w = torch.zeros(n, n1)
+    u = torch.rand(1, n, n2)
+    rays = torch.cat([torch.rand(n, 3), torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)], -1)
+    tf, _, z, _, _ = ops.resample(dev(t.unsqueeze(1)), dev(w.unsqueeze(1)), n2, dev(rays), u=dev(u), debug=True)
+    z_ref = O.sample_pdf(t, w[:, 1:-1], u[0])
+    assert torch.equal(z[:, 0].cpu(), z_ref)
+    assert torch.equal(tf[:, 0].cpu(), torch.sort(torch.cat([t, z_ref], -1), -1)[0])
+    tf2, _ = ops.resample(dev(t.unsqueeze(1)), dev(w.unsqueeze(1)), n2, dev(rays), u=dev(u))   # production path
+    assert torch.equal(tf2, tf)
 
 
 def test_encode_and_gen_weight_op_level(ops):

@@ -9,7 +9,8 @@ from oracle import stnerf_oracle as O
 from stnerf_amd import synthetic as syn
 
 FWD_CASES = ["fwd_c1", "fwd_c3", "fwd_edit", "fwd_hide", "fwd_nonretime", "fwd_only_coarse",
-             "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet", "fwd_deep_rgb", "fwd_no_raw_no_dir", "fwd_c4", "fwd_c5"]
+             "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet", "fwd_deep_rgb", "fwd_no_raw_no_dir", "fwd_c4", "fwd_c5",
+             "fwd_c3_90_30", "fwd_c3_90_30_chunked", "fwd_c3_64_64", "fwd_grazing"]
 
 
 def test_generate_rays():
@@ -70,6 +71,25 @@ def test_sample_pdf():
     assert torch.equal(z, a["z"])
     assert inds.dtype == torch.int64 and inds.min() >= 1 and inds.max() <= a["t"].shape[1] - 1
     assert O.sample_pdf(a["t"], a["w"], a["u"][:, :0]).shape == a["z_empty"].shape
+
+
+@pytest.mark.parametrize("name", ["sample_pdf_90_30", "sample_pdf_128_64"])
+def test_sample_pdf_at_production_sample_counts(name):
+    """The shipped yml's 90 + 30 and the metric's 64 + 64 (per layer 128 + 64 at C5) on peaky weights: z bit-equal."""
+    _, a = load_golden(name)
+    assert torch.equal(O.sample_pdf(a["t"], a["w"], a["u"]), a["z"])
+
+
+def test_grazing_fixture_has_the_background_corner_cases():
+    """fwd_grazing pins what the reference does with rays that touch the background box in one point (ray_mask[0]
+    False, bin width 0) -- it still evaluates and composites the background there (layered_rfrender.py:382-392) --
+    and with rays that miss it (far = -1000, descending depths)."""
+    _, a = load_golden("fwd_grazing")
+    grazing = ~a["mask0"]
+    assert int(grazing.sum()) == 2
+    assert float(a["fine_mixed_acc"][grazing].min()) > 0.99 and float(a["fine_layer0_color"][grazing].min()) > 0.1
+    miss = a["mask0"] & (a["fine_mixed_acc"].squeeze(-1) == 0)
+    assert int(miss.sum()) >= 2
 
 
 def _replayer(draws):
