@@ -82,10 +82,11 @@ class KernelTimer:
     kernel launch, stnerf_profile_begin/_end) joined with the hit masks of each stnerf_render_rays call, which
     give the number of rows a masked performer launch really processed."""
 
-    def __init__(self, n1=64):
+    def __init__(self, n1=64, layer_flops=None):
         self.masks = []
         self._orig = None
         self.n1 = n1
+        self.layer_flops = layer_flops or []     # per layer: FLOPs of one evaluation in the fused stage kernel
 
     def start(self):
         self._orig = ops.render_rays
@@ -108,7 +109,12 @@ class KernelTimer:
             name = r["kernel"]
             if name == "sample_coarse":
                 call += 1                                          # every pipeline call starts with the sampler
-            if name in ("spacenet", "motionnet"):
+            if name == "mlp_stage":                                # one persistent launch = every layer of a stage
+                hits = [r["n_rays"]] + [int(c) for c in counts[call][1:]]
+                d = out.setdefault(name, dict(launches=0, ms=0.0, evals=0, flop=0))
+                d["evals"] += sum(hits) * r["ns"]
+                d["flop"] += sum(h * r["ns"] * f for h, f in zip(hits, self.layer_flops))
+            elif name in ("spacenet", "motionnet"):
                 rays = r["n_rays"] if r["tag"] <= 0 else int(counts[call][r["tag"]])
                 flop = FLOP_MOTION if name == "motionnet" else (FLOP_SPACE_TIME if r["kind"] in (1, 4) else FLOP_SPACE)
                 if name == "spacenet" and r["kind"] in (3, 4):     # deep_rgb: two more 128x128 layers
@@ -274,6 +280,8 @@ def main():
                     help=">0: also time the oracle restatement through eager PyTorch-ROCm on this GPU (informative)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3"],
                     help="arithmetic of the headline run: exact f32 MFMA (default) or fp32-accurate split-fp16 MFMA")
+    ap.add_argument("--mlp-schedule", default="stage", choices=["stage", "per_net"],
+                    help="exact-f32 MLP scheduling: one persistent launch per stage (default) or one launch per network (round 1)")
     ap.add_argument("--no-second-precision", action="store_true",
                     help="skip the extra (untimed-for-`value`) leg that measures the other precision mode")
     args = ap.parse_args()
@@ -302,6 +310,7 @@ def main():
     info = hip.device_info()
     model, (H, W, L, n1, n2, st, dt) = build_scene(args.workload, device)
     model.max_rays_per_launch = args.rays_per_launch
+    model.mlp_schedule = args.mlp_schedule
     l = L + 1
     n_rays = H * W
     frame_ids = [1.0] + [2.5] * L
@@ -358,7 +367,8 @@ def main():
         model.set_precision(precision)
         for i in range(warmup):
             step(-1 - i, mode)
-        timer = KernelTimer(n1)
+        deep_extra = 0
+        timer = KernelTimer(n1, [FLOP_SPACE] + [(FLOP_SPACE_TIME if st else FLOP_SPACE) + (FLOP_MOTION if dt else 0) + deep_extra] * L)
         timer.start()
         fence()
         t0 = time.perf_counter()
@@ -379,7 +389,7 @@ def main():
             dist.all_reduce(allc)
             per_rank = allc.tolist()
         ksum = timer.summarise()  # this rank's launches over the timed steps
-        evals = sum(d["evals"] for name, d in ksum.items() if name == "spacenet")
+        evals = sum(d["evals"] for name, d in ksum.items() if name in ("spacenet", "mlp_stage"))
         hit = torch.stack([m.float().mean() for m in masks]).double() if masks is not None else torch.zeros(l, dtype=torch.float64, device=device)
         if world > 1:
             ev = torch.tensor([evals], dtype=torch.float64, device=device)
@@ -407,7 +417,8 @@ def main():
     psnr_check = psnr_vs_reference(model, device) if (rank == 0 and not args.no_psnr_check) else None
 
     if rank == 0:
-        sp = ksum["spacenet"]
+        staged = "mlp_stage" in ksum
+        sp = ksum["mlp_stage"] if staged else ksum["spacenet"]
         achieved = sp["flop"] / (sp["ms"] * 1e-3) / 1e12
         if args.precision == "fp16x3":   # executed MFMA work is 3 fp16 terms per algorithmic product
             achieved, peak_used = 3.0 * achieved, PEAK_F16_MFMA_TFLOPS
@@ -464,14 +475,16 @@ def main():
             "mask_fraction": head["mask_fraction"],
             "per_rank_compute_s": {"min": min(per_rank), "mean": sum(per_rank) / len(per_rank), "max": max(per_rank),
                                    "all": per_rank, "note": "render time of each rank's share over the timed steps, before the all-gather"},
-            "roofline": {"kernel": "stnerf::spacenet_kernel (fused PE + 9-layer MLP, v_mfma_f32_32x32x2_f32)",
+            "roofline": {"kernel": ("stnerf::mlp_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, "
+                                    "fused PE + MLP, v_mfma_f32_32x32x2_f32)") if staged else
+                                   "stnerf::spacenet_kernel (fused PE + 9-layer MLP, v_mfma_f32_32x32x2_f32)",
                          "bound": "mfma", "achieved": achieved, "peak": peak_used, "unit": "TFLOP/s",
                          "frac": achieved / peak_used, "traffic": traffic,
                          "traffic_source": ("profiles/" + os.path.basename(PMC_TRAFFIC_JSON)) if traffic else None,
-                         "algorithmic_bytes_per_launch": 28 * sp["evals"] / sp["launches"],
+                         "algorithmic_bytes_per_launch": 28 * sp["evals"] / sp["launches"],   # 12 B point in + 16 B raw out per SpaceNet evaluation
                          "launches": sp["launches"], "avg_launch_ms": sp["ms"] / sp["launches"],
                          "algorithmic_flop_per_launch": sp["flop"] / sp["launches"],
-                         "note": "algorithmic FLOPs = network evaluations x 924,672 (930,048 with time), "
+                         "note": "algorithmic FLOPs = network evaluations x 924,672 (930,048 with time; + 153,344 per MotionNet evaluation in the fused stage kernel), "
                                  "HIP events recorded by the library on the launch stream around every launch of the timed steps (rank 0)"},
             "kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / args.steps,
                             "tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12} for k, d in ksum.items() if "flop" in d},
@@ -481,7 +494,7 @@ def main():
             "device": info,
         }
         if other is not None:
-            osp = other["ksum"]["spacenet"]
+            osp = other["ksum"]["mlp_stage"] if "mlp_stage" in other["ksum"] else other["ksum"]["spacenet"]
             o_ach = osp["flop"] / (osp["ms"] * 1e-3) / 1e12
             peak_o = PEAK_F16_MFMA_TFLOPS if other["precision"] == "fp16x3" else PEAK_F32_MFMA_TFLOPS
             mult = 3.0 if other["precision"] == "fp16x3" else 1.0

@@ -181,6 +181,31 @@ int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32
                          const float* times, int64_t times_ray_stride, float* flow,
                          int64_t flow_ray_stride, int add_to_xyz, stnerf_stream_t stream);
 
+/* a8 + a9 for a whole network stage of the pipeline (coarse or fine, modeling/layered_rfrender.py:340-418 / :495-576):
+ * ONE persistent launch evaluates every listed layer -- one workgroup per CU pops 128-row (SpaceNet only) or 256-row
+ * (MotionNet fused in front of its SpaceNet, the flow stays on chip) work items from a device-side queue.  Results are
+ * bit-identical to stnerf_motionnet_fwd(ADD_TO_XYZ) followed by stnerf_spacenet_fwd per layer, except that the deformed
+ * points are NOT written back to xyz.  Exact-f32 arithmetic only.  `queue`: one zeroed uint32 on the device.
+ * flags: STNERF_STAGE_DEEP_RGB = the SpaceNets are of a *_DEEP kind; STNERF_STAGE_SIGMOID_RGB = store sigmoid(rgb)
+ * instead of the raw colour head output (torch.sigmoid of layers/render_layer.py:47 moved into the network epilogue,
+ * where it is free; pair it with stnerf_composite_params.rgb_activated = 1). */
+#define STNERF_STAGE_DEEP_RGB 1
+#define STNERF_STAGE_SIGMOID_RGB 2
+typedef struct stnerf_stage_layer {
+    const void* space;         /* packed SpaceNet (kind given by use_time and the deep_rgb argument)                 */
+    const void* motion;        /* packed MotionNet evaluated first on the same rows (xyz + flow), or NULL            */
+    const int32_t* ray_list;   /* compacted hit rays of the layer (stnerf_compact_rays) or NULL = every ray          */
+    const int32_t* ray_count;
+    const float* xyz;          /* [n][ns][3] with ray stride xyz_ray_stride                                         */
+    float* raw;                /* [n][ns][4] with ray stride raw_ray_stride                                         */
+    const float* times;        /* frame id of ray j at times[j * times_ray_stride]; NULL if neither net takes it    */
+    int32_t use_time;          /* the SpaceNet is of a *_TIME kind                                                  */
+    int32_t motion_flags;      /* STNERF_MOTION_PLAIN_TIME                                                          */
+} stnerf_stage_layer;
+int stnerf_mlp_stage(const stnerf_stage_layer* layers_host, int n_layers, int64_t n_rays, int ns, const float* dirs,
+                     int64_t dirs_ray_stride, int64_t times_ray_stride, int64_t xyz_ray_stride,
+                     int64_t raw_ray_stride, int flags, uint32_t* queue, stnerf_stream_t stream);
+
 /* a7 standalone: NeRF positional encoding [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)],
  * each block `dim` wide.  utils/dimension_kernel.py:3-73 (Trigonometric_kernel.__call__).  In the render
  * path the encoding is fused into the MLP kernels; this entry point serves the op-level API.
@@ -204,6 +229,9 @@ typedef struct stnerf_composite_params {
     float threshold[STNERF_MAX_LAYERS];        /* sigma < threshold -> 0 (retiming)        */
     int32_t use_threshold[STNERF_MAX_LAYERS];
     float sigma_scale[STNERF_MAX_LAYERS];      /* fine: layer 2 *= alpha (:575-576), else 1 */
+    int32_t rgb_activated;                     /* 1: raw[..][0..2] already hold sigmoid(rgb) (stnerf_mlp_stage with
+                                                * STNERF_STAGE_SIGMOID_RGB applies it in the network epilogue);
+                                                * 0: raw network output, torch.sigmoid is applied here (render_layer.py:47) */
     int32_t evaluated[STNERF_MAX_LAYERS];      /* 0: layer's nets were skipped (hidden): raw is not read;
                                                 * 1: evaluated on the rays `mask` marks (performers, :397-413);
                                                 * 2: evaluated on EVERY ray, `mask` is not consulted (the background:
@@ -257,7 +285,8 @@ typedef struct stnerf_render_params {
     int32_t retiming;             /* 1: frame id of layer i in column 6+i; 0: per-ray frame id in column 6   */
     int32_t only_coarse;
     int32_t use_deform_time, use_space_time;
-    int32_t precision;            /* 0: exact f32 MFMA, 1: fp16x3                                            */
+    int32_t precision;            /* 0: exact f32 MFMA, one persistent stnerf_mlp_stage launch per stage; 1: fp16x3 (one launch
+                                     per network); 2: exact f32, one launch per network (round-1 scheduling, for A/B runs)  */
     int32_t has_edits;            /* edits_* / pivot are meaningful                                          */
     int32_t bkgd_use_deform_time; /* BKGD_USE_DEFORM_TIME: nets.motion[0] warps the background samples (:358-367) */
     int32_t bkgd_use_space_time;  /* BKGD_USE_SPACE_TIME: background SpaceNets take the frame id (needs use_space_time, :382-390) */

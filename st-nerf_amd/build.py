@@ -18,6 +18,7 @@ SOURCES = [
     ("sampler.hip", ["-ffp-contract=off"]),
     ("render.hip", ["-ffp-contract=off"]),
     ("mlp.hip", []),
+    ("mlp_stage.hip", []),
     ("mlp_f16x3.hip", []),
     ("pipeline.hip", []),
 ]

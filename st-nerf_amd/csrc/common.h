@@ -17,7 +17,7 @@ int reserve_dynamic_lds(const void* kernel, int bytes, const char* what);
 
 // Optional launch profiler (stnerf_profile_begin / _end): while enabled, every kernel launch of the op-level
 // entry points is bracketed by a HIP event pair recorded on the launch stream.
-enum ProfKernel { PROF_SPACENET = 0, PROF_MOTIONNET = 1, PROF_COMPOSITE = 2, PROF_RESAMPLE = 3, PROF_SAMPLE_COARSE = 4 };
+enum ProfKernel { PROF_SPACENET = 0, PROF_MOTIONNET = 1, PROF_COMPOSITE = 2, PROF_RESAMPLE = 3, PROF_SAMPLE_COARSE = 4, PROF_MLP_STAGE = 5 };
 bool profiling_enabled();
 void set_launch_tag(int tag);  // e.g. the layer a pipeline launch works on; -1 = none
 struct LaunchTimer {            // RAII: records start on construction, stop + bookkeeping on destruction

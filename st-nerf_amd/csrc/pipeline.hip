@@ -38,7 +38,7 @@ Plan make_plan(int64_t n, int l, int n1, int n2, int only_coarse) {
     p.xyz_f = only_coarse ? 0 : n * l * S * 3;
     p.raw_f = only_coarse ? 0 : n * l * S * 4;
     p.list = (int64_t)l * n;
-    p.count = STNERF_MAX_LAYERS;
+    p.count = STNERF_MAX_LAYERS + 2;  // hit-ray counts + the work-queue heads of the two network stages
     return p;
 }
 
@@ -66,7 +66,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
     const int l = p->l, n1 = p->n1, n2 = p->n2, S = n1 + n2, rs = p->ray_stride;
     STNERF_REQUIRE(n >= 0 && l >= 1 && l <= STNERF_MAX_LAYERS && n1 >= 3 && n2 >= 0, "render_rays: bad shape");
     STNERF_REQUIRE(rs >= (p->retiming ? 6 + l : 7), "render_rays: ray stride %d too small for the frame-id columns", rs);
-    STNERF_REQUIRE(p->precision == 0 || p->precision == 1, "render_rays: unknown precision %d", p->precision);
+    STNERF_REQUIRE(p->precision >= 0 && p->precision <= 2, "render_rays: unknown precision %d", p->precision);
     STNERF_REQUIRE(nets->bkgd && (p->only_coarse || nets->bkgd_fine), "render_rays: background network missing");
     STNERF_REQUIRE(!p->bkgd_use_deform_time || nets->motion[0], "render_rays: bkgd_time_deform_net missing");
     STNERF_REQUIRE(!p->bkgd_use_space_time || p->use_space_time,
@@ -101,7 +101,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
                               p->ray_index_stripe, p->ray_index_period,
                               p->has_edits ? p->edits_coarse : nullptr, p->pivot, t_c, xyz_c, mask, stream);
     if (rc) return rc;
-    if (hipMemsetAsync(ray_count, 0, sizeof(int32_t) * STNERF_MAX_LAYERS, st) != hipSuccess) {
+    if (hipMemsetAsync(ray_count, 0, sizeof(int32_t) * (STNERF_MAX_LAYERS + 2), st) != hipSuccess) {
         set_error("render_rays: hipMemsetAsync failed");
         return STNERF_ELAUNCH;
     }
@@ -111,6 +111,36 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
     // ---- one network stage: deform + evaluate every shown layer on its hit rays (:340-418 / :495-576)
     auto stage = [&](float* xyz, float* raw, int ns, bool fine) -> int {
         const int64_t xs = (int64_t)l * ns * 3, ws_ = (int64_t)l * ns * 4;
+        if (p->precision == 0) {
+            // exact f32: ONE persistent launch over every shown layer (csrc/mlp_stage.hip); deformed performers first
+            // (256-row items), the background last (128-row items: the finest grain drains the queue)
+            stnerf_stage_layer sl[STNERF_MAX_LAYERS];
+            int ns_l = 0;
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int i = 0; i < l; ++i) {
+                    if (i > 0 && !p->shown[i]) continue;
+                    const bool deform = i == 0 ? p->bkgd_use_deform_time != 0 : p->use_deform_time != 0;
+                    if ((pass == 0) != deform) continue;
+                    const bool timed = (i > 0 ? 1 : p->bkgd_use_space_time) && p->use_space_time;
+                    stnerf_stage_layer& e = sl[ns_l++];
+                    e.space = i == 0 ? (fine ? nets->bkgd_fine : nets->bkgd) : (fine ? nets->space_fine[i] : nets->space[i]);
+                    e.motion = deform ? nets->motion[i] : nullptr;
+                    e.ray_list = i == 0 ? nullptr : ray_list + (int64_t)i * n;
+                    e.ray_count = i == 0 ? nullptr : ray_count + i;
+                    e.xyz = xyz + (int64_t)i * ns * 3;
+                    e.raw = raw + (int64_t)i * ns * 4;
+                    e.times = (timed || deform) ? rays + (p->retiming ? 6 + i : 6) : nullptr;
+                    e.use_time = timed ? 1 : 0;
+                    e.motion_flags = i == 0 ? STNERF_MOTION_PLAIN_TIME : 0;
+                }
+            }
+            set_launch_tag(fine ? 1 : 0);
+            const int r2 = stnerf_mlp_stage(sl, ns_l, n, ns, rays + 3, rs, rs, xs, ws_,
+                                            (p->deep_rgb ? STNERF_STAGE_DEEP_RGB : 0) | STNERF_STAGE_SIGMOID_RGB,
+                                            reinterpret_cast<uint32_t*>(ray_count + STNERF_MAX_LAYERS + (fine ? 1 : 0)), stream);
+            set_launch_tag(-1);
+            return r2;
+        }
         for (int i = 0; i < l; ++i) {
             if (i == 0 ? !p->bkgd_use_deform_time : !p->use_deform_time) continue;
             if (i > 0 && !p->shown[i]) continue;  // a hidden layer's points are never consumed
@@ -158,6 +188,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
     cp.near = p->near;
     cp.fine = 0;
     cp.cut_negative_t = 1;
+    cp.rgb_activated = p->precision == 0;  // the persistent stage kernel stores sigmoid(rgb)
     for (int i = 0; i < STNERF_MAX_LAYERS; ++i) {
         cp.sigma_scale[i] = 1.f;
         cp.evaluated[i] = i < l ? (i == 0 ? 2 : p->shown[i]) : 1;  // background: every ray, mask or not (:382-392)

@@ -158,8 +158,12 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// torch.sigmoid: 1/(1+exp(-x)) with the accurate expf and a 1-ulp reciprocal
-__device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.f + expf(-x)); }
+// exp(-x) on the hardware exponential: v_exp_f32 is 2^y to 1 ulp; the scaling by log2(e) adds |x| * 2^-24 of relative
+// error, which only matters where exp(-x) has already left the fp32 range of 1 - exp(-x).  ocml's expf costs ~3x the
+// issue slots and this kernel is bound by them.
+__device__ __forceinline__ float exp_neg(float x) { return __builtin_amdgcn_exp2f(x * -1.44269504088896340736f); }
+// torch.sigmoid: 1/(1+exp(-x)), 1-ulp exponential and 1-ulp reciprocal
+__device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.f + exp_neg(x)); }
 
 // ---------------------------------------------------------------------------------------------
 // Alpha-composite `count` samples read through accessor functors, in index order.
@@ -192,7 +196,7 @@ __device__ __forceinline__ int composite_run(int count, float border, int lane, 
                 not_descending = not_descending || !(tn < tk);
                 delta = tn - tk;
             }
-            alpha = 1.f - expf(-fmaxf(rw.w, 0.f) * delta);
+            alpha = 1.f - exp_neg(fmaxf(rw.w, 0.f) * delta);
             tr = (1.f - alpha) + 1e-10f;
         }
         const float incl = wave_scan_mul(tr);
@@ -216,6 +220,49 @@ __device__ __forceinline__ int composite_run(int count, float border, int lane, 
     return (descending ? 1 : 0) | (not_descending ? 2 : 0);
 }
 
+// The same composite with the whole layer in registers (block b of lane i = sample 64 b + i): the path of a ray with
+// ONE live layer, which needs neither the LDS staging nor the merge.  cut_near: the merged stream's `t < near` cut of
+// the fine stage (modeling/layered_rfrender.py:605).
+template <int MAXB, class WOut>
+__device__ __forceinline__ void composite_regs(int S, float border, int lane, const float (&tk)[MAXB], const float (&tn)[MAXB],
+                                               const float4 (&rw)[MAXB], bool cut_near, float nearv, WOut w_out,
+                                               float (&out)[5]) {
+    float carry = 1.f;
+    float cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        if (b * 64 < S) {  // (uniform)
+            const int k = b * 64 + lane;
+            const bool ok = k < S;
+            float tr = 1.f, alpha = 0.f;
+            if (ok) {
+                const float delta = (k + 1 < S) ? tn[b] - tk[b] : border;
+                float sg = rw[b].w;
+                if (cut_near && tk[b] < nearv) sg = 0.f;
+                alpha = 1.f - exp_neg(fmaxf(sg, 0.f) * delta);
+                tr = (1.f - alpha) + 1e-10f;
+            }
+            const float incl = wave_scan_mul(tr);
+            const float excl = wave_prev(incl, 1.f);
+            const float w = alpha * (carry * excl);
+            carry = carry * wave_last(incl);
+            if (ok) {
+                w_out(k, w);
+                cr += w * rw[b].x;
+                cg += w * rw[b].y;
+                cb += w * rw[b].z;
+                cd += w * tk[b];
+                ca += w;
+            }
+        }
+    }
+    out[0] = wave_last(wave_scan_add(cr));
+    out[1] = wave_last(wave_scan_add(cg));
+    out[2] = wave_last(wave_scan_add(cb));
+    out[3] = wave_last(wave_scan_add(cd));
+    out[4] = wave_last(wave_scan_add(ca));
+}
+
 // gen_weight stand-alone: one wave per row.
 __global__ void gen_weight_kernel(const float* __restrict__ sigma, const float* __restrict__ delta, int64_t n, int S,
                                   float* __restrict__ weights) {
@@ -227,7 +274,7 @@ __global__ void gen_weight_kernel(const float* __restrict__ sigma, const float* 
         const int k = base + lane;
         float tr = 1.f, alpha = 0.f;
         if (k < S) {
-            alpha = 1.f - expf(-fmaxf(sigma[row * S + k], 0.f) * delta[row * S + k]);
+            alpha = 1.f - exp_neg(fmaxf(sigma[row * S + k], 0.f) * delta[row * S + k]);
             tr = (1.f - alpha) + 1e-10f;
         }
         const float incl = wave_scan_mul(tr);
@@ -281,10 +328,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
         // (tests/test_gpu_ops.py::test_composite_production_shortcuts_are_bitwise_neutral).
         // (A not-evaluated layer with real depths -- hidden, or a grazing hit -- still takes part: its depths
         // shape its neighbours' deltas.)
-        unsigned live = 0;  // bit i: layer i takes part
+        unsigned live = 0, have_m = 0;  // bit i: layer i takes part / has network output on this ray
         if (active) {
             const float* tsrc = a.t + ray * LS;
-            const float4* rsrc = a.raw + ray * LS;
             for (int layer = 0; layer < a.l; ++layer) {
                 // evaluated: 0 = no network output for this layer (hidden), 1 = on the rays its hit mask marks,
                 // 2 = on every ray whatever the mask says -- the background: bkgd_spacenet runs on all rays and its
@@ -292,38 +338,126 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
                 // box: start == end, bin width 0; layered_rfrender.py:382-392,435-444, fixture fwd_grazing)
                 const int ev = a.p.evaluated[layer];
                 const bool have = ev == 2 || (ev != 0 && (!a.mask || a.mask[ray * a.l + layer]));
+                bool lv = have;
+                if (!have) {  // without output a layer still takes part if it has real depths (hidden, or a grazing hit)
+                    bool missed = true;
+                    for (int k = lane; k < a.S; k += 64) missed = missed && tsrc[layer * a.S + k] == -1000.f;
+                    lv = !__all(missed);
+                }
+                if (lv) live |= 1u << layer;
+                if (have) have_m |= 1u << layer;
+            }
+        }
+        // ---- ONE live layer (about half the rays of a view: the background alone): composite it straight from
+        // registers -- no LDS staging, no merge; the mix is that layer's composite (same samples, deltas, arithmetic)
+        // unless the fine stage's `t < near` cut bites, which costs a second pass over the registers.
+        bool done = false;
+        constexpr int MAXB = 3;
+        if (active && __popc(live) == 1 && a.S <= 64 * MAXB) {
+            const int layer = __ffs(live) - 1;
+            const bool have = (have_m >> layer & 1u) != 0;
+            const bool cut_neg = !a.p.fine && a.p.cut_negative_t && layer > 0;
+            const bool cut_near = !a.p.fine && layer == 0;
+            const bool use_thr = a.p.use_threshold[layer] != 0;
+            const float thr = a.p.threshold[layer], sscale = a.p.sigma_scale[layer], nearv = a.p.near;
+            const float* tl = a.t + ray * LS + layer * a.S;
+            const float4* rl = a.raw + ray * LS + layer * a.S;
+            float tk[MAXB], tn[MAXB];
+            float4 rw[MAXB];
+            bool desc = false;
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) {
+                const int k = b * 64 + lane;
+                tk[b] = tn[b] = 0.f;
+                rw[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < a.S) {
+                    tk[b] = tl[k];
+                    if (k + 1 < a.S) {
+                        tn[b] = tl[k + 1];
+                        desc = desc || (tn[b] < tk[b]);
+                    }
+                    if (have) {
+                        float4 v = rl[k];
+                        if (cut_neg && tk[b] < 0.f) v.w = 0.f;
+                        if (use_thr && v.w < thr) v.w = 0.f;
+                        v.w = v.w * sscale;
+                        if (cut_near && tk[b] < nearv) v.w = 0.f;
+                        if (!a.p.rgb_activated) {
+                            v.x = sigmoidf(v.x);
+                            v.y = sigmoidf(v.y);
+                            v.z = sigmoidf(v.z);
+                        }
+                        rw[b] = v;
+                    }
+                }
+            }
+            if (!__any(desc)) {  // (a descending list needs the merge to turn it round: general path)
+                float* wdst = a.weights ? a.weights + (ray * a.l + layer) * a.S : nullptr;
+                float o5[5];
+                composite_regs<MAXB>(a.S, a.p.border, lane, tk, tn, rw, false, 0.f, [&](int k, float w) { if (wdst) wdst[k] = w; }, o5);
+                for (int other = 0; other < a.l; ++other) {  // the layers the ray misses: zero weights and outputs
+                    if (other == layer) continue;
+                    if (a.weights)
+                        for (int k = lane; k < a.S; k += 64) a.weights[(ray * a.l + other) * a.S + k] = 0.f;
+                    if (a.layer_out && lane < 5) a.layer_out[(ray * a.l + other) * 5 + lane] = 0.f;
+                }
+                auto pick = [&](const float (&o)[5]) { return lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : lane == 3 ? o[3] : o[4]; };
+                if (a.layer_out && lane < 5) a.layer_out[(ray * a.l + layer) * 5 + lane] = pick(o5);
+                if (a.mixed_out) {
+                    const float t_first = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tk[0]), 0));
+                    if (a.p.fine && t_first < nearv) {
+                        float m5[5];
+                        composite_regs<MAXB>(a.S, a.p.border, lane, tk, tn, rw, true, nearv, [&](int, float) {}, m5);
+                        if (lane < 5) a.mixed_out[ray * 5 + lane] = pick(m5);
+                    } else if (lane < 5) {
+                        a.mixed_out[ray * 5 + lane] = pick(o5);
+                    }
+                }
+                if (a.order) {  // ascending single layer + leading -1000 samples of the others: computed below
+                    const float* tsrc = a.t + ray * LS;
+                    for (int e = lane; e < LS; e += 64) ts[e] = tsrc[e];
+                }
+                done = true;
+            }
+        }
+        // ---- general path: stage the ray in LDS, applying the post-network density edits (a10); layer-major so
+        // every edit switch is wave-uniform.
+        if (active && !done) {
+            const float* tsrc = a.t + ray * LS;
+            const float4* rsrc = a.raw + ray * LS;
+            for (int layer = 0; layer < a.l; ++layer) {
+                const bool have = (have_m >> layer & 1u) != 0;
                 const bool cut_neg = !a.p.fine && a.p.cut_negative_t && layer > 0;             // :414
                 const bool cut_near = !a.p.fine && layer == 0;                                 // :422
                 const bool use_thr = a.p.use_threshold[layer] != 0;                            // :416-418, :538-547, :564-566
                 const float thr = a.p.threshold[layer], sscale = a.p.sigma_scale[layer], nearv = a.p.near;
-                bool missed = true;
                 for (int k = lane; k < a.S; k += 64) {
                     const int e = layer * a.S + k;
                     const float tv = tsrc[e];
                     ts[e] = tv;
-                    missed = missed && tv == -1000.f;
                     if (have) {
                         float4 rw = rsrc[e];
                         if (cut_neg && tv < 0.f) rw.w = 0.f;
                         if (use_thr && rw.w < thr) rw.w = 0.f;
                         rw.w = rw.w * sscale;                                      // :575-576
                         if (cut_near && tv < nearv) rw.w = 0.f;
-                        rw.x = sigmoidf(rw.x);  // torch.sigmoid(rgb), render_layer.py:47
-                        rw.y = sigmoidf(rw.y);
-                        rw.z = sigmoidf(rw.z);
+                        if (!a.p.rgb_activated) {
+                            rw.x = sigmoidf(rw.x);  // torch.sigmoid(rgb), render_layer.py:47
+                            rw.y = sigmoidf(rw.y);
+                            rw.z = sigmoidf(rw.z);
+                        }
                         raws[e] = rw;
                     } else {
                         raws[e] = make_float4(0.f, 0.f, 0.f, 0.f);  // zero tensors (:398-399); sigma = 0 makes the colour moot
                     }
                 }
-                if (have || !__all(missed)) live |= 1u << layer;
             }
         }
         wave_sync();
         // ---- per-layer composites (:435-444 / :598-603)
         bool merged_done = false, unsorted_any = false;
         unsigned reversed_all = 0;
-        if (active) {
+        if (active && !done) {
             // a layer's list is ascending, unless its bin width is negative: a box edit, or a ray that misses the
             // background box (far = -1000, start clamped to 0: depths run from 0 down to -1000).  Such a list is strictly
             // descending and is merged through a reversed view; anything else (ties inside a descending list) takes
@@ -409,7 +543,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
         }
         wave_sync();
         // ---- merged composite (:448 / :605-606)
-        if (active && !merged_done && a.mixed_out) {
+        if (active && !done && !merged_done && a.mixed_out) {
             float o5[5];
             const bool cut_near = a.p.fine != 0;
             const float nearv = a.p.near;

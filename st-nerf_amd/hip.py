@@ -30,12 +30,19 @@ class LayerEdit(C.Structure):
 class CompositeParams(C.Structure):
     _fields_ = [("border", C.c_float), ("near", C.c_float), ("fine", C.c_int32), ("cut_negative_t", C.c_int32),
                 ("threshold", C.c_float * MAX_LAYERS), ("use_threshold", C.c_int32 * MAX_LAYERS),
-                ("sigma_scale", C.c_float * MAX_LAYERS), ("evaluated", C.c_int32 * MAX_LAYERS)]
+                ("sigma_scale", C.c_float * MAX_LAYERS), ("rgb_activated", C.c_int32),
+                ("evaluated", C.c_int32 * MAX_LAYERS)]
 
 
 class Nets(C.Structure):
     _fields_ = [("bkgd", C.c_void_p), ("bkgd_fine", C.c_void_p), ("space", C.c_void_p * MAX_LAYERS),
                 ("space_fine", C.c_void_p * MAX_LAYERS), ("motion", C.c_void_p * MAX_LAYERS)]
+
+
+class StageLayer(C.Structure):
+    _fields_ = [("space", C.c_void_p), ("motion", C.c_void_p), ("ray_list", C.c_void_p), ("ray_count", C.c_void_p),
+                ("xyz", C.c_void_p), ("raw", C.c_void_p), ("times", C.c_void_p), ("use_time", C.c_int32),
+                ("motion_flags", C.c_int32)]
 
 
 class RenderParams(C.Structure):
@@ -84,6 +91,8 @@ _PROTOS = {
                                              c_i64, c_f32p, c_i64, C.c_int, C.c_void_p]),
     "stnerf_motionnet_fwd": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_i64, c_f32p,
                                        c_i64, c_f32p, c_i64, C.c_int, C.c_void_p]),
+    "stnerf_mlp_stage": (C.c_int, [C.POINTER(StageLayer), C.c_int, c_i64, C.c_int, c_f32p, c_i64, c_i64, c_i64, c_i64, C.c_int,
+                                   C.c_void_p, C.c_void_p]),
     "stnerf_encode": (C.c_int, [c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "stnerf_gen_weight": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "stnerf_composite": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_i64, C.c_int, C.c_int, C.POINTER(CompositeParams),

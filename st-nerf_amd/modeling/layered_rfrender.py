@@ -80,6 +80,8 @@ class LayeredRFRender(nn.Module):
         self.seed = 0                      # Philox seed of the on-device jitter / resampling draws
         self.max_rays_per_launch = 1 << 19 # rays per kernel sequence (workspace bound ~20 KB/ray, not a semantic chunk)
         self.replay = None                 # {"jitter": (l,N,N1), "u": (l,N,N2)} to replay recorded uniforms
+        self.mlp_schedule = "stage"        # "stage": one persistent MLP launch per stage (stnerf_mlp_stage); "per_net":
+                                           # one launch per (layer, network) as in round 1 (A/B measurements)
         self.ray_window = (0, 0, 0)        # (first, stripe, period): which rays of the view `rays` are (include/stnerf.h);
                                            # keeps the RNG stream of a view under multi-GPU sharding
 
@@ -211,7 +213,8 @@ class LayeredRFRender(nn.Module):
         p.use_deform_time, p.use_space_time = int(self.use_deform_time), int(self.use_space_time)
         p.bkgd_use_deform_time, p.bkgd_use_space_time = int(self.bkgd_use_deform_time), int(self.bkgd_use_space_time)
         p.deep_rgb = int(self.deep_rgb)
-        p.precision = ops.PRECISIONS.index(self.bkgd_spacenet.precision)
+        # 0: exact f32, one persistent launch per network stage; 1: fp16x3; 2: exact f32, one launch per network
+        p.precision = 1 if self.bkgd_spacenet.precision == "fp16x3" else (0 if self.mlp_schedule == "stage" else 2)
         for i in range(l):
             p.shown[i] = int(self.is_shown_layer(i))
         p.border, p.near, p.alpha = float(self.boarder_weight), float(self.near), float(self.alpha)

@@ -223,7 +223,7 @@ def pack_motionnet(state: dict, prefix: str, device="cuda", precision: str = "fp
     return pack_net(hip.NET_MOTION, ws, bs, device, precision)
 
 
-PROFILE_KERNELS = ("spacenet", "motionnet", "composite", "resample", "sample_coarse")
+PROFILE_KERNELS = ("spacenet", "motionnet", "composite", "resample", "sample_coarse", "mlp_stage")
 
 
 def profile_begin() -> None:
@@ -289,6 +289,37 @@ def motionnet_fwd(net: PackedNet, xyz: Tensor, times: Tensor, flow: Optional[Ten
     return flow
 
 
+def mlp_stage(layers: Sequence[dict], dirs: Tensor, ns: int, deep_rgb: bool = False, sigmoid_rgb: bool = False) -> None:
+    """One persistent launch over every listed layer (stnerf_mlp_stage).  Each dict: space (PackedNet), motion
+    (PackedNet | None), xyz (n,ns,3), raw (n,ns,4) out, times (n,) | None, ray_list / ray_count | None,
+    plain_time (bool).  Views may be strided as long as all layers share the ray strides."""
+    n = dirs.shape[0]
+    arr = (hip.StageLayer * len(layers))()
+    strides = None
+    dp, ds = _strided_view_ptr(dirs, (3,), "dirs")
+    for i, ly in enumerate(layers):
+        xp, xs = _strided_view_ptr(ly["xyz"], (ns, 3), "xyz")
+        rp, rs = _strided_view_ptr(ly["raw"], (ns, 4), "raw")
+        tp, ts = (_strided_view_ptr(ly["times"].reshape(n), (), "times") if ly.get("times") is not None else (C.c_void_p(0), 0))
+        if strides is None:
+            strides = [xs, rs, ts]
+        if ts and not strides[2]:
+            strides[2] = ts
+        if (xs, rs) != tuple(strides[:2]) or (ts and ts != strides[2]):
+            raise ValueError("mlp_stage: every layer must share the xyz / raw / times ray strides")
+        if ly["space"].precision != "fp32" or (ly.get("motion") is not None and ly["motion"].precision != "fp32"):
+            raise ValueError("mlp_stage runs the exact-f32 kernels: pack the networks with precision='fp32'")
+        lp, cp = _worklist(ly.get("ray_list"), ly.get("ray_count"))
+        a = arr[i]
+        a.space, a.motion = ly["space"].blob.data_ptr(), (ly["motion"].blob.data_ptr() if ly.get("motion") is not None else None)
+        a.ray_list, a.ray_count, a.xyz, a.raw, a.times = lp.value, cp.value, xp.value, rp.value, tp.value
+        a.use_time, a.motion_flags = int(ly["space"].use_time), (hip.MOTION_PLAIN_TIME if ly.get("plain_time") else 0)
+    queue = torch.zeros(1, dtype=torch.int32, device=dirs.device)
+    hip.check(hip.lib().stnerf_mlp_stage(arr, len(layers), n, ns, dp, ds, strides[2], strides[0], strides[1],
+                                         (1 if deep_rgb else 0) | (2 if sigmoid_rgb else 0),
+                                         C.c_void_p(queue.data_ptr()), hip.stream_ptr()), "stnerf_mlp_stage")
+
+
 def encode(x: Tensor, n_freq: int, include_input: bool = True) -> Tensor:
     """Positional encoding of x (..., dim) -> (..., dim*(include_input + 2*n_freq)); utils/dimension_kernel.py:3-73."""
     dim = x.shape[-1]
@@ -313,7 +344,7 @@ def gen_weight(sigma: Tensor, delta: Tensor) -> Tensor:
 def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e10, near: float = 0.0,
               fine: bool = False, cut_negative_t: bool = False, thresholds: Optional[Sequence[Optional[float]]] = None,
               sigma_scale: Optional[Sequence[float]] = None, evaluated: Optional[Sequence[int]] = None,
-              want_weights: bool = False, want_order: bool = False):
+              want_weights: bool = False, want_order: bool = False, rgb_activated: bool = False):
     """t (n,l,S), raw (n,l,S,4), mask (n,l) uint8 | None ->
     layer_out (n,l,5), mixed_out (n,5), weights (n,l,S) | None, order (n,l*S) int32 | None.
     layers/render_layer.py:8-58 + modeling/layered_rfrender.py:414-448 / :538-606.
@@ -321,6 +352,7 @@ def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e
     n, l, S = t.shape
     p = hip.CompositeParams()
     p.border, p.near, p.fine, p.cut_negative_t = border, near, int(fine), int(cut_negative_t)
+    p.rgb_activated = int(rgb_activated)
     for i in range(hip.MAX_LAYERS):
         th = thresholds[i] if thresholds is not None and i < len(thresholds) else None
         p.threshold[i] = 0.0 if th is None else float(th)

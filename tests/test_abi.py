@@ -35,7 +35,7 @@ def test_exports_every_declared_symbol(lib):
 
 def test_struct_layouts_match_header():
     assert C.sizeof(hip.LayerEdit) == 24
-    assert C.sizeof(hip.CompositeParams) == 16 + 4 * 4 * hip.MAX_LAYERS
+    assert C.sizeof(hip.CompositeParams) == 16 + 4 + 4 * 4 * hip.MAX_LAYERS
 
 
 def test_packed_sizes_and_bad_kind(lib):

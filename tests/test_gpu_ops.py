@@ -243,6 +243,72 @@ def test_spacenet_worklist_and_strided_views(ops):
     assert torch.equal(raw, raw2)
 
 
+@pytest.mark.parametrize("deep, bkgd_deform, ns", [(False, False, 13), (False, False, 64), (True, True, 9), (False, True, 128)])
+def test_mlp_stage_is_bit_identical_to_the_per_network_launches(ops, deep, bkgd_deform, ns):
+    """stnerf_mlp_stage (one persistent launch: work queue over every layer, MotionNet fused in front of its SpaceNet,
+    256-row deformed items, 128-row plain items) == stnerf_motionnet_fwd(ADD_TO_XYZ) + stnerf_spacenet_fwd per layer,
+    bit for bit; rows of rays a layer does not list stay untouched."""
+    torch.manual_seed(41 + ns)
+    rs = np.random.RandomState(9)
+    n, l = 1100, 3
+    sd_b = syn.spacenet_state("net", rs, bkgd_deform, deep_rgb=deep)        # (a timed background only together with its deform net)
+    sd_p = [syn.spacenet_state("net", rs, True, deep_rgb=deep) for _ in range(l - 1)]
+    sd_m = [syn.motionnet_state("net", rs) for _ in range(l)]
+    xyz = (torch.rand(n, l, ns, 3) - 0.5) * 5.0
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
+    times = torch.where(torch.rand(n, l) < 0.5, torch.floor(torch.rand(n, l) * 30), torch.rand(n, l) * 30) + 1
+    rays = torch.cat([torch.zeros(n, 3), dirs, times], -1)
+    mask = (torch.rand(n, l) < 0.45).to(torch.uint8)
+    mask[:, 0] = 1
+    dr, dm = dev(rays), dev(mask)
+    lst, cnt = ops.compact_rays(dm)
+    bk = ops.pack_spacenet(sd_b, "net")
+    sp = [ops.pack_spacenet(s_, "net") for s_ in sd_p]
+    mo = [ops.pack_motionnet(s_, "net") for s_ in sd_m]
+    # ---- per-network launches (round-1 scheduling)
+    x1 = dev(xyz)
+    raw1 = torch.full((n, l, ns, 4), 7.0, device="cuda")
+    if bkgd_deform:
+        ops.motionnet_fwd(mo[0], x1[:, 0], dr[:, 6], add_to_xyz=True, plain_time=True)
+    ops.spacenet_fwd(bk, x1[:, 0], dr[:, 3:6], dr[:, 6] if bkgd_deform else None, raw1[:, 0])
+    for i in range(1, l):
+        ops.motionnet_fwd(mo[i], x1[:, i], dr[:, 6 + i], add_to_xyz=True, ray_list=lst[i], ray_count=cnt[i:i + 1])
+        ops.spacenet_fwd(sp[i - 1], x1[:, i], dr[:, 3:6], dr[:, 6 + i], raw1[:, i], ray_list=lst[i], ray_count=cnt[i:i + 1])
+    # ---- one persistent launch
+    x2 = dev(xyz)
+    raw2 = torch.full((n, l, ns, 4), 7.0, device="cuda")
+    layers = [dict(space=sp[i - 1], motion=mo[i], xyz=x2[:, i], raw=raw2[:, i], times=dr[:, 6 + i], ray_list=lst[i],
+                   ray_count=cnt[i:i + 1]) for i in range(1, l)]
+    layers.append(dict(space=bk, motion=mo[0] if bkgd_deform else None, xyz=x2[:, 0], raw=raw2[:, 0],
+                       times=dr[:, 6] if bkgd_deform else None, plain_time=True))
+    ops.mlp_stage(layers, dr[:, 3:6], ns, deep_rgb=deep)
+    for i in range(l):
+        bad = (raw2[:, i] != raw1[:, i]).reshape(n, -1).any(-1)
+        assert not bool(bad.any()), f"layer {i}: {int(bad.sum())} rays differ, max |d| {float((raw2[:, i] - raw1[:, i]).abs().max()):.3e}"
+    assert torch.equal(x2.cpu(), xyz)                              # the deformed points are not written back
+    hit = mask.bool()
+    assert bool((raw2.cpu()[~hit] == 7.0).all()) and bool(torch.isfinite(raw2).all())
+    # STNERF_STAGE_SIGMOID_RGB: the colour comes out as torch.sigmoid(rgb), sigma untouched; the compositor then skips its
+    # own sigmoid (rgb_activated) and produces bit-identical images
+    raw4 = torch.full((n, l, ns, 4), 7.0, device="cuda")
+    for ly, i in zip(layers, list(range(1, l)) + [0]):
+        ly["raw"] = raw4[:, i]
+    ops.mlp_stage(layers, dr[:, 3:6], ns, deep_rgb=deep, sigmoid_rgb=True)
+    hit_d = dm.bool()
+    assert torch.equal(raw4[..., 3][hit_d], raw2[..., 3][hit_d])
+    torch.testing.assert_close(raw4[..., :3][hit_d], torch.sigmoid(raw2[..., :3][hit_d]), rtol=3e-7, atol=1e-7)
+    tt = torch.sort(torch.rand(n, l, ns, device="cuda") * 4.0, -1)[0]
+    img_a = ops.composite(tt, raw2.contiguous(), dm, evaluated=[1] * l)
+    img_b = ops.composite(tt, raw4.contiguous(), dm, evaluated=[1] * l, rgb_activated=True)
+    assert torch.equal(img_a[0], img_b[0]) and torch.equal(img_a[1], img_b[1])
+    # and once more: same queue, same bits (dynamic scheduling does not touch the arithmetic)
+    raw3 = torch.full((n, l, ns, 4), 7.0, device="cuda")
+    for ly, i in zip(layers, list(range(1, l)) + [0]):
+        ly["raw"] = raw3[:, i]
+    ops.mlp_stage(layers, dr[:, 3:6], ns, deep_rgb=deep)
+    assert torch.equal(raw3, raw2)
+
+
 def test_motionnet_vs_fp64_oracle(ops):
     torch.manual_seed(13)
     rs = np.random.RandomState(7)
