@@ -243,10 +243,13 @@ typedef struct stnerf_composite_params {
  * rgb = sigma = 0 as the reference's zero tensors, :398-399).
  * Outputs (any may be NULL): layer_out[n][l][5] = {color(3), depth, acc}; mixed_out[n][5];
  * weights[n][l][S] per-layer weights (needed by stnerf_resample); order[n][l*S] int32 = source
- * index (layer*S + k) of each merged sample (torch.sort's index, ties broken by source index). */
+ * index (layer*S + k) of each merged sample (torch.sort's index, ties broken by source index).
+ * scratch: n bytes of device memory or NULL.  With scratch the rays that hit a single layer (about half of a view)
+ * are composited first by a latency-pipelined kernel that needs no LDS, the others by the general kernel; without
+ * it the general kernel takes every ray.  Same results bit for bit. */
 int stnerf_composite(const float* t, const float* raw, const uint8_t* mask, int64_t n, int l, int S,
                      const stnerf_composite_params* params_host, float* layer_out, float* mixed_out,
-                     float* weights, int32_t* order, stnerf_stream_t stream);
+                     float* weights, int32_t* order, uint8_t* scratch, stnerf_stream_t stream);
 
 /* a13 (+ the sort/merge and point generation of layered_rfrender.py:459-475): inverse-CDF
  * resampling of every layer.  utils/sample_pdf.py:18-63.

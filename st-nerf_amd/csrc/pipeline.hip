@@ -25,7 +25,7 @@ struct Carve {
 
 // sizes of the workspace regions for n rays (shared by the size query and the carve)
 struct Plan {
-    int64_t t_c, xyz_c, raw_c, w_c, t_f, xyz_f, raw_f, list, count;
+    int64_t t_c, xyz_c, raw_c, w_c, t_f, xyz_f, raw_f, list, count, flags;
 };
 Plan make_plan(int64_t n, int l, int n1, int n2, int only_coarse) {
     Plan p;
@@ -38,6 +38,7 @@ Plan make_plan(int64_t n, int l, int n1, int n2, int only_coarse) {
     p.xyz_f = only_coarse ? 0 : n * l * S * 3;
     p.raw_f = only_coarse ? 0 : n * l * S * 4;
     p.list = (int64_t)l * n;
+    p.flags = n;                      // one byte per ray: the compositor's scratch
     p.count = STNERF_MAX_LAYERS + 2;  // hit-ray counts + the work-queue heads of the two network stages
     return p;
 }
@@ -52,7 +53,7 @@ extern "C" int64_t stnerf_render_workspace_bytes(int64_t n, int l, int n1, int n
     const Plan p = make_plan(n, l, n1, n2, only_coarse);
     // xyz_c / raw_c are dead once the fine stage starts, but a single bump carve keeps the accounting obvious
     const int64_t floats = p.t_c + p.xyz_c + p.raw_c + p.w_c + p.t_f + p.xyz_f + p.raw_f;
-    return floats * 4 + (p.list + p.count) * 4 + 16 * 256;
+    return floats * 4 + (p.list + p.count) * 4 + p.flags + 16 * 256;
 }
 
 extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* boxes, int64_t box_ray_stride,
@@ -93,6 +94,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
     float* raw_f = ws.take<float>(pl.raw_f);
     int32_t* ray_list = ws.take<int32_t>(pl.list);
     int32_t* ray_count = ws.take<int32_t>(pl.count);
+    uint8_t* ray_flags = ws.take<uint8_t>(pl.flags);
     hipStream_t st = as_stream(stream);
     int rc;
 
@@ -196,7 +198,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
         cp.threshold[i] = p->density_threshold;
     }
     rc = stnerf_composite(t_c, raw_c, mask, n, l, n1, &cp, layer_coarse, mixed_coarse, p->only_coarse ? nullptr : w_c,
-                          nullptr, stream);
+                          nullptr, ray_flags, stream);
     if (rc || p->only_coarse) return rc;
 
     // ---- resample + fine points (:459-475), fine networks, fine composite (:538-606)
@@ -213,5 +215,5 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
         cp.threshold[i] = i == 0 ? p->bkgd_density_threshold : p->density_threshold;
     }
     if (l > 2) cp.sigma_scale[2] = p->alpha;                             // :575-576
-    return stnerf_composite(t_f, raw_f, mask, n, l, S, &cp, layer_fine, mixed_fine, nullptr, nullptr, stream);
+    return stnerf_composite(t_f, raw_f, mask, n, l, S, &cp, layer_fine, mixed_fine, nullptr, nullptr, ray_flags, stream);
 }

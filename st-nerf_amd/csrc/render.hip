@@ -10,6 +10,17 @@
 //            modeling/layered_rfrender.py:414-475, :538-606.
 #include "common.h"
 
+// Occupancy targets (waves per SIMD) of the three kernels: the VGPR budget follows from them (512 / waves).
+#ifndef STNERF_WAVES_COMPOSITE
+#define STNERF_WAVES_COMPOSITE 6
+#endif
+#ifndef STNERF_WAVES_SINGLE
+#define STNERF_WAVES_SINGLE 6
+#endif
+#ifndef STNERF_WAVES_RESAMPLE
+#define STNERF_WAVES_RESAMPLE 6
+#endif
+
 namespace stnerf {
 
 // ---- wave64 cross-lane primitives on DPP (gfx9 row_shr / row_bcast / wave_shr controls: one VALU op per
@@ -297,9 +308,10 @@ struct CompositeArgs {
     int32_t* order;
     int waves_per_block;
     int p2;  // floor_pow2(S)
+    uint8_t* handled;  // [n] or nullptr: rays composite_single_kernel has already finished (it writes 0 / 1 for every ray)
 };
 
-__global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(CompositeArgs a) {
+__global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) composite_kernel(CompositeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -312,9 +324,23 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
     unsigned short* mord = reinterpret_cast<unsigned short*>(ts + LS);
 
     const int64_t rays_per_iter = (int64_t)gridDim.x * a.waves_per_block;
+    // hit mask (lanes 0 .. l-1) and `handled` flag (lane 63) of a ray in ONE load each, fetched one ray ahead: the
+    // chain "flags -> which layers -> their samples" is otherwise two or more dependent HBM round trips per ray
+    auto ray_flags = [&](int64_t ray) -> int {
+        int v = 0;
+        if (ray < a.n) {
+            if (lane < a.l && a.mask) v = a.mask[ray * a.l + lane];
+            if (lane == 63 && a.handled) v = a.handled[ray];
+        }
+        return v;
+    };
+    int flags_next = ray_flags((int64_t)blockIdx.x * a.waves_per_block + wave);
     for (int64_t ray0 = (int64_t)blockIdx.x * a.waves_per_block; ray0 < a.n; ray0 += rays_per_iter) {
         const int64_t ray = ray0 + wave;
-        const bool active = ray < a.n;
+        const unsigned long long fb = __ballot(flags_next != 0);
+        flags_next = ray_flags(ray + rays_per_iter);
+        const unsigned mask_bits = (unsigned)fb;
+        const bool active = ray < a.n && !(fb >> 63 & 1ull);
         int n_merged = 0;
         // ---- stage the ray, applying the post-network density edits (a10); layer-major so every edit
         // switch is wave-uniform.
@@ -337,7 +363,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
                 // output is composited even where ray_mask[0] is False (a ray through an edge of the background
                 // box: start == end, bin width 0; layered_rfrender.py:382-392,435-444, fixture fwd_grazing)
                 const int ev = a.p.evaluated[layer];
-                const bool have = ev == 2 || (ev != 0 && (!a.mask || a.mask[ray * a.l + layer]));
+                const bool have = ev == 2 || (ev != 0 && (!a.mask || (mask_bits >> layer & 1u)));
                 bool lv = have;
                 if (!have) {  // without output a layer still takes part if it has real depths (hidden, or a grazing hit)
                     bool missed = true;
@@ -431,24 +457,42 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
                 const bool cut_near = !a.p.fine && layer == 0;                                 // :422
                 const bool use_thr = a.p.use_threshold[layer] != 0;                            // :416-418, :538-547, :564-566
                 const float thr = a.p.threshold[layer], sscale = a.p.sigma_scale[layer], nearv = a.p.near;
-                for (int k = lane; k < a.S; k += 64) {
-                    const int e = layer * a.S + k;
-                    const float tv = tsrc[e];
-                    ts[e] = tv;
-                    if (have) {
-                        float4 rw = rsrc[e];
-                        if (cut_neg && tv < 0.f) rw.w = 0.f;
-                        if (use_thr && rw.w < thr) rw.w = 0.f;
-                        rw.w = rw.w * sscale;                                      // :575-576
-                        if (cut_near && tv < nearv) rw.w = 0.f;
-                        if (!a.p.rgb_activated) {
-                            rw.x = sigmoidf(rw.x);  // torch.sigmoid(rgb), render_layer.py:47
-                            rw.y = sigmoidf(rw.y);
-                            rw.z = sigmoidf(rw.z);
+                // every load of the layer is issued before the first one is consumed: written as a plain
+                // load -> edit -> store loop each 64-sample block costs its own HBM round trip
+                constexpr int SB = 3;
+                for (int k0 = 0; k0 < a.S; k0 += 64 * SB) {
+                    float tv[SB];
+                    float4 rv[SB];
+#pragma unroll
+                    for (int b = 0; b < SB; ++b) {
+                        const int k = k0 + b * 64 + lane;
+                        tv[b] = 0.f;
+                        rv[b] = make_float4(0.f, 0.f, 0.f, 0.f);  // zero tensors (:398-399); sigma = 0 makes the colour moot
+                        if (k < a.S) {
+                            tv[b] = tsrc[layer * a.S + k];
+                            if (have) rv[b] = rsrc[layer * a.S + k];
                         }
-                        raws[e] = rw;
-                    } else {
-                        raws[e] = make_float4(0.f, 0.f, 0.f, 0.f);  // zero tensors (:398-399); sigma = 0 makes the colour moot
+                    }
+#pragma unroll
+                    for (int b = 0; b < SB; ++b) {
+                        const int k = k0 + b * 64 + lane;
+                        if (k < a.S) {
+                            const int e = layer * a.S + k;
+                            float4 rw = rv[b];
+                            ts[e] = tv[b];
+                            if (have) {
+                                if (cut_neg && tv[b] < 0.f) rw.w = 0.f;
+                                if (use_thr && rw.w < thr) rw.w = 0.f;
+                                rw.w = rw.w * sscale;                                      // :575-576
+                                if (cut_near && tv[b] < nearv) rw.w = 0.f;
+                                if (!a.p.rgb_activated) {
+                                    rw.x = sigmoidf(rw.x);  // torch.sigmoid(rgb), render_layer.py:47
+                                    rw.y = sigmoidf(rw.y);
+                                    rw.z = sigmoidf(rw.z);
+                                }
+                            }
+                            raws[e] = rw;
+                        }
                     }
                 }
             }
@@ -596,6 +640,145 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) composite_kernel(Comp
 }
 
 // ---------------------------------------------------------------------------------------------
+// Rays with ONE live layer (about half the rays of a view: the background alone), software pipelined.
+// composite_kernel spends ~10 us per ray on such a ray although it needs ~150 instructions: the chain
+// "hit mask -> (which layer?) -> its samples -> composite -> store" is two dependent HBM round trips per ray with
+// nothing else for the wave to do, and 8 waves per SIMD cannot hide that.  This kernel needs no LDS and runs the
+// chain as a three-stage pipeline over the rays of a wave: while ray j is composited from registers, the samples of ray
+// j+1 (whose mask arrived one iteration earlier) and the mask of ray j+2 are in flight.  It writes handled[ray] = 1
+// for the rays it finishes and 0 for the others (several live layers, a descending list, a masked-out layer with real
+// depths, ...), which composite_kernel then takes.  Same arithmetic, same lanes as composite_kernel: bit-identical.
+// ---------------------------------------------------------------------------------------------
+template <int MAXB, int MAXCHK>
+struct SingleBuf {
+    float tk[MAXB], tn[MAXB], chk[MAXCHK];
+    float4 rw[MAXB];
+    int layer;
+    bool eligible;
+};
+
+template <int MAXB, int MAXCHK>
+__global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_SINGLE, 8))) composite_single_kernel(CompositeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t first = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int LS = a.l * a.S, B = (a.S + 63) >> 6;
+    unsigned ev1 = 0, ev2 = 0;
+    for (int i = 0; i < a.l; ++i) {
+        if (a.p.evaluated[i] == 2) ev2 |= 1u << i;
+        else if (a.p.evaluated[i] != 0) ev1 |= 1u << i;
+    }
+    using Buf = SingleBuf<MAXB, MAXCHK>;
+    auto mask_lane = [&](int64_t ray) -> int { return (a.mask && ray < a.n && lane < a.l) ? (int)a.mask[ray * a.l + lane] : 0; };
+    auto have_of = [&](int mv) -> unsigned {
+        const unsigned mb = (unsigned)__ballot(mv != 0);
+        return ev2 | (ev1 & (a.mask ? mb : ~0u));
+    };
+    auto issue = [&](Buf& b, int64_t ray, unsigned have) {
+        b.eligible = ray < a.n && __popc(have) == 1;
+        b.layer = b.eligible ? __ffs(have) - 1 : 0;
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) {
+            b.tk[i] = b.tn[i] = 0.f;
+            b.rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < MAXCHK; ++c) b.chk[c] = -1000.f;
+        if (b.eligible) {
+            const float* tsrc = a.t + ray * LS;
+            const float* tl = tsrc + b.layer * a.S;
+            const float4* rl = a.raw + ray * LS + b.layer * a.S;
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                const int k = i * 64 + lane;
+                if (k < a.S) {
+                    b.tk[i] = tl[k];
+                    if (k + 1 < a.S) b.tn[i] = tl[k + 1];
+                    b.rw[i] = rl[k];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < MAXCHK; ++c) {  // depths of the other layers: "missed" means every one of them is -1000
+                const int oi = c / B, blk = c - oi * B;
+                const int x = oi < b.layer ? oi : oi + 1;
+                const int k = blk * 64 + lane;
+                if (oi < a.l - 1 && k < a.S) b.chk[c] = tsrc[x * a.S + k];
+            }
+        }
+    };
+    int64_t r0 = first, r1 = first + stride, r2 = first + 2 * stride;
+    Buf cur, nxt;
+    int m1;
+    {
+        const int m0 = mask_lane(r0);
+        m1 = mask_lane(r1);
+        issue(cur, r0, have_of(m0));
+    }
+    for (; r0 < a.n; r0 = r1, r1 = r2, r2 += stride) {
+        const unsigned have1 = have_of(m1);
+        const int m2 = mask_lane(r2);
+        issue(nxt, r1, have1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads of the next ray ahead of this ray's arithmetic
+        // ---- ray r0 from `cur`
+        bool ok = cur.eligible;
+        if (ok) {
+            bool others_missed = true, desc = false;
+#pragma unroll
+            for (int c = 0; c < MAXCHK; ++c) others_missed = others_missed && cur.chk[c] == -1000.f;
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) desc = desc || (i * 64 + lane + 1 < a.S && cur.tn[i] < cur.tk[i]);
+            ok = __all(others_missed) && !__any(desc);
+        }
+        if (ok) {
+            const int layer = cur.layer;
+            const bool cut_neg = !a.p.fine && a.p.cut_negative_t && layer > 0;
+            const bool cut_near = !a.p.fine && layer == 0;
+            const bool use_thr = a.p.use_threshold[layer] != 0;
+            const float thr = a.p.threshold[layer], sscale = a.p.sigma_scale[layer], nearv = a.p.near;
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                float4 v = cur.rw[i];
+                if (cut_neg && cur.tk[i] < 0.f) v.w = 0.f;
+                if (use_thr && v.w < thr) v.w = 0.f;
+                v.w = v.w * sscale;
+                if (cut_near && cur.tk[i] < nearv) v.w = 0.f;
+                if (!a.p.rgb_activated) {
+                    v.x = sigmoidf(v.x);
+                    v.y = sigmoidf(v.y);
+                    v.z = sigmoidf(v.z);
+                }
+                cur.rw[i] = v;
+            }
+            float* wdst = a.weights ? a.weights + (r0 * a.l + layer) * a.S : nullptr;
+            float o5[5];
+            composite_regs<MAXB>(a.S, a.p.border, lane, cur.tk, cur.tn, cur.rw, false, 0.f,
+                                 [&](int k, float w) { if (wdst) wdst[k] = w; }, o5);
+            for (int other = 0; other < a.l; ++other) {  // the layers the ray misses: zero weights and outputs
+                if (other == layer) continue;
+                if (a.weights)
+                    for (int k = lane; k < a.S; k += 64) a.weights[(r0 * a.l + other) * a.S + k] = 0.f;
+                if (a.layer_out && lane < 5) a.layer_out[(r0 * a.l + other) * 5 + lane] = 0.f;
+            }
+            auto pick = [&](const float (&o)[5]) { return lane == 0 ? o[0] : lane == 1 ? o[1] : lane == 2 ? o[2] : lane == 3 ? o[3] : o[4]; };
+            if (a.layer_out && lane < 5) a.layer_out[(r0 * a.l + layer) * 5 + lane] = pick(o5);
+            if (a.mixed_out) {
+                const float t_first = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur.tk[0]), 0));
+                if (a.p.fine && t_first < nearv) {
+                    float m5[5];
+                    composite_regs<MAXB>(a.S, a.p.border, lane, cur.tk, cur.tn, cur.rw, true, nearv, [&](int, float) {}, m5);
+                    if (lane < 5) a.mixed_out[r0 * 5 + lane] = pick(m5);
+                } else if (lane < 5) {
+                    a.mixed_out[r0 * 5 + lane] = pick(o5);
+                }
+            }
+        }
+        if (lane == 0) a.handled[r0] = ok ? 1 : 0;
+        cur = nxt;
+        m1 = m2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Resampler: one wave per (ray, layer).
 // ---------------------------------------------------------------------------------------------
 struct ResampleArgs {
@@ -616,7 +799,7 @@ struct ResampleArgs {
     float* cdf_out;
 };
 
-__global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) resample_kernel(ResampleArgs a) {
+__global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_RESAMPLE, 8))) resample_kernel(ResampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -823,7 +1006,7 @@ extern "C" int stnerf_gen_weight(const float* sigma, const float* delta, int64_t
 
 extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t* mask, int64_t n, int l, int S,
                                 const stnerf_composite_params* params_host, float* layer_out, float* mixed_out,
-                                float* weights, int32_t* order, stnerf_stream_t stream) {
+                                float* weights, int32_t* order, uint8_t* scratch, stnerf_stream_t stream) {
     STNERF_REQUIRE(t && raw && params_host, "composite: null pointer");
     STNERF_REQUIRE(n >= 0 && l >= 1 && l <= STNERF_MAX_LAYERS && S >= 1, "composite: bad shape n=%lld l=%d S=%d",
                    (long long)n, l, S);
@@ -838,12 +1021,23 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
     if (lds > 64 * 1024)
         if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(composite_kernel), lds, "composite")) return rc;
     CompositeArgs a{t, reinterpret_cast<const float4*>(raw), mask, n, l, S, *params_host, layer_out, mixed_out,
-                    weights, order, wpb, floor_pow2(S)};
-    int64_t blocks = (n + wpb - 1) / wpb;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+                    weights, order, wpb, floor_pow2(S), nullptr};
     LaunchTimer timer(PROF_COMPOSITE, 0, n, S,
                       20ll * l * S + l + 20ll * (l + 1) + (weights ? 4ll * l * S : 0) + (order ? 4ll * l * S : 0),
                       as_stream(stream));
+    // two passes when the caller lends n bytes of scratch: the rays with one live layer first (pipelined, no LDS),
+    // the rest in the general kernel.  The `order` parity output and very deep layers take the general kernel alone.
+    constexpr int MAXB = 2, MAXCHK = 6;
+    const int nblk = (S + 63) / 64;
+    if (scratch && !order && nblk <= MAXB && (l - 1) * nblk <= MAXCHK && (layer_out || mixed_out || weights)) {
+        a.handled = scratch;
+        int64_t waves = n < 256 * 32 ? n : 256 * 32;  // 8 waves per SIMD, every wave strides over the rays
+        hipLaunchKernelGGL((composite_single_kernel<MAXB, MAXCHK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                           as_stream(stream), a);
+        STNERF_CHECK_LAUNCH("composite (single-layer rays)");
+    }
+    int64_t blocks = (n + wpb - 1) / wpb;
+    if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(wpb * 64), lds, as_stream(stream), a);
     STNERF_CHECK_LAUNCH("composite");
     return STNERF_OK;

@@ -344,7 +344,7 @@ def gen_weight(sigma: Tensor, delta: Tensor) -> Tensor:
 def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e10, near: float = 0.0,
               fine: bool = False, cut_negative_t: bool = False, thresholds: Optional[Sequence[Optional[float]]] = None,
               sigma_scale: Optional[Sequence[float]] = None, evaluated: Optional[Sequence[int]] = None,
-              want_weights: bool = False, want_order: bool = False, rgb_activated: bool = False):
+              want_weights: bool = False, want_order: bool = False, rgb_activated: bool = False, two_pass: bool = True):
     """t (n,l,S), raw (n,l,S,4), mask (n,l) uint8 | None ->
     layer_out (n,l,5), mixed_out (n,5), weights (n,l,S) | None, order (n,l*S) int32 | None.
     layers/render_layer.py:8-58 + modeling/layered_rfrender.py:414-448 / :538-606.
@@ -363,10 +363,11 @@ def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e
     mixed_out = torch.empty(n, 5, dtype=torch.float32, device=t.device)
     weights = torch.empty(n, l, S, dtype=torch.float32, device=t.device) if want_weights else None
     order = torch.empty(n, l * S, dtype=torch.int32, device=t.device) if want_order else None
+    scratch = torch.empty(n, dtype=torch.uint8, device=t.device) if two_pass else None   # single-layer rays first (see the header)
     hip.check(hip.lib().stnerf_composite(hip.dptr(t, name="t"), hip.dptr(raw, name="raw"),
                                          hip.dptr(mask, torch.uint8, "mask"), n, l, S, C.byref(p), hip.dptr(layer_out),
                                          hip.dptr(mixed_out), hip.dptr(weights), hip.dptr(order, torch.int32),
-                                         hip.stream_ptr()), "stnerf_composite")
+                                         hip.dptr(scratch, torch.uint8), hip.stream_ptr()), "stnerf_composite")
     return layer_out, mixed_out, weights, order
 
 

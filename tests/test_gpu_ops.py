@@ -440,7 +440,10 @@ def test_composite_production_shortcuts_are_bitwise_neutral(ops, fine):
     bits = lambda x: x.contiguous().view(torch.int32)      # bit patterns: a descending fine-stage background has negative
     assert torch.equal(bits(lo_a), bits(lo_b))             # deltas, i.e. inf / NaN composites in the reference as well
     assert torch.equal(bits(mo_a), bits(mo_b)) and torch.equal(bits(w_a), bits(w_b))
-    assert float(torch.nan_to_num(mo_a[:, 4], nan=0.0, posinf=0.0, neginf=0.0).max()) > 0.5 and int(((~miss1) & (~miss2)).sum()) > 100 and int((miss1 & miss2).sum()) > 100
+    assert float(torch.nan_to_num(mo_a[:, 4], nan=0.0, posinf=0.0, neginf=0.0).max()) > 0.5
+    # ... and the latency-pipelined kernel for single-layer rays (two_pass, the default) == the general kernel alone
+    lo_c, mo_c, w_c, _ = ops.composite(dev(t), dev(raw), dev(mask), want_order=False, two_pass=False, **kw)
+    assert torch.equal(bits(lo_a), bits(lo_c)) and torch.equal(bits(mo_a), bits(mo_c)) and torch.equal(bits(w_a), bits(w_c)) and int(((~miss1) & (~miss2)).sum()) > 100 and int((miss1 & miss2).sum()) > 100
     _, order = torch.sort(t.reshape(n, l * S), dim=-1, stable=True)
     assert torch.equal(od.cpu().long(), order)
 
