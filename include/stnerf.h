@@ -154,7 +154,12 @@ int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays, int ns, co
  * fp32 operand is split x = hi + lo into two fp16 numbers (22 significand bits) and a*b is evaluated as
  * ah*bh + ah*bl + al*bh with fp32 accumulation (exact fp16 products); encodings, bias, ReLU, heads and
  * outputs stay fp32.  Same work list, layouts and parity tolerances as stnerf_spacenet_fwd; needs its own
- * packed blob (stnerf_packed_bytes_f16x3 / stnerf_pack_net_f16x3; |W| must be < 234).  All three net kinds. */
+ * packed blob (stnerf_packed_bytes_f16x3 / stnerf_pack_net_f16x3; |W| must be < 234).  All three net kinds.
+ * Range guard: an activation beyond the fp16 range (>= 65520) turns into inf in the split; the NaNs that follow are
+ * flushed to 0 by the next layer's ReLU, i.e. the damage is SILENT (finite, wrong outputs).  The kernels therefore
+ * track the largest activation they split: `overflow` (device uint32, may be NULL) is OR-ed with 1 when one left the
+ * range (or an output is not finite), so that the caller can re-run the launch in exact f32 (the Python model does:
+ * LayeredRFRender._render_launch). */
 int64_t stnerf_packed_bytes_f16x3(int kind);
 int stnerf_pack_net_f16x3(int kind, const float* const* weights_host, const float* const* biases_host,
                           int n_tensors, void* dst_host, int64_t dst_bytes);
@@ -162,11 +167,11 @@ int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n_rays, int 
                               const int32_t* ray_count, const float* xyz, int64_t xyz_ray_stride,
                               const float* dirs, int64_t dirs_ray_stride, const float* times,
                               int64_t times_ray_stride, float* raw, int64_t raw_ray_stride,
-                              stnerf_stream_t stream);
+                              uint32_t* overflow, stnerf_stream_t stream);
 int stnerf_motionnet_fwd_f16x3(const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
                                const int32_t* ray_count, float* xyz, int64_t xyz_ray_stride,
                                const float* times, int64_t times_ray_stride, float* flow,
-                               int64_t flow_ray_stride, int add_to_xyz, stnerf_stream_t stream);
+                               int64_t flow_ray_stride, int add_to_xyz, uint32_t* overflow, stnerf_stream_t stream);
 
 /* a7 + a8: fused positional encoding (with the fractional-time lerp) + MotionNet MLP.
  * modeling/motion_net.py:34-71.  Same work list as above.  flow (may be NULL) gets the 3-vector at
@@ -306,12 +311,13 @@ typedef struct stnerf_render_params {
 
 int64_t stnerf_render_workspace_bytes(int64_t n, int l, int n1, int n2, int only_coarse);
 /* Outputs: mixed_*[n][5], layer_*[n][l][5] = {colour(3), depth, acc}; mask[n][l].  jitter [l][n][n1] / u [l][n][n2]
- * replay uniform draws (NULL = device RNG).  With only_coarse the fine outputs may be NULL. */
+ * replay uniform draws (NULL = device RNG).  With only_coarse the fine outputs may be NULL.  overflow: device uint32 or
+ * NULL, OR-ed with 1 if an fp16x3 network produced a non-finite output (see stnerf_spacenet_fwd_f16x3). */
 int stnerf_render_rays(const float* rays, int64_t n, const float* boxes, int64_t box_ray_stride,
                        const stnerf_nets* nets_host, const stnerf_render_params* params_host, const float* jitter,
                        const float* u, void* workspace, int64_t workspace_bytes, float* mixed_fine,
                        float* mixed_coarse, float* layer_fine, float* layer_coarse, uint8_t* mask,
-                       stnerf_stream_t stream);
+                       uint32_t* overflow, stnerf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -155,6 +155,7 @@ struct SpaceArgs {
     int64_t times_ray_stride;
     float* raw;
     int64_t raw_ray_stride;
+    uint32_t* overflow;  // fp16x3 kernels: set to 1 if an output is not finite (an activation left the fp16 range); may be null
 };
 
 struct MotionArgs {
@@ -167,6 +168,7 @@ struct MotionArgs {
     float* flow;
     int64_t flow_ray_stride;
     int add_to_xyz;  // STNERF_MOTION_* flag bits
+    uint32_t* overflow;  // as SpaceArgs::overflow
 };
 
 // Positional-encoding feature f of a tile sample lives at col[(f >> 2) * TM * 4 + (f & 3)], col = encf + s * 4.

@@ -219,8 +219,11 @@ __device__ __forceinline__ void mma_segment_h(f32x16 (&acc)[NFB][NSB], const hal
 // One dense layer: out = relu(W in + b) for this wave's NFB*32 features x NSB*32 samples, written back as
 // hi/lo fp16 planes.  Accumulators carry the 2^8 weight scale: C starts at 2^8 * bias, the epilogue
 // multiplies by 2^-8 (exact).
+// Returns the largest activation this lane wrote: one beyond the fp16 range (>= 65520) turns into inf in the split (and the
+// NaNs that follow are flushed to 0 by the integer ReLU of the next layer: silently wrong, finite pixels), so the
+// kernels raise the caller's overflow flag when it is seen.
 template <int TM, int NFB, int NSB, int NFB_NEXT>
-__device__ __forceinline__ void dense_layer_h(const half8* __restrict__ whi, const half8* __restrict__ wlo, int n_total,
+__device__ __forceinline__ float dense_layer_h(const half8* __restrict__ whi, const half8* __restrict__ wlo, int n_total,
                                               const half8* inA_hi, const half8* inA_lo, int octA, const half8* inB_hi,
                                               const half8* inB_lo, int octB, half8* out_hi, half8* out_lo, int n0,
                                               int sb0, int lane, const HFrag<NFB>& wfirst, const half8* next_hi,
@@ -261,6 +264,7 @@ __device__ __forceinline__ void dense_layer_h(const half8* __restrict__ whi, con
     PH(PH_BAR1);
     _Float16* oh = reinterpret_cast<_Float16*>(out_hi);
     _Float16* ol = reinterpret_cast<_Float16*>(out_lo);
+    float vmax = 0.f;
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb) {
 #pragma unroll
@@ -272,6 +276,7 @@ __device__ __forceinline__ void dense_layer_h(const half8* __restrict__ whi, con
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = relu_bits(acc[fb][sb][4 * q + r]) * WSCALE_INV;
+                    vmax = fmaxf(vmax, v);
                     _Float16 a_, b_;
                     split_f16(v, a_, b_);
                     vh[r] = a_;
@@ -284,6 +289,7 @@ __device__ __forceinline__ void dense_layer_h(const half8* __restrict__ whi, con
         }
     }
     PH(PH_EPI);
+    return vmax;
 }
 
 // feature f of tile sample s in a plane: element ((f>>3)*TM + s)*8 + (f&7)
@@ -314,12 +320,12 @@ __device__ __forceinline__ void head_partial_h(const half8* act_hi, const half8*
 }
 
 #define DENSE_H(TM_, NW_, N_, NN_, LI_, INA_, OCTA_, INB_, OCTB_, WFIRST_, LNEXT_, WNEXT_)                              \
-    dense_layer_h<TM_, WaveSplit<TM_, NW_, N_>::NFB, WaveSplit<TM_, NW_, N_>::NSB, WaveSplit<TM_, NW_, NN_>::NFB>(      \
+    amax = fmaxf(amax, dense_layer_h<TM_, WaveSplit<TM_, NW_, N_>::NFB, WaveSplit<TM_, NW_, N_>::NSB, WaveSplit<TM_, NW_, NN_>::NFB>(      \
         hreg + L.whi[LI_], hreg + L.wlo[LI_], N_, INA_##_hi, INA_##_lo, OCTA_, INB_##_hi, INB_##_lo, OCTB_, act_hi,     \
         act_lo, WaveSplit<TM_, NW_, N_>::n0(wave), WaveSplit<TM_, NW_, N_>::sb0(wave), lane, WFIRST_,                   \
         hweight_lane_ptr(hreg + L.whi[LNEXT_], NN_, WaveSplit<TM_, NW_, NN_>::n0(wave), lane),                          \
         hweight_lane_ptr(hreg + L.wlo[LNEXT_], NN_, WaveSplit<TM_, NW_, NN_>::n0(wave), lane),                          \
-        net + BIAS_OFF(LNEXT_) + WaveSplit<TM_, NW_, NN_>::n0(wave) + 4 * (lane >> 5), WNEXT_ PH_ARGS)
+        net + BIAS_OFF(LNEXT_) + WaveSplit<TM_, NW_, NN_>::n0(wave) + 4 * (lane >> 5), WNEXT_ PH_ARGS))
 
 // ---------------------------------------------------------------------------------------------
 // SpaceNet
@@ -347,6 +353,7 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_h_
     const int64_t rows = worklist_rows(a.wl);
     const int ns = a.wl.ns;
     PH_DECL
+    float amax = 0.f;  // largest activation this lane has split into fp16 planes (range guard)
     const half8* hreg0 = reinterpret_cast<const half8*>(a.net + L.f32.total);
     HFrag<WaveSplit<TM, NW, 256>::NFB> wA, wB;
     HFrag<WaveSplit<TM, NW, 128>::NFB> wR, wR2;
@@ -502,12 +509,14 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_h_
                     o.z += scratch_rgb[(pp * 3 + 2) * TM + s];
                 }
                 o.w = sigma;
+                if (a.overflow && !(isfinite(o.x) && isfinite(o.y) && isfinite(o.z) && isfinite(o.w))) atomicOr(a.overflow, 1u);
                 *reinterpret_cast<float4*>(a.raw + ray * a.raw_ray_stride + 4 * k) = o;
             }
         }
         __syncthreads();
         PH(PH_HEAD);
     }
+    if (a.overflow && amax >= 65520.f) atomicOr(a.overflow, 1u);  // (once per lane per launch, and only when it happened)
     PH_FLUSH;
 #undef BIAS_OFF
 }
@@ -519,12 +528,12 @@ template <int TM, int NW>
 constexpr int motion_h_lds_bytes() { return 16 * 2 * TM * 16 + 3 * NW * 64 * 4; }
 
 #define DENSE_HM(TM_, NW_, LI_, INA_, OCTA_, WFIRST_, LNEXT_, WNEXT_)                                                   \
-    dense_layer_h<TM_, WaveSplit<TM_, NW_, 128>::NFB, WaveSplit<TM_, NW_, 128>::NSB, WaveSplit<TM_, NW_, 128>::NFB>(    \
+    amax = fmaxf(amax, dense_layer_h<TM_, WaveSplit<TM_, NW_, 128>::NFB, WaveSplit<TM_, NW_, 128>::NSB, WaveSplit<TM_, NW_, 128>::NFB>(    \
         hreg + L.whi[LI_], hreg + L.wlo[LI_], 128, INA_##_hi, INA_##_lo, OCTA_, null_hi, null_lo, 0, act_hi, act_lo,    \
         WaveSplit<TM_, NW_, 128>::n0(wave), WaveSplit<TM_, NW_, 128>::sb0(wave), lane, WFIRST_,                         \
         hweight_lane_ptr(hreg + L.whi[LNEXT_], 128, WaveSplit<TM_, NW_, 128>::n0(wave), lane),                          \
         hweight_lane_ptr(hreg + L.wlo[LNEXT_], 128, WaveSplit<TM_, NW_, 128>::n0(wave), lane),                          \
-        net + L.f32.b[LNEXT_] + WaveSplit<TM_, NW_, 128>::n0(wave) + 4 * (lane >> 5), WNEXT_ PH_ARGS)
+        net + L.f32.b[LNEXT_] + WaveSplit<TM_, NW_, 128>::n0(wave) + 4 * (lane >> 5), WNEXT_ PH_ARGS))
 
 template <int TM, int NW>
 __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_h_kernel(MotionArgs a) {
@@ -547,6 +556,7 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_h
     const int64_t rows = worklist_rows(a.wl);
     const int ns = a.wl.ns;
     PH_DECL
+    float amax = 0.f;  // largest activation this lane has split into fp16 planes (range guard)
     const half8* hreg0 = reinterpret_cast<const half8*>(a.net + L.f32.total);
     HFrag<WaveSplit<TM, NW, 128>::NFB> wA, wB;
     load_hfrag(wA, hweight_lane_ptr(hreg0 + L.whi[0], 128, WaveSplit<TM, NW, 128>::n0(wave), lane),
@@ -641,6 +651,7 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_h
 #pragma unroll
                     for (int pp = 0; pp < NPARTS; ++pp) fl[c] += scratch[(pp * 3 + c) * TM + s];
                 }
+                if (a.overflow && !(isfinite(fl[0]) && isfinite(fl[1]) && isfinite(fl[2]))) atomicOr(a.overflow, 1u);
                 if (a.flow) {
                     float* dst = a.flow + ray * a.flow_ray_stride + 3 * k;
                     dst[0] = fl[0];
@@ -657,6 +668,7 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_h
         }
         __syncthreads();
     }
+    if (a.overflow && amax >= 65520.f) atomicOr(a.overflow, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -744,7 +756,7 @@ extern "C" int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n
                                          const int32_t* ray_count, const float* xyz, int64_t xyz_ray_stride,
                                          const float* dirs, int64_t dirs_ray_stride, const float* times,
                                          int64_t times_ray_stride, float* raw, int64_t raw_ray_stride,
-                                         stnerf_stream_t stream) {
+                                         uint32_t* overflow, stnerf_stream_t stream) {
     STNERF_REQUIRE(STNERF_NET_IS_SPACE(kind), "spacenet_fwd_f16x3: bad kind %d", kind);
     STNERF_REQUIRE(packed && xyz && dirs && raw, "spacenet_fwd_f16x3: null pointer");
     STNERF_REQUIRE(!STNERF_NET_USES_TIME(kind) || times, "spacenet_fwd_f16x3: net takes time but times is null");
@@ -753,7 +765,7 @@ extern "C" int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n
                    "spacenet_fwd_f16x3: raw / packed must be 16-byte aligned");
     if (n_rays == 0) return STNERF_OK;
     SpaceArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, dirs,
-                dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride};
+                dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride, overflow};
     const char* e = getenv("STNERF_TILE_H");
     const bool four = e && !strcmp(e, "128");
     const bool small = e && !strcmp(e, "64") && !STNERF_NET_IS_DEEP(kind);
@@ -785,14 +797,15 @@ extern "C" int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n
 extern "C" int stnerf_motionnet_fwd_f16x3(const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
                                           const int32_t* ray_count, float* xyz, int64_t xyz_ray_stride,
                                           const float* times, int64_t times_ray_stride, float* flow,
-                                          int64_t flow_ray_stride, int add_to_xyz, stnerf_stream_t stream) {
+                                          int64_t flow_ray_stride, int add_to_xyz, uint32_t* overflow,
+                                          stnerf_stream_t stream) {
     STNERF_REQUIRE(packed && xyz && times, "motionnet_fwd_f16x3: null pointer");
     STNERF_REQUIRE(flow || (add_to_xyz & STNERF_MOTION_ADD_TO_XYZ), "motionnet_fwd_f16x3: nothing to write");
     STNERF_REQUIRE(n_rays >= 0 && ns >= 1, "motionnet_fwd_f16x3: bad shape");
     STNERF_REQUIRE(((uintptr_t)packed & 15) == 0, "motionnet_fwd_f16x3: packed weights must be 16-byte aligned");
     if (n_rays == 0) return STNERF_OK;
     MotionArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, times,
-                 times_ray_stride, flow, flow_ray_stride, add_to_xyz};
+                 times_ray_stride, flow, flow_ray_stride, add_to_xyz, overflow};
     const char* e = getenv("STNERF_TILE_HM");
     const bool big = e && !strcmp(e, "128x8");
     auto launch = [&](auto kernel, int lds, int nthreads, int tm) -> int {

@@ -60,7 +60,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
                                   const stnerf_nets* nets, const stnerf_render_params* p, const float* jitter,
                                   const float* u, void* workspace, int64_t workspace_bytes, float* mixed_fine,
                                   float* mixed_coarse, float* layer_fine, float* layer_coarse, uint8_t* mask,
-                                  stnerf_stream_t stream) {
+                                  uint32_t* overflow, stnerf_stream_t stream) {
     STNERF_REQUIRE(rays && boxes && nets && p && workspace && mask, "render_rays: null pointer");
     STNERF_REQUIRE(mixed_coarse && layer_coarse, "render_rays: coarse outputs are required");
     STNERF_REQUIRE(p->only_coarse || (mixed_fine && layer_fine), "render_rays: fine outputs are required");
@@ -155,7 +155,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
             const int flags = STNERF_MOTION_ADD_TO_XYZ | (i == 0 ? STNERF_MOTION_PLAIN_TIME : 0);
             const int r2 = p->precision == 1
                                ? stnerf_motionnet_fwd_f16x3(nets->motion[i], n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs,
-                                                            times, rs, nullptr, 0, flags, stream)
+                                                            times, rs, nullptr, 0, flags, overflow, stream)
                                : stnerf_motionnet_fwd(nets->motion[i], n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs, times,
                                                       rs, nullptr, 0, flags, stream);
             if (r2) return r2;
@@ -172,7 +172,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
             const int32_t* cnt = i == 0 ? nullptr : ray_count + i;
             const int r2 = p->precision == 1
                                ? stnerf_spacenet_fwd_f16x3(kind, net, n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs, rays + 3,
-                                                           rs, times, rs, raw + (int64_t)i * ns * 4, ws_, stream)
+                                                           rs, times, rs, raw + (int64_t)i * ns * 4, ws_, overflow, stream)
                                : stnerf_spacenet_fwd(kind, net, n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs, rays + 3, rs,
                                                      times, rs, raw + (int64_t)i * ns * 4, ws_, stream);
             if (r2) return r2;

@@ -202,7 +202,7 @@ class LayeredRFRender(nn.Module):
             ops.spacenet_fwd(nets[i - 1]._packed(), xyz[:, i], rays[:, 3:6], tm, raw[:, i], ray_list=lst[i],
                              ray_count=cnt[i:i + 1])
 
-    def _render_launch(self, rays, boxes, pivot, retiming, only_coarse, thr, bthr, window, replay):
+    def _render_launch(self, rays, boxes, pivot, retiming, only_coarse, thr, bthr, window, replay, force_fp32=False):
         """One kernel sequence over `rays` (n <= max_rays_per_launch) = ONE call into the C ABI
         (stnerf_render_rays, csrc/pipeline.hip).  boxes: (l,8,3) shared or (n,l,8,3)."""
         from stnerf_amd import hip
@@ -214,7 +214,10 @@ class LayeredRFRender(nn.Module):
         p.bkgd_use_deform_time, p.bkgd_use_space_time = int(self.bkgd_use_deform_time), int(self.bkgd_use_space_time)
         p.deep_rgb = int(self.deep_rgb)
         # 0: exact f32, one persistent launch per network stage; 1: fp16x3; 2: exact f32, one launch per network
-        p.precision = 1 if self.bkgd_spacenet.precision == "fp16x3" else (0 if self.mlp_schedule == "stage" else 2)
+        f16 = self.bkgd_spacenet.precision == "fp16x3"
+        if force_fp32:      # the fp16x3 range guard fired: this launch again in exact f32 (packs the f32 blobs on first use)
+            self.set_precision("fp32")
+        p.precision = 1 if (f16 and not force_fp32) else (0 if self.mlp_schedule == "stage" else 2)
         for i in range(l):
             p.shown[i] = int(self.is_shown_layer(i))
         p.border, p.near, p.alpha = float(self.boarder_weight), float(self.near), float(self.alpha)
@@ -246,8 +249,22 @@ class LayeredRFRender(nn.Module):
         ws = getattr(self, "_workspace", None)
         if ws is None or ws.numel() < need or ws.device != rays.device:
             self._workspace = ws = torch.empty(need, dtype=torch.uint8, device=rays.device)
-        return ops.render_rays(rays, boxes, nets, p, ws, jitter=replay["jitter"] if replay else None,
-                               u=(replay.get("u") if replay else None))
+        guard = None
+        if p.precision == 1:   # fp16x3: a device flag says whether an activation left the fp16 range (non-finite output)
+            guard = getattr(self, "_f16_guard", None)
+            if guard is None or guard.device != rays.device:
+                self._f16_guard = guard = torch.zeros(1, dtype=torch.int32, device=rays.device)
+            guard.zero_()
+        try:
+            out = ops.render_rays(rays, boxes, nets, p, ws, jitter=replay["jitter"] if replay else None,
+                                  u=(replay.get("u") if replay else None), overflow=guard)
+        finally:
+            if force_fp32:
+                self.set_precision("fp16x3")
+        if guard is not None and int(guard.item()) != 0:   # (one 4-byte D2H per launch sequence, fp16x3 mode only)
+            self.f16_fallbacks = getattr(self, "f16_fallbacks", 0) + 1
+            return self._render_launch(rays, boxes, pivot, retiming, only_coarse, thr, bthr, window, replay, force_fp32=True)
+        return out
 
     def render_rays(self, rays, only_coarse=False, density_threshold=0.0001, bkgd_density_threshold=0.0,
                     ref_chunk: Optional[int] = None):

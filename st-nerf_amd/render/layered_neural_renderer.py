@@ -257,3 +257,55 @@ class LayeredNeuralRenderer:
                         self.depths_layer[layer_id].append(depth_layer[layer_id].cpu())
             self.image_num += 1
         return self.images, self.depths
+
+    def render_path_walking(self, inverse_y_axis=False, density_threshold=0, bkgd_density_threshold=0, auto_save=True,
+                            on_frame: Optional[Callable] = None):
+        """``render_path`` without the per-frame edit schedule plus the occlusion composite of the walking demo
+        (:550-618): layer 2 is pasted over the background image wherever it is in front of it
+        (``depth_layer[2] < depth_layer[0]``) and has colour.  The composites are kept in ``self.images_hide``."""
+        self.images, self.depths, self.images_hide = [], [], []
+        self.images_layer = [[] for _ in range(self.layer_num + 1)]
+        self.depths_layer = [[] for _ in range(self.layer_num + 1)]
+        self.image_num = 0
+        for idx in range(len(self.poses)):
+            color, depth, color_layer, depth_layer = self.render_pose(self.poses[idx], self.Ks[idx],
+                                                                     self.layer_frame_pairs[idx], density_threshold,
+                                                                     bkgd_density_threshold)
+            if inverse_y_axis:
+                color, depth = torch.flip(color, [0]), torch.flip(depth, [0])
+                color_layer = [torch.flip(i, [0]) for i in color_layer]
+                depth_layer = [torch.flip(i, [0]) for i in depth_layer]
+            color_hide = None
+            if self.layer_num >= 2:
+                color_hide = color_layer[0].clone()                                   # :606-611
+                index = depth_layer[2] < depth_layer[0]
+                index = torch.cat([index, index, index], dim=2)
+                index = torch.logical_and(index, color_layer[2] != 0)
+                color_hide[index] = color_layer[2][index]
+            if on_frame is not None:
+                on_frame(idx, color, depth, color_layer, depth_layer)
+            if auto_save:
+                self.images.append(color.cpu())
+                self.depths.append(depth.cpu())
+                if color_hide is not None:
+                    self.images_hide.append(color_hide.cpu())
+                for layer_id in range(self.layer_num + 1):
+                    self.images_layer[layer_id].append(color_layer[layer_id].cpu())
+                    self.depths_layer[layer_id].append(depth_layer[layer_id].cpu())
+            self.image_num += 1
+        return self.images, self.depths
+
+    def save_video(self, writer: Optional[Callable] = None):
+        """The reference writes ``color_<n>.mp4`` / ``depth_<n>.mp4`` with imageio (:624-637); imageio is not a
+        dependency here, so the frames are handed to ``writer(kind, index, frames, fps)`` (``kind`` in
+        {"color", "depth"}), e.g. ``lambda kind, i, frames, fps: imageio.mimwrite(f"{kind}_{i}.mp4", frames, fps=fps,
+        quality=8)``.  As in the reference an empty renderer only warns."""
+        if len(self.images) == 0:
+            print("Warning: Cannot generate video for all rendered images, data is empty.")
+            return False
+        if writer is None:
+            raise NotImplementedError("pass writer=...: video encoding (imageio) is outside the MI355X hot path")
+        writer("color", self.save_count, self.images, self.fps)
+        writer("depth", self.save_count, self.depths, self.fps)
+        self.save_count += 1
+        return True

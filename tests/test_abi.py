@@ -181,4 +181,4 @@ def test_render_workspace_query_and_argument_errors(lib):
     assert lib.stnerf_render_workspace_bytes(1000, 3, 64, 64, 1) < nb
     assert lib.stnerf_render_workspace_bytes(10, 99, 64, 64, 0) == hip.EINVAL
     null = C.c_void_p(0)
-    assert lib.stnerf_render_rays(null, 4, null, 0, None, None, null, null, null, 0, null, null, null, null, null, null) == hip.EINVAL
+    assert lib.stnerf_render_rays(null, 4, null, 0, None, None, null, null, null, 0, null, null, null, null, null, null, null) == hip.EINVAL

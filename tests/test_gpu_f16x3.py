@@ -125,3 +125,48 @@ def test_c2_full_view_fp16x3_agrees_with_fp32():
     quality = float(-10 * torch.log10(torch.mean((a - b) ** 2)))
     print(f"fp16x3 vs fp32 at C2: {100 * frac:.3f} % of pixels within {R.COLOR_ATOL}, PSNR {quality:.1f} dB, max {float(per_pix.max()):.2e}")
     assert frac >= 0.99 and quality >= 70.0     # two fp32-accurate evaluations of one view (mostly background rays)
+
+
+def test_f16x3_range_guard_flags_overflow_and_the_model_falls_back_to_f32(ops):
+    """An activation beyond the fp16 range (>= 65520) becomes inf in the hi/lo split.  The kernels track the largest
+    activation they split and raise a device flag; LayeredRFRender re-runs the launch in exact f32."""
+    import test_gpu_render as R
+    rs = np.random.RandomState(3)
+    sd = syn.spacenet_state("net", rs, False)
+    for k in ("net.stage1.2.weight", "net.stage1.4.weight"):           # |W| stays < 234, activations reach ~1e5 .. 1e6
+        sd[k] = sd[k] * 1500.0
+    n, s = 300, 8
+    pos = (torch.rand(n, s, 3) - 0.5) * 4.0
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
+    ref_rgb, ref_sig = O.space_net(sd, "net", pos, dirs)
+    assert bool(torch.isfinite(ref_sig).all()), "the f32 network itself must be fine"
+    net = ops.pack_spacenet(sd, "net", precision="fp16x3")
+    raw = torch.empty(n, s, 4, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.spacenet_fwd(net, dev(pos), dev(dirs), None, raw, overflow=flag)
+    # the damage is SILENT without the flag: inf - inf = NaN in the next layer's products, which that layer's integer ReLU
+    # flushes to 0 -- finite, wrong outputs
+    assert int(flag.item()) == 1
+    assert float((raw[..., 3:].cpu() - ref_sig).abs().max()) > 0.5 * float(ref_sig.abs().max()) and bool(torch.isfinite(raw).all())
+    # a well-scaled network leaves the flag alone
+    ok = ops.pack_spacenet(syn.spacenet_state("net", np.random.RandomState(3), False), "net", precision="fp16x3")
+    flag.zero_()
+    ops.spacenet_fwd(ok, dev(pos), dev(dirs), None, raw, overflow=flag)
+    assert int(flag.item()) == 0 and bool(torch.isfinite(raw).all())
+    # whole path: a model whose background net overflows in fp16x3 renders exactly what the f32 mode renders
+    meta = dict(L=1, n1=12, n2=6, space_time=True, deform_time=False, weight_seed=77, edit={})
+    model = R.build_model(meta)
+    with torch.no_grad():
+        for name in ("stage1", ):
+            getattr(model.bkgd_spacenet, name)[2].weight.mul_(1500.0)
+            getattr(model.bkgd_spacenet, name)[4].weight.mul_(1500.0)
+    K, T = syn.camera(20, 32, 9.0)
+    rays = ops.generate_rays(K, T, 20, 32, frame_ids=[1.0, 2.5])
+    model.seed = 4
+    with torch.no_grad():
+        want = model(rays, None, None)
+        model.set_precision("fp16x3")
+        model.f16_fallbacks = 0
+        got = model(rays, None, None)
+    assert model.f16_fallbacks == 1 and model.bkgd_spacenet.precision == "fp16x3"
+    assert torch.equal(got[0][0], want[0][0]) and torch.equal(got[1][0], want[1][0]) and bool(torch.isfinite(got[0][0]).all())

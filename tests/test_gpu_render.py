@@ -476,3 +476,15 @@ def test_user_facing_render_path_runs_the_demo_flow():
     assert not torch.equal(images[0], images[2])                 # the camera actually moved
     assert len(r.images_layer[1]) == 3 and r.image_num == 3
     assert model.alpha == pytest.approx(0.3)                     # last frame of the alpha schedule was poked
+    # the walking demo's loop (occlusion composite of layer 2 over the background, :550-618) and the video hook (:624-637)
+    r.render_path_walking(density_threshold=0.01)
+    assert len(r.images_hide) == 3 and r.images_hide[0].shape == (h, w, 3)
+    cl0, cl2 = r.images_layer[0][1], r.images_layer[2][1]
+    dl0, dl2 = r.depths_layer[0][1], r.depths_layer[2][1]
+    want = cl0.clone()
+    idx = torch.logical_and(torch.cat([dl2 < dl0] * 3, 2), cl2 != 0)
+    want[idx] = cl2[idx]
+    assert torch.equal(r.images_hide[1], want)
+    written = []
+    assert r.save_video(lambda kind, i, frames, fps: written.append((kind, i, len(frames), fps))) is True
+    assert written == [("color", 0, 3, 25), ("depth", 0, 3, 25)] and r.save_count == 1

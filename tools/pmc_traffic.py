@@ -13,7 +13,7 @@ import json
 import sqlite3
 
 KERNELS = {"spacenet": "%spacenet_kernel%", "motionnet": "%motionnet_kernel%", "mlp_stage": "%mlp_stage_kernel%",
-           "composite": "%composite_kernel%", "resample": "%resample_kernel%", "sample_coarse": "%sample_coarse_kernel%"}
+           "composite": "%composite%kernel%", "resample": "%resample_kernel%", "sample_coarse": "%sample_coarse_kernel%"}
 
 
 def total(path, counter, like):
