@@ -157,13 +157,17 @@ def _oracle_ray_window(O, K, T, H, W, first, n):
     return part[first - rows0 * W: first - rows0 * W + n]
 
 
-def cpu_baseline(workload, budget_rays):
+def cpu_baseline(workload, budget_rays, threads=0):
     """The CPU oracle (a restatement of the reference algorithm, oracle/stnerf_oracle.py) timed on this box's host
     cores on a bounded sample of the same workload: whole 3584-ray reference chunks spread
     evenly over the image height -- border rows see the background only, centre rows hit the performers -- each
     timed on its own; `value` = rays of all chunks / their total time = the whole-frame rate they extrapolate to."""
     import platform
     from oracle import stnerf_oracle as O
+    # a fair CPU figure needs a sensible thread count: on the 2 x 64-core host of the MI355X box the chunk-sized GEMMs of
+    # the reference peak at 32 threads (555 rays/s) and lose more than half of that at torch's default of 128
+    # (tools/cpu_threads_probe.py, profiles/r02_cpu_threads_probe.md)
+    torch.set_num_threads(threads if threads > 0 else min(32, os.cpu_count() or 1))
     H, W, L, n1, n2, st, dt = WORKLOADS[workload]
     K, T = syn.camera(H, W, 10.0)
     bk, per = syn.scene_boxes(L)
@@ -265,6 +269,7 @@ def main():
     ap.add_argument("--workload", default="taekwondo-1080p-64+64", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-baseline-rays", type=int, default=8 * 3584,
                     help="0 disables the CPU baseline leg; default = 8 reference chunks spread over the image (BASELINE.md 3.3)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline leg (0 = min(32, host cores))")
     ap.add_argument("--rays-per-launch", type=int, default=1 << 19)
     ap.add_argument("--partition", default=None, choices=["views", "stripes"],
                     help="N>1 headline: 'stripes' (default) = ONE view per step in interleaved row stripes over the GPUs "
@@ -522,7 +527,7 @@ def main():
         if world == 1 and args.eager_gpu_baseline_rays > 0:
             rec["eager_gpu_baseline"] = eager_gpu_baseline(args.workload, args.eager_gpu_baseline_rays, device)
         if world == 1 and args.cpu_baseline_rays > 0:
-            rec["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline_rays)
+            rec["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline_rays, args.cpu_threads)
         else:
             rec["cpu_baseline"] = None
         print(json.dumps(rec))
