@@ -23,6 +23,19 @@
 
 namespace stnerf {
 
+// Optional per-phase cycle accounting of composite_kernel (development builds: -DSTNERF_COMP_PROF): every wave adds its
+// s_memtime deltas per phase; read back with stnerf_debug_composite_phases().
+#ifdef STNERF_COMP_PROF
+static __device__ unsigned long long g_cphase[8];
+#define CP_DECL unsigned long long cp_t = clock64(), cp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define CP(i) do { const unsigned long long n_ = clock64(); cp_acc[i] += n_ - cp_t; cp_t = n_; } while (0)
+#define CP_FLUSH do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_cphase[i_], cp_acc[i_]); } while (0)
+#else
+#define CP_DECL
+#define CP(i) do { } while (0)
+#define CP_FLUSH do { } while (0)
+#endif
+
 // ---- wave64 cross-lane primitives on DPP (gfx9 row_shr / row_bcast / wave_shr controls: one VALU op per
 // scan step, no LDS crossbar traffic; ds_bpermute-based __shfl_up costs ~5 instructions per step).
 template <int CTRL, int ROW_MASK = 0xf>
@@ -335,6 +348,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) 
         return v;
     };
     int flags_next = ray_flags((int64_t)blockIdx.x * a.waves_per_block + wave);
+    CP_DECL
     for (int64_t ray0 = (int64_t)blockIdx.x * a.waves_per_block; ray0 < a.n; ray0 += rays_per_iter) {
         const int64_t ray = ray0 + wave;
         const unsigned long long fb = __ballot(flags_next != 0);
@@ -342,6 +356,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) 
         const unsigned mask_bits = (unsigned)fb;
         const bool active = ray < a.n && !(fb >> 63 & 1ull);
         int n_merged = 0;
+        CP(0);
         // ---- stage the ray, applying the post-network density edits (a10); layer-major so every edit
         // switch is wave-uniform.
         // A layer the ray misses altogether (not evaluated, every t == -1000: bin width 0 from start = end = -1000,
@@ -374,6 +389,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) 
                 if (have) have_m |= 1u << layer;
             }
         }
+        CP(1);
         // ---- ONE live layer (about half the rays of a view: the background alone): composite it straight from
         // registers -- no LDS staging, no merge; the mix is that layer's composite (same samples, deltas, arithmetic)
         // unless the fine stage's `t < near` cut bites, which costs a second pass over the registers.
@@ -446,6 +462,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) 
                 done = true;
             }
         }
+        CP(2);
         // ---- general path: stage the ray in LDS, applying the post-network density edits (a10); layer-major so
         // every edit switch is wave-uniform.
         if (active && !done) {
@@ -498,6 +515,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) 
             }
         }
         wave_sync();
+        CP(3);
         // ---- per-layer composites (:435-444 / :598-603)
         bool merged_done = false, unsorted_any = false;
         unsigned reversed_all = 0;
@@ -538,6 +556,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) 
                     merged_done = !a.p.fine || !(tl[0] < a.p.near);
                 }
             }
+            CP(4);
             const bool sorted_ok = !unsorted;  // (wave-uniform)
             unsorted_any = unsorted;
             reversed_all = reversed;
@@ -586,6 +605,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) 
             }
         }
         wave_sync();
+        CP(5);
         // ---- merged composite (:448 / :605-606)
         if (active && !done && !merged_done && a.mixed_out) {
             float o5[5];
@@ -604,6 +624,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) 
                 a.mixed_out[ray * 5 + lane] = v;
             }
         }
+        CP(6);
         // ---- optional parity output: torch.sort's index over ALL l * S samples (the composites above leave the
         // layers a ray misses out; their samples, t = -1000, sort in front of everything and carry no weight)
         if (active && a.order) {
@@ -637,6 +658,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) 
         }
         wave_sync();
     }
+    CP_FLUSH;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -992,6 +1014,17 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_RESAMPLE, 8))) r
 }  // namespace stnerf
 
 using namespace stnerf;
+
+#ifdef STNERF_COMP_PROF
+extern "C" int stnerf_debug_composite_phases(unsigned long long* host8, int reset) {
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_cphase), sizeof(unsigned long long) * 8) != hipSuccess) return STNERF_ELAUNCH;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_cphase), z, sizeof(z)) != hipSuccess) return STNERF_ELAUNCH;
+    }
+    return STNERF_OK;
+}
+#endif
 
 extern "C" int stnerf_gen_weight(const float* sigma, const float* delta, int64_t n, int S, float* weights,
                                  stnerf_stream_t stream) {
