@@ -65,13 +65,24 @@ __device__ __forceinline__ float wave_scan_add(float v) {  // inclusive
     return v;
 }
 
-// Inclusive add-scan in fp64 (cdf accumulation of the resampler, see resample_kernel).
+// Inclusive add-scan in fp64 (cdf accumulation of the resampler, see resample_kernel): the same DPP ladder as the fp32
+// scans, moving the two halves of the double separately (2 DPP moves + one v_add_f64 per step; a __shfl_up of a double
+// is two ds_bpermute round trips per step).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_move_f64(double v) {  // lanes the control leaves out receive +0.0
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_scan_add_f64(double v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double up = __shfl_up(v, o);
-        if (lane >= o) v += up;
-    }
+    (void)lane;
+    v += dpp_move_f64<DPP_ROW_SHR1>(v);
+    v += dpp_move_f64<DPP_ROW_SHR2>(v);
+    v += dpp_move_f64<DPP_ROW_SHR4>(v);
+    v += dpp_move_f64<DPP_ROW_SHR8>(v);
+    v += dpp_move_f64<DPP_ROW_BCAST15, 0xa>(v);
+    v += dpp_move_f64<DPP_ROW_BCAST31, 0xc>(v);
     return v;
 }
 
@@ -887,7 +898,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_RESAMPLE, 8))) r
                 const double pdf = (k < n1 - 2) ? (double)(wv[k] / total) : 0.0;
                 const double incl = wave_scan_add_f64(pdf, lane);
                 if (k < n1 - 2) cdf[k + 1] = (float)(carry + incl);
-                carry = carry + __shfl(incl, 63);
+                carry = carry + __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(incl) >> 32), 63) << 32) |
+                                                     (unsigned int)__builtin_amdgcn_readlane((int)(__double_as_longlong(incl) & 0xffffffffll), 63));
             }
         }
         wave_sync();
