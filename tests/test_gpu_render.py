@@ -304,6 +304,7 @@ def _oracle_model(meta, sd):
 @pytest.mark.parametrize("cfg_name, meta", [
     ("C2: 512x512, L=1, 64+64", dict(L=1, n1=64, n2=64, space_time=True, deform_time=False, weight_seed=40, edit={}, H=512, W=512)),
     ("C3: 1080p, L=2, 64+64", dict(L=2, n1=64, n2=64, space_time=True, deform_time=True, weight_seed=41, edit={}, H=1080, W=1920)),
+    ("C4: 1080p, L=4, 64+64, deformation only", dict(L=4, n1=64, n2=64, space_time=False, deform_time=True, weight_seed=42, edit={}, H=1080, W=1920)),
 ])
 def test_full_sample_counts_on_a_ray_subset_match_the_oracle(cfg_name, meta):
     """The real sample counts of C2 / C3 on 768 rays spread over the view (what the oracle finishes in seconds)."""
