@@ -433,7 +433,8 @@ def main():
         # of the same command (profiles/), per launch, with the gfx950 FETCH_SIZE correction applied.
         pmc = json.load(open(PMC_TRAFFIC_JSON)) if os.path.exists(PMC_TRAFFIC_JSON) else {}
         pmc_ok = pmc.get("workload") == args.workload and world == 1
-        traffic = pmc["kernels"]["spacenet"]["hbm_bytes_per_launch"] if pmc_ok and "spacenet" in pmc.get("kernels", {}) else None
+        dom = "mlp_stage" if "mlp_stage" in ksum else "spacenet"
+        traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"] if pmc_ok and dom in pmc.get("kernels", {}) else None
         measured = json.load(open(MEASURED_HBM_JSON)) if os.path.exists(MEASURED_HBM_JSON) else {}
         hbm_meas = {"composite": measured.get("read_GBps"), "resample": measured.get("copy_GBps"),
                     "sample_coarse": measured.get("write_GBps")}

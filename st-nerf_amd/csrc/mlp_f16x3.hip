@@ -219,16 +219,17 @@ __device__ __forceinline__ void mma_segment_h(f32x16 (&acc)[NFB][NSB], const hal
 // One dense layer: out = relu(W in + b) for this wave's NFB*32 features x NSB*32 samples, written back as
 // hi/lo fp16 planes.  Accumulators carry the 2^8 weight scale: C starts at 2^8 * bias, the epilogue
 // multiplies by 2^-8 (exact).
-// Returns the largest activation this lane wrote: one beyond the fp16 range (>= 65520) turns into inf in the split (and the
-// NaNs that follow are flushed to 0 by the integer ReLU of the next layer: silently wrong, finite pixels), so the
-// kernels raise the caller's overflow flag when it is seen.
+// Range guard: an activation beyond the fp16 range (>= 65520) turns into inf in the split (and the NaNs that follow are
+// flushed to 0 by the integer ReLU of the next layer: silently wrong, finite pixels), so the epilogue tracks the largest
+// value it splits and raises the caller's `overflow` flag right there (nothing is kept live across layers: carrying
+// a running maximum through the kernel cost 130+ VGPR spills).
 template <int TM, int NFB, int NSB, int NFB_NEXT>
-__device__ __forceinline__ float dense_layer_h(const half8* __restrict__ whi, const half8* __restrict__ wlo, int n_total,
+__device__ __forceinline__ void dense_layer_h(const half8* __restrict__ whi, const half8* __restrict__ wlo, int n_total,
                                               const half8* inA_hi, const half8* inA_lo, int octA, const half8* inB_hi,
                                               const half8* inB_lo, int octB, half8* out_hi, half8* out_lo, int n0,
                                               int sb0, int lane, const HFrag<NFB>& wfirst, const half8* next_hi,
                                               const half8* next_lo, const float* next_lane_bias,
-                                              HFrag<NFB_NEXT>& wnext PH_PARAMS) {
+                                              HFrag<NFB_NEXT>& wnext, uint32_t* overflow PH_PARAMS) {
     const int h = lane >> 5, c = lane & 31;
     const int s0 = sb0 * 32 + c;
     f32x16 cinit[NFB];
@@ -264,7 +265,8 @@ __device__ __forceinline__ float dense_layer_h(const half8* __restrict__ whi, co
     PH(PH_BAR1);
     _Float16* oh = reinterpret_cast<_Float16*>(out_hi);
     _Float16* ol = reinterpret_cast<_Float16*>(out_lo);
-    float vmax = 0.f;
+    int vmax_bits = 0;  // max over the RAW accumulator bit patterns: negative floats are negative ints (the ReLU for free), a
+                        // positive NaN beats every finite value; one v_max3_i32 per two values
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb) {
 #pragma unroll
@@ -274,9 +276,14 @@ __device__ __forceinline__ float dense_layer_h(const half8* __restrict__ whi, co
             for (int sb = 0; sb < NSB; ++sb) {
                 half4 vh, vl;
 #pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const int b0 = __float_as_int(acc[fb][sb][4 * q + r]), b1 = __float_as_int(acc[fb][sb][4 * q + r + 1]);
+                    const int m01 = b0 > b1 ? b0 : b1;
+                    vmax_bits = vmax_bits > m01 ? vmax_bits : m01;
+                }
+#pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = relu_bits(acc[fb][sb][4 * q + r]) * WSCALE_INV;
-                    vmax = fmaxf(vmax, v);
                     _Float16 a_, b_;
                     split_f16(v, a_, b_);
                     vh[r] = a_;
@@ -288,8 +295,8 @@ __device__ __forceinline__ float dense_layer_h(const half8* __restrict__ whi, co
             }
         }
     }
+    if (overflow && vmax_bits >= __float_as_int(65520.f * WSCALE)) atomicOr(overflow, 1u);  // (accumulators carry the 2^8 weight scale)
     PH(PH_EPI);
-    return vmax;
 }
 
 // feature f of tile sample s in a plane: element ((f>>3)*TM + s)*8 + (f&7)
@@ -320,12 +327,12 @@ __device__ __forceinline__ void head_partial_h(const half8* act_hi, const half8*
 }
 
 #define DENSE_H(TM_, NW_, N_, NN_, LI_, INA_, OCTA_, INB_, OCTB_, WFIRST_, LNEXT_, WNEXT_)                              \
-    amax = fmaxf(amax, dense_layer_h<TM_, WaveSplit<TM_, NW_, N_>::NFB, WaveSplit<TM_, NW_, N_>::NSB, WaveSplit<TM_, NW_, NN_>::NFB>(      \
+    dense_layer_h<TM_, WaveSplit<TM_, NW_, N_>::NFB, WaveSplit<TM_, NW_, N_>::NSB, WaveSplit<TM_, NW_, NN_>::NFB>(      \
         hreg + L.whi[LI_], hreg + L.wlo[LI_], N_, INA_##_hi, INA_##_lo, OCTA_, INB_##_hi, INB_##_lo, OCTB_, act_hi,     \
         act_lo, WaveSplit<TM_, NW_, N_>::n0(wave), WaveSplit<TM_, NW_, N_>::sb0(wave), lane, WFIRST_,                   \
         hweight_lane_ptr(hreg + L.whi[LNEXT_], NN_, WaveSplit<TM_, NW_, NN_>::n0(wave), lane),                          \
         hweight_lane_ptr(hreg + L.wlo[LNEXT_], NN_, WaveSplit<TM_, NW_, NN_>::n0(wave), lane),                          \
-        net + BIAS_OFF(LNEXT_) + WaveSplit<TM_, NW_, NN_>::n0(wave) + 4 * (lane >> 5), WNEXT_ PH_ARGS))
+        net + BIAS_OFF(LNEXT_) + WaveSplit<TM_, NW_, NN_>::n0(wave) + 4 * (lane >> 5), WNEXT_, a.overflow PH_ARGS)
 
 // ---------------------------------------------------------------------------------------------
 // SpaceNet
@@ -353,7 +360,6 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_h_
     const int64_t rows = worklist_rows(a.wl);
     const int ns = a.wl.ns;
     PH_DECL
-    float amax = 0.f;  // largest activation this lane has split into fp16 planes (range guard)
     const half8* hreg0 = reinterpret_cast<const half8*>(a.net + L.f32.total);
     HFrag<WaveSplit<TM, NW, 256>::NFB> wA, wB;
     HFrag<WaveSplit<TM, NW, 128>::NFB> wR, wR2;
@@ -516,7 +522,6 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_h_
         __syncthreads();
         PH(PH_HEAD);
     }
-    if (a.overflow && amax >= 65520.f) atomicOr(a.overflow, 1u);  // (once per lane per launch, and only when it happened)
     PH_FLUSH;
 #undef BIAS_OFF
 }
@@ -528,12 +533,12 @@ template <int TM, int NW>
 constexpr int motion_h_lds_bytes() { return 16 * 2 * TM * 16 + 3 * NW * 64 * 4; }
 
 #define DENSE_HM(TM_, NW_, LI_, INA_, OCTA_, WFIRST_, LNEXT_, WNEXT_)                                                   \
-    amax = fmaxf(amax, dense_layer_h<TM_, WaveSplit<TM_, NW_, 128>::NFB, WaveSplit<TM_, NW_, 128>::NSB, WaveSplit<TM_, NW_, 128>::NFB>(    \
+    dense_layer_h<TM_, WaveSplit<TM_, NW_, 128>::NFB, WaveSplit<TM_, NW_, 128>::NSB, WaveSplit<TM_, NW_, 128>::NFB>(    \
         hreg + L.whi[LI_], hreg + L.wlo[LI_], 128, INA_##_hi, INA_##_lo, OCTA_, null_hi, null_lo, 0, act_hi, act_lo,    \
         WaveSplit<TM_, NW_, 128>::n0(wave), WaveSplit<TM_, NW_, 128>::sb0(wave), lane, WFIRST_,                         \
         hweight_lane_ptr(hreg + L.whi[LNEXT_], 128, WaveSplit<TM_, NW_, 128>::n0(wave), lane),                          \
         hweight_lane_ptr(hreg + L.wlo[LNEXT_], 128, WaveSplit<TM_, NW_, 128>::n0(wave), lane),                          \
-        net + L.f32.b[LNEXT_] + WaveSplit<TM_, NW_, 128>::n0(wave) + 4 * (lane >> 5), WNEXT_ PH_ARGS))
+        net + L.f32.b[LNEXT_] + WaveSplit<TM_, NW_, 128>::n0(wave) + 4 * (lane >> 5), WNEXT_, a.overflow PH_ARGS)
 
 template <int TM, int NW>
 __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_h_kernel(MotionArgs a) {
@@ -556,7 +561,6 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_h
     const int64_t rows = worklist_rows(a.wl);
     const int ns = a.wl.ns;
     PH_DECL
-    float amax = 0.f;  // largest activation this lane has split into fp16 planes (range guard)
     const half8* hreg0 = reinterpret_cast<const half8*>(a.net + L.f32.total);
     HFrag<WaveSplit<TM, NW, 128>::NFB> wA, wB;
     load_hfrag(wA, hweight_lane_ptr(hreg0 + L.whi[0], 128, WaveSplit<TM, NW, 128>::n0(wave), lane),
@@ -668,7 +672,6 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void motionnet_h
         }
         __syncthreads();
     }
-    if (a.overflow && amax >= 65520.f) atomicOr(a.overflow, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
