@@ -110,7 +110,9 @@ __device__ __forceinline__ float aten_cpu_row_sum(const float* x, int n, int lan
     const int nv = n >> 3, rows = nv >> 2, j = lane & 7;  // lanes 8.. repeat column lane & 7 (uniform control flow)
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
     int i = 0;
+#pragma unroll 1
     for (; i + 16 <= rows;) {  // cascade level 1: every 16 rows the running accumulators are folded away
+#pragma unroll 1
         for (int r = 0; r < 16; ++r, ++i) {
             a0 += x[(4 * i + 0) * 8 + j];
             a1 += x[(4 * i + 1) * 8 + j];
@@ -120,6 +122,7 @@ __device__ __forceinline__ float aten_cpu_row_sum(const float* x, int n, int lan
         b0 += a0; b1 += a1; b2 += a2; b3 += a3;
         a0 = a1 = a2 = a3 = 0.f;
     }
+#pragma unroll 1
     for (; i < rows; ++i) {
         a0 += x[(4 * i + 0) * 8 + j];
         a1 += x[(4 * i + 1) * 8 + j];
@@ -127,9 +130,11 @@ __device__ __forceinline__ float aten_cpu_row_sum(const float* x, int n, int lan
         a3 += x[(4 * i + 3) * 8 + j];
     }
     a0 += b0; a1 += b1; a2 += b2; a3 += b3;  // (levels 2 and 3 stay zero below 256 rows = 8192 elements)
+#pragma unroll 1
     for (int v = rows * 4; v < nv; ++v) a0 += x[v * 8 + j];
     const float col = ((a0 + a1) + a2) + a3;
     float fin = 0.f;
+#pragma unroll 1
     for (int k = nv * 8; k < n; ++k) fin += x[k];
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) fin += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(col), jj));
@@ -335,7 +340,10 @@ struct CompositeArgs {
     uint8_t* handled;  // [n] or nullptr: rays composite_single_kernel has already finished (it writes 0 / 1 for every ray)
 };
 
-__global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) composite_kernel(CompositeArgs a) {
+// FASTPATH: also composite rays with one live layer from registers (the kernel then serves every ray on its own: callers
+// without scratch); without it the kernel is the lean second pass behind composite_single_kernel (58 VGPRs: 8 waves per SIMD).
+template <bool FASTPATH>
+__global__ void __attribute__((amdgpu_waves_per_eu(FASTPATH ? STNERF_WAVES_COMPOSITE : 8, 8))) composite_kernel(CompositeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -406,7 +414,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) 
         // unless the fine stage's `t < near` cut bites, which costs a second pass over the registers.
         bool done = false;
         constexpr int MAXB = 3;
-        if (active && __popc(live) == 1 && a.S <= 64 * MAXB) {
+        if (FASTPATH && active && __popc(live) == 1 && a.S <= 64 * MAXB) {
             const int layer = __ffs(live) - 1;
             const bool have = (have_m >> layer & 1u) != 0;
             const bool cut_neg = !a.p.fine && a.p.cut_negative_t && layer > 0;
@@ -1063,8 +1071,10 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
     STNERF_REQUIRE(wpb >= 1, "composite: %d samples per ray do not fit the 160 KiB LDS", l * S);
     if (wpb > 4) wpb = 4;
     const int lds = (int)(per_wave * wpb);
-    if (lds > 64 * 1024)
-        if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(composite_kernel), lds, "composite")) return rc;
+    if (lds > 64 * 1024) {
+        if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(composite_kernel<true>), lds, "composite")) return rc;
+        if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(composite_kernel<false>), lds, "composite")) return rc;
+    }
     CompositeArgs a{t, reinterpret_cast<const float4*>(raw), mask, n, l, S, *params_host, layer_out, mixed_out,
                     weights, order, wpb, floor_pow2(S), nullptr};
     LaunchTimer timer(PROF_COMPOSITE, 0, n, S,
@@ -1083,7 +1093,10 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
     }
     int64_t blocks = (n + wpb - 1) / wpb;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(wpb * 64), lds, as_stream(stream), a);
+    if (a.handled)
+        hipLaunchKernelGGL(composite_kernel<false>, dim3((unsigned)blocks), dim3(wpb * 64), lds, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(composite_kernel<true>, dim3((unsigned)blocks), dim3(wpb * 64), lds, as_stream(stream), a);
     STNERF_CHECK_LAUNCH("composite");
     return STNERF_OK;
 }
