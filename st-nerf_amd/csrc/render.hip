@@ -18,7 +18,7 @@
 #define STNERF_WAVES_SINGLE 6
 #endif
 #ifndef STNERF_WAVES_RESAMPLE
-#define STNERF_WAVES_RESAMPLE 6
+#define STNERF_WAVES_RESAMPLE 8
 #endif
 
 namespace stnerf {
@@ -346,7 +346,7 @@ template <bool FASTPATH>
 __global__ void __attribute__((amdgpu_waves_per_eu(FASTPATH ? STNERF_WAVES_COMPOSITE : 8, 8))) composite_kernel(CompositeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (uniform: ray index and addresses on the scalar unit)
     const int LS = a.l * a.S;
     // per-wave LDS: raws[LS] float4 | ts[LS] float | mord[LS] u16 (merged position -> source sample), 16-B rounded
     const int per_wave = ((LS * 22 + 15) / 16) * 16;
@@ -702,7 +702,7 @@ template <int MAXB, int MAXCHK>
 __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_SINGLE, 8))) composite_single_kernel(CompositeArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t first = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t first = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int LS = a.l * a.S, B = (a.S + 63) >> 6;
     unsigned ev1 = 0, ev2 = 0;
     for (int i = 0; i < a.l; ++i) {
@@ -843,7 +843,8 @@ struct ResampleArgs {
 __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_RESAMPLE, 8))) resample_kernel(ResampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: the pair index, its 64-bit divisions and
+                                                                        // the RNG key of the pair stay on the scalar unit
     const int n1 = a.n1, n2 = a.n2, S = n1 + n2, nb = n1 - 1;  // nb = #bins = len(cdf)
     float* mine = reinterpret_cast<float*>(smem_raw) + (size_t)wave * (4 * n1 + n2 + S);
     float* tc = mine;          // [n1]  coarse depths
@@ -919,10 +920,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_RESAMPLE, 8))) r
         wave_sync();
         // ---- invert the cdf (sample_pdf.py:44-61)
         if (active) {
+            const uint64_t gray = a.u ? 0ull : (uint64_t)global_ray(a.win, ray);  // (wave-uniform)
             for (int j = lane; j < n2; j += 64) {
                 const float u = a.u ? a.u[((int64_t)layer * a.n + ray) * n2 + j]
-                                    : philox_uniform(a.seed, (uint64_t)global_ray(a.win, ray), (uint32_t)layer, 1u,
-                                                     (uint32_t)j);
+                                    : philox_uniform(a.seed, gray, (uint32_t)layer, 1u, (uint32_t)j);
                 const int ind = upper_bound_lds(cdf, nb, p2_nb, u);   // searchsorted(right=True)
                 const int below = ind - 1 > 0 ? ind - 1 : 0;
                 const int above = ind < nb - 1 ? ind : nb - 1;
