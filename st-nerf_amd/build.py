@@ -9,7 +9,11 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
-LIB = os.path.join(PKG, "libstnerf_hip.so")
+# STNERF_LIB_TAG (development): build a variant beside the product library, e.g. STNERF_LIB_TAG=dbg
+# STNERF_EXTRA_FLAGS=-DSTNERF_WAVE_DEBUG -> libstnerf_hip_dbg.so (objects under build_dbg/); load it with STNERF_LIB=<path>.
+TAG = os.environ.get("STNERF_LIB_TAG", "")
+LIB = os.path.join(PKG, "libstnerf_hip%s.so" % ("_" + TAG if TAG else ""))
+OBJDIR = os.path.join(PKG, "build" + ("_" + TAG if TAG else ""))
 
 # (source, extra flags).  The sampler/compositor set is compiled with contraction OFF so that its
 # elementwise arithmetic is bit-identical to the reference's ATen CPU ops (no implicit FMA).
@@ -19,6 +23,9 @@ SOURCES = [
     ("render.hip", ["-ffp-contract=off"]),
     ("mlp.hip", []),
     ("mlp_stage.hip", []),
+    # VGPR-form MFMA: accumulators in arch VGPRs (the bias loads land in them directly, the ReLU reads them without a
+    # v_accvgpr_read), the read-only activations in AGPRs
+    ("mlp_wave.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
     ("mlp_f16x3.hip", []),
     ("pipeline.hip", []),
 ]
@@ -46,12 +53,12 @@ def build(force=False, verbose=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(REPO, "include", "stnerf.h"))
     objs = []
-    os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
     for src, extra in SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             continue
-        obj = os.path.join(PKG, "build", src.replace(".hip", ".o"))
+        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         if force or _stale(obj, [sp] + headers + [os.path.abspath(__file__)]):
             cmd = [hipcc] + COMMON + extra + ["-c", sp, "-o", obj]
             if verbose:

@@ -16,9 +16,14 @@
 //     bit-identical to stnerf_motionnet_fwd followed by stnerf_spacenet_fwd (tests/test_gpu_ops.py).
 //
 // Reference: modeling/spacenet.py:16-160, modeling/motion_net.py:7-71, modeling/layered_rfrender.py:340-418,495-576.
+#include <stdlib.h>
 #include <string.h>
 
-#include "mlp_blocks.h"
+#include "mlp_stage.h"
+
+#ifndef STNERF_STAGE_KERNEL_DEFAULT
+#define STNERF_STAGE_KERNEL_DEFAULT STAGE_KERNEL_LDS
+#endif
 
 namespace stnerf {
 
@@ -27,28 +32,6 @@ constexpr int ST_MTM = 256;       // MotionNet tile = two SpaceNet tiles
 constexpr int ST_NW = 8;
 constexpr int ST_THREADS = ST_NW * 64;
 constexpr int ST_LDS = (64 + 16) * ST_TM * 16;   // act [64][128] float4 + enc [16][128] float4 = 160 KiB
-
-struct StageLayer {
-    const float* space;        // packed SpaceNet
-    const float* motion;       // packed MotionNet or nullptr
-    const int32_t* ray_list;   // compacted hit rays or nullptr (every ray)
-    const int32_t* ray_count;
-    const float* xyz;          // this layer's sample points (ray stride StageArgs::xyz_ray_stride)
-    float* raw;                // this layer's {r,g,b,sigma} (ray stride StageArgs::raw_ray_stride)
-    const float* times;        // this layer's frame-id column or nullptr
-    int32_t use_time;          // the SpaceNet takes the time encoding
-    int32_t motion_flags;      // STNERF_MOTION_PLAIN_TIME
-};
-
-struct StageArgs {
-    StageLayer layer[STNERF_MAX_LAYERS];
-    int32_t n_layers, ns;
-    int64_t n_rays;
-    int64_t xyz_ray_stride, raw_ray_stride, dirs_ray_stride, times_ray_stride;
-    const float* dirs;
-    uint32_t* queue;           // one counter, zero at launch
-    int32_t sigmoid_rgb;       // store sigmoid(rgb) (layers/render_layer.py:47) instead of the raw colour output
-};
 
 // First layer of whatever network runs next on this workgroup (its step-0 weights and bias are fetched during the
 // current network's last layer).
@@ -298,31 +281,6 @@ __device__ __forceinline__ void motion_tile(const float* net_in, float4* act, fl
     __syncthreads();
 }
 
-// rows of a layer = hit rays x samples per ray
-__device__ __forceinline__ int64_t layer_rows(const StageLayer& ly, int64_t n_rays, int ns) {
-    int64_t cnt = n_rays;
-    if (ly.ray_count) {
-        const int64_t c = *ly.ray_count;
-        cnt = c < cnt ? c : cnt;
-    }
-    return cnt * ns;
-}
-
-struct RowRef {
-    int64_t ray;
-    int k;
-    bool valid;
-};
-__device__ __forceinline__ RowRef locate_row(const int32_t* ray_list, int64_t row, int64_t rows, int ns) {
-    RowRef r{0, 0, row < rows};
-    if (r.valid) {
-        const int64_t slot = row / ns;
-        r.k = (int)(row - slot * ns);
-        r.ray = ray_list ? (int64_t)ray_list[slot] : slot;
-    }
-    return r;
-}
-
 template <bool DEEP>
 __global__ __launch_bounds__(ST_THREADS, 2) void mlp_stage_kernel(StageArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
@@ -489,6 +447,19 @@ __global__ __launch_bounds__(ST_THREADS, 2) void mlp_stage_kernel(StageArgs a) {
 
 using namespace stnerf;
 
+// Which of the two organisations runs behind stnerf_mlp_stage: STNERF_STAGE_KERNEL = "wave" (mlp_wave.hip: sample-split
+// waves, activations in registers) | "lds" (this file: feature-split waves, activations in LDS).  Read on every call so
+// that a test can compare the two inside one process; the results are bit-identical.
+namespace {
+enum { STAGE_KERNEL_LDS = 0, STAGE_KERNEL_WAVE = 1 };
+int stage_kernel_choice() {
+    const char* e = getenv("STNERF_STAGE_KERNEL");
+    if (e && !strcmp(e, "lds")) return STAGE_KERNEL_LDS;
+    if (e && !strcmp(e, "wave")) return STAGE_KERNEL_WAVE;
+    return STNERF_STAGE_KERNEL_DEFAULT;
+}
+}  // namespace
+
 // One network stage of the pipeline.  layers[i] describes slot i of the queue (heavier, deformed layers first);
 // `queue` is a zeroed uint32 on the device.  Called by stnerf_render_rays only (csrc/pipeline.hip).
 extern "C" int stnerf_mlp_stage(const stnerf_stage_layer* layers, int n_layers, int64_t n_rays, int ns, const float* dirs,
@@ -522,6 +493,7 @@ extern "C" int stnerf_mlp_stage(const stnerf_stage_layer* layers, int n_layers, 
     a.queue = queue;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (stage_kernel_choice() == STAGE_KERNEL_WAVE) return launch_wave_stage(a, deep_rgb != 0, cus, as_stream(stream));
     const int64_t max_items = ((n_rays * ns + ST_TM - 1) / ST_TM) * n_layers;
     const int grid = (int)(max_items < cus ? max_items : cus);  // one persistent workgroup per CU
     const void* kfn = deep_rgb ? reinterpret_cast<const void*>(mlp_stage_kernel<true>) : reinterpret_cast<const void*>(mlp_stage_kernel<false>);

@@ -1,0 +1,657 @@
+// Persistent stage kernel, second organisation: SAMPLE-split waves with the activations in registers.
+//
+// mlp_stage.hip splits a layer's OUTPUT FEATURES over the 8 waves of a workgroup, so every layer is an all-to-all
+// through LDS: 128 KiB of activations are written (ds_write_b128: ~79 B/clk/CU, ~1.1k cycles per layer with the matrix
+// pipe idle) and two workgroup barriers are taken per layer; that, the heads' LDS reductions and the issue slots of
+// the activation reads are the ~9 % the kernel stands below the f32 MFMA peak.  Here a wave owns 32 SAMPLES and all
+// features of a layer:
+//   * v_mfma_f32_32x32x2_f32 computed transposed (A = weights, B = activations) leaves a lane (h, c) with the
+//     output features 32 fb + 8 q + 4 h + r of sample c in accumulator register 4 q + r of block fb -- and with the
+//     k permutation the packed weights already use (lane half h takes k = 8 s + 4 h + {0..3}) that is exactly the B
+//     operand the NEXT layer needs from this lane: K step s, instruction kk reads register 4 (s & 3) + kk of block
+//     s >> 2.  The activations of the whole network therefore never leave the register file: no LDS traffic, no
+//     barrier, no epilogue stores between layers; a layer boundary is 128 ReLUs (v_max_i32) and nothing else.
+//   * 256 features x 32 samples = 128 registers in + 128 accumulators out: one wave per SIMD with the unified
+//     512-entry register file (accumulators in AGPRs), 4 waves = 128 samples per CU.
+//   * Weights: the A operand of a K step is 8 x 16 B per lane straight from the packed blob (buffer loads, SGPR
+//     offsets, one step ahead); the four waves of a CU run the same network in step, so each line comes out of L2
+//     once per CU and the other three waves hit the vector L1.
+//   * Encodings are staged through a wave-private 11 KiB LDS window (the two lanes of a sample split the frequencies,
+//     then each lane reads its half of the feature quads back) -- ordering inside a wave only, no barrier.
+//   * Heads: a lane holds every second feature quad of its sample; the partial-sum grouping of the LDS kernels
+//     (4 parts x 4 interleaved chains) is kept, the two lanes of a sample swap their chains with ds_bpermute.
+// Every output accumulates the same products in the same order as in mlp.hip / mlp_stage.hip (same instruction, same k
+// order, bias as the C operand of the first MFMA, same head grouping): results are bit-identical to those kernels
+// (tests/test_gpu_ops.py).
+//
+// Reference: modeling/spacenet.py:16-160, modeling/motion_net.py:7-71, modeling/layered_rfrender.py:340-418,495-576.
+#include <stdlib.h>
+#include <string.h>
+
+#include "mlp_stage.h"
+
+namespace stnerf {
+
+constexpr int WV_ROWS = 32;                       // samples per wave
+constexpr int WV_NW = 4;                          // waves per workgroup: one per SIMD
+constexpr int WV_THREADS = WV_NW * 64;
+constexpr int WV_ITEM = WV_NW * WV_ROWS;          // rows per work item
+constexpr int WV_ENC_QUADS = 22;                  // widest staged encoding: MotionNet's 84 (+4) features
+constexpr int WV_ENC_FLOATS = WV_ENC_QUADS * WV_ROWS * 4;
+constexpr int WV_LDS = WV_NW * WV_ENC_FLOATS * 4 + 16;
+
+// feature f of the lane's sample inside the wave-private staging window (col = window + 4 * c)
+#define ENCW(col, f) (col)[((f) >> 2) * (WV_ROWS * 4) + ((f) & 3)]
+
+// The window is private to one wave: LDS operations of a wave execute in issue order, the fences stop the compiler
+// from moving accesses across the phase boundary.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// quad rows 2 s + h, s < STEPS, of the staged encoding -> B-operand registers (block s >> 2, registers 4 (s & 3) ..)
+template <int NBLK, int STEPS>
+__device__ __forceinline__ void read_enc_blocks(const float* encw, int lane, f32x16 (&blk)[NBLK]) {
+    const float4* e4 = reinterpret_cast<const float4*>(encw);
+    const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const float4 v = e4[(2 * s + h) * WV_ROWS + c];
+        blk[s >> 2][4 * (s & 3) + 0] = v.x;
+        blk[s >> 2][4 * (s & 3) + 1] = v.y;
+        blk[s >> 2][4 * (s & 3) + 2] = v.z;
+        blk[s >> 2][4 * (s & 3) + 3] = v.w;
+    }
+}
+
+// PE_10(pos): 63 features + one zero pad (utils/dimension_kernel.py:8-33); lane half h takes the frequencies 2 i + h
+__device__ __forceinline__ void encode_pos(float* encw, int lane, const float (&p)[3]) {
+    const int h = lane >> 5, c = lane & 31;
+    float* col = encw + c * 4;
+    if (h == 0) {
+#pragma unroll
+        for (int dmn = 0; dmn < 3; ++dmn) ENCW(col, dmn) = p[dmn];
+    } else {
+        ENCW(col, 63) = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int fq = 2 * i + h;
+        const float freq = (float)(1 << fq);
+#pragma unroll
+        for (int dmn = 0; dmn < 3; ++dmn) {
+            float sn, cs;
+            sincos_pe(p[dmn] * freq, sn, cs);
+            const int fs = 3 + fq * 6 + dmn, fc = fs + 3;
+            ENCW(col, fs) = sn;
+            ENCW(col, fc) = cs;
+        }
+    }
+}
+
+// relu(PE_4(dir)) (27) and relu(PE_10(time)) (21) -> features 0..47 (modeling/spacenet.py:80-86,141-149); without the
+// time encoding features 27..31 are zero pads
+__device__ __forceinline__ void encode_dir_time(float* encw, int lane, const float (&dv)[3], float tv, bool use_time) {
+    const int h = lane >> 5, c = lane & 31;
+    float* col = encw + c * 4;
+    if (h == 0) {
+#pragma unroll
+        for (int dmn = 0; dmn < 3; ++dmn) ENCW(col, dmn) = fmaxf(dv[dmn], 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int fq = 2 * i + h;
+        const float freq = (float)(1 << fq);
+#pragma unroll
+        for (int dmn = 0; dmn < 3; ++dmn) {
+            float sn, cs;
+            sincos_pe(dv[dmn] * freq, sn, cs);
+            const int fs = 3 + fq * 6 + dmn, fc = fs + 3;
+            ENCW(col, fs) = relu_bits(sn);
+            ENCW(col, fc) = relu_bits(cs);
+        }
+    }
+    if (use_time) {
+        if (h == 1) ENCW(col, 27) = fmaxf(tv, 0.f);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int fq = 2 * i + h;
+            float sn, cs;
+            sincos_pe(tv * (float)(1 << fq), sn, cs);
+            const int fs = 28 + 2 * fq, fc = fs + 1;
+            ENCW(col, fs) = relu_bits(sn);
+            ENCW(col, fc) = relu_bits(cs);
+        }
+    } else if (h == 1) {
+#pragma unroll
+        for (int f = 27; f < 32; ++f) ENCW(col, f) = 0.f;
+    }
+}
+
+// PE_10([x,y,z,t]) with the fractional-time lerp of modeling/motion_net.py:49-60: 84 features + 4 zero pads
+__device__ __forceinline__ void encode_motion(float* encw, int lane, const float (&p)[3], float tv, int flags) {
+    const int h = lane >> 5, c = lane & 31;
+    float* col = encw + c * 4;
+    const float lo = (flags & STNERF_MOTION_PLAIN_TIME) ? tv : floorf(tv);  // input_time=False: PE(input) as is
+    const float wgt = tv - lo;
+    const bool frac = wgt != 0.f;
+    const float om = 1.f - wgt;
+    if (h == 0) {
+#pragma unroll
+        for (int dmn = 0; dmn < 3; ++dmn) ENCW(col, dmn) = lerp_enc(frac, om, wgt, p[dmn], p[dmn]);
+        ENCW(col, 3) = lerp_enc(frac, om, wgt, lo, lo + 1.f);
+    } else {
+#pragma unroll
+        for (int f = 84; f < 88; ++f) ENCW(col, f) = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int fq = 2 * i + h;
+        const float freq = (float)(1 << fq);
+#pragma unroll
+        for (int dmn = 0; dmn < 4; ++dmn) {
+            float sn, cs, sn2, cs2;
+            if (dmn < 3) {
+                sincos_pe(p[dmn] * freq, sn, cs);
+                sn2 = sn;
+                cs2 = cs;
+            } else {
+                sincos_pe(lo * freq, sn, cs);
+                sn2 = sn;
+                cs2 = cs;
+                if (frac) sincos_pe((lo + 1.f) * freq, sn2, cs2);
+            }
+            const int fs = 4 + fq * 8 + dmn, fc = fs + 4;
+            ENCW(col, fs) = lerp_enc(frac, om, wgt, sn, sn2);
+            ENCW(col, fc) = lerp_enc(frac, om, wgt, cs, cs2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The K loop on registers.  w holds the A operands of one K step: 16 B per feature block, straight from the packed
+// [K/4][N][4] blob (lane half h reads quad row 2 s + h, column 32 fb + c).
+// ---------------------------------------------------------------------------------------------
+// (the block offset fb * 512 travels in the per-lane address -- 8 loop-invariant VGPRs -- so that an unrolled layer needs
+// one scalar offset per K step; with it on the scalar side the compiler materialises STEPS x NFB offsets up front and
+// spills them through VGPR lanes)
+struct LaneOfs {
+    uint32_t v[8];
+};
+__device__ __forceinline__ LaneOfs lane_offsets(uint32_t wlane) {
+    LaneOfs o;
+#pragma unroll
+    for (int fb = 0; fb < 8; ++fb) {
+        o.v[fb] = wlane + fb * 512u;
+        asm volatile("" : "+v"(o.v[fb]));  // opaque: keep eight registers instead of re-deriving the sums at every load
+    }
+    return o;
+}
+template <int NFB>
+__device__ __forceinline__ void load_w(float4 (&w)[8], __amdgpu_buffer_rsrc_t rsrc, const LaneOfs& wl, uint32_t soff) {
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) w[fb] = load_weight(rsrc, wl.v[fb], soff);
+}
+
+// acc[fb] = this lane's 16 bias values of block fb: the C operand of the block's first MFMA (no accumulator
+// initialisation, no bias add).  blane = 16 h bytes; register 4 q + r <-> feature 32 fb + 8 q + 4 h + r.
+template <int NFB>
+__device__ __forceinline__ void load_bias(f32x16 (&acc)[8], __amdgpu_buffer_rsrc_t rsrc, uint32_t blane, uint32_t boff) {
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = load_weight(rsrc, blane, boff + (uint32_t)(fb * 32 + 8 * q) * 4u);
+            acc[fb][4 * q + 0] = b.x;
+            acc[fb][4 * q + 1] = b.y;
+            acc[fb][4 * q + 2] = b.z;
+            acc[fb][4 * q + 3] = b.w;
+        }
+}
+
+// STEPS K steps whose B operands are blk[s >> 2][4 (s & 3) + kk].  The A operands ping-pong between wa and wb: step s
+// reads buffer (s + PAR) & 1, which holds its weights on entry of the step; the loads of step s + 1 -- for the last
+// step: NFB_NEXT blocks at (next_wlane, next_soff), the first step of whatever runs next -- are issued in front of the
+// MFMAs of step s, one behind each of the first MFMAs (see mma_segment in mlp_blocks.h for the scheduling notes).
+// The 4 * NFB MFMAs of one K step (B operands b0..b3 = the four k of this lane half), with the NL operand loads the caller
+// has just issued for the following step pinned one behind each of the first MFMAs.
+template <int NFB, int NL>
+__device__ __forceinline__ void step_r(f32x16 (&acc)[8], const float4 (&wc)[8], float b0, float b1, float b2, float b3) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const float bv = kk == 0 ? b0 : kk == 1 ? b1 : kk == 2 ? b2 : b3;
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) {
+            const float wv = kk == 0 ? wc[fb].x : kk == 1 ? wc[fb].y : kk == 2 ? wc[fb].z : wc[fb].w;
+            acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, bv, acc[fb], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NFB - NL, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NFB, int NBLK, int STEPS, int PAR, int NFB_NEXT>
+__device__ __forceinline__ void segment_r(f32x16 (&acc)[8], const f32x16 (&blk)[NBLK], float4 (&wa)[8], float4 (&wb)[8],
+                                          __amdgpu_buffer_rsrc_t rsrc, const LaneOfs& wlane, uint32_t soff, uint32_t wstep,
+                                          const LaneOfs& next_wlane, uint32_t next_soff) {
+    static_assert(STEPS >= 1 && STEPS <= 4 * NBLK, "segment_r: not enough input blocks");
+    static_assert(NFB_NEXT <= 4 * NFB, "segment_r: more operand loads than MFMAs to hide them behind");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s + 1 < STEPS; ++s) {
+        float4 (&wc)[8] = ((s + PAR) & 1) ? wb : wa;
+        float4 (&wn)[8] = ((s + PAR) & 1) ? wa : wb;
+        load_w<NFB>(wn, rsrc, wlane, soff + (uint32_t)(s + 1) * wstep);
+        step_r<NFB, NFB>(acc, wc, blk[s >> 2][4 * (s & 3) + 0], blk[s >> 2][4 * (s & 3) + 1], blk[s >> 2][4 * (s & 3) + 2],
+                         blk[s >> 2][4 * (s & 3) + 3]);
+    }
+    {
+        constexpr int s = STEPS - 1;
+        float4 (&wc)[8] = ((s + PAR) & 1) ? wb : wa;
+        float4 (&wn)[8] = ((s + PAR) & 1) ? wa : wb;
+        load_w<NFB_NEXT>(wn, rsrc, next_wlane, next_soff);
+        step_r<NFB, NFB_NEXT>(acc, wc, blk[s >> 2][4 * (s & 3) + 0], blk[s >> 2][4 * (s & 3) + 1], blk[s >> 2][4 * (s & 3) + 2],
+                              blk[s >> 2][4 * (s & 3) + 3]);
+    }
+}
+
+// Layer boundary: in = relu(acc) (one v_max_i32 per value); as soon as a block is consumed, the bias of the NEXT
+// layer's block is loaded into the freed accumulator registers (its first MFMA issues ~450 cycles later).
+template <int NFB, int NFB_NEXT>
+__device__ __forceinline__ void relu_rebias(f32x16 (&acc)[8], f32x16 (&in)[8], __amdgpu_buffer_rsrc_t rsrc, uint32_t blane,
+                                            uint32_t next_boff) {
+#pragma unroll
+    for (int fb = 0; fb < (NFB > NFB_NEXT ? NFB : NFB_NEXT); ++fb) {
+        if (fb < NFB) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) in[fb][i] = relu_bits(acc[fb][i]);
+        }
+        if (fb < NFB_NEXT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b = load_weight(rsrc, blane, next_boff + (uint32_t)(fb * 32 + 8 * q) * 4u);
+                acc[fb][4 * q + 0] = b.x;
+                acc[fb][4 * q + 1] = b.y;
+                acc[fb][4 * q + 2] = b.z;
+                acc[fb][4 * q + 3] = b.w;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+#ifdef STNERF_WAVE_DEBUG
+// development: this lane's registers of `nblk` blocks -> dbg[row][256] in feature order (register 4 q + r of block fb
+// <-> feature 32 fb + 8 q + 4 h + r)
+struct WaveDbg {
+    float* buf;
+    int stage;
+    int64_t row;   // row of this lane's sample inside its layer, -1: do not dump
+};
+template <int NBLK>
+__device__ __forceinline__ void dbg_dump(const WaveDbg& d, int stage, const f32x16 (&blk)[NBLK], int nblk, int lane) {
+    if (!d.buf || d.stage != stage || d.row < 0) return;
+    const int h = lane >> 5;
+    for (int fb = 0; fb < nblk; ++fb)
+        for (int i = 0; i < 16; ++i) d.buf[d.row * 256 + fb * 32 + 8 * (i >> 2) + 4 * h + (i & 3)] = blk[fb][i];
+}
+#define WV_DBG_PARAM , const WaveDbg& dbg
+#define WV_DBG_ARG , dbg
+#define WV_DBG(stage, blk, nblk) dbg_dump(dbg, stage, blk, nblk, lane)
+#else
+#define WV_DBG_PARAM
+#define WV_DBG_ARG
+#define WV_DBG(stage, blk, nblk) do { } while (0)
+#endif
+
+__device__ __forceinline__ float partner(float x, int lane) {  // the value of the other lane of this sample (lane ^ 32)
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(x)));
+}
+
+// sigma head (256 -> 1) in the grouping of head_partial<TM, 1> with four parts of 16 quads: part pp, chain u runs over
+// the quads 16 pp + u + 4 m, m = 0..3, four fmas each; S_pp = (c0 + c1) + (c2 + c3); sigma = (((b + S_0) + S_1) + S_2) + S_3.
+// This lane holds the quads 2 s + h: its chains are u = h (s = 8 pp + 2 m) and u = h + 2 (s = 8 pp + 2 m + 1).
+__device__ __forceinline__ float head_sigma(const f32x16 (&in)[8], __amdgpu_buffer_rsrc_t rsrc, uint32_t blane, uint32_t w_off,
+                                            float bias, int lane) {
+    float sigma = bias;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+        float4 wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[j] = load_weight(rsrc, blane, w_off + 32u * (uint32_t)(8 * pp + j));
+        float ca = 0.f, cb = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int sa = 8 * pp + 2 * m, sb = sa + 1;
+            ca = fmaf(in[sa >> 2][4 * (sa & 3) + 0], wv[2 * m].x, ca);
+            ca = fmaf(in[sa >> 2][4 * (sa & 3) + 1], wv[2 * m].y, ca);
+            ca = fmaf(in[sa >> 2][4 * (sa & 3) + 2], wv[2 * m].z, ca);
+            ca = fmaf(in[sa >> 2][4 * (sa & 3) + 3], wv[2 * m].w, ca);
+            cb = fmaf(in[sb >> 2][4 * (sb & 3) + 0], wv[2 * m + 1].x, cb);
+            cb = fmaf(in[sb >> 2][4 * (sb & 3) + 1], wv[2 * m + 1].y, cb);
+            cb = fmaf(in[sb >> 2][4 * (sb & 3) + 2], wv[2 * m + 1].z, cb);
+            cb = fmaf(in[sb >> 2][4 * (sb & 3) + 3], wv[2 * m + 1].w, cb);
+        }
+        const float pa = partner(ca, lane), pb = partner(cb, lane);
+        sigma += (ca + pa) + (cb + pb);
+    }
+    return sigma;
+}
+
+// 128 -> 3 head (rgb_net's last layer, MotionNet's flow) in the grouping of head_partial<TM, 3> with four parts of 8
+// quads: part pp, chain u over the quads 8 pp + u + 4 m, m = 0, 1.  Weights [3][128] at w_off, bias b3.
+__device__ __forceinline__ void head3(const f32x16 (&in)[8], __amdgpu_buffer_rsrc_t rsrc, uint32_t blane, uint32_t w_off,
+                                      const float* __restrict__ b3, int lane, float (&out)[3]) {
+#pragma unroll
+    for (int o = 0; o < 3; ++o) out[o] = b3[o];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float4 wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[j] = load_weight(rsrc, blane, w_off + (uint32_t)(o * 128 + 8 * (4 * pp + j)) * 4u);
+            float ca = 0.f, cb = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int sa = 4 * pp + 2 * m, sb = sa + 1;
+                ca = fmaf(in[sa >> 2][4 * (sa & 3) + 0], wv[2 * m].x, ca);
+                ca = fmaf(in[sa >> 2][4 * (sa & 3) + 1], wv[2 * m].y, ca);
+                ca = fmaf(in[sa >> 2][4 * (sa & 3) + 2], wv[2 * m].z, ca);
+                ca = fmaf(in[sa >> 2][4 * (sa & 3) + 3], wv[2 * m].w, ca);
+                cb = fmaf(in[sb >> 2][4 * (sb & 3) + 0], wv[2 * m + 1].x, cb);
+                cb = fmaf(in[sb >> 2][4 * (sb & 3) + 1], wv[2 * m + 1].y, cb);
+                cb = fmaf(in[sb >> 2][4 * (sb & 3) + 2], wv[2 * m + 1].z, cb);
+                cb = fmaf(in[sb >> 2][4 * (sb & 3) + 3], wv[2 * m + 1].w, cb);
+            }
+            const float pa = partner(ca, lane), pb = partner(cb, lane);
+            out[o] += (ca + pa) + (cb + pb);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpaceNet on the wave's 32 samples (point p, direction dv, frame id tv of sample c in both lanes of the sample).
+// Returns {r, g, b, sigma} (raw) in every lane.  `mid` is called once, in front of the direction / time encoding -- a
+// stretch of ~1k cycles of vector arithmetic without a memory wait, where the caller issues the HBM loads of the next
+// work item (the counters are in order: a load issued elsewhere stalls the next weight wait for its whole latency).
+// ---------------------------------------------------------------------------------------------
+template <bool DEEP, class Mid>
+__device__ __forceinline__ float4 space_wave(const float* net, const bool use_time, float* encw, const float (&p)[3],
+                                             const float (&dv)[3], float tv, int lane, f32x16 (&acc)[8], f32x16 (&in)[8],
+                                             float4 (&wa)[8], float4 (&wb)[8], Mid mid WV_DBG_PARAM) {
+    const SpaceLayout L = space_layout(use_time, DEEP);
+    const __amdgpu_buffer_rsrc_t rsrc = weight_rsrc(net);
+    const int h = lane >> 5, c = lane & 31;
+    const LaneOfs wl256 = lane_offsets((uint32_t)(h * 256 + c) * 16u), wl128 = lane_offsets((uint32_t)(h * 128 + c) * 16u);
+    const uint32_t blane = (uint32_t)h * 16u;
+    constexpr uint32_t WSTEP256 = 2u * 256u * 16u, WSTEP128 = 2u * 128u * 16u;
+    // ---- stage1.0: bias + first weights in flight behind the encoding arithmetic
+    load_bias<8>(acc, rsrc, blane, (uint32_t)L.b[0] * 4u);
+    load_w<8>(wa, rsrc, wl256, (uint32_t)L.w[0] * 4u);
+    f32x16 pe[2];
+    encode_pos(encw, lane, p);
+    wave_lds_sync();
+    read_enc_blocks<2, 8>(encw, lane, pe);
+    wave_lds_sync();
+    WV_DBG(100, pe, 2);
+    segment_r<8, 2, 8, 0, 8>(acc, pe, wa, wb, rsrc, wl256, (uint32_t)L.w[0] * 4u, WSTEP256, wl256, (uint32_t)L.w[1] * 4u);
+    relu_rebias<8, 8>(acc, in, rsrc, blane, (uint32_t)L.b[1] * 4u);
+    WV_DBG(0, in, 8);
+    // ---- stage1.2 .. stage2.4: six 256-wide layers, stage2.0 (li == 4) with the PE(pos) skip segment behind its 256
+    // features (modeling/spacenet.py:45-57,136-138)
+    uint32_t soff = (uint32_t)L.w[1] * 4u;
+#pragma unroll 1
+    for (int li = 1; li <= 6; ++li) {
+        const uint32_t kq = li == 4 ? 80u : 64u;
+        const uint32_t boff = soff + kq * 4096u;           // this layer's bias
+        const uint32_t after = boff + 1024u;               // the next layer's weights (stage2.4: density_net follows)
+        const uint32_t next_w = li == 6 ? (uint32_t)L.w_rgb1 * 4u : after;
+        const uint32_t next_b = li == 6 ? (uint32_t)L.b_rgb1 * 4u : after + (li == 3 ? 80u : 64u) * 4096u;
+        LaneOfs next_wl;  // (selected value by value: a reference to one of two arrays would send both through memory)
+#pragma unroll
+        for (int fb = 0; fb < 8; ++fb) next_wl.v[fb] = li == 6 ? wl128.v[fb] : wl256.v[fb];
+        // (one copy of the 32-step body: behind stage2.0's 256 features the skip segment simply continues in the blob)
+        segment_r<8, 8, 32, 0, 8>(acc, in, wa, wb, rsrc, wl256, soff, WSTEP256, next_wl,  // (li == 4: next_wl == wl256)
+                                  li == 4 ? soff + 32u * WSTEP256 : next_w);
+        if (li == 4) segment_r<8, 2, 8, 0, 8>(acc, pe, wa, wb, rsrc, wl256, soff + 32u * WSTEP256, WSTEP256, next_wl, next_w);
+        relu_rebias<8, 8>(acc, in, rsrc, blane, next_b);  // (stage2.4 -> rgb_net.1: blocks 4..7 of the bias fetch are unused)
+        WV_DBG(li, in, 8);
+        soff = after;
+    }
+    // ---- sigma = density_net(h) (:139), raw
+    const float sigma = head_sigma(in, rsrc, blane, (uint32_t)L.w_sigma * 4u, net[L.b_sigma], lane);
+    // ---- rgb_net: relu -> Linear(283|304, 128) -> relu -> Linear(128, 3)   (:80-86); h is already >= 0, the
+    // encodings are clamped when written
+    mid();
+    f32x16 de[2];
+    encode_dir_time(encw, lane, dv, tv, use_time);
+    wave_lds_sync();
+    if (use_time) read_enc_blocks<2, 6>(encw, lane, de);
+    else read_enc_blocks<2, 4>(encw, lane, de);
+    wave_lds_sync();
+    WV_DBG(101, de, 2);
+    const uint32_t wr = (uint32_t)L.w_rgb1 * 4u;
+    segment_r<4, 8, 32, 0, 4>(acc, in, wa, wb, rsrc, wl128, wr, WSTEP128, wl128, wr + 32u * WSTEP128);
+    const uint32_t w_after = DEEP ? (uint32_t)L.w_deep[0] * 4u : wr;  // (not deep: nothing follows; the fetch is discarded)
+    if (use_time) segment_r<4, 2, 6, 0, 4>(acc, de, wa, wb, rsrc, wl128, wr + 32u * WSTEP128, WSTEP128, wl128, w_after);
+    else segment_r<4, 2, 4, 0, 4>(acc, de, wa, wb, rsrc, wl128, wr + 32u * WSTEP128, WSTEP128, wl128, w_after);
+    if constexpr (DEEP) {  // deep_rgb (:68-79): two more 128-wide hidden layers
+        relu_rebias<4, 4>(acc, in, rsrc, blane, (uint32_t)L.b_deep[0] * 4u);
+        segment_r<4, 8, 16, 0, 4>(acc, in, wa, wb, rsrc, wl128, (uint32_t)L.w_deep[0] * 4u, WSTEP128, wl128, (uint32_t)L.w_deep[1] * 4u);
+        relu_rebias<4, 4>(acc, in, rsrc, blane, (uint32_t)L.b_deep[1] * 4u);
+        segment_r<4, 8, 16, 0, 4>(acc, in, wa, wb, rsrc, wl128, (uint32_t)L.w_deep[1] * 4u, WSTEP128, wl128, (uint32_t)L.w_deep[1] * 4u);
+    }
+    relu_rebias<4, 0>(acc, in, rsrc, blane, 0u);
+    WV_DBG(7, in, 4);
+    float rgb[3];
+    head3(in, rsrc, blane, (uint32_t)L.w_rgb2 * 4u, net + L.b_rgb2, lane, rgb);
+    return make_float4(rgb[0], rgb[1], rgb[2], sigma);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MotionNet on the wave's 32 samples: p += flow (modeling/layered_rfrender.py:356,510).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void motion_wave(const float* net, float* encw, float (&p)[3], float tv, int flags, int lane,
+                                            f32x16 (&acc)[8], f32x16 (&in)[8], float4 (&wa)[8], float4 (&wb)[8] WV_DBG_PARAM) {
+    const MotionLayout L = motion_layout();
+    const __amdgpu_buffer_rsrc_t rsrc = weight_rsrc(net);
+    const int h = lane >> 5, c = lane & 31;
+    const LaneOfs wl128 = lane_offsets((uint32_t)(h * 128 + c) * 16u);
+    const uint32_t blane = (uint32_t)h * 16u;
+    constexpr uint32_t WSTEP128 = 2u * 128u * 16u;
+    load_bias<4>(acc, rsrc, blane, (uint32_t)L.b[0] * 4u);
+    load_w<4>(wa, rsrc, wl128, (uint32_t)L.w[0] * 4u);
+    f32x16 me[3];
+    encode_motion(encw, lane, p, tv, flags);
+    wave_lds_sync();
+    read_enc_blocks<3, 11>(encw, lane, me);
+    wave_lds_sync();
+    WV_DBG(199, me, 3);
+    // motion_net.0: 11 K steps (22 quads); an odd count leaves the next layer's first weights in wb
+    segment_r<4, 3, 11, 0, 4>(acc, me, wa, wb, rsrc, wl128, (uint32_t)L.w[0] * 4u, WSTEP128, wl128, (uint32_t)L.w[1] * 4u);
+    relu_rebias<4, 4>(acc, in, rsrc, blane, (uint32_t)L.b[1] * 4u);
+    WV_DBG(200, in, 4);
+#pragma unroll 1
+    for (int li = 1; li <= 4; ++li) {
+        const uint32_t soff = (uint32_t)L.w[1] * 4u + (uint32_t)(li - 1) * (32u * 128u * 16u + 512u);
+        const uint32_t next_w = soff + 32u * 128u * 16u + 512u;
+        // (behind motion_net.8 nothing follows: the fetch is discarded, so it re-reads this layer's first rows -- a full
+        // operand fetch at the output layer's 1.5 KB would run past the end of the blob)
+        segment_r<4, 8, 16, 1, 4>(acc, in, wa, wb, rsrc, wl128, soff, WSTEP128, wl128, li < 4 ? next_w : soff);
+        if (li < 4) relu_rebias<4, 4>(acc, in, rsrc, blane, next_w + 32u * 128u * 16u);
+        else relu_rebias<4, 0>(acc, in, rsrc, blane, 0u);
+        WV_DBG(200 + li, in, 4);
+    }
+    float fl[3];
+    head3(in, rsrc, blane, (uint32_t)L.w_out * 4u, net + L.b_out, lane, fl);
+#pragma unroll
+    for (int c3 = 0; c3 < 3; ++c3) p[c3] = p[c3] + fl[c3];
+}
+
+// What a wave needs of a work item: its sample's point, direction and frame id, and where the result goes.
+struct WaveInputs {
+    float p[3], dv[3], tv;
+    int64_t raw_off;   // float offset of the sample's {r,g,b,sigma} in the layer's raw
+    bool valid;
+};
+
+template <bool DEEP>
+__global__ __launch_bounds__(WV_THREADS, 1) void mlp_wave_stage_kernel(StageArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* encw = reinterpret_cast<float*>(smem) + wave * WV_ENC_FLOATS;
+    uint32_t* qslot = reinterpret_cast<uint32_t*>(reinterpret_cast<float*>(smem) + WV_NW * WV_ENC_FLOATS);
+    // ---- the queue: items (128 rows) of layer slot j are [pre[j], pre[j+1])
+    uint32_t pre[STNERF_MAX_LAYERS + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int j = 0; j < STNERF_MAX_LAYERS; ++j) {
+        uint32_t items = 0;
+        if (j < a.n_layers) items = (uint32_t)((layer_rows(a.layer[j], a.n_rays, a.ns) + WV_ITEM - 1) / WV_ITEM);
+        pre[j + 1] = pre[j] + items;
+    }
+    const uint32_t total = pre[STNERF_MAX_LAYERS];
+    auto slot_of = [&](uint32_t item) {
+        int slot = 0;
+#pragma unroll
+        for (int j = 1; j < STNERF_MAX_LAYERS; ++j) slot += (item >= pre[j]) ? 1 : 0;
+        return slot;
+    };
+    auto base_of = [&](uint32_t item) {
+        uint32_t b = 0;
+#pragma unroll
+        for (int j = 1; j < STNERF_MAX_LAYERS; ++j) b = (item >= pre[j]) ? pre[j] : b;
+        return b;
+    };
+    // row of this lane's sample in an item, and the ray it belongs to (first half of an item's fetch)
+    auto row_of = [&](uint32_t item, RowRef& rr) {
+        rr = RowRef{0, 0, false};
+        if (item >= total) return;
+        const StageLayer& ly = a.layer[slot_of(item)];
+        const int64_t rows = layer_rows(ly, a.n_rays, a.ns);
+        const int64_t row = (int64_t)(item - base_of(item)) * WV_ITEM + wave * WV_ROWS + (lane & 31);
+        rr = locate_row(ly.ray_list, row, rows, a.ns);
+    };
+    // second half: the sample's inputs (HBM loads)
+    auto fetch = [&](uint32_t item, const RowRef& rr, WaveInputs& in) {
+        in.valid = rr.valid;
+        in.raw_off = 0;
+        in.tv = 0.f;
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) in.p[c3] = in.dv[c3] = 0.f;
+        if (rr.valid) {
+            const StageLayer& ly = a.layer[slot_of(item)];
+            const float* src = ly.xyz + rr.ray * a.xyz_ray_stride + 3 * rr.k;
+            const float* dsrc = a.dirs + rr.ray * a.dirs_ray_stride;
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) {
+                in.p[c3] = src[c3];
+                in.dv[c3] = dsrc[c3];
+            }
+            if (ly.times) in.tv = ly.times[rr.ray * a.times_ray_stride];
+            in.raw_off = rr.ray * a.raw_ray_stride + 4 * rr.k;
+        }
+    };
+
+    // ---- prime the pipeline: two items popped, the first one's inputs loaded
+    if (tid == 0) {
+        qslot[0] = atomicAdd(a.queue, 1u);
+        qslot[1] = atomicAdd(a.queue, 1u);
+    }
+    __syncthreads();
+    uint32_t it0 = __builtin_amdgcn_readfirstlane(qslot[0]);
+    uint32_t it1 = __builtin_amdgcn_readfirstlane(qslot[1]);
+    __syncthreads();
+    WaveInputs cur, nxt;
+    {
+        RowRef rr;
+        row_of(it0, rr);
+        fetch(it0, rr, cur);
+    }
+    int par = 0;
+    f32x16 acc[8], in[8];
+    float4 wa[8], wb[8];
+    while (it0 < total) {
+        // the item after next (consumed at the end of this one) and the ray index of the next item's sample
+        uint32_t pending = 0;
+        if (tid == 0) pending = atomicAdd(a.queue, 1u);
+        RowRef rr_next;
+        row_of(it1, rr_next);
+        const StageLayer& ly = a.layer[slot_of(it0)];
+        float p[3], dv[3];
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            p[c3] = cur.p[c3];
+            dv[c3] = cur.dv[c3];
+        }
+#ifdef STNERF_WAVE_DEBUG
+        WaveDbg dbg{a.dbg, a.dbg_stage, -1};
+        if (slot_of(it0) == 0 && cur.valid) dbg.row = (int64_t)(it0 - base_of(it0)) * WV_ITEM + wave * WV_ROWS + (lane & 31);
+#endif
+        if (ly.motion) motion_wave(ly.motion, encw, p, cur.tv, ly.motion_flags, lane, acc, in, wa, wb WV_DBG_ARG);
+        const float tvs = ly.use_time ? cur.tv : 0.f;
+        float4 o = space_wave<DEEP>(ly.space, ly.use_time != 0, encw, p, dv, tvs, lane, acc, in, wa, wb,
+                                    [&]() { fetch(it1, rr_next, nxt); } WV_DBG_ARG);
+        if (cur.valid && lane < 32) {
+            if (a.sigmoid_rgb) {  // torch.sigmoid(rgb): 1-ulp v_exp_f32 / v_rcp_f32, the same expression the compositor uses
+                o.x = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(o.x * -1.44269504088896340736f));
+                o.y = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(o.y * -1.44269504088896340736f));
+                o.z = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(o.z * -1.44269504088896340736f));
+            }
+            *reinterpret_cast<float4*>(ly.raw + cur.raw_off) = o;
+        }
+        if (tid == 0) qslot[par] = pending;
+        __syncthreads();
+        const uint32_t it2 = __builtin_amdgcn_readfirstlane(qslot[par]);
+        par ^= 1;
+        it0 = it1;
+        it1 = it2;
+        cur = nxt;
+    }
+}
+
+#ifdef STNERF_WAVE_DEBUG
+static float* g_dbg_buf = nullptr;
+static int g_dbg_stage = -1;
+#endif
+
+int launch_wave_stage(const StageArgs& a_in, bool deep_rgb, int cus, hipStream_t stream) {
+    StageArgs a = a_in;
+#ifdef STNERF_WAVE_DEBUG
+    a.dbg = g_dbg_buf;
+    a.dbg_stage = g_dbg_stage;
+#endif
+    const int64_t max_items = ((a.n_rays * a.ns + WV_ITEM - 1) / WV_ITEM) * a.n_layers;
+    const int grid = (int)(max_items < cus ? max_items : cus);  // one persistent workgroup per CU
+    const void* kfn = deep_rgb ? reinterpret_cast<const void*>(mlp_wave_stage_kernel<true>)
+                               : reinterpret_cast<const void*>(mlp_wave_stage_kernel<false>);
+    if (const int rc = reserve_dynamic_lds(kfn, WV_LDS, "mlp_stage (wave)")) return rc;
+    LaunchTimer timer(PROF_MLP_STAGE, deep_rgb ? 1 : 0, a.n_rays, a.ns, 0, stream);
+    if (deep_rgb)
+        hipLaunchKernelGGL(mlp_wave_stage_kernel<true>, dim3(grid), dim3(WV_THREADS), WV_LDS, stream, a);
+    else
+        hipLaunchKernelGGL(mlp_wave_stage_kernel<false>, dim3(grid), dim3(WV_THREADS), WV_LDS, stream, a);
+    STNERF_CHECK_LAUNCH("mlp_stage (wave)");
+    return STNERF_OK;
+}
+
+}  // namespace stnerf
+
+#ifdef STNERF_WAVE_DEBUG
+// development builds only: where the next stnerf_mlp_stage launches dump the activations of queue slot 0
+extern "C" int stnerf_debug_wave_dump(float* buf, int stage) {
+    stnerf::g_dbg_buf = buf;
+    stnerf::g_dbg_stage = stage;
+    return STNERF_OK;
+}
+#endif

@@ -13,7 +13,8 @@ from typing import Optional
 import torch  # imported first on purpose: the HIP runtime of the process must be torch's (same SONAME)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libstnerf_hip.so")
+# STNERF_LIB (development): load a variant build (st-nerf_amd/build.py with STNERF_LIB_TAG) instead of the product library
+LIB_PATH = os.environ.get("STNERF_LIB") or os.path.join(_PKG, "libstnerf_hip.so")
 
 OK, EINVAL, ELAUNCH, EARCH = 0, -1, -2, -3
 MAX_LAYERS = 16
