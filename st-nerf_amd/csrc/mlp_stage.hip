@@ -22,7 +22,7 @@
 #include "mlp_stage.h"
 
 #ifndef STNERF_STAGE_KERNEL_DEFAULT
-#define STNERF_STAGE_KERNEL_DEFAULT STAGE_KERNEL_LDS
+#define STNERF_STAGE_KERNEL_DEFAULT STAGE_KERNEL_WAVE
 #endif
 
 namespace stnerf {

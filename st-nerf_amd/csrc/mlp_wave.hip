@@ -19,7 +19,7 @@
 //   * Encodings are staged through a wave-private 11 KiB LDS window (the two lanes of a sample split the frequencies,
 //     then each lane reads its half of the feature quads back) -- ordering inside a wave only, no barrier.
 //   * Heads: a lane holds every second feature quad of its sample; the partial-sum grouping of the LDS kernels
-//     (4 parts x 4 interleaved chains) is kept, the two lanes of a sample swap their chains with ds_bpermute.
+//     (4 parts x 4 interleaved chains) is kept, the two lanes of a sample swap their chains with v_permlane32_swap.
 // Every output accumulates the same products in the same order as in mlp.hip / mlp_stage.hip (same instruction, same k
 // order, bias as the C operand of the first MFMA, same head grouping): results are bit-identical to those kernels
 // (tests/test_gpu_ops.py).
@@ -39,6 +39,24 @@ constexpr int WV_ITEM = WV_NW * WV_ROWS;          // rows per work item
 constexpr int WV_ENC_QUADS = 22;                  // widest staged encoding: MotionNet's 84 (+4) features
 constexpr int WV_ENC_FLOATS = WV_ENC_QUADS * WV_ROWS * 4;
 constexpr int WV_LDS = WV_NW * WV_ENC_FLOATS * 4 + 16;
+
+// Optional per-phase cycle accounting (development builds: -DSTNERF_WAVE_PROF): every wave adds its s_memtime deltas per
+// phase; read back with stnerf_debug_wave_phases().
+#ifdef STNERF_WAVE_PROF
+static __device__ unsigned long long g_wphase[16];
+struct WaveProf {
+    unsigned long long t, acc[12];
+};
+#define WP_PARAM , WaveProf& wp
+#define WP_ARG , wp
+#define WP(i) do { const unsigned long long n_ = clock64(); wp.acc[i] += n_ - wp.t; wp.t = n_; } while (0)
+#else
+#define WP_PARAM
+#define WP_ARG
+#define WP(i) do { } while (0)
+#endif
+enum { WP_TOP = 0, WP_M_ENC = 1, WP_M_LAYERS = 2, WP_M_HEAD = 3, WP_S_PE = 4, WP_S_L0 = 5, WP_S_LOOP = 6, WP_S_MID = 7,
+       WP_S_RGB1 = 8, WP_S_HEAD = 9, WP_END = 10 };
 
 // feature f of the lane's sample inside the wave-private staging window (col = window + 4 * c)
 #define ENCW(col, f) (col)[((f) >> 2) * (WV_ROWS * 4) + ((f) & 3)]
@@ -191,8 +209,13 @@ __device__ __forceinline__ LaneOfs lane_offsets(uint32_t wlane) {
 }
 template <int NFB>
 __device__ __forceinline__ void load_w(float4 (&w)[8], __amdgpu_buffer_rsrc_t rsrc, const LaneOfs& wl, uint32_t soff) {
+#ifdef STNERF_WAVE_EXP_NOLOADW  /* development experiment: wrong results, isolates the cost of the operand loads */
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) asm volatile("" : "+v"(w[fb].x), "+v"(w[fb].y), "+v"(w[fb].z), "+v"(w[fb].w));
+#else
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb) w[fb] = load_weight(rsrc, wl.v[fb], soff);
+#endif
 }
 
 // acc[fb] = this lane's 16 bias values of block fb: the C operand of the block's first MFMA (no accumulator
@@ -267,6 +290,12 @@ __device__ __forceinline__ void segment_r(f32x16 (&acc)[8], const f32x16 (&blk)[
 template <int NFB, int NFB_NEXT>
 __device__ __forceinline__ void relu_rebias(f32x16 (&acc)[8], f32x16 (&in)[8], __amdgpu_buffer_rsrc_t rsrc, uint32_t blane,
                                             uint32_t next_boff) {
+#ifdef STNERF_WAVE_EXP_NOEPI  /* development experiment: no ReLU pass, no bias fetch (wrong results) */
+    return;
+#endif
+#ifdef STNERF_WAVE_LAYER_BARRIER  /* keep the four waves of a CU in step (vector-L1 sharing of the weight lines) */
+    __builtin_amdgcn_s_barrier();
+#endif
 #pragma unroll
     for (int fb = 0; fb < (NFB > NFB_NEXT ? NFB : NFB_NEXT); ++fb) {
         if (fb < NFB) {
@@ -311,69 +340,96 @@ __device__ __forceinline__ void dbg_dump(const WaveDbg& d, int stage, const f32x
 #define WV_DBG(stage, blk, nblk) do { } while (0)
 #endif
 
-__device__ __forceinline__ float partner(float x, int lane) {  // the value of the other lane of this sample (lane ^ 32)
-    return __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(x)));
+// (ca + partner's ca) + (cb + partner's cb), partner = the other lane of this sample (lane ^ 32), in every lane: two
+// v_permlane32_swap (upper half of the first operand <-> lower half of the second) instead of two ds_bpermute round
+// trips.  After swap(ca, cb) the lower lanes hold {own ca, partner's ca}, the upper lanes {partner's cb, own cb}; the
+// second swap hands both half sums to both halves.  Same additions, same order as in the LDS kernels' reduction.
+__device__ __forceinline__ float pair_sum(float ca, float cb) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ca), __float_as_uint(cb), false, false);
+    const float t = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Heads.  Three phases each, placed apart by the callers: the weights are fetched into registers EARLY (behind a stretch
+// of arithmetic that covers their latency), the fma chains run on registers only, and the two lanes of a sample swap
+// their chains with v_permlane32_swap.  (Written as load -> use per part, a head is a chain of 4 .. 12
+// dependent L2 round trips plus as many LDS-crossbar round trips with nothing else for the single wave of the SIMD to
+// do: measured 3.6 % of the kernel for 0.2 % worth of arithmetic.)
+// ---------------------------------------------------------------------------------------------
 // sigma head (256 -> 1) in the grouping of head_partial<TM, 1> with four parts of 16 quads: part pp, chain u runs over
 // the quads 16 pp + u + 4 m, m = 0..3, four fmas each; S_pp = (c0 + c1) + (c2 + c3); sigma = (((b + S_0) + S_1) + S_2) + S_3.
 // This lane holds the quads 2 s + h: its chains are u = h (s = 8 pp + 2 m) and u = h + 2 (s = 8 pp + 2 m + 1).
-__device__ __forceinline__ float head_sigma(const f32x16 (&in)[8], __amdgpu_buffer_rsrc_t rsrc, uint32_t blane, uint32_t w_off,
-                                            float bias, int lane) {
-    float sigma = bias;
+struct HeadSigmaW {
+    float4 w[32];  // the weights of quad 2 s + h, s = 0..31
+};
+__device__ __forceinline__ void load_head_sigma(HeadSigmaW& hw, __amdgpu_buffer_rsrc_t rsrc, uint32_t blane, uint32_t w_off) {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) hw.w[s] = load_weight(rsrc, blane, w_off + 32u * (uint32_t)s);
+}
+__device__ __forceinline__ float head_sigma(const f32x16 (&in)[8], const HeadSigmaW& hw, float bias, int lane) {
+    float ca[4], cb[4];
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
-        float4 wv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) wv[j] = load_weight(rsrc, blane, w_off + 32u * (uint32_t)(8 * pp + j));
-        float ca = 0.f, cb = 0.f;
+        ca[pp] = cb[pp] = 0.f;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int sa = 8 * pp + 2 * m, sb = sa + 1;
-            ca = fmaf(in[sa >> 2][4 * (sa & 3) + 0], wv[2 * m].x, ca);
-            ca = fmaf(in[sa >> 2][4 * (sa & 3) + 1], wv[2 * m].y, ca);
-            ca = fmaf(in[sa >> 2][4 * (sa & 3) + 2], wv[2 * m].z, ca);
-            ca = fmaf(in[sa >> 2][4 * (sa & 3) + 3], wv[2 * m].w, ca);
-            cb = fmaf(in[sb >> 2][4 * (sb & 3) + 0], wv[2 * m + 1].x, cb);
-            cb = fmaf(in[sb >> 2][4 * (sb & 3) + 1], wv[2 * m + 1].y, cb);
-            cb = fmaf(in[sb >> 2][4 * (sb & 3) + 2], wv[2 * m + 1].z, cb);
-            cb = fmaf(in[sb >> 2][4 * (sb & 3) + 3], wv[2 * m + 1].w, cb);
+            ca[pp] = fmaf(in[sa >> 2][4 * (sa & 3) + 0], hw.w[sa].x, ca[pp]);
+            ca[pp] = fmaf(in[sa >> 2][4 * (sa & 3) + 1], hw.w[sa].y, ca[pp]);
+            ca[pp] = fmaf(in[sa >> 2][4 * (sa & 3) + 2], hw.w[sa].z, ca[pp]);
+            ca[pp] = fmaf(in[sa >> 2][4 * (sa & 3) + 3], hw.w[sa].w, ca[pp]);
+            cb[pp] = fmaf(in[sb >> 2][4 * (sb & 3) + 0], hw.w[sb].x, cb[pp]);
+            cb[pp] = fmaf(in[sb >> 2][4 * (sb & 3) + 1], hw.w[sb].y, cb[pp]);
+            cb[pp] = fmaf(in[sb >> 2][4 * (sb & 3) + 2], hw.w[sb].z, cb[pp]);
+            cb[pp] = fmaf(in[sb >> 2][4 * (sb & 3) + 3], hw.w[sb].w, cb[pp]);
         }
-        const float pa = partner(ca, lane), pb = partner(cb, lane);
-        sigma += (ca + pa) + (cb + pb);
     }
+    float sigma = bias;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) sigma += pair_sum(ca[pp], cb[pp]);
     return sigma;
 }
 
 // 128 -> 3 head (rgb_net's last layer, MotionNet's flow) in the grouping of head_partial<TM, 3> with four parts of 8
 // quads: part pp, chain u over the quads 8 pp + u + 4 m, m = 0, 1.  Weights [3][128] at w_off, bias b3.
-__device__ __forceinline__ void head3(const f32x16 (&in)[8], __amdgpu_buffer_rsrc_t rsrc, uint32_t blane, uint32_t w_off,
-                                      const float* __restrict__ b3, int lane, float (&out)[3]) {
+struct Head3W {
+    float4 w[3][16];  // [output][s]: the weights of quad 2 s + h, s = 0..15
+};
+__device__ __forceinline__ void load_head3(Head3W& hw, __amdgpu_buffer_rsrc_t rsrc, uint32_t blane, uint32_t w_off) {
 #pragma unroll
-    for (int o = 0; o < 3; ++o) out[o] = b3[o];
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) hw.w[o][s] = load_weight(rsrc, blane, w_off + (uint32_t)(o * 128 + 8 * s) * 4u);
+}
+__device__ __forceinline__ void head3(const f32x16 (&in)[8], const Head3W& hw, const float* __restrict__ b3, int lane,
+                                      float (&out)[3]) {
+    float ca[4][3], cb[4][3];
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
-            float4 wv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wv[j] = load_weight(rsrc, blane, w_off + (uint32_t)(o * 128 + 8 * (4 * pp + j)) * 4u);
-            float ca = 0.f, cb = 0.f;
+            ca[pp][o] = cb[pp][o] = 0.f;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int sa = 4 * pp + 2 * m, sb = sa + 1;
-                ca = fmaf(in[sa >> 2][4 * (sa & 3) + 0], wv[2 * m].x, ca);
-                ca = fmaf(in[sa >> 2][4 * (sa & 3) + 1], wv[2 * m].y, ca);
-                ca = fmaf(in[sa >> 2][4 * (sa & 3) + 2], wv[2 * m].z, ca);
-                ca = fmaf(in[sa >> 2][4 * (sa & 3) + 3], wv[2 * m].w, ca);
-                cb = fmaf(in[sb >> 2][4 * (sb & 3) + 0], wv[2 * m + 1].x, cb);
-                cb = fmaf(in[sb >> 2][4 * (sb & 3) + 1], wv[2 * m + 1].y, cb);
-                cb = fmaf(in[sb >> 2][4 * (sb & 3) + 2], wv[2 * m + 1].z, cb);
-                cb = fmaf(in[sb >> 2][4 * (sb & 3) + 3], wv[2 * m + 1].w, cb);
+                ca[pp][o] = fmaf(in[sa >> 2][4 * (sa & 3) + 0], hw.w[o][sa].x, ca[pp][o]);
+                ca[pp][o] = fmaf(in[sa >> 2][4 * (sa & 3) + 1], hw.w[o][sa].y, ca[pp][o]);
+                ca[pp][o] = fmaf(in[sa >> 2][4 * (sa & 3) + 2], hw.w[o][sa].z, ca[pp][o]);
+                ca[pp][o] = fmaf(in[sa >> 2][4 * (sa & 3) + 3], hw.w[o][sa].w, ca[pp][o]);
+                cb[pp][o] = fmaf(in[sb >> 2][4 * (sb & 3) + 0], hw.w[o][sb].x, cb[pp][o]);
+                cb[pp][o] = fmaf(in[sb >> 2][4 * (sb & 3) + 1], hw.w[o][sb].y, cb[pp][o]);
+                cb[pp][o] = fmaf(in[sb >> 2][4 * (sb & 3) + 2], hw.w[o][sb].z, cb[pp][o]);
+                cb[pp][o] = fmaf(in[sb >> 2][4 * (sb & 3) + 3], hw.w[o][sb].w, cb[pp][o]);
             }
-            const float pa = partner(ca, lane), pb = partner(cb, lane);
-            out[o] += (ca + pa) + (cb + pb);
         }
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        out[o] = b3[o];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) out[o] += pair_sum(ca[pp][o], cb[pp][o]);
     }
 }
 
@@ -386,7 +442,7 @@ __device__ __forceinline__ void head3(const f32x16 (&in)[8], __amdgpu_buffer_rsr
 template <bool DEEP, class Mid>
 __device__ __forceinline__ float4 space_wave(const float* net, const bool use_time, float* encw, const float (&p)[3],
                                              const float (&dv)[3], float tv, int lane, f32x16 (&acc)[8], f32x16 (&in)[8],
-                                             float4 (&wa)[8], float4 (&wb)[8], Mid mid WV_DBG_PARAM) {
+                                             float4 (&wa)[8], float4 (&wb)[8], Mid mid WV_DBG_PARAM WP_PARAM) {
     const SpaceLayout L = space_layout(use_time, DEEP);
     const __amdgpu_buffer_rsrc_t rsrc = weight_rsrc(net);
     const int h = lane >> 5, c = lane & 31;
@@ -397,14 +453,20 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
     load_bias<8>(acc, rsrc, blane, (uint32_t)L.b[0] * 4u);
     load_w<8>(wa, rsrc, wl256, (uint32_t)L.w[0] * 4u);
     f32x16 pe[2];
+#ifdef STNERF_WAVE_EXP_NOPE
+    pe[0] = acc[0] + p[0]; pe[1] = acc[1] + p[1];
+#else
     encode_pos(encw, lane, p);
     wave_lds_sync();
     read_enc_blocks<2, 8>(encw, lane, pe);
     wave_lds_sync();
+#endif
     WV_DBG(100, pe, 2);
+    WP(WP_S_PE);
     segment_r<8, 2, 8, 0, 8>(acc, pe, wa, wb, rsrc, wl256, (uint32_t)L.w[0] * 4u, WSTEP256, wl256, (uint32_t)L.w[1] * 4u);
     relu_rebias<8, 8>(acc, in, rsrc, blane, (uint32_t)L.b[1] * 4u);
     WV_DBG(0, in, 8);
+    WP(WP_S_L0);
     // ---- stage1.2 .. stage2.4: six 256-wide layers, stage2.0 (li == 4) with the PE(pos) skip segment behind its 256
     // features (modeling/spacenet.py:45-57,136-138)
     uint32_t soff = (uint32_t)L.w[1] * 4u;
@@ -426,20 +488,45 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
         WV_DBG(li, in, 8);
         soff = after;
     }
-    // ---- sigma = density_net(h) (:139), raw
-    const float sigma = head_sigma(in, rsrc, blane, (uint32_t)L.w_sigma * 4u, net[L.b_sigma], lane);
+    WP(WP_S_LOOP);
+    // ---- sigma = density_net(h) (:139), raw: its weights go out first, the direction / time encoding covers their
+    // latency (and that of the next item's HBM loads, issued by `mid`)
+#ifndef STNERF_WAVE_EXP_NOHEADS
+    HeadSigmaW hs;
+    load_head_sigma(hs, rsrc, blane, (uint32_t)L.w_sigma * 4u);
+    const float b_sigma = net[L.b_sigma];
+#endif
+    mid();
     // ---- rgb_net: relu -> Linear(283|304, 128) -> relu -> Linear(128, 3)   (:80-86); h is already >= 0, the
     // encodings are clamped when written
-    mid();
     f32x16 de[2];
+#ifndef STNERF_WAVE_EXP_NOPE
     encode_dir_time(encw, lane, dv, tv, use_time);
+#endif
+    // (the sigma chains sit between the encoding's LDS writes and its read-back: their weights and the encoding
+    // blocks are never live together)
+#ifdef STNERF_WAVE_EXP_NOHEADS
+    const float sigma = in[0][0];
+#else
+    const float sigma = head_sigma(in, hs, b_sigma, lane);
+#endif
+#ifdef STNERF_WAVE_EXP_NOPE
+    de[0] = in[0] + dv[0]; de[1] = in[1] + tv;
+#else
     wave_lds_sync();
     if (use_time) read_enc_blocks<2, 6>(encw, lane, de);
     else read_enc_blocks<2, 4>(encw, lane, de);
     wave_lds_sync();
+#endif
     WV_DBG(101, de, 2);
+    WP(WP_S_MID);
     const uint32_t wr = (uint32_t)L.w_rgb1 * 4u;
     segment_r<4, 8, 32, 0, 4>(acc, in, wa, wb, rsrc, wl128, wr, WSTEP128, wl128, wr + 32u * WSTEP128);
+    // the colour head's weights travel behind the encoding segment (`in` is dead from here on: registers to spare)
+#ifndef STNERF_WAVE_EXP_NOHEADS
+    Head3W hr;
+    load_head3(hr, rsrc, blane, (uint32_t)L.w_rgb2 * 4u);
+#endif
     const uint32_t w_after = DEEP ? (uint32_t)L.w_deep[0] * 4u : wr;  // (not deep: nothing follows; the fetch is discarded)
     if (use_time) segment_r<4, 2, 6, 0, 4>(acc, de, wa, wb, rsrc, wl128, wr + 32u * WSTEP128, WSTEP128, wl128, w_after);
     else segment_r<4, 2, 4, 0, 4>(acc, de, wa, wb, rsrc, wl128, wr + 32u * WSTEP128, WSTEP128, wl128, w_after);
@@ -449,10 +536,16 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
         relu_rebias<4, 4>(acc, in, rsrc, blane, (uint32_t)L.b_deep[1] * 4u);
         segment_r<4, 8, 16, 0, 4>(acc, in, wa, wb, rsrc, wl128, (uint32_t)L.w_deep[1] * 4u, WSTEP128, wl128, (uint32_t)L.w_deep[1] * 4u);
     }
+    WP(WP_S_RGB1);
     relu_rebias<4, 0>(acc, in, rsrc, blane, 0u);
     WV_DBG(7, in, 4);
     float rgb[3];
-    head3(in, rsrc, blane, (uint32_t)L.w_rgb2 * 4u, net + L.b_rgb2, lane, rgb);
+#ifdef STNERF_WAVE_EXP_NOHEADS
+    rgb[0] = in[0][1]; rgb[1] = in[1][2]; rgb[2] = in[2][3];
+#else
+    head3(in, hr, net + L.b_rgb2, lane, rgb);
+#endif
+    WP(WP_S_HEAD);
     return make_float4(rgb[0], rgb[1], rgb[2], sigma);
 }
 
@@ -460,7 +553,7 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
 // MotionNet on the wave's 32 samples: p += flow (modeling/layered_rfrender.py:356,510).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void motion_wave(const float* net, float* encw, float (&p)[3], float tv, int flags, int lane,
-                                            f32x16 (&acc)[8], f32x16 (&in)[8], float4 (&wa)[8], float4 (&wb)[8] WV_DBG_PARAM) {
+                                            f32x16 (&acc)[8], f32x16 (&in)[8], float4 (&wa)[8], float4 (&wb)[8] WV_DBG_PARAM WP_PARAM) {
     const MotionLayout L = motion_layout();
     const __amdgpu_buffer_rsrc_t rsrc = weight_rsrc(net);
     const int h = lane >> 5, c = lane & 31;
@@ -475,10 +568,13 @@ __device__ __forceinline__ void motion_wave(const float* net, float* encw, float
     read_enc_blocks<3, 11>(encw, lane, me);
     wave_lds_sync();
     WV_DBG(199, me, 3);
+    WP(WP_M_ENC);
     // motion_net.0: 11 K steps (22 quads); an odd count leaves the next layer's first weights in wb
     segment_r<4, 3, 11, 0, 4>(acc, me, wa, wb, rsrc, wl128, (uint32_t)L.w[0] * 4u, WSTEP128, wl128, (uint32_t)L.w[1] * 4u);
     relu_rebias<4, 4>(acc, in, rsrc, blane, (uint32_t)L.b[1] * 4u);
     WV_DBG(200, in, 4);
+    Head3W hf;  // the flow head's weights: fetched here, used behind the four hidden layers
+    load_head3(hf, rsrc, blane, (uint32_t)L.w_out * 4u);
 #pragma unroll 1
     for (int li = 1; li <= 4; ++li) {
         const uint32_t soff = (uint32_t)L.w[1] * 4u + (uint32_t)(li - 1) * (32u * 128u * 16u + 512u);
@@ -490,10 +586,12 @@ __device__ __forceinline__ void motion_wave(const float* net, float* encw, float
         else relu_rebias<4, 0>(acc, in, rsrc, blane, 0u);
         WV_DBG(200 + li, in, 4);
     }
+    WP(WP_M_LAYERS);
     float fl[3];
-    head3(in, rsrc, blane, (uint32_t)L.w_out * 4u, net + L.b_out, lane, fl);
+    head3(in, hf, net + L.b_out, lane, fl);
 #pragma unroll
     for (int c3 = 0; c3 < 3; ++c3) p[c3] = p[c3] + fl[c3];
+    WP(WP_M_HEAD);
 }
 
 // What a wave needs of a work item: its sample's point, direction and frame id, and where the result goes.
@@ -581,6 +679,11 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_wave_stage_kernel(StageArgs
     int par = 0;
     f32x16 acc[8], in[8];
     float4 wa[8], wb[8];
+#ifdef STNERF_WAVE_PROF
+    WaveProf wp;
+    for (int i = 0; i < 12; ++i) wp.acc[i] = 0;
+    wp.t = clock64();
+#endif
     while (it0 < total) {
         // the item after next (consumed at the end of this one) and the ray index of the next item's sample
         uint32_t pending = 0;
@@ -598,10 +701,11 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_wave_stage_kernel(StageArgs
         WaveDbg dbg{a.dbg, a.dbg_stage, -1};
         if (slot_of(it0) == 0 && cur.valid) dbg.row = (int64_t)(it0 - base_of(it0)) * WV_ITEM + wave * WV_ROWS + (lane & 31);
 #endif
-        if (ly.motion) motion_wave(ly.motion, encw, p, cur.tv, ly.motion_flags, lane, acc, in, wa, wb WV_DBG_ARG);
+        WP(WP_TOP);
+        if (ly.motion) motion_wave(ly.motion, encw, p, cur.tv, ly.motion_flags, lane, acc, in, wa, wb WV_DBG_ARG WP_ARG);
         const float tvs = ly.use_time ? cur.tv : 0.f;
         float4 o = space_wave<DEEP>(ly.space, ly.use_time != 0, encw, p, dv, tvs, lane, acc, in, wa, wb,
-                                    [&]() { fetch(it1, rr_next, nxt); } WV_DBG_ARG);
+                                    [&]() { fetch(it1, rr_next, nxt); } WV_DBG_ARG WP_ARG);
         if (cur.valid && lane < 32) {
             if (a.sigmoid_rgb) {  // torch.sigmoid(rgb): 1-ulp v_exp_f32 / v_rcp_f32, the same expression the compositor uses
                 o.x = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(o.x * -1.44269504088896340736f));
@@ -617,7 +721,15 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_wave_stage_kernel(StageArgs
         it0 = it1;
         it1 = it2;
         cur = nxt;
+        WP(WP_END);
+#ifdef STNERF_WAVE_PROF
+        wp.acc[11] += 1;
+#endif
     }
+#ifdef STNERF_WAVE_PROF
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_wphase[i], wp.acc[i]);
+#endif
 }
 
 #ifdef STNERF_WAVE_DEBUG
@@ -646,6 +758,17 @@ int launch_wave_stage(const StageArgs& a_in, bool deep_rgb, int cus, hipStream_t
 }
 
 }  // namespace stnerf
+
+#ifdef STNERF_WAVE_PROF
+extern "C" int stnerf_debug_wave_phases(unsigned long long* host16, int reset) {
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(stnerf::g_wphase), sizeof(unsigned long long) * 16) != hipSuccess) return STNERF_ELAUNCH;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(stnerf::g_wphase), z, sizeof(z)) != hipSuccess) return STNERF_ELAUNCH;
+    }
+    return STNERF_OK;
+}
+#endif
 
 #ifdef STNERF_WAVE_DEBUG
 // development builds only: where the next stnerf_mlp_stage launches dump the activations of queue slot 0

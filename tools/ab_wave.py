@@ -240,8 +240,11 @@ def time_():
         "performer, no motion": ([dict(space=sp, motion=None, xyz=xyz, raw=raw, times=times)], FLOP_SPACE_TIME),
         "performer fused with motion": ([dict(space=sp, motion=mo, xyz=xyz, raw=raw, times=times)], FLOP_MOTION + FLOP_SPACE_TIME),
     }
+    only = os.environ.get("CASES")
     for name, (ls, flop) in cases.items():
-        for kern in ("lds", "wave"):
+        if only and not any(name.startswith(o) for o in only.split(",")):
+            continue
+        for kern in os.environ.get("KERNELS", "lds,wave").split(","):
             os.environ["STNERF_STAGE_KERNEL"] = kern
             ms = timeit(lambda: ops.mlp_stage(ls, dirs, ns, sigmoid_rgb=True), iters)
             print(f"{name:30s} {kern:5s} {ms:9.3f} ms  {rows * flop / (ms * 1e-3) / 1e12:7.2f} TF/s", flush=True)
