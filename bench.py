@@ -481,8 +481,11 @@ def main():
             "mask_fraction": head["mask_fraction"],
             "per_rank_compute_s": {"min": min(per_rank), "mean": sum(per_rank) / len(per_rank), "max": max(per_rank),
                                    "all": per_rank, "note": "render time of each rank's share over the timed steps, before the all-gather"},
-            "roofline": {"kernel": ("stnerf::mlp_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, "
-                                    "fused PE + MLP, v_mfma_f32_32x32x2_f32)") if staged else
+            "roofline": {"kernel": (("stnerf::mlp_wave_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, "
+                                     "a wave owns 32 samples and keeps their activations in registers, v_mfma_f32_32x32x2_f32)")
+                                    if os.environ.get("STNERF_STAGE_KERNEL", "wave") != "lds" else
+                                    ("stnerf::mlp_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, "
+                                     "feature-split waves with the activations in LDS, v_mfma_f32_32x32x2_f32)")) if staged else
                                    "stnerf::spacenet_kernel (fused PE + 9-layer MLP, v_mfma_f32_32x32x2_f32)",
                          "bound": "mfma", "achieved": achieved, "peak": peak_used, "unit": "TFLOP/s",
                          "frac": achieved / peak_used, "traffic": traffic,

@@ -38,14 +38,17 @@ constexpr int WV_THREADS = WV_NW * 64;
 constexpr int WV_ITEM = WV_NW * WV_ROWS;          // rows per work item
 constexpr int WV_ENC_QUADS = 22;                  // widest staged encoding: MotionNet's 84 (+4) features
 constexpr int WV_ENC_FLOATS = WV_ENC_QUADS * WV_ROWS * 4;
-constexpr int WV_LDS = WV_NW * WV_ENC_FLOATS * 4 + 16;
+constexpr int WV_BIAS_SLOTS = 10;                 // bias vectors of one network staged per wave (256 floats each)
+constexpr int WV_BIAS_FLOATS = WV_BIAS_SLOTS * 256;
+constexpr int WV_WAVE_FLOATS = WV_ENC_FLOATS + WV_BIAS_FLOATS;   // a wave's private LDS window
+constexpr int WV_LDS = WV_NW * WV_WAVE_FLOATS * 4 + 16 + STNERF_MAX_LAYERS * 8;   // + queue slots + rows per layer
 
 // Optional per-phase cycle accounting (development builds: -DSTNERF_WAVE_PROF): every wave adds its s_memtime deltas per
 // phase; read back with stnerf_debug_wave_phases().
 #ifdef STNERF_WAVE_PROF
 static __device__ unsigned long long g_wphase[16];
 struct WaveProf {
-    unsigned long long t, acc[12];
+    unsigned long long t, acc[16];
 };
 #define WP_PARAM , WaveProf& wp
 #define WP_ARG , wp
@@ -56,7 +59,7 @@ struct WaveProf {
 #define WP(i) do { } while (0)
 #endif
 enum { WP_TOP = 0, WP_M_ENC = 1, WP_M_LAYERS = 2, WP_M_HEAD = 3, WP_S_PE = 4, WP_S_L0 = 5, WP_S_LOOP = 6, WP_S_MID = 7,
-       WP_S_RGB1 = 8, WP_S_HEAD = 9, WP_END = 10 };
+       WP_S_RGB1 = 8, WP_S_HEAD = 9, WP_END = 10, WP_ITEMS = 11, WP_L_SEG = 12, WP_L_EPI = 13 };
 
 // feature f of the lane's sample inside the wave-private staging window (col = window + 4 * c)
 #define ENCW(col, f) (col)[((f) >> 2) * (WV_ROWS * 4) + ((f) & 3)]
@@ -251,6 +254,7 @@ __device__ __forceinline__ void step_r(f32x16 (&acc)[8], const float4 (&wc)[8], 
             acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, bv, acc[fb], 0, 0, 0);
         }
     }
+    // (spreading the loads over the whole step -- one behind every 2nd .. 4th MFMA -- measures the same)
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
@@ -285,17 +289,99 @@ __device__ __forceinline__ void segment_r(f32x16 (&acc)[8], const f32x16 (&blk)[
     }
 }
 
+// 128-wide layers (4 feature blocks: 16 MFMAs = 1024 cycles per K step) in PAIRS of K steps: one operand fetch of 8 x 16 B
+// per lane covers two steps (blocks 0..3: step 2 m, blocks 4..7: step 2 m + 1 -- the lane offsets of `wlp` carry the
+// extra row pair), so the fetch runs 2048 cycles ahead of its use like in the 256-wide layers instead of 1024 (the L2
+// latency under load is of that order: the single-step form lost 6 .. 11 % of these layers' MFMA time to operand
+// waits).  Per accumulator the MFMAs come in the same order as in the single-step form.
+__device__ __forceinline__ LaneOfs lane_offsets_paired(uint32_t wlane, uint32_t wstep) {
+    LaneOfs o;
+#pragma unroll
+    for (int fb = 0; fb < 8; ++fb) {
+        o.v[fb] = wlane + (fb & 3) * 512u + (fb >> 2) * wstep;
+        asm volatile("" : "+v"(o.v[fb]));
+    }
+    return o;
+}
+template <int NL, bool BOTH>
+__device__ __forceinline__ void pair_r(f32x16 (&acc)[8], const float4 (&wc)[8], const f32x16& b0, int r0, const f32x16& b1, int r1) {
+#pragma unroll
+    for (int half = 0; half < (BOTH ? 2 : 1); ++half) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float bv = half == 0 ? b0[r0 + kk] : b1[r1 + kk];
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) {
+                const float4& w4 = wc[4 * half + fb];
+                const float wv = kk == 0 ? w4.x : kk == 1 ? w4.y : kk == 2 ? w4.z : w4.w;
+                acc[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, bv, acc[fb], 0, 0, 0);
+            }
+        }
+    }
+    constexpr int NM = BOTH ? 32 : 16;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - NL, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+// STEPS K steps (an odd count ends on a half pair); pair m reads buffer (m + PAR) & 1; on entry that buffer holds pair 0;
+// the last pair fetches NFB_NEXT blocks at (next_wlane, next_soff) into the other buffer.
+template <int NBLK, int STEPS, int PAR, int NFB_NEXT>
+__device__ __forceinline__ void segment_p(f32x16 (&acc)[8], const f32x16 (&blk)[NBLK], float4 (&wa)[8], float4 (&wb)[8],
+                                          __amdgpu_buffer_rsrc_t rsrc, const LaneOfs& wlp, uint32_t soff, uint32_t wstep,
+                                          const LaneOfs& next_wlane, uint32_t next_soff) {
+    static_assert(STEPS >= 1 && STEPS <= 4 * NBLK, "segment_p: not enough input blocks");
+    constexpr int PAIRS = (STEPS + 1) / 2;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m + 1 < PAIRS; ++m) {
+        float4 (&wc)[8] = ((m + PAR) & 1) ? wb : wa;
+        float4 (&wn)[8] = ((m + PAR) & 1) ? wa : wb;
+        load_w<8>(wn, rsrc, wlp, soff + (uint32_t)(m + 1) * 2u * wstep);
+        pair_r<8, true>(acc, wc, blk[(2 * m) >> 2], 4 * ((2 * m) & 3), blk[(2 * m + 1) >> 2], 4 * ((2 * m + 1) & 3));
+    }
+    {
+        constexpr int m = PAIRS - 1;
+        constexpr bool both = (STEPS & 1) == 0;
+        float4 (&wc)[8] = ((m + PAR) & 1) ? wb : wa;
+        float4 (&wn)[8] = ((m + PAR) & 1) ? wa : wb;
+        load_w<NFB_NEXT>(wn, rsrc, next_wlane, next_soff);
+        pair_r<NFB_NEXT, both>(acc, wc, blk[(2 * m) >> 2], 4 * ((2 * m) & 3), blk[both ? (2 * m + 1) >> 2 : (2 * m) >> 2],
+                               both ? 4 * ((2 * m + 1) & 3) : 0);
+    }
+}
+
+// Biases through LDS.  Fetched from the blob at the layer boundary, a layer's bias costs one exposed L2 round trip
+// (~900 cycles: the accumulators it goes into are busy until the previous layer's ReLU pass, and there are no registers
+// to park it in) -- measured 1.6 .. 2.0 k cycles of overhead per layer whatever its size.  Instead every bias vector of
+// the network is copied once, at the start of the network, into the wave's private LDS window (one 16-byte load per
+// lane and vector, behind the encoding arithmetic); the layer boundary reads it back with ds_read_b128 (both lanes
+// halves broadcast), ~100 cycles ahead of its first use.
+template <int NB>
+struct BiasStage {
+    float4 v[NB];
+};
+template <int NB>
+__device__ __forceinline__ void stage_bias_issue(BiasStage<NB>& st, __amdgpu_buffer_rsrc_t rsrc, int lane, const uint32_t (&boff)[NB]) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) st.v[i] = load_weight(rsrc, (uint32_t)lane * 16u, boff[i]);  // floats 4 lane .. of vector i
+}
+template <int NB>
+__device__ __forceinline__ void stage_bias_store(const BiasStage<NB>& st, float* biasw, int lane) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) reinterpret_cast<float4*>(biasw + i * 256)[lane] = st.v[i];
+    wave_lds_sync();
+}
+
 // Layer boundary: in = relu(acc) (one v_max_i32 per value); as soon as a block is consumed, the bias of the NEXT
-// layer's block is loaded into the freed accumulator registers (its first MFMA issues ~450 cycles later).
+// layer's block (next_bias = that vector in the wave's LDS window, nullptr-free: NFB_NEXT = 0 after the last layer) is
+// read into the freed accumulator registers.  Register 4 q + r of block fb <-> feature 32 fb + 8 q + 4 h + r.
 template <int NFB, int NFB_NEXT>
-__device__ __forceinline__ void relu_rebias(f32x16 (&acc)[8], f32x16 (&in)[8], __amdgpu_buffer_rsrc_t rsrc, uint32_t blane,
-                                            uint32_t next_boff) {
-#ifdef STNERF_WAVE_EXP_NOEPI  /* development experiment: no ReLU pass, no bias fetch (wrong results) */
-    return;
-#endif
-#ifdef STNERF_WAVE_LAYER_BARRIER  /* keep the four waves of a CU in step (vector-L1 sharing of the weight lines) */
-    __builtin_amdgcn_s_barrier();
-#endif
+__device__ __forceinline__ void relu_rebias(f32x16 (&acc)[8], f32x16 (&in)[8], const float* next_bias, int lane) {
+    const float4* nb4 = reinterpret_cast<const float4*>(next_bias) + (lane >> 5);
 #pragma unroll
     for (int fb = 0; fb < (NFB > NFB_NEXT ? NFB : NFB_NEXT); ++fb) {
         if (fb < NFB) {
@@ -305,7 +391,7 @@ __device__ __forceinline__ void relu_rebias(f32x16 (&acc)[8], f32x16 (&in)[8], _
         if (fb < NFB_NEXT) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 b = load_weight(rsrc, blane, next_boff + (uint32_t)(fb * 32 + 8 * q) * 4u);
+                const float4 b = nb4[fb * 8 + 2 * q];
                 acc[fb][4 * q + 0] = b.x;
                 acc[fb][4 * q + 1] = b.y;
                 acc[fb][4 * q + 2] = b.z;
@@ -446,25 +532,38 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
     const SpaceLayout L = space_layout(use_time, DEEP);
     const __amdgpu_buffer_rsrc_t rsrc = weight_rsrc(net);
     const int h = lane >> 5, c = lane & 31;
-    const LaneOfs wl256 = lane_offsets((uint32_t)(h * 256 + c) * 16u), wl128 = lane_offsets((uint32_t)(h * 128 + c) * 16u);
-    const uint32_t blane = (uint32_t)h * 16u;
     constexpr uint32_t WSTEP256 = 2u * 256u * 16u, WSTEP128 = 2u * 128u * 16u;
-    // ---- stage1.0: bias + first weights in flight behind the encoding arithmetic
+    const LaneOfs wl256 = lane_offsets((uint32_t)(h * 256 + c) * 16u);
+    const LaneOfs wl128p = lane_offsets_paired((uint32_t)(h * 128 + c) * 16u, WSTEP128);  // (entries 0..3 = the single-step offsets)
+    const uint32_t blane = (uint32_t)h * 16u;
+    // ---- every later bias vector on its way into the wave's LDS window: slots 0..5 = stage1.2 .. stage2.4, 6 = rgb_net.1,
+    // 7 / 8 = the deep_rgb layers; then stage1.0's bias + first weights, all in flight behind the encoding arithmetic
+    float* biasw = encw + WV_ENC_FLOATS;
+    constexpr int NBS = DEEP ? 9 : 7;
+    BiasStage<NBS> bst;
+    {
+        uint32_t bo[NBS];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) bo[i] = (uint32_t)L.b[i + 1] * 4u;
+        bo[6] = (uint32_t)L.b_rgb1 * 4u;
+        if constexpr (DEEP) {
+            bo[7] = (uint32_t)L.b_deep[0] * 4u;
+            bo[8] = (uint32_t)L.b_deep[1] * 4u;
+        }
+        stage_bias_issue<NBS>(bst, rsrc, lane, bo);
+    }
     load_bias<8>(acc, rsrc, blane, (uint32_t)L.b[0] * 4u);
     load_w<8>(wa, rsrc, wl256, (uint32_t)L.w[0] * 4u);
     f32x16 pe[2];
-#ifdef STNERF_WAVE_EXP_NOPE
-    pe[0] = acc[0] + p[0]; pe[1] = acc[1] + p[1];
-#else
     encode_pos(encw, lane, p);
     wave_lds_sync();
     read_enc_blocks<2, 8>(encw, lane, pe);
     wave_lds_sync();
-#endif
+    stage_bias_store<NBS>(bst, biasw, lane);
     WV_DBG(100, pe, 2);
     WP(WP_S_PE);
     segment_r<8, 2, 8, 0, 8>(acc, pe, wa, wb, rsrc, wl256, (uint32_t)L.w[0] * 4u, WSTEP256, wl256, (uint32_t)L.w[1] * 4u);
-    relu_rebias<8, 8>(acc, in, rsrc, blane, (uint32_t)L.b[1] * 4u);
+    relu_rebias<8, 8>(acc, in, biasw, lane);
     WV_DBG(0, in, 8);
     WP(WP_S_L0);
     // ---- stage1.2 .. stage2.4: six 256-wide layers, stage2.0 (li == 4) with the PE(pos) skip segment behind its 256
@@ -476,75 +575,57 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
         const uint32_t boff = soff + kq * 4096u;           // this layer's bias
         const uint32_t after = boff + 1024u;               // the next layer's weights (stage2.4: density_net follows)
         const uint32_t next_w = li == 6 ? (uint32_t)L.w_rgb1 * 4u : after;
-        const uint32_t next_b = li == 6 ? (uint32_t)L.b_rgb1 * 4u : after + (li == 3 ? 80u : 64u) * 4096u;
         LaneOfs next_wl;  // (selected value by value: a reference to one of two arrays would send both through memory)
 #pragma unroll
-        for (int fb = 0; fb < 8; ++fb) next_wl.v[fb] = li == 6 ? wl128.v[fb] : wl256.v[fb];
+        for (int fb = 0; fb < 8; ++fb) next_wl.v[fb] = li == 6 ? wl128p.v[fb] : wl256.v[fb];  // (rgb_net.1 runs in step pairs)
         // (one copy of the 32-step body: behind stage2.0's 256 features the skip segment simply continues in the blob)
         segment_r<8, 8, 32, 0, 8>(acc, in, wa, wb, rsrc, wl256, soff, WSTEP256, next_wl,  // (li == 4: next_wl == wl256)
                                   li == 4 ? soff + 32u * WSTEP256 : next_w);
         if (li == 4) segment_r<8, 2, 8, 0, 8>(acc, pe, wa, wb, rsrc, wl256, soff + 32u * WSTEP256, WSTEP256, next_wl, next_w);
-        relu_rebias<8, 8>(acc, in, rsrc, blane, next_b);  // (stage2.4 -> rgb_net.1: blocks 4..7 of the bias fetch are unused)
+        WP(WP_L_SEG);
+        relu_rebias<8, 8>(acc, in, biasw + li * 256, lane);  // (stage2.4 -> rgb_net.1: blocks 4..7 of the bias read are unused)
+        WP(WP_L_EPI);
         WV_DBG(li, in, 8);
         soff = after;
     }
-    WP(WP_S_LOOP);
     // ---- sigma = density_net(h) (:139), raw: its weights go out first, the direction / time encoding covers their
     // latency (and that of the next item's HBM loads, issued by `mid`)
-#ifndef STNERF_WAVE_EXP_NOHEADS
     HeadSigmaW hs;
     load_head_sigma(hs, rsrc, blane, (uint32_t)L.w_sigma * 4u);
     const float b_sigma = net[L.b_sigma];
-#endif
     mid();
     // ---- rgb_net: relu -> Linear(283|304, 128) -> relu -> Linear(128, 3)   (:80-86); h is already >= 0, the
     // encodings are clamped when written
     f32x16 de[2];
-#ifndef STNERF_WAVE_EXP_NOPE
     encode_dir_time(encw, lane, dv, tv, use_time);
-#endif
     // (the sigma chains sit between the encoding's LDS writes and its read-back: their weights and the encoding
     // blocks are never live together)
-#ifdef STNERF_WAVE_EXP_NOHEADS
-    const float sigma = in[0][0];
-#else
     const float sigma = head_sigma(in, hs, b_sigma, lane);
-#endif
-#ifdef STNERF_WAVE_EXP_NOPE
-    de[0] = in[0] + dv[0]; de[1] = in[1] + tv;
-#else
     wave_lds_sync();
     if (use_time) read_enc_blocks<2, 6>(encw, lane, de);
     else read_enc_blocks<2, 4>(encw, lane, de);
     wave_lds_sync();
-#endif
     WV_DBG(101, de, 2);
     WP(WP_S_MID);
     const uint32_t wr = (uint32_t)L.w_rgb1 * 4u;
-    segment_r<4, 8, 32, 0, 4>(acc, in, wa, wb, rsrc, wl128, wr, WSTEP128, wl128, wr + 32u * WSTEP128);
+    segment_p<8, 32, 0, 4>(acc, in, wa, wb, rsrc, wl128p, wr, WSTEP128, wl128p, wr + 32u * WSTEP128);  // (the short encoding segment: single steps)
     // the colour head's weights travel behind the encoding segment (`in` is dead from here on: registers to spare)
-#ifndef STNERF_WAVE_EXP_NOHEADS
     Head3W hr;
     load_head3(hr, rsrc, blane, (uint32_t)L.w_rgb2 * 4u);
-#endif
     const uint32_t w_after = DEEP ? (uint32_t)L.w_deep[0] * 4u : wr;  // (not deep: nothing follows; the fetch is discarded)
-    if (use_time) segment_r<4, 2, 6, 0, 4>(acc, de, wa, wb, rsrc, wl128, wr + 32u * WSTEP128, WSTEP128, wl128, w_after);
-    else segment_r<4, 2, 4, 0, 4>(acc, de, wa, wb, rsrc, wl128, wr + 32u * WSTEP128, WSTEP128, wl128, w_after);
+    if (use_time) segment_r<4, 2, 6, 0, 8>(acc, de, wa, wb, rsrc, wl128p, wr + 32u * WSTEP128, WSTEP128, wl128p, w_after);
+    else segment_r<4, 2, 4, 0, 8>(acc, de, wa, wb, rsrc, wl128p, wr + 32u * WSTEP128, WSTEP128, wl128p, w_after);
     if constexpr (DEEP) {  // deep_rgb (:68-79): two more 128-wide hidden layers
-        relu_rebias<4, 4>(acc, in, rsrc, blane, (uint32_t)L.b_deep[0] * 4u);
-        segment_r<4, 8, 16, 0, 4>(acc, in, wa, wb, rsrc, wl128, (uint32_t)L.w_deep[0] * 4u, WSTEP128, wl128, (uint32_t)L.w_deep[1] * 4u);
-        relu_rebias<4, 4>(acc, in, rsrc, blane, (uint32_t)L.b_deep[1] * 4u);
-        segment_r<4, 8, 16, 0, 4>(acc, in, wa, wb, rsrc, wl128, (uint32_t)L.w_deep[1] * 4u, WSTEP128, wl128, (uint32_t)L.w_deep[1] * 4u);
+        relu_rebias<4, 4>(acc, in, biasw + 7 * 256, lane);
+        segment_p<8, 16, 0, 8>(acc, in, wa, wb, rsrc, wl128p, (uint32_t)L.w_deep[0] * 4u, WSTEP128, wl128p, (uint32_t)L.w_deep[1] * 4u);
+        relu_rebias<4, 4>(acc, in, biasw + 8 * 256, lane);
+        segment_p<8, 16, 0, 8>(acc, in, wa, wb, rsrc, wl128p, (uint32_t)L.w_deep[1] * 4u, WSTEP128, wl128p, (uint32_t)L.w_deep[1] * 4u);
     }
     WP(WP_S_RGB1);
-    relu_rebias<4, 0>(acc, in, rsrc, blane, 0u);
+    relu_rebias<4, 0>(acc, in, biasw, lane);
     WV_DBG(7, in, 4);
     float rgb[3];
-#ifdef STNERF_WAVE_EXP_NOHEADS
-    rgb[0] = in[0][1]; rgb[1] = in[1][2]; rgb[2] = in[2][3];
-#else
     head3(in, hr, net + L.b_rgb2, lane, rgb);
-#endif
     WP(WP_S_HEAD);
     return make_float4(rgb[0], rgb[1], rgb[2], sigma);
 }
@@ -557,21 +638,30 @@ __device__ __forceinline__ void motion_wave(const float* net, float* encw, float
     const MotionLayout L = motion_layout();
     const __amdgpu_buffer_rsrc_t rsrc = weight_rsrc(net);
     const int h = lane >> 5, c = lane & 31;
-    const LaneOfs wl128 = lane_offsets((uint32_t)(h * 128 + c) * 16u);
-    const uint32_t blane = (uint32_t)h * 16u;
     constexpr uint32_t WSTEP128 = 2u * 128u * 16u;
+    const LaneOfs wl128p = lane_offsets_paired((uint32_t)(h * 128 + c) * 16u, WSTEP128);
+    const uint32_t blane = (uint32_t)h * 16u;
+    float* biasw = encw + WV_ENC_FLOATS;
+    BiasStage<4> bst;  // motion_net.2 .. .8 -> slots 0..3 of the wave's LDS window
+    {
+        uint32_t bo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bo[i] = (uint32_t)L.b[i + 1] * 4u;
+        stage_bias_issue<4>(bst, rsrc, lane, bo);
+    }
     load_bias<4>(acc, rsrc, blane, (uint32_t)L.b[0] * 4u);
-    load_w<4>(wa, rsrc, wl128, (uint32_t)L.w[0] * 4u);
+    load_w<8>(wa, rsrc, wl128p, (uint32_t)L.w[0] * 4u);
     f32x16 me[3];
     encode_motion(encw, lane, p, tv, flags);
     wave_lds_sync();
     read_enc_blocks<3, 11>(encw, lane, me);
     wave_lds_sync();
+    stage_bias_store<4>(bst, biasw, lane);
     WV_DBG(199, me, 3);
     WP(WP_M_ENC);
-    // motion_net.0: 11 K steps (22 quads); an odd count leaves the next layer's first weights in wb
-    segment_r<4, 3, 11, 0, 4>(acc, me, wa, wb, rsrc, wl128, (uint32_t)L.w[0] * 4u, WSTEP128, wl128, (uint32_t)L.w[1] * 4u);
-    relu_rebias<4, 4>(acc, in, rsrc, blane, (uint32_t)L.b[1] * 4u);
+    // motion_net.0: 11 K steps (22 quads) = 5 step pairs + a half pair (every layer here runs in step pairs)
+    segment_p<3, 11, 0, 8>(acc, me, wa, wb, rsrc, wl128p, (uint32_t)L.w[0] * 4u, WSTEP128, wl128p, (uint32_t)L.w[1] * 4u);
+    relu_rebias<4, 4>(acc, in, biasw, lane);
     WV_DBG(200, in, 4);
     Head3W hf;  // the flow head's weights: fetched here, used behind the four hidden layers
     load_head3(hf, rsrc, blane, (uint32_t)L.w_out * 4u);
@@ -580,10 +670,11 @@ __device__ __forceinline__ void motion_wave(const float* net, float* encw, float
         const uint32_t soff = (uint32_t)L.w[1] * 4u + (uint32_t)(li - 1) * (32u * 128u * 16u + 512u);
         const uint32_t next_w = soff + 32u * 128u * 16u + 512u;
         // (behind motion_net.8 nothing follows: the fetch is discarded, so it re-reads this layer's first rows -- a full
-        // operand fetch at the output layer's 1.5 KB would run past the end of the blob)
-        segment_r<4, 8, 16, 1, 4>(acc, in, wa, wb, rsrc, wl128, soff, WSTEP128, wl128, li < 4 ? next_w : soff);
-        if (li < 4) relu_rebias<4, 4>(acc, in, rsrc, blane, next_w + 32u * 128u * 16u);
-        else relu_rebias<4, 0>(acc, in, rsrc, blane, 0u);
+        // operand fetch at the output layer's 1.5 KB would run past the end of the blob.  6 and 8 pairs per layer: every
+        // layer starts in wa)
+        segment_p<8, 16, 0, 8>(acc, in, wa, wb, rsrc, wl128p, soff, WSTEP128, wl128p, li < 4 ? next_w : soff);
+        if (li < 4) relu_rebias<4, 4>(acc, in, biasw + li * 256, lane);
+        else relu_rebias<4, 0>(acc, in, biasw, lane);
         WV_DBG(200 + li, in, 4);
     }
     WP(WP_M_LAYERS);
@@ -607,15 +698,21 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_wave_stage_kernel(StageArgs
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* encw = reinterpret_cast<float*>(smem) + wave * WV_ENC_FLOATS;
-    uint32_t* qslot = reinterpret_cast<uint32_t*>(reinterpret_cast<float*>(smem) + WV_NW * WV_ENC_FLOATS);
-    // ---- the queue: items (128 rows) of layer slot j are [pre[j], pre[j+1])
+    float* encw = reinterpret_cast<float*>(smem) + wave * WV_WAVE_FLOATS;  // [encodings | bias vectors]
+    uint32_t* qslot = reinterpret_cast<uint32_t*>(reinterpret_cast<float*>(smem) + WV_NW * WV_WAVE_FLOATS);
+    // ---- the queue: items (128 rows) of layer slot j are [pre[j], pre[j+1]); the row counts (one global load each) are
+    // kept in LDS for the per-item lookups
+    int64_t* lrows = reinterpret_cast<int64_t*>(qslot + 4);
     uint32_t pre[STNERF_MAX_LAYERS + 1];
     pre[0] = 0;
 #pragma unroll
     for (int j = 0; j < STNERF_MAX_LAYERS; ++j) {
         uint32_t items = 0;
-        if (j < a.n_layers) items = (uint32_t)((layer_rows(a.layer[j], a.n_rays, a.ns) + WV_ITEM - 1) / WV_ITEM);
+        if (j < a.n_layers) {
+            const int64_t rows = layer_rows(a.layer[j], a.n_rays, a.ns);
+            items = (uint32_t)((rows + WV_ITEM - 1) / WV_ITEM);
+            if (tid == 0) lrows[j] = rows;
+        }
         pre[j + 1] = pre[j] + items;
     }
     const uint32_t total = pre[STNERF_MAX_LAYERS];
@@ -635,10 +732,23 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_wave_stage_kernel(StageArgs
     auto row_of = [&](uint32_t item, RowRef& rr) {
         rr = RowRef{0, 0, false};
         if (item >= total) return;
-        const StageLayer& ly = a.layer[slot_of(item)];
-        const int64_t rows = layer_rows(ly, a.n_rays, a.ns);
+        const int slot = slot_of(item);
+        const int64_t rows = lrows[slot];
         const int64_t row = (int64_t)(item - base_of(item)) * WV_ITEM + wave * WV_ROWS + (lane & 31);
-        rr = locate_row(ly.ray_list, row, rows, a.ns);
+        rr.valid = row < rows;
+        if (rr.valid) {
+            int64_t rslot;
+            if (rows <= 0x7fffffffll) {  // (uniform) the usual case: a 32-bit division
+                const uint32_t q = (uint32_t)row / (uint32_t)a.ns;
+                rslot = q;
+                rr.k = (int)((uint32_t)row - q * (uint32_t)a.ns);
+            } else {
+                rslot = row / a.ns;
+                rr.k = (int)(row - rslot * a.ns);
+            }
+            const int32_t* rl = a.layer[slot].ray_list;
+            rr.ray = rl ? (int64_t)rl[rslot] : rslot;
+        }
     };
     // second half: the sample's inputs (HBM loads)
     auto fetch = [&](uint32_t item, const RowRef& rr, WaveInputs& in) {
@@ -681,7 +791,7 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_wave_stage_kernel(StageArgs
     float4 wa[8], wb[8];
 #ifdef STNERF_WAVE_PROF
     WaveProf wp;
-    for (int i = 0; i < 12; ++i) wp.acc[i] = 0;
+    for (int i = 0; i < 16; ++i) wp.acc[i] = 0;
     wp.t = clock64();
 #endif
     while (it0 < total) {
@@ -723,12 +833,12 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_wave_stage_kernel(StageArgs
         cur = nxt;
         WP(WP_END);
 #ifdef STNERF_WAVE_PROF
-        wp.acc[11] += 1;
+        wp.acc[WP_ITEMS] += 1;
 #endif
     }
 #ifdef STNERF_WAVE_PROF
     if (lane == 0)
-        for (int i = 0; i < 12; ++i) atomicAdd(&g_wphase[i], wp.acc[i]);
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_wphase[i], wp.acc[i]);
 #endif
 }
 

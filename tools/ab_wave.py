@@ -75,7 +75,7 @@ def check():
         sc = scenario(name, **kw)
         n, l, ns = sc["n"], sc["l"], sc["ns"]
         out = {}
-        for kern in ("lds", "wave"):
+        for kern in os.environ.get("ORDER", "lds,wave").split(","):
             raw = torch.full((n, l, ns, 4), 7.0, device="cuda")
             run(kern, sc["layers_for"](raw), sc["dirs"], ns, deep_rgb=sc["deep"])
             out[kern] = raw

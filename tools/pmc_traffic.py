@@ -12,7 +12,7 @@ import argparse
 import json
 import sqlite3
 
-KERNELS = {"spacenet": "%spacenet_kernel%", "motionnet": "%motionnet_kernel%", "mlp_stage": "%mlp_stage_kernel%",
+KERNELS = {"spacenet": "%spacenet_kernel%", "motionnet": "%motionnet_kernel%", "mlp_stage": "%mlp%stage_kernel%",
            "composite": "%composite%kernel%", "resample": "%resample_kernel%", "sample_coarse": "%sample_coarse_kernel%"}
 
 

@@ -29,6 +29,7 @@ for name, (ls, rgb1_ideal) in cases.items():
     ops.mlp_stage(ls, dirs, ns, sigmoid_rgb=True); torch.cuda.synchronize()
     lib.stnerf_debug_wave_phases(buf, 1)
     items = buf[11]
+    buf[6] = buf[12] + buf[13]   # the layer loop = its K segments + its ReLU / bias passes
     tot = sum(buf[i] for i in range(11))
     print(f"{name}: {items} item-waves, {tot / items:.0f} cycles per item-wave")
     idl = dict(ideal); idl[8] = rgb1_ideal
@@ -36,3 +37,4 @@ for name, (ls, rgb1_ideal) in cases.items():
         c = buf[i] / items
         extra = f"   ideal MFMA {idl[i]:7d}  -> overhead {c - idl[i]:8.0f}" if i in idl and c > 0 else ""
         print(f"  {nm:30s} {c:10.0f} cycles  {100.0 * buf[i] / tot:5.1f} %{extra}")
+    print(f"  layer loop split: K segments {buf[12] / items:.0f} (ideal {idl[6]}), ReLU + bias passes {buf[13] / items:.0f} cycles per item-wave")
