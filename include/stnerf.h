@@ -187,10 +187,13 @@ int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32
                          int64_t flow_ray_stride, int add_to_xyz, stnerf_stream_t stream);
 
 /* a8 + a9 for a whole network stage of the pipeline (coarse or fine, modeling/layered_rfrender.py:340-418 / :495-576):
- * ONE persistent launch evaluates every listed layer -- one workgroup per CU pops 128-row (SpaceNet only) or 256-row
- * (MotionNet fused in front of its SpaceNet, the flow stays on chip) work items from a device-side queue.  Results are
- * bit-identical to stnerf_motionnet_fwd(ADD_TO_XYZ) followed by stnerf_spacenet_fwd per layer, except that the deformed
- * points are NOT written back to xyz.  Exact-f32 arithmetic only.  `queue`: one zeroed uint32 on the device.
+ * ONE persistent launch evaluates every listed layer -- one workgroup per CU pops work items (128 rows of a layer; the
+ * MotionNet of a deformed layer runs in front of its SpaceNet on the same rows, the flow stays on chip) from a device-side
+ * queue.  Two organisations of the tile arithmetic, selected by the environment variable STNERF_STAGE_KERNEL (read on
+ * every call): "wave" (default; csrc/mlp_wave.hip: a wave owns 32 samples, the activations never leave its registers)
+ * and "lds" (csrc/mlp_stage.hip: feature-split waves, activations in LDS).  Either way the results are bit-identical to
+ * stnerf_motionnet_fwd(ADD_TO_XYZ) followed by stnerf_spacenet_fwd per layer, except that the deformed points are NOT
+ * written back to xyz.  Exact-f32 arithmetic only.  `queue`: one zeroed uint32 on the device.
  * flags: STNERF_STAGE_DEEP_RGB = the SpaceNets are of a *_DEEP kind; STNERF_STAGE_SIGMOID_RGB = store sigmoid(rgb)
  * instead of the raw colour head output (torch.sigmoid of layers/render_layer.py:47 moved into the network epilogue,
  * where it is free; pair it with stnerf_composite_params.rgb_activated = 1). */
