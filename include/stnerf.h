@@ -147,8 +147,18 @@ int stnerf_pack_net(int kind, const float* const* weights_host, const float* con
 int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
                         const int32_t* ray_count, const float* xyz, int64_t xyz_ray_stride,
                         const float* dirs, int64_t dirs_ray_stride, const float* times,
-                        int64_t times_ray_stride, float* raw, int64_t raw_ray_stride,
+                        int64_t times_ray_stride, float* raw, int64_t raw_ray_stride, float* ray_bias,
                         stnerf_stream_t stream);
+
+/* The per-ray part of rgb_net.1 (modeling/spacenet.py:80-86,141-151): the layer reads the 256 backbone features of a
+ * sample and the encodings of the ray's direction and frame id -- the same 27 (+ 21) numbers for every sample of the ray
+ * (:115,118 repeat them).  out[j][0..127] = bias + W[:, 256:] * relu([PE_4(dir_j), PE_10(time_j)]) for the listed rays j
+ * (rows of other rays are left untouched); the exact-f32 MLP kernels take row j as the C operand of the layer's first
+ * MFMA.  stnerf_spacenet_fwd and stnerf_mlp_stage call this themselves into their `ray_bias` workspaces
+ * ([n_rays][128] floats per layer, 16-byte aligned); exported for tests and for callers that want the table. */
+int stnerf_rgb_ray_bias(int kind, const void* packed, int64_t n_rays, const int32_t* ray_list, const int32_t* ray_count,
+                        const float* dirs, int64_t dirs_ray_stride, const float* times, int64_t times_ray_stride,
+                        float* out, stnerf_stream_t stream);
 
 /* "fp16x3" variant of the SpaceNet kernel: fp32-accurate matrix products on the fp16 MFMA pipe.  Every
  * fp32 operand is split x = hi + lo into two fp16 numbers (22 significand bits) and a*b is evaluated as
@@ -193,7 +203,8 @@ int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32
  * every call): "wave" (default; csrc/mlp_wave.hip: a wave owns 32 samples, the activations never leave its registers)
  * and "lds" (csrc/mlp_stage.hip: feature-split waves, activations in LDS).  Either way the results are bit-identical to
  * stnerf_motionnet_fwd(ADD_TO_XYZ) followed by stnerf_spacenet_fwd per layer, except that the deformed points are NOT
- * written back to xyz.  Exact-f32 arithmetic only.  `queue`: one zeroed uint32 on the device.
+ * written back to xyz.  Exact-f32 arithmetic only.  `queue`: one zeroed uint32 on the device.  `ray_bias`: workspace of
+ * n_layers x n_rays x 128 floats (16-byte aligned) for the per-ray part of rgb_net.1 (stnerf_rgb_ray_bias).
  * flags: STNERF_STAGE_DEEP_RGB = the SpaceNets are of a *_DEEP kind; STNERF_STAGE_SIGMOID_RGB = store sigmoid(rgb)
  * instead of the raw colour head output (torch.sigmoid of layers/render_layer.py:47 moved into the network epilogue,
  * where it is free; pair it with stnerf_composite_params.rgb_activated = 1). */
@@ -212,7 +223,7 @@ typedef struct stnerf_stage_layer {
 } stnerf_stage_layer;
 int stnerf_mlp_stage(const stnerf_stage_layer* layers_host, int n_layers, int64_t n_rays, int ns, const float* dirs,
                      int64_t dirs_ray_stride, int64_t times_ray_stride, int64_t xyz_ray_stride,
-                     int64_t raw_ray_stride, int flags, uint32_t* queue, stnerf_stream_t stream);
+                     int64_t raw_ray_stride, int flags, uint32_t* queue, float* ray_bias, stnerf_stream_t stream);
 
 /* a7 standalone: NeRF positional encoding [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)],
  * each block `dim` wide.  utils/dimension_kernel.py:3-73 (Trigonometric_kernel.__call__).  In the render

@@ -22,6 +22,7 @@ SOURCES = [
     ("sampler.hip", ["-ffp-contract=off"]),
     ("render.hip", ["-ffp-contract=off"]),
     ("mlp.hip", []),
+    ("mlp_raybias.hip", []),
     ("mlp_stage.hip", []),
     # (no -mllvm -amdgpu-mfma-vgpr-form=1 here: it saves the v_accvgpr_read of every ReLU (+0.3 %), but with it two of
     # three instrumented variants of this file computed wrong, run-to-run varying results on the MI355X -- hipcc 7.2)

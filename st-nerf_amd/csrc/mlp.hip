@@ -117,46 +117,11 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_ke
         __syncthreads();
         // ---- stage2.0 on [h, PE(pos)] (:56-57, :137)
         DENSE(TM, NW, 256, 256, net, L.w[4], L.b[4], act, 64, enc, 16, act, wA, L.w[5], L.b[5], wB);
-        // enc is free now (all waves passed the barrier inside dense_layer): write
-        // relu(PE_4(dir)) (27) and relu(PE_10(time)) (21) -> enc features 0..47  (:80-86, :141-149)
-        {
-            float dv[3] = {0.f, 0.f, 0.f};
-            if (valid) {
-                const float* src = a.dirs + ray * a.dirs_ray_stride;
-                dv[0] = src[0];
-                dv[1] = src[1];
-                dv[2] = src[2];
-            }
-            if (part == 0) {
-#pragma unroll
-                for (int dmn = 0; dmn < 3; ++dmn) ENC_AT(col, dmn) = fmaxf(dv[dmn], 0.f);
-            }
-            for (int fq = part; fq < 4; fq += NPARTS) {
-                const float freq = (float)(1 << fq);
-#pragma unroll
-                for (int dmn = 0; dmn < 3; ++dmn) {
-                    float sn, cs;
-                    sincos_pe(dv[dmn] * freq, sn, cs);
-                    const int fs = 3 + fq * 6 + dmn, fc = fs + 3;
-                    ENC_AT(col, fs) = relu_bits(sn);
-                    ENC_AT(col, fc) = relu_bits(cs);
-                }
-            }
-            if (USE_TIME) {
-                const float tv = valid ? a.times[ray * a.times_ray_stride] : 0.f;
-                if (part == NPARTS - 1) ENC_AT(col, 27) = fmaxf(tv, 0.f);
-                for (int fq = NPARTS - 1 - part; fq < 10; fq += NPARTS) {
-                    float sn, cs;
-                    sincos_pe(tv * (float)(1 << fq), sn, cs);
-                    const int fs = 28 + 2 * fq, fc = fs + 1;
-                    ENC_AT(col, fs) = relu_bits(sn);
-                    ENC_AT(col, fc) = relu_bits(cs);
-                }
-            } else if (part == NPARTS - 1) {
-#pragma unroll
-                for (int f = 27; f < 32; ++f) ENC_AT(col, f) = 0.f;
-            }
-        }
+        // enc is free now (all waves passed the barrier inside dense_layer).  rgb_net.1's direction / time columns are
+        // not encoded here any more: they are part of the ray's C operand (mlp_raybias.hip); the tile keeps the ray of
+        // every sample for that fetch
+        int32_t* ray_of = reinterpret_cast<int32_t*>(enc);
+        if (part == 0) ray_of[s] = valid ? (int32_t)ray : 0;
         PH(PH_ENC2);
         __syncthreads();
         PH(PH_BAR2);
@@ -166,6 +131,9 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_ke
         DENSE(TM, NW, 256, 128, net, L.w[6], L.b[6], act, 64, nullptr, 0, act, wA, L.w_rgb1, L.b_rgb1, wR);
         __syncthreads();
         PH(PH_BAR2);
+        // rgb_net.1's C operands (bias + the ray's direction / time columns) on their way behind the sigma head
+        RayC<WaveSplit<TM, NW, 128>::NFB, WaveSplit<TM, NW, 128>::NSB> rayc;
+        load_rayc(rayc, a.raybias, ray_of, WaveSplit<TM, NW, 128>::n0(wave), WaveSplit<TM, NW, 128>::sb0(wave), lane);
         // ---- sigma = density_net(h) (:139), raw
         float sigma;
         {
@@ -181,9 +149,9 @@ __global__ __launch_bounds__(NW * 64, (TM == 128 ? NW / 4 : 2)) void spacenet_ke
         // ---- rgb_net: relu -> Linear(283|304,128) -> relu -> Linear(128,3)   (:80-86)
         // (h is already >= 0; the encodings were clamped when written)
         if constexpr (!DEEP) {
-            DENSE(TM, NW, 128, 256, net, L.w_rgb1, L.b_rgb1, act, 64, enc, L.kq_rgb1 - 64, act, wR, L.w[0], L.b[0], wA);  // + next tile's layer 0
+            DENSE_RAYC(TM, NW, 128, 256, net, L.w_rgb1, act, 64, act, wR, L.w[0], L.b[0], wA, rayc);  // + next tile's layer 0
         } else {  // deep_rgb (:68-79): two more 128-wide hidden layers before the 3-wide output
-            DENSE(TM, NW, 128, 128, net, L.w_rgb1, L.b_rgb1, act, 64, enc, L.kq_rgb1 - 64, act, wR, L.w_deep[0], L.b_deep[0], wR2);
+            DENSE_RAYC(TM, NW, 128, 128, net, L.w_rgb1, act, 64, act, wR, L.w_deep[0], L.b_deep[0], wR2, rayc);
             __syncthreads();
             DENSE(TM, NW, 128, 128, net, L.w_deep[0], L.b_deep[0], act, 32, nullptr, 0, act, wR2, L.w_deep[1], L.b_deep[1], wR);
             __syncthreads();
@@ -515,17 +483,22 @@ extern "C" int stnerf_encode(const float* x, int64_t n, int dim, int n_freq, int
 extern "C" int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
                                    const int32_t* ray_count, const float* xyz, int64_t xyz_ray_stride,
                                    const float* dirs, int64_t dirs_ray_stride, const float* times,
-                                   int64_t times_ray_stride, float* raw, int64_t raw_ray_stride,
+                                   int64_t times_ray_stride, float* raw, int64_t raw_ray_stride, float* ray_bias,
                                    stnerf_stream_t stream) {
     STNERF_REQUIRE(STNERF_NET_IS_SPACE(kind), "spacenet_fwd: bad kind %d", kind);
-    STNERF_REQUIRE(packed && xyz && dirs && raw, "spacenet_fwd: null pointer");
+    STNERF_REQUIRE(packed && xyz && dirs && raw && ray_bias, "spacenet_fwd: null pointer");
+    STNERF_REQUIRE(((uintptr_t)ray_bias & 15) == 0, "spacenet_fwd: ray_bias must be 16-byte aligned");
     STNERF_REQUIRE(!STNERF_NET_USES_TIME(kind) || times, "spacenet_fwd: net takes time but times is null");
     STNERF_REQUIRE(n_rays >= 0 && ns >= 1, "spacenet_fwd: bad shape n_rays=%lld ns=%d", (long long)n_rays, ns);
     STNERF_REQUIRE((raw_ray_stride & 3) == 0 && ((uintptr_t)raw & 15) == 0, "spacenet_fwd: raw must be 16-byte aligned");
     STNERF_REQUIRE(((uintptr_t)packed & 15) == 0, "spacenet_fwd: packed weights must be 16-byte aligned");
     if (n_rays == 0) return STNERF_OK;
+    // rgb_net.1's direction / time columns once per ray (mlp_raybias.hip) -> the C operands of that layer
+    if (const int rc = launch_ray_bias(kind, static_cast<const float*>(packed), n_rays, ray_list, ray_count, dirs, dirs_ray_stride,
+                                       times, times_ray_stride, ray_bias, as_stream(stream)))
+        return rc;
     SpaceArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, dirs,
-                dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride};
+                dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride, nullptr, ray_bias};
     const TileCfg tc = tile_config(TILE_128X8);
     const int tm = tc == TILE_64 ? 64 : 128;
     const int lds = (64 + 16) * tm * 16;

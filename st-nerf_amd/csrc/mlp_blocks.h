@@ -2,6 +2,8 @@
 // launch per pipeline stage): the pipelined MFMA K loop, one dense layer on an LDS-resident tile, the VALU heads.
 // Design notes: mlp.hip header and DESIGN.md section 4.1.
 #pragma once
+#include <type_traits>
+
 #include "mlp_common.h"
 
 namespace stnerf {
@@ -52,9 +54,11 @@ __device__ __forceinline__ void load_wfrag(WFrag<NFB>& f, const float4* __restri
 
 // 4 * NFB * NSB MFMAs of one K step.  ZERO_C (first step of a layer): C = `cinit` = the bias, so neither an
 // accumulator initialisation nor a bias add in the epilogue is needed.
-template <int NFB, int NSB, bool ZERO_C>
+// NSC = 1: the C operand is the bias, the same registers for every sample block; NSC = NSB: one C operand per sample
+// block (rgb_net.1: bias + the ray's direction / time columns, mlp_raybias.hip).
+template <int NFB, int NSB, bool ZERO_C, int NSC>
 __device__ __forceinline__ void mma_step(f32x16 (&acc)[NFB][NSB], const float4 (&w)[NFB], const float4 (&a)[NSB],
-                                         const f32x16 (&cinit)[NFB]) {
+                                         const f32x16 (&cinit)[NFB][NSC]) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -63,8 +67,8 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[NFB][NSB], const float4 (
 #pragma unroll
             for (int sb = 0; sb < NSB; ++sb) {
                 const float av = kk == 0 ? a[sb].x : kk == 1 ? a[sb].y : kk == 2 ? a[sb].z : a[sb].w;
-                if (ZERO_C && kk == 0) {  // first MFMAs of the layer: C = bias (the same registers for every sample block)
-                    acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, cinit[fb], 0, 0, 0);
+                if (ZERO_C && kk == 0) {  // first MFMAs of the layer: C = bias
+                    acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, cinit[fb][NSC == 1 ? 0 : sb], 0, 0, 0);
                 } else {
                     acc[fb][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, av, acc[fb][sb], 0, 0, 0);
                 }
@@ -79,9 +83,9 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[NFB][NSB], const float4 (
 // load -> wait -> use, which with one wave per SIMD exposes the full L2 latency every step.
 // `wfirst` = the step-0 weights, already loaded by the caller (prefetched during the previous layer's
 // epilogue); requires steps >= 2.
-template <int TM, int NFB, int NSB, bool FIRST>
+template <int TM, int NFB, int NSB, bool FIRST, int NSC>
 __device__ __forceinline__ void mma_segment(f32x16 (&acc)[NFB][NSB], const float4 (&wfirst)[NFB],
-                                            const f32x16 (&cinit)[NFB], __amdgpu_buffer_rsrc_t rsrc, uint32_t wwave,
+                                            const f32x16 (&cinit)[NFB][NSC], __amdgpu_buffer_rsrc_t rsrc, uint32_t wwave,
                                             uint32_t wlane, int n_total, const float4* in, int steps) {
     // rsrc + wwave (wave-uniform byte offset) + wlane (this lane's byte offset) / in point at the first quad row of the
     // segment; one step = 2 quad rows = 8 k values.
@@ -128,26 +132,26 @@ __device__ __forceinline__ void mma_segment(f32x16 (&acc)[NFB][NSB], const float
     __builtin_amdgcn_sched_barrier(0);
     // peeled first pair of steps (the very first MFMAs of a layer take C = 0)
     STNERF_LOAD_STEP(w1, a1, 1)
-    mma_step<NFB, NSB, FIRST>(acc, w0, a0, cinit);
+    mma_step<NFB, NSB, FIRST, NSC>(acc, w0, a0, cinit);
     STNERF_INTERLEAVE()
     {
         const int nx = 2 < steps ? 2 : steps - 1;
         STNERF_LOAD_STEP(w0, a0, nx)
     }
-    mma_step<NFB, NSB, false>(acc, w1, a1, cinit);
+    mma_step<NFB, NSB, false, NSC>(acc, w1, a1, cinit);
     STNERF_INTERLEAVE()
     int s = 2;
 #pragma unroll 1
     for (; s + 2 <= steps; s += 2) {
         STNERF_LOAD_STEP(w1, a1, s + 1)
-        mma_step<NFB, NSB, false>(acc, w0, a0, cinit);
+        mma_step<NFB, NSB, false, NSC>(acc, w0, a0, cinit);
         STNERF_INTERLEAVE()
         const int nx = (s + 2 < steps) ? (s + 2) : (steps - 1);  // clamped: never out of bounds
         STNERF_LOAD_STEP(w0, a0, nx)
-        mma_step<NFB, NSB, false>(acc, w1, a1, cinit);
+        mma_step<NFB, NSB, false, NSC>(acc, w1, a1, cinit);
         STNERF_INTERLEAVE()
     }
-    if (s < steps) mma_step<NFB, NSB, false>(acc, w0, a0, cinit);
+    if (s < steps) mma_step<NFB, NSB, false, NSC>(acc, w0, a0, cinit);
 #undef STNERF_INTERLEAVE
 #undef STNERF_LOAD_STEP
 #undef STNERF_LOAD_W
@@ -158,35 +162,65 @@ __device__ __forceinline__ void mma_segment(f32x16 (&acc)[NFB][NSB], const float
 // [sb0, sb0 + NSB) of the tile.  `wfirst` holds this layer's step-0 weights (already in flight);
 // before the barrier/epilogue the step-0 weights of the NEXT layer (`next_lane_ptr`) are issued into
 // `wnext`, so the next layer's pipeline fill overlaps this layer's epilogue instead of following it.
-template <int TM, int NFB, int NSB, bool RELU, int NFB_NEXT>
+// The C operands of rgb_net.1 for this lane's samples: row ray_of[sample] of the layer's ray-bias table (bias + the
+// direction / time columns of the ray, mlp_raybias.hip), fetched ahead of the layer.
+template <int NFB, int NSB>
+struct RayC {
+    f32x16 c[NFB][NSB];
+};
+template <int NFB, int NSB>
+__device__ __forceinline__ void load_rayc(RayC<NFB, NSB>& rc, const float* __restrict__ raybias, const int32_t* ray_of /* LDS, [TM] */,
+                                          int n0, int sb0, int lane) {
+    const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) {
+        const float* row = raybias + (int64_t)ray_of[(sb0 + sb) * 32 + c] * 128 + n0 + 4 * h;
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(row + fb * 32 + 8 * q);
+                rc.c[fb][sb][4 * q + 0] = v.x;
+                rc.c[fb][sb][4 * q + 1] = v.y;
+                rc.c[fb][sb][4 * q + 2] = v.z;
+                rc.c[fb][sb][4 * q + 3] = v.w;
+            }
+    }
+}
+
+template <int TM, int NFB, int NSB, bool RELU, int NFB_NEXT, class RC = void>
 __device__ __forceinline__ void dense_layer(const float* __restrict__ base, int64_t w_off, int64_t b_off, int n_total,
                                             const float4* inA, int kqA, const float4* inB, int kqB, float4* out,
                                             int n0, int sb0, int lane, const WFrag<NFB>& wfirst,
                                             const float4* next_lane_ptr, const float* next_lane_bias,
-                                            WFrag<NFB_NEXT>& wnext PH_PARAMS) {
+                                            WFrag<NFB_NEXT>& wnext PH_PARAMS, const RayC<NFB, NSB>* rayc = nullptr) {
     const int h = lane >> 5, c = lane & 31;
     const int s0 = sb0 * 32 + c;  // this lane's sample column within the tile (+ sb*32)
-    f32x16 cinit[NFB];
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            cinit[fb][4 * q + 0] = wfirst.b[fb][q].x;
-            cinit[fb][4 * q + 1] = wfirst.b[fb][q].y;
-            cinit[fb][4 * q + 2] = wfirst.b[fb][q].z;
-            cinit[fb][4 * q + 3] = wfirst.b[fb][q].w;
-        }
     f32x16 acc[NFB][NSB];
     const __amdgpu_buffer_rsrc_t rsrc = weight_rsrc(base);
     const uint32_t wwave = (uint32_t)(w_off * 4) + (uint32_t)n0 * 16u;
     const uint32_t wlane = weight_lane_bytes(n_total, lane);
-    mma_segment<TM, NFB, NSB, true>(acc, wfirst.w, cinit, rsrc, wwave, wlane, n_total, inA + h * TM + s0, kqA / 2);
-    if (kqB > 0) {
-        const uint32_t wwave2 = wwave + (uint32_t)kqA * (uint32_t)n_total * 16u;
-        float4 wseg[NFB];
+    if constexpr (!std::is_void<RC>::value) {  // one C operand per sample block (rgb_net.1)
+        mma_segment<TM, NFB, NSB, true, NSB>(acc, wfirst.w, rayc->c, rsrc, wwave, wlane, n_total, inA + h * TM + s0, kqA / 2);
+    } else {
+        f32x16 cinit[NFB][1];
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) wseg[fb] = load_weight(rsrc, wlane + fb * 512u, wwave2);
-        mma_segment<TM, NFB, NSB, false>(acc, wseg, cinit, rsrc, wwave2, wlane, n_total, inB + h * TM + s0, kqB / 2);
+        for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cinit[fb][0][4 * q + 0] = wfirst.b[fb][q].x;
+                cinit[fb][0][4 * q + 1] = wfirst.b[fb][q].y;
+                cinit[fb][0][4 * q + 2] = wfirst.b[fb][q].z;
+                cinit[fb][0][4 * q + 3] = wfirst.b[fb][q].w;
+            }
+        mma_segment<TM, NFB, NSB, true, 1>(acc, wfirst.w, cinit, rsrc, wwave, wlane, n_total, inA + h * TM + s0, kqA / 2);
+        if (kqB > 0) {
+            const uint32_t wwave2 = wwave + (uint32_t)kqA * (uint32_t)n_total * 16u;
+            float4 wseg[NFB];
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) wseg[fb] = load_weight(rsrc, wlane + fb * 512u, wwave2);
+            mma_segment<TM, NFB, NSB, false, 1>(acc, wseg, cinit, rsrc, wwave2, wlane, n_total, inB + h * TM + s0, kqB / 2);
+        }
     }
     load_wfrag<NFB_NEXT>(wnext, next_lane_ptr, next_lane_bias);
     PH(PH_MMA);
@@ -258,5 +292,13 @@ __device__ __forceinline__ void head_partial(const float4* act, int s, int q_beg
         WaveSplit<TM_, NW_, N_>::sb0(wave), lane, WFIRST_,                                                               \
         weight_lane_ptr(BASE_, NEXT_WOFF_, NN_, WaveSplit<TM_, NW_, NN_>::n0(wave), lane),                               \
         (BASE_) + (NEXT_BOFF_) + WaveSplit<TM_, NW_, NN_>::n0(wave) + 4 * (lane >> 5), WNEXT_ PH_ARGS)
+
+// rgb_net.1: one C operand per sample block (RAYC_ = the prefetched RayC), no bias, no second K segment.
+#define DENSE_RAYC(TM_, NW_, N_, NN_, BASE_, WOFF_, INA_, KQA_, OUT_, WFIRST_, NEXT_WOFF_, NEXT_BOFF_, WNEXT_, RAYC_)             \
+    dense_layer<TM_, WaveSplit<TM_, NW_, N_>::NFB, WaveSplit<TM_, NW_, N_>::NSB, true, WaveSplit<TM_, NW_, NN_>::NFB, int>(       \
+        BASE_, WOFF_, 0, N_, INA_, KQA_, nullptr, 0, OUT_, WaveSplit<TM_, NW_, N_>::n0(wave),                                     \
+        WaveSplit<TM_, NW_, N_>::sb0(wave), lane, WFIRST_,                                                                        \
+        weight_lane_ptr(BASE_, NEXT_WOFF_, NN_, WaveSplit<TM_, NW_, NN_>::n0(wave), lane),                                        \
+        (BASE_) + (NEXT_BOFF_) + WaveSplit<TM_, NW_, NN_>::n0(wave) + 4 * (lane >> 5), WNEXT_ PH_ARGS, &(RAYC_))
 
 }  // namespace stnerf

@@ -156,7 +156,13 @@ struct SpaceArgs {
     float* raw;
     int64_t raw_ray_stride;
     uint32_t* overflow;  // fp16x3 kernels: set to 1 if an output is not finite (an activation left the fp16 range); may be null
+    const float* raybias;  // exact-f32 kernels: [n_rays][128] C operands of rgb_net.1 (mlp_raybias.hip)
 };
+
+// rgb_net.1's direction / time columns once per ray (mlp_raybias.hip): out[ray][128] for the listed rays.
+int launch_ray_bias(int kind, const float* net, int64_t n_rays, const int32_t* ray_list, const int32_t* ray_count,
+                    const float* dirs, int64_t dirs_ray_stride, const float* times, int64_t times_ray_stride, float* out,
+                    hipStream_t stream);
 
 struct MotionArgs {
     const float* net;

@@ -15,6 +15,7 @@ struct StageLayer {
     const float* times;        // this layer's frame-id column or nullptr
     int32_t use_time;          // the SpaceNet takes the time encoding
     int32_t motion_flags;      // STNERF_MOTION_PLAIN_TIME
+    const float* raybias;      // [n_rays][128]: C operands of rgb_net.1 per ray (mlp_raybias.hip)
 };
 
 struct StageArgs {

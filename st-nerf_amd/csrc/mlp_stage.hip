@@ -54,14 +54,15 @@ static_assert(WaveSplit<ST_TM, ST_NW, 256>::NFB == 1 && WaveSplit<ST_TM, ST_NW, 
               WaveSplit<ST_MTM, ST_NW, 128>::NFB == 1, "stage kernel assumes one feature block per wave");
 
 // ---------------------------------------------------------------------------------------------
-// SpaceNet on one 128-sample tile whose (already deformed) point p, direction dv and time tv sit in registers.
+// SpaceNet on one 128-sample tile whose (already deformed) point p sits in registers; ray_idx = the sample's row of the
+// layer's ray-bias table (rgb_net.1's bias + direction / time columns, mlp_raybias.hip).
 // wA: step-0 weights + bias of stage1.0 (prefetched); on return wA holds those of `nf`.  Part 0 of every valid
 // sample returns its {r,g,b,sigma}.  Body = spacenet_kernel<128, 8, USE_TIME, DEEP> of mlp.hip with USE_TIME a
 // (workgroup-uniform) run-time value: one instance serves the background and the performers.
 // ---------------------------------------------------------------------------------------------
 template <bool DEEP>
 __device__ __forceinline__ float4 space_tile(const float* net_in, const bool USE_TIME, float4* act, float4* enc,
-                                             const float (&p)[3], const float (&dv)[3], float tv, int lane, int wave,
+                                             const float (&p)[3], const float* raybias, int32_t ray_idx, int lane, int wave,
                                              int part, int s, WF& wA, const NextFirst& nf PH_PARAMS) {
     constexpr int TM = ST_TM, NW = ST_NW, NTHREADS = ST_THREADS, NPARTS = NTHREADS / TM;
     float* encf = reinterpret_cast<float*>(enc);
@@ -101,40 +102,18 @@ __device__ __forceinline__ float4 space_tile(const float* net_in, const bool USE
     __syncthreads();
     // ---- stage2.0 on [h, PE(pos)] (:56-57, :137)
     DENSE(TM, NW, 256, 256, net, L.w[4], L.b[4], act, 64, enc, 16, act, wA, L.w[5], L.b[5], wB);
-    // enc is free now: relu(PE_4(dir)), relu(PE_10(time)) -> enc features 0..47  (:80-86, :141-149)
-    if (part == 0) {
-#pragma unroll
-        for (int dmn = 0; dmn < 3; ++dmn) ENC_AT(col, dmn) = fmaxf(dv[dmn], 0.f);
-    }
-    for (int fq = part; fq < 4; fq += NPARTS) {
-        const float freq = (float)(1 << fq);
-#pragma unroll
-        for (int dmn = 0; dmn < 3; ++dmn) {
-            float sn, cs;
-            sincos_pe(dv[dmn] * freq, sn, cs);
-            const int fs = 3 + fq * 6 + dmn, fc = fs + 3;
-            ENC_AT(col, fs) = relu_bits(sn);
-            ENC_AT(col, fc) = relu_bits(cs);
-        }
-    }
-    if (USE_TIME) {
-        if (part == NPARTS - 1) ENC_AT(col, 27) = fmaxf(tv, 0.f);
-        for (int fq = NPARTS - 1 - part; fq < 10; fq += NPARTS) {
-            float sn, cs;
-            sincos_pe(tv * (float)(1 << fq), sn, cs);
-            const int fs = 28 + 2 * fq, fc = fs + 1;
-            ENC_AT(col, fs) = relu_bits(sn);
-            ENC_AT(col, fc) = relu_bits(cs);
-        }
-    } else if (part == NPARTS - 1) {
-#pragma unroll
-        for (int f = 27; f < 32; ++f) ENC_AT(col, f) = 0.f;
-    }
+    // enc is free now; rgb_net.1's direction / time columns come with the ray's C operand (mlp_raybias.hip): the tile keeps
+    // the ray of every sample for that fetch
+    int32_t* ray_of = reinterpret_cast<int32_t*>(enc);
+    if (part == 0) ray_of[s] = ray_idx;
     __syncthreads();
     DENSE(TM, NW, 256, 256, net, L.w[5], L.b[5], act, 64, nullptr, 0, act, wB, L.w[6], L.b[6], wA);
     __syncthreads();
     DENSE(TM, NW, 256, 128, net, L.w[6], L.b[6], act, 64, nullptr, 0, act, wA, L.w_rgb1, L.b_rgb1, wR);
     __syncthreads();
+    // rgb_net.1's C operands on their way behind the sigma head
+    RayC<1, WaveSplit<TM, NW, 128>::NSB> rayc;
+    load_rayc(rayc, raybias, ray_of, WaveSplit<TM, NW, 128>::n0(wave), WaveSplit<TM, NW, 128>::sb0(wave), lane);
     // ---- sigma = density_net(h) (:139), raw
     float sigma;
     {
@@ -150,11 +129,11 @@ __device__ __forceinline__ float4 space_tile(const float* net_in, const bool USE
     const float4* nwp = next_w_ptr(nf, wave, lane);
     const float* nbp = next_b_ptr(nf, wave, lane);
     if constexpr (!DEEP) {
-        dense_layer<TM, 1, WaveSplit<TM, NW, 128>::NSB, true, 1>(net, L.w_rgb1, L.b_rgb1, 128, act, 64, enc, L.kq_rgb1 - 64, act,
-                                                                WaveSplit<TM, NW, 128>::n0(wave), WaveSplit<TM, NW, 128>::sb0(wave),
-                                                                lane, wR, nwp, nbp, wA PH_ARGS);
+        dense_layer<TM, 1, WaveSplit<TM, NW, 128>::NSB, true, 1, int>(net, L.w_rgb1, 0, 128, act, 64, nullptr, 0, act,
+                                                                     WaveSplit<TM, NW, 128>::n0(wave), WaveSplit<TM, NW, 128>::sb0(wave),
+                                                                     lane, wR, nwp, nbp, wA PH_ARGS, &rayc);
     } else {
-        DENSE(TM, NW, 128, 128, net, L.w_rgb1, L.b_rgb1, act, 64, enc, L.kq_rgb1 - 64, act, wR, L.w_deep[0], L.b_deep[0], wR2);
+        DENSE_RAYC(TM, NW, 128, 128, net, L.w_rgb1, act, 64, act, wR, L.w_deep[0], L.b_deep[0], wR2, rayc);
         __syncthreads();
         DENSE(TM, NW, 128, 128, net, L.w_deep[0], L.b_deep[0], act, 32, nullptr, 0, act, wR2, L.w_deep[1], L.b_deep[1], wR);
         __syncthreads();
@@ -409,26 +388,19 @@ __global__ __launch_bounds__(ST_THREADS, 2) void mlp_stage_kernel(StageArgs a) {
             const int64_t rbase = r0 + half * ST_TM;
             if (rbase >= rows) break;   // (uniform) the second half of a layer's last item may be empty
             const RowRef rr = locate_row(ly.ray_list, rbase + s4, rows, a.ns);
-            float p[3], dv[3] = {0.f, 0.f, 0.f};
-            float tvs = 0.f;
+            float p[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) p[c] = half == 0 ? pa[c] : pb[c];
-            if (rr.valid) {
-                if (!deform) {
-                    const float* src = ly.xyz + rr.ray * a.xyz_ray_stride + 3 * rr.k;
-                    p[0] = src[0];
-                    p[1] = src[1];
-                    p[2] = src[2];
-                }
-                const float* dsrc = a.dirs + rr.ray * a.dirs_ray_stride;
-                dv[0] = dsrc[0];
-                dv[1] = dsrc[1];
-                dv[2] = dsrc[2];
-                if (use_time) tvs = ly.times[rr.ray * a.times_ray_stride];
+            if (rr.valid && !deform) {
+                const float* src = ly.xyz + rr.ray * a.xyz_ray_stride + 3 * rr.k;
+                p[0] = src[0];
+                p[1] = src[1];
+                p[2] = src[2];
             }
             const bool more = deform && half == 0 && rbase + ST_TM < rows;   // the other half follows on this net
             const NextFirst nf = more ? nf_space : nf_next;
-            float4 o = space_tile<DEEP>(ly.space, use_time, act, enc, p, dv, tvs, lane, wave, part4, s4, wA, nf PH_ARGS);
+            float4 o = space_tile<DEEP>(ly.space, use_time, act, enc, p, ly.raybias, rr.valid ? (int32_t)rr.ray : 0, lane, wave,
+                                        part4, s4, wA, nf PH_ARGS);
             if (part4 == 0 && rr.valid) {
                 if (a.sigmoid_rgb) {  // torch.sigmoid(rgb): 1-ulp v_exp_f32 / v_rcp_f32, the same expression the compositor uses
                     o.x = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(o.x * -1.44269504088896340736f));
@@ -464,8 +436,9 @@ int stage_kernel_choice() {
 // `queue` is a zeroed uint32 on the device.  Called by stnerf_render_rays only (csrc/pipeline.hip).
 extern "C" int stnerf_mlp_stage(const stnerf_stage_layer* layers, int n_layers, int64_t n_rays, int ns, const float* dirs,
                                 int64_t dirs_ray_stride, int64_t times_ray_stride, int64_t xyz_ray_stride,
-                                int64_t raw_ray_stride, int flags, uint32_t* queue, stnerf_stream_t stream) {
-    STNERF_REQUIRE(layers && dirs && queue, "mlp_stage: null pointer");
+                                int64_t raw_ray_stride, int flags, uint32_t* queue, float* ray_bias, stnerf_stream_t stream) {
+    STNERF_REQUIRE(layers && dirs && queue && ray_bias, "mlp_stage: null pointer");
+    STNERF_REQUIRE(((uintptr_t)ray_bias & 15) == 0, "mlp_stage: ray_bias must be 16-byte aligned");
     STNERF_REQUIRE(n_layers >= 1 && n_layers <= STNERF_MAX_LAYERS && n_rays >= 0 && ns >= 1, "mlp_stage: bad shape");
     STNERF_REQUIRE((raw_ray_stride & 3) == 0, "mlp_stage: raw ray stride must be a multiple of 4 floats");
     if (n_rays == 0) return STNERF_OK;
@@ -473,6 +446,8 @@ extern "C" int stnerf_mlp_stage(const stnerf_stage_layer* layers, int n_layers, 
     StageArgs a;
     memset(&a, 0, sizeof(a));
     a.sigmoid_rgb = (flags & STNERF_STAGE_SIGMOID_RGB) != 0;
+    // (the profiler's record of the stage covers the per-ray prologues too: their work is part of the networks' FLOPs)
+    LaunchTimer timer(PROF_MLP_STAGE, deep_rgb, n_rays, ns, 0, as_stream(stream));
     for (int i = 0; i < n_layers; ++i) {
         const stnerf_stage_layer& s = layers[i];
         STNERF_REQUIRE(s.space && s.xyz && s.raw, "mlp_stage: layer %d: null pointer", i);
@@ -480,7 +455,15 @@ extern "C" int stnerf_mlp_stage(const stnerf_stage_layer* layers, int n_layers, 
                        "mlp_stage: layer %d: packed weights / raw must be 16-byte aligned", i);
         STNERF_REQUIRE(!(s.use_time || s.motion) || s.times, "mlp_stage: layer %d needs its frame-id column", i);
         a.layer[i] = StageLayer{static_cast<const float*>(s.space), static_cast<const float*>(s.motion), s.ray_list,
-                                s.ray_count, s.xyz, s.raw, s.times, s.use_time, s.motion_flags};
+                                s.ray_count, s.xyz, s.raw, s.times, s.use_time, s.motion_flags,
+                                ray_bias + (int64_t)i * n_rays * 128};
+        // rgb_net.1's direction / time columns once per ray of this layer (mlp_raybias.hip)
+        const int kind = s.use_time ? (deep_rgb ? STNERF_NET_SPACE_TIME_DEEP : STNERF_NET_SPACE_TIME)
+                                    : (deep_rgb ? STNERF_NET_SPACE_DEEP : STNERF_NET_SPACE);
+        if (const int rc = launch_ray_bias(kind, static_cast<const float*>(s.space), n_rays, s.ray_list, s.ray_count, dirs,
+                                           dirs_ray_stride, s.times, times_ray_stride, ray_bias + (int64_t)i * n_rays * 128,
+                                           as_stream(stream)))
+            return rc;
     }
     a.n_layers = n_layers;
     a.ns = ns;
@@ -498,7 +481,6 @@ extern "C" int stnerf_mlp_stage(const stnerf_stage_layer* layers, int n_layers, 
     const int grid = (int)(max_items < cus ? max_items : cus);  // one persistent workgroup per CU
     const void* kfn = deep_rgb ? reinterpret_cast<const void*>(mlp_stage_kernel<true>) : reinterpret_cast<const void*>(mlp_stage_kernel<false>);
     if (const int rc = reserve_dynamic_lds(kfn, ST_LDS, "mlp_stage")) return rc;
-    LaunchTimer timer(PROF_MLP_STAGE, deep_rgb, n_rays, ns, 0, as_stream(stream));
     if (deep_rgb)
         hipLaunchKernelGGL(mlp_stage_kernel<true>, dim3(grid), dim3(ST_THREADS), ST_LDS, as_stream(stream), a);
     else

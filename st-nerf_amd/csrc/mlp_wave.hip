@@ -16,6 +16,7 @@
 //   * Weights: the A operand of a K step is 8 x 16 B per lane straight from the packed blob (buffer loads, SGPR
 //     offsets, one step ahead); the four waves of a CU run the same network in step, so each line comes out of L2
 //     once per CU and the other three waves hit the vector L1.
+//   * rgb_net.1's direction / time columns come per RAY from mlp_raybias.hip as the layer's C operand.
 //   * Encodings are staged through a wave-private 11 KiB LDS window (the two lanes of a sample split the frequencies,
 //     then each lane reads its half of the feature quads back) -- ordering inside a wave only, no barrier.
 //   * Heads: a lane holds every second feature quad of its sample; the partial-sum grouping of the LDS kernels
@@ -112,45 +113,6 @@ __device__ __forceinline__ void encode_pos(float* encw, int lane, const float (&
     }
 }
 
-// relu(PE_4(dir)) (27) and relu(PE_10(time)) (21) -> features 0..47 (modeling/spacenet.py:80-86,141-149); without the
-// time encoding features 27..31 are zero pads
-__device__ __forceinline__ void encode_dir_time(float* encw, int lane, const float (&dv)[3], float tv, bool use_time) {
-    const int h = lane >> 5, c = lane & 31;
-    float* col = encw + c * 4;
-    if (h == 0) {
-#pragma unroll
-        for (int dmn = 0; dmn < 3; ++dmn) ENCW(col, dmn) = fmaxf(dv[dmn], 0.f);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int fq = 2 * i + h;
-        const float freq = (float)(1 << fq);
-#pragma unroll
-        for (int dmn = 0; dmn < 3; ++dmn) {
-            float sn, cs;
-            sincos_pe(dv[dmn] * freq, sn, cs);
-            const int fs = 3 + fq * 6 + dmn, fc = fs + 3;
-            ENCW(col, fs) = relu_bits(sn);
-            ENCW(col, fc) = relu_bits(cs);
-        }
-    }
-    if (use_time) {
-        if (h == 1) ENCW(col, 27) = fmaxf(tv, 0.f);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int fq = 2 * i + h;
-            float sn, cs;
-            sincos_pe(tv * (float)(1 << fq), sn, cs);
-            const int fs = 28 + 2 * fq, fc = fs + 1;
-            ENCW(col, fs) = relu_bits(sn);
-            ENCW(col, fc) = relu_bits(cs);
-        }
-    } else if (h == 1) {
-#pragma unroll
-        for (int f = 27; f < 32; ++f) ENCW(col, f) = 0.f;
-    }
-}
-
 // PE_10([x,y,z,t]) with the fractional-time lerp of modeling/motion_net.py:49-60: 84 features + 4 zero pads
 __device__ __forceinline__ void encode_motion(float* encw, int lane, const float (&p)[3], float tv, int flags) {
     const int h = lane >> 5, c = lane & 31;
@@ -210,6 +172,22 @@ __device__ __forceinline__ LaneOfs lane_offsets(uint32_t wlane) {
     }
     return o;
 }
+// Where the first operand fetch of whatever runs NEXT goes (issued once, in the last K step of a segment): its eight
+// lane offsets are derived on the spot from one register -- a second LaneOfs kept through the layer loop pushes the loop's
+// own offsets out to scratch, and a reload inside the K loop queues up in front of the operand loads.
+struct NextOfs {
+    uint32_t base;  // (h * N + c) * 16 of the next matrix
+    bool paired;    // 128-wide layer in K-step pairs (blocks 4..7 = the second step's rows)
+    uint32_t wstep; // its step stride (paired only)
+};
+template <int NFB>
+__device__ __forceinline__ void load_w_next(float4 (&w)[8], __amdgpu_buffer_rsrc_t rsrc, const NextOfs& nx, uint32_t soff) {
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+        const uint32_t ofs = nx.paired ? (uint32_t)(fb & 3) * 512u + (uint32_t)(fb >> 2) * nx.wstep : (uint32_t)fb * 512u;  // (scalar)
+        w[fb] = load_weight(rsrc, nx.base + ofs, soff);
+    }
+}
 template <int NFB>
 __device__ __forceinline__ void load_w(float4 (&w)[8], __amdgpu_buffer_rsrc_t rsrc, const LaneOfs& wl, uint32_t soff) {
 #ifdef STNERF_WAVE_EXP_NOLOADW  /* development experiment: wrong results, isolates the cost of the operand loads */
@@ -267,7 +245,7 @@ __device__ __forceinline__ void step_r(f32x16 (&acc)[8], const float4 (&wc)[8], 
 template <int NFB, int NBLK, int STEPS, int PAR, int NFB_NEXT>
 __device__ __forceinline__ void segment_r(f32x16 (&acc)[8], const f32x16 (&blk)[NBLK], float4 (&wa)[8], float4 (&wb)[8],
                                           __amdgpu_buffer_rsrc_t rsrc, const LaneOfs& wlane, uint32_t soff, uint32_t wstep,
-                                          const LaneOfs& next_wlane, uint32_t next_soff) {
+                                          const NextOfs& next_wlane, uint32_t next_soff) {
     static_assert(STEPS >= 1 && STEPS <= 4 * NBLK, "segment_r: not enough input blocks");
     static_assert(NFB_NEXT <= 4 * NFB, "segment_r: more operand loads than MFMAs to hide them behind");
     __builtin_amdgcn_sched_barrier(0);
@@ -283,7 +261,7 @@ __device__ __forceinline__ void segment_r(f32x16 (&acc)[8], const f32x16 (&blk)[
         constexpr int s = STEPS - 1;
         float4 (&wc)[8] = ((s + PAR) & 1) ? wb : wa;
         float4 (&wn)[8] = ((s + PAR) & 1) ? wa : wb;
-        load_w<NFB_NEXT>(wn, rsrc, next_wlane, next_soff);
+        load_w_next<NFB_NEXT>(wn, rsrc, next_wlane, next_soff);
         step_r<NFB, NFB_NEXT>(acc, wc, blk[s >> 2][4 * (s & 3) + 0], blk[s >> 2][4 * (s & 3) + 1], blk[s >> 2][4 * (s & 3) + 2],
                               blk[s >> 2][4 * (s & 3) + 3]);
     }
@@ -332,7 +310,7 @@ __device__ __forceinline__ void pair_r(f32x16 (&acc)[8], const float4 (&wc)[8], 
 template <int NBLK, int STEPS, int PAR, int NFB_NEXT>
 __device__ __forceinline__ void segment_p(f32x16 (&acc)[8], const f32x16 (&blk)[NBLK], float4 (&wa)[8], float4 (&wb)[8],
                                           __amdgpu_buffer_rsrc_t rsrc, const LaneOfs& wlp, uint32_t soff, uint32_t wstep,
-                                          const LaneOfs& next_wlane, uint32_t next_soff) {
+                                          const NextOfs& next_wlane, uint32_t next_soff) {
     static_assert(STEPS >= 1 && STEPS <= 4 * NBLK, "segment_p: not enough input blocks");
     constexpr int PAIRS = (STEPS + 1) / 2;
     __builtin_amdgcn_sched_barrier(0);
@@ -348,7 +326,7 @@ __device__ __forceinline__ void segment_p(f32x16 (&acc)[8], const f32x16 (&blk)[
         constexpr bool both = (STEPS & 1) == 0;
         float4 (&wc)[8] = ((m + PAR) & 1) ? wb : wa;
         float4 (&wn)[8] = ((m + PAR) & 1) ? wa : wb;
-        load_w<NFB_NEXT>(wn, rsrc, next_wlane, next_soff);
+        load_w_next<NFB_NEXT>(wn, rsrc, next_wlane, next_soff);
         pair_r<NFB_NEXT, both>(acc, wc, blk[(2 * m) >> 2], 4 * ((2 * m) & 3), blk[both ? (2 * m + 1) >> 2 : (2 * m) >> 2],
                                both ? 4 * ((2 * m + 1) & 3) : 0);
     }
@@ -447,34 +425,39 @@ __device__ __forceinline__ float pair_sum(float ca, float cb) {
 // sigma head (256 -> 1) in the grouping of head_partial<TM, 1> with four parts of 16 quads: part pp, chain u runs over
 // the quads 16 pp + u + 4 m, m = 0..3, four fmas each; S_pp = (c0 + c1) + (c2 + c3); sigma = (((b + S_0) + S_1) + S_2) + S_3.
 // This lane holds the quads 2 s + h: its chains are u = h (s = 8 pp + 2 m) and u = h + 2 (s = 8 pp + 2 m + 1).
+// The head is written in two halves (parts 0, 1 over the feature blocks 0..3, parts 2, 3 over blocks 4..7), each with 64
+// registers of weights.
 struct HeadSigmaW {
-    float4 w[32];  // the weights of quad 2 s + h, s = 0..31
+    float4 w[16];  // the weights of quad 2 s + h, s = 16 half .. 16 half + 15
 };
-__device__ __forceinline__ void load_head_sigma(HeadSigmaW& hw, __amdgpu_buffer_rsrc_t rsrc, uint32_t blane, uint32_t w_off) {
+__device__ __forceinline__ void load_head_sigma(HeadSigmaW& hw, __amdgpu_buffer_rsrc_t rsrc, uint32_t blane, uint32_t w_off, int half) {
 #pragma unroll
-    for (int s = 0; s < 32; ++s) hw.w[s] = load_weight(rsrc, blane, w_off + 32u * (uint32_t)s);
+    for (int j = 0; j < 16; ++j) hw.w[j] = load_weight(rsrc, blane, w_off + 32u * (uint32_t)(16 * half + j));
 }
-__device__ __forceinline__ float head_sigma(const f32x16 (&in)[8], const HeadSigmaW& hw, float bias, int lane) {
-    float ca[4], cb[4];
+// sigma_in = the bias (half 0) or the result of half 0 (half 1)
+template <int HALF>
+__device__ __forceinline__ float head_sigma(const f32x16 (&in)[8], const HeadSigmaW& hw, float sigma_in, int lane) {
+    float ca[2], cb[2];
 #pragma unroll
-    for (int pp = 0; pp < 4; ++pp) {
-        ca[pp] = cb[pp] = 0.f;
+    for (int pl = 0; pl < 2; ++pl) {
+        const int pp = 2 * HALF + pl;
+        ca[pl] = cb[pl] = 0.f;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int sa = 8 * pp + 2 * m, sb = sa + 1;
-            ca[pp] = fmaf(in[sa >> 2][4 * (sa & 3) + 0], hw.w[sa].x, ca[pp]);
-            ca[pp] = fmaf(in[sa >> 2][4 * (sa & 3) + 1], hw.w[sa].y, ca[pp]);
-            ca[pp] = fmaf(in[sa >> 2][4 * (sa & 3) + 2], hw.w[sa].z, ca[pp]);
-            ca[pp] = fmaf(in[sa >> 2][4 * (sa & 3) + 3], hw.w[sa].w, ca[pp]);
-            cb[pp] = fmaf(in[sb >> 2][4 * (sb & 3) + 0], hw.w[sb].x, cb[pp]);
-            cb[pp] = fmaf(in[sb >> 2][4 * (sb & 3) + 1], hw.w[sb].y, cb[pp]);
-            cb[pp] = fmaf(in[sb >> 2][4 * (sb & 3) + 2], hw.w[sb].z, cb[pp]);
-            cb[pp] = fmaf(in[sb >> 2][4 * (sb & 3) + 3], hw.w[sb].w, cb[pp]);
+            ca[pl] = fmaf(in[sa >> 2][4 * (sa & 3) + 0], hw.w[sa - 16 * HALF].x, ca[pl]);
+            ca[pl] = fmaf(in[sa >> 2][4 * (sa & 3) + 1], hw.w[sa - 16 * HALF].y, ca[pl]);
+            ca[pl] = fmaf(in[sa >> 2][4 * (sa & 3) + 2], hw.w[sa - 16 * HALF].z, ca[pl]);
+            ca[pl] = fmaf(in[sa >> 2][4 * (sa & 3) + 3], hw.w[sa - 16 * HALF].w, ca[pl]);
+            cb[pl] = fmaf(in[sb >> 2][4 * (sb & 3) + 0], hw.w[sb - 16 * HALF].x, cb[pl]);
+            cb[pl] = fmaf(in[sb >> 2][4 * (sb & 3) + 1], hw.w[sb - 16 * HALF].y, cb[pl]);
+            cb[pl] = fmaf(in[sb >> 2][4 * (sb & 3) + 2], hw.w[sb - 16 * HALF].z, cb[pl]);
+            cb[pl] = fmaf(in[sb >> 2][4 * (sb & 3) + 3], hw.w[sb - 16 * HALF].w, cb[pl]);
         }
     }
-    float sigma = bias;
+    float sigma = sigma_in;
 #pragma unroll
-    for (int pp = 0; pp < 4; ++pp) sigma += pair_sum(ca[pp], cb[pp]);
+    for (int pl = 0; pl < 2; ++pl) sigma += pair_sum(ca[pl], cb[pl]);
     return sigma;
 }
 
@@ -520,35 +503,36 @@ __device__ __forceinline__ void head3(const f32x16 (&in)[8], const Head3W& hw, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// SpaceNet on the wave's 32 samples (point p, direction dv, frame id tv of sample c in both lanes of the sample).
-// Returns {r, g, b, sigma} (raw) in every lane.  `mid` is called once, in front of the direction / time encoding -- a
-// stretch of ~1k cycles of vector arithmetic without a memory wait, where the caller issues the HBM loads of the next
-// work item (the counters are in order: a load issued elsewhere stalls the next weight wait for its whole latency).
+// SpaceNet on the wave's 32 samples (point p of sample c in both lanes of the sample; `ray` = the sample's row of the
+// layer's ray-bias table: rgb_net.1's bias + direction / time columns, mlp_raybias.hip).  Returns {r, g, b, sigma} (raw)
+// in every lane.  `mid` is called once, in front of the sigma head's chains -- a stretch of ~1k cycles of vector
+// arithmetic without a memory wait, where the caller issues the HBM loads of the next work item (the counters are in
+// order: a load issued elsewhere stalls the next weight wait for its whole latency).
 // ---------------------------------------------------------------------------------------------
 template <bool DEEP, class Mid>
 __device__ __forceinline__ float4 space_wave(const float* net, const bool use_time, float* encw, const float (&p)[3],
-                                             const float (&dv)[3], float tv, int lane, f32x16 (&acc)[8], f32x16 (&in)[8],
-                                             float4 (&wa)[8], float4 (&wb)[8], Mid mid WV_DBG_PARAM WP_PARAM) {
+                                             const float* __restrict__ raybias, int32_t ray, int lane, f32x16 (&acc)[8],
+                                             f32x16 (&in)[8], float4 (&wa)[8], float4 (&wb)[8], Mid mid WV_DBG_PARAM WP_PARAM) {
     const SpaceLayout L = space_layout(use_time, DEEP);
     const __amdgpu_buffer_rsrc_t rsrc = weight_rsrc(net);
     const int h = lane >> 5, c = lane & 31;
     constexpr uint32_t WSTEP256 = 2u * 256u * 16u, WSTEP128 = 2u * 128u * 16u;
     const LaneOfs wl256 = lane_offsets((uint32_t)(h * 256 + c) * 16u);
-    const LaneOfs wl128p = lane_offsets_paired((uint32_t)(h * 128 + c) * 16u, WSTEP128);  // (entries 0..3 = the single-step offsets)
+    const NextOfs nx256{(uint32_t)(h * 256 + c) * 16u, false, 0u}, nx128p{(uint32_t)(h * 128 + c) * 16u, true, WSTEP128};
     const uint32_t blane = (uint32_t)h * 16u;
-    // ---- every later bias vector on its way into the wave's LDS window: slots 0..5 = stage1.2 .. stage2.4, 6 = rgb_net.1,
-    // 7 / 8 = the deep_rgb layers; then stage1.0's bias + first weights, all in flight behind the encoding arithmetic
+    // ---- every later bias vector on its way into the wave's LDS window: slots 0..5 = stage1.2 .. stage2.4, 6 / 7 = the
+    // deep_rgb layers (rgb_net.1 has none: its C operand is the ray's row of `raybias`); then stage1.0's bias + first
+    // weights, all in flight behind the encoding arithmetic
     float* biasw = encw + WV_ENC_FLOATS;
-    constexpr int NBS = DEEP ? 9 : 7;
+    constexpr int NBS = DEEP ? 8 : 6;
     BiasStage<NBS> bst;
     {
         uint32_t bo[NBS];
 #pragma unroll
         for (int i = 0; i < 6; ++i) bo[i] = (uint32_t)L.b[i + 1] * 4u;
-        bo[6] = (uint32_t)L.b_rgb1 * 4u;
         if constexpr (DEEP) {
-            bo[7] = (uint32_t)L.b_deep[0] * 4u;
-            bo[8] = (uint32_t)L.b_deep[1] * 4u;
+            bo[6] = (uint32_t)L.b_deep[0] * 4u;
+            bo[7] = (uint32_t)L.b_deep[1] * 4u;
         }
         stage_bias_issue<NBS>(bst, rsrc, lane, bo);
     }
@@ -562,7 +546,7 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
     stage_bias_store<NBS>(bst, biasw, lane);
     WV_DBG(100, pe, 2);
     WP(WP_S_PE);
-    segment_r<8, 2, 8, 0, 8>(acc, pe, wa, wb, rsrc, wl256, (uint32_t)L.w[0] * 4u, WSTEP256, wl256, (uint32_t)L.w[1] * 4u);
+    segment_r<8, 2, 8, 0, 8>(acc, pe, wa, wb, rsrc, wl256, (uint32_t)L.w[0] * 4u, WSTEP256, nx256, (uint32_t)L.w[1] * 4u);
     relu_rebias<8, 8>(acc, in, biasw, lane);
     WV_DBG(0, in, 8);
     WP(WP_S_L0);
@@ -575,51 +559,61 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
         const uint32_t boff = soff + kq * 4096u;           // this layer's bias
         const uint32_t after = boff + 1024u;               // the next layer's weights (stage2.4: density_net follows)
         const uint32_t next_w = li == 6 ? (uint32_t)L.w_rgb1 * 4u : after;
-        LaneOfs next_wl;  // (selected value by value: a reference to one of two arrays would send both through memory)
-#pragma unroll
-        for (int fb = 0; fb < 8; ++fb) next_wl.v[fb] = li == 6 ? wl128p.v[fb] : wl256.v[fb];  // (rgb_net.1 runs in step pairs)
+        const NextOfs next_wl{li == 6 ? nx128p.base : nx256.base, li == 6, WSTEP128};  // (rgb_net.1 runs in step pairs)
         // (one copy of the 32-step body: behind stage2.0's 256 features the skip segment simply continues in the blob)
         segment_r<8, 8, 32, 0, 8>(acc, in, wa, wb, rsrc, wl256, soff, WSTEP256, next_wl,  // (li == 4: next_wl == wl256)
                                   li == 4 ? soff + 32u * WSTEP256 : next_w);
         if (li == 4) segment_r<8, 2, 8, 0, 8>(acc, pe, wa, wb, rsrc, wl256, soff + 32u * WSTEP256, WSTEP256, next_wl, next_w);
         WP(WP_L_SEG);
-        relu_rebias<8, 8>(acc, in, biasw + li * 256, lane);  // (stage2.4 -> rgb_net.1: blocks 4..7 of the bias read are unused)
+        relu_rebias<8, 8>(acc, in, biasw + li * 256, lane);  // (behind stage2.4 the bias read is overwritten just below)
         WP(WP_L_EPI);
         WV_DBG(li, in, 8);
         soff = after;
     }
-    // ---- sigma = density_net(h) (:139), raw: its weights go out first, the direction / time encoding covers their
-    // latency (and that of the next item's HBM loads, issued by `mid`)
-    HeadSigmaW hs;
-    load_head_sigma(hs, rsrc, blane, (uint32_t)L.w_sigma * 4u);
+    // ---- rgb_net.1's C operands: this sample's row of the ray-bias table straight into the accumulators.  (Fetching them
+    // inside the preceding ReLU pass, block by block, would cover their latency, but keeps the row pointer live through
+    // the layer loop -- the loop's lane offsets then go to scratch and every phase slows down.)
+    {
+        const float* row = raybias + (int64_t)ray * 128 + 4 * h;
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(row + fb * 32 + 8 * q);
+                acc[fb][4 * q + 0] = v.x;
+                acc[fb][4 * q + 1] = v.y;
+                acc[fb][4 * q + 2] = v.z;
+                acc[fb][4 * q + 3] = v.w;
+            }
+    }
+    // ---- sigma = density_net(h) (:139), raw, then rgb_net: relu -> Linear(283|304, 128) -> relu -> Linear(128, 3)
+    // (:80-86); h is already >= 0, and only the 256 backbone columns are left of the first layer.  The sigma weights go
+    // out first, then the next item's HBM loads (`mid`); the chains cover the latter.  (Weaving the two halves of the head
+    // into the layer -- weights behind one half of the K loop, chains after it -- hides the weight latency too, but measured
+    // 0.6 % slower: more values live across the K loop, less room for the allocator.)  The colour head's weights travel
+    // behind the second half of the layer (its first four input blocks are dead by then: registers to spare).
+    HeadSigmaW hs0, hs1;
+    load_head_sigma(hs0, rsrc, blane, (uint32_t)L.w_sigma * 4u, 0);
+    load_head_sigma(hs1, rsrc, blane, (uint32_t)L.w_sigma * 4u, 1);
     const float b_sigma = net[L.b_sigma];
-    mid();
-    // ---- rgb_net: relu -> Linear(283|304, 128) -> relu -> Linear(128, 3)   (:80-86); h is already >= 0, the
-    // encodings are clamped when written
-    f32x16 de[2];
-    encode_dir_time(encw, lane, dv, tv, use_time);
-    // (the sigma chains sit between the encoding's LDS writes and its read-back: their weights and the encoding
-    // blocks are never live together)
-    const float sigma = head_sigma(in, hs, b_sigma, lane);
-    wave_lds_sync();
-    if (use_time) read_enc_blocks<2, 6>(encw, lane, de);
-    else read_enc_blocks<2, 4>(encw, lane, de);
-    wave_lds_sync();
-    WV_DBG(101, de, 2);
-    WP(WP_S_MID);
     const uint32_t wr = (uint32_t)L.w_rgb1 * 4u;
-    segment_p<8, 32, 0, 4>(acc, in, wa, wb, rsrc, wl128p, wr, WSTEP128, wl128p, wr + 32u * WSTEP128);  // (the short encoding segment: single steps)
-    // the colour head's weights travel behind the encoding segment (`in` is dead from here on: registers to spare)
+    const LaneOfs wl128p = lane_offsets_paired(nx128p.base, WSTEP128);  // (not live through the layer loop)
+    mid();
+    float sigma = head_sigma<0>(in, hs0, b_sigma, lane);
+    sigma = head_sigma<1>(in, hs1, sigma, lane);
+    WP(WP_S_MID);
+    segment_p<4, 16, 0, 8>(acc, reinterpret_cast<const f32x16 (&)[4]>(in[0]), wa, wb, rsrc, wl128p, wr, WSTEP128, nx128p,
+                           wr + 16u * WSTEP128);
     Head3W hr;
     load_head3(hr, rsrc, blane, (uint32_t)L.w_rgb2 * 4u);
     const uint32_t w_after = DEEP ? (uint32_t)L.w_deep[0] * 4u : wr;  // (not deep: nothing follows; the fetch is discarded)
-    if (use_time) segment_r<4, 2, 6, 0, 8>(acc, de, wa, wb, rsrc, wl128p, wr + 32u * WSTEP128, WSTEP128, wl128p, w_after);
-    else segment_r<4, 2, 4, 0, 8>(acc, de, wa, wb, rsrc, wl128p, wr + 32u * WSTEP128, WSTEP128, wl128p, w_after);
+    segment_p<4, 16, 0, 8>(acc, reinterpret_cast<const f32x16 (&)[4]>(in[4]), wa, wb, rsrc, wl128p, wr + 16u * WSTEP128, WSTEP128,
+                           nx128p, w_after);
     if constexpr (DEEP) {  // deep_rgb (:68-79): two more 128-wide hidden layers
+        relu_rebias<4, 4>(acc, in, biasw + 6 * 256, lane);
+        segment_p<8, 16, 0, 8>(acc, in, wa, wb, rsrc, wl128p, (uint32_t)L.w_deep[0] * 4u, WSTEP128, nx128p, (uint32_t)L.w_deep[1] * 4u);
         relu_rebias<4, 4>(acc, in, biasw + 7 * 256, lane);
-        segment_p<8, 16, 0, 8>(acc, in, wa, wb, rsrc, wl128p, (uint32_t)L.w_deep[0] * 4u, WSTEP128, wl128p, (uint32_t)L.w_deep[1] * 4u);
-        relu_rebias<4, 4>(acc, in, biasw + 8 * 256, lane);
-        segment_p<8, 16, 0, 8>(acc, in, wa, wb, rsrc, wl128p, (uint32_t)L.w_deep[1] * 4u, WSTEP128, wl128p, (uint32_t)L.w_deep[1] * 4u);
+        segment_p<8, 16, 0, 8>(acc, in, wa, wb, rsrc, wl128p, (uint32_t)L.w_deep[1] * 4u, WSTEP128, nx128p, (uint32_t)L.w_deep[1] * 4u);
     }
     WP(WP_S_RGB1);
     relu_rebias<4, 0>(acc, in, biasw, lane);
@@ -640,6 +634,7 @@ __device__ __forceinline__ void motion_wave(const float* net, float* encw, float
     const int h = lane >> 5, c = lane & 31;
     constexpr uint32_t WSTEP128 = 2u * 128u * 16u;
     const LaneOfs wl128p = lane_offsets_paired((uint32_t)(h * 128 + c) * 16u, WSTEP128);
+    const NextOfs nx128p{(uint32_t)(h * 128 + c) * 16u, true, WSTEP128};
     const uint32_t blane = (uint32_t)h * 16u;
     float* biasw = encw + WV_ENC_FLOATS;
     BiasStage<4> bst;  // motion_net.2 .. .8 -> slots 0..3 of the wave's LDS window
@@ -660,7 +655,7 @@ __device__ __forceinline__ void motion_wave(const float* net, float* encw, float
     WV_DBG(199, me, 3);
     WP(WP_M_ENC);
     // motion_net.0: 11 K steps (22 quads) = 5 step pairs + a half pair (every layer here runs in step pairs)
-    segment_p<3, 11, 0, 8>(acc, me, wa, wb, rsrc, wl128p, (uint32_t)L.w[0] * 4u, WSTEP128, wl128p, (uint32_t)L.w[1] * 4u);
+    segment_p<3, 11, 0, 8>(acc, me, wa, wb, rsrc, wl128p, (uint32_t)L.w[0] * 4u, WSTEP128, nx128p, (uint32_t)L.w[1] * 4u);
     relu_rebias<4, 4>(acc, in, biasw, lane);
     WV_DBG(200, in, 4);
     Head3W hf;  // the flow head's weights: fetched here, used behind the four hidden layers
@@ -672,7 +667,7 @@ __device__ __forceinline__ void motion_wave(const float* net, float* encw, float
         // (behind motion_net.8 nothing follows: the fetch is discarded, so it re-reads this layer's first rows -- a full
         // operand fetch at the output layer's 1.5 KB would run past the end of the blob.  6 and 8 pairs per layer: every
         // layer starts in wa)
-        segment_p<8, 16, 0, 8>(acc, in, wa, wb, rsrc, wl128p, soff, WSTEP128, wl128p, li < 4 ? next_w : soff);
+        segment_p<8, 16, 0, 8>(acc, in, wa, wb, rsrc, wl128p, soff, WSTEP128, nx128p, li < 4 ? next_w : soff);
         if (li < 4) relu_rebias<4, 4>(acc, in, biasw + li * 256, lane);
         else relu_rebias<4, 0>(acc, in, biasw, lane);
         WV_DBG(200 + li, in, 4);
@@ -687,8 +682,9 @@ __device__ __forceinline__ void motion_wave(const float* net, float* encw, float
 
 // What a wave needs of a work item: its sample's point, direction and frame id, and where the result goes.
 struct WaveInputs {
-    float p[3], dv[3], tv;
+    float p[3], tv;
     int64_t raw_off;   // float offset of the sample's {r,g,b,sigma} in the layer's raw
+    int32_t ray;       // row of the layer's ray-bias table
     bool valid;
 };
 
@@ -754,20 +750,18 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_wave_stage_kernel(StageArgs
     auto fetch = [&](uint32_t item, const RowRef& rr, WaveInputs& in) {
         in.valid = rr.valid;
         in.raw_off = 0;
+        in.ray = 0;
         in.tv = 0.f;
 #pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) in.p[c3] = in.dv[c3] = 0.f;
+        for (int c3 = 0; c3 < 3; ++c3) in.p[c3] = 0.f;
         if (rr.valid) {
             const StageLayer& ly = a.layer[slot_of(item)];
             const float* src = ly.xyz + rr.ray * a.xyz_ray_stride + 3 * rr.k;
-            const float* dsrc = a.dirs + rr.ray * a.dirs_ray_stride;
 #pragma unroll
-            for (int c3 = 0; c3 < 3; ++c3) {
-                in.p[c3] = src[c3];
-                in.dv[c3] = dsrc[c3];
-            }
-            if (ly.times) in.tv = ly.times[rr.ray * a.times_ray_stride];
+            for (int c3 = 0; c3 < 3; ++c3) in.p[c3] = src[c3];
+            if (ly.motion) in.tv = ly.times[rr.ray * a.times_ray_stride];
             in.raw_off = rr.ray * a.raw_ray_stride + 4 * rr.k;
+            in.ray = (int32_t)rr.ray;
         }
     };
 
@@ -801,20 +795,16 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_wave_stage_kernel(StageArgs
         RowRef rr_next;
         row_of(it1, rr_next);
         const StageLayer& ly = a.layer[slot_of(it0)];
-        float p[3], dv[3];
+        float p[3];
 #pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) {
-            p[c3] = cur.p[c3];
-            dv[c3] = cur.dv[c3];
-        }
+        for (int c3 = 0; c3 < 3; ++c3) p[c3] = cur.p[c3];
 #ifdef STNERF_WAVE_DEBUG
         WaveDbg dbg{a.dbg, a.dbg_stage, -1};
         if (slot_of(it0) == 0 && cur.valid) dbg.row = (int64_t)(it0 - base_of(it0)) * WV_ITEM + wave * WV_ROWS + (lane & 31);
 #endif
         WP(WP_TOP);
         if (ly.motion) motion_wave(ly.motion, encw, p, cur.tv, ly.motion_flags, lane, acc, in, wa, wb WV_DBG_ARG WP_ARG);
-        const float tvs = ly.use_time ? cur.tv : 0.f;
-        float4 o = space_wave<DEEP>(ly.space, ly.use_time != 0, encw, p, dv, tvs, lane, acc, in, wa, wb,
+        float4 o = space_wave<DEEP>(ly.space, ly.use_time != 0, encw, p, ly.raybias, cur.ray, lane, acc, in, wa, wb,
                                     [&]() { fetch(it1, rr_next, nxt); } WV_DBG_ARG WP_ARG);
         if (cur.valid && lane < 32) {
             if (a.sigmoid_rgb) {  // torch.sigmoid(rgb): 1-ulp v_exp_f32 / v_rcp_f32, the same expression the compositor uses
@@ -858,7 +848,6 @@ int launch_wave_stage(const StageArgs& a_in, bool deep_rgb, int cus, hipStream_t
     const void* kfn = deep_rgb ? reinterpret_cast<const void*>(mlp_wave_stage_kernel<true>)
                                : reinterpret_cast<const void*>(mlp_wave_stage_kernel<false>);
     if (const int rc = reserve_dynamic_lds(kfn, WV_LDS, "mlp_stage (wave)")) return rc;
-    LaunchTimer timer(PROF_MLP_STAGE, deep_rgb ? 1 : 0, a.n_rays, a.ns, 0, stream);
     if (deep_rgb)
         hipLaunchKernelGGL(mlp_wave_stage_kernel<true>, dim3(grid), dim3(WV_THREADS), WV_LDS, stream, a);
     else

@@ -25,7 +25,7 @@ struct Carve {
 
 // sizes of the workspace regions for n rays (shared by the size query and the carve)
 struct Plan {
-    int64_t t_c, xyz_c, raw_c, w_c, t_f, xyz_f, raw_f, list, count, flags;
+    int64_t t_c, xyz_c, raw_c, w_c, t_f, xyz_f, raw_f, list, count, flags, raybias;
 };
 Plan make_plan(int64_t n, int l, int n1, int n2, int only_coarse) {
     Plan p;
@@ -40,6 +40,7 @@ Plan make_plan(int64_t n, int l, int n1, int n2, int only_coarse) {
     p.list = (int64_t)l * n;
     p.flags = n;                      // one byte per ray: the compositor's scratch
     p.count = STNERF_MAX_LAYERS + 2;  // hit-ray counts + the work-queue heads of the two network stages
+    p.raybias = (int64_t)l * n * 128;  // per (layer, ray): the C operands of rgb_net.1 (mlp_raybias.hip), reused by both stages
     return p;
 }
 
@@ -52,7 +53,7 @@ extern "C" int64_t stnerf_render_workspace_bytes(int64_t n, int l, int n1, int n
     }
     const Plan p = make_plan(n, l, n1, n2, only_coarse);
     // xyz_c / raw_c are dead once the fine stage starts, but a single bump carve keeps the accounting obvious
-    const int64_t floats = p.t_c + p.xyz_c + p.raw_c + p.w_c + p.t_f + p.xyz_f + p.raw_f;
+    const int64_t floats = p.t_c + p.xyz_c + p.raw_c + p.w_c + p.t_f + p.xyz_f + p.raw_f + p.raybias;
     return floats * 4 + (p.list + p.count) * 4 + p.flags + 16 * 256;
 }
 
@@ -95,6 +96,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
     int32_t* ray_list = ws.take<int32_t>(pl.list);
     int32_t* ray_count = ws.take<int32_t>(pl.count);
     uint8_t* ray_flags = ws.take<uint8_t>(pl.flags);
+    float* ray_bias = ws.take<float>(pl.raybias);
     hipStream_t st = as_stream(stream);
     int rc;
 
@@ -139,7 +141,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
             set_launch_tag(fine ? 1 : 0);
             const int r2 = stnerf_mlp_stage(sl, ns_l, n, ns, rays + 3, rs, rs, xs, ws_,
                                             (p->deep_rgb ? STNERF_STAGE_DEEP_RGB : 0) | STNERF_STAGE_SIGMOID_RGB,
-                                            reinterpret_cast<uint32_t*>(ray_count + STNERF_MAX_LAYERS + (fine ? 1 : 0)), stream);
+                                            reinterpret_cast<uint32_t*>(ray_count + STNERF_MAX_LAYERS + (fine ? 1 : 0)), ray_bias, stream);
             set_launch_tag(-1);
             return r2;
         }
@@ -174,7 +176,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
                                ? stnerf_spacenet_fwd_f16x3(kind, net, n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs, rays + 3,
                                                            rs, times, rs, raw + (int64_t)i * ns * 4, ws_, overflow, stream)
                                : stnerf_spacenet_fwd(kind, net, n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs, rays + 3, rs,
-                                                     times, rs, raw + (int64_t)i * ns * 4, ws_, stream);
+                                                     times, rs, raw + (int64_t)i * ns * 4, ws_, ray_bias + (int64_t)i * n * 128, stream);
             if (r2) return r2;
         }
         set_launch_tag(-1);

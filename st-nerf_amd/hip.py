@@ -82,7 +82,9 @@ _PROTOS = {
     "stnerf_packed_bytes": (c_i64, [C.c_int]),
     "stnerf_pack_net": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, c_i64]),
     "stnerf_spacenet_fwd": (C.c_int, [C.c_int, C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_i64,
-                                      c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, C.c_void_p]),
+                                      c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, C.c_void_p]),
+    "stnerf_rgb_ray_bias": (C.c_int, [C.c_int, C.c_void_p, c_i64, C.c_void_p, C.c_void_p, c_f32p, c_i64, c_f32p, c_i64,
+                                      c_f32p, C.c_void_p]),
     "stnerf_packed_bytes_f16x3": (c_i64, [C.c_int]),
     "stnerf_pack_net_f16x3": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
                                         c_i64]),
@@ -93,7 +95,7 @@ _PROTOS = {
     "stnerf_motionnet_fwd": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_i64, c_f32p,
                                        c_i64, c_f32p, c_i64, C.c_int, C.c_void_p]),
     "stnerf_mlp_stage": (C.c_int, [C.POINTER(StageLayer), C.c_int, c_i64, C.c_int, c_f32p, c_i64, c_i64, c_i64, c_i64, C.c_int,
-                                   C.c_void_p, C.c_void_p]),
+                                   C.c_void_p, c_f32p, C.c_void_p]),
     "stnerf_encode": (C.c_int, [c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "stnerf_gen_weight": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "stnerf_composite": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_i64, C.c_int, C.c_int, C.POINTER(CompositeParams),

@@ -268,9 +268,30 @@ def spacenet_fwd(net: PackedNet, xyz: Tensor, dirs: Tensor, times: Optional[Tens
                                                       hip.dptr(overflow, torch.int32, "overflow"), hip.stream_ptr()),
                   "stnerf_spacenet_fwd_f16x3")
     else:
+        # workspace of the per-ray part of rgb_net.1 (stnerf_rgb_ray_bias): one row of 128 floats per ray
+        ray_bias = torch.empty(n, 128, dtype=torch.float32, device=raw.device)
         hip.check(hip.lib().stnerf_spacenet_fwd(net.kind, hip.dptr(net.blob), n, ns, lp, cp, xp, xs, dp, ds, tp, ts, rp, rs,
-                                                hip.stream_ptr()), "stnerf_spacenet_fwd")
+                                                hip.dptr(ray_bias), hip.stream_ptr()), "stnerf_spacenet_fwd")
     return raw
+
+
+def rgb_ray_bias(net: PackedNet, dirs: Tensor, times: Optional[Tensor], ray_list: Optional[Tensor] = None,
+                 ray_count: Optional[Tensor] = None) -> Tensor:
+    """The per-ray part of rgb_net.1 (stnerf_rgb_ray_bias): (n, 128) = bias + W[:, 256:] relu([PE_4(dir), PE_10(time)]) for
+    the listed rays (other rows are zero here).  modeling/spacenet.py:80-86,141-151."""
+    n = dirs.shape[0]
+    dp, ds = _strided_view_ptr(dirs, (3,), "dirs")
+    if net.use_time:
+        if times is None:
+            raise ValueError("this SpaceNet takes time: pass times (n,)")
+        tp, ts = _strided_view_ptr(times.reshape(n), (), "times")
+    else:
+        tp, ts = C.c_void_p(0), 0
+    lp, cp = _worklist(ray_list, ray_count)
+    out = torch.zeros(n, 128, dtype=torch.float32, device=dirs.device)
+    hip.check(hip.lib().stnerf_rgb_ray_bias(net.kind, hip.dptr(net.blob), n, lp, cp, dp, ds, tp, ts, hip.dptr(out),
+                                            hip.stream_ptr()), "stnerf_rgb_ray_bias")
+    return out
 
 
 def motionnet_fwd(net: PackedNet, xyz: Tensor, times: Tensor, flow: Optional[Tensor] = None,
@@ -324,9 +345,10 @@ def mlp_stage(layers: Sequence[dict], dirs: Tensor, ns: int, deep_rgb: bool = Fa
         a.ray_list, a.ray_count, a.xyz, a.raw, a.times = lp.value, cp.value, xp.value, rp.value, tp.value
         a.use_time, a.motion_flags = int(ly["space"].use_time), (hip.MOTION_PLAIN_TIME if ly.get("plain_time") else 0)
     queue = torch.zeros(1, dtype=torch.int32, device=dirs.device)
+    ray_bias = torch.empty(len(layers), n, 128, dtype=torch.float32, device=dirs.device)   # rgb_net.1 per ray (stnerf_rgb_ray_bias)
     hip.check(hip.lib().stnerf_mlp_stage(arr, len(layers), n, ns, dp, ds, strides[2], strides[0], strides[1],
                                          (1 if deep_rgb else 0) | (2 if sigmoid_rgb else 0),
-                                         C.c_void_p(queue.data_ptr()), hip.stream_ptr()), "stnerf_mlp_stage")
+                                         C.c_void_p(queue.data_ptr()), hip.dptr(ray_bias), hip.stream_ptr()), "stnerf_mlp_stage")
 
 
 def encode(x: Tensor, n_freq: int, include_input: bool = True) -> Tensor:

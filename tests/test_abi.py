@@ -90,7 +90,7 @@ def test_pack_spacenet_layout(lib):
 def test_argument_errors_before_any_launch(lib):
     null = C.c_void_p(0)
     assert lib.stnerf_sample_coarse(null, 4, 9, null, 0, 3, 8, null, 0, 0, 0, 0, None, None, null, null, null, null) == hip.EINVAL
-    assert lib.stnerf_spacenet_fwd(7, null, 1, 1, null, null, null, 0, null, 0, null, 0, null, 0, null) == hip.EINVAL
+    assert lib.stnerf_spacenet_fwd(7, null, 1, 1, null, null, null, 0, null, 0, null, 0, null, 0, null, null) == hip.EINVAL
     assert "bad kind" in hip.last_error()
 
 
@@ -176,7 +176,7 @@ int main(void) {
 
 def test_render_workspace_query_and_argument_errors(lib):
     nb = lib.stnerf_render_workspace_bytes(1000, 3, 64, 64, 0)
-    floats = 1000 * 3 * (64 * (1 + 3 + 4 + 1) + 128 * (1 + 3 + 4))
+    floats = 1000 * 3 * (64 * (1 + 3 + 4 + 1) + 128 * (1 + 3 + 4) + 128)           # + 128 per (ray, layer): rgb_net.1's per-ray part
     assert nb >= 4 * floats and nb < 4 * floats + 3 * 1000 * 4 + 1000 + 8192      # + ray lists, one flag byte per ray, counters, alignment
     assert lib.stnerf_render_workspace_bytes(1000, 3, 64, 64, 1) < nb
     assert lib.stnerf_render_workspace_bytes(10, 99, 64, 64, 0) == hip.EINVAL

@@ -243,6 +243,34 @@ def test_spacenet_worklist_and_strided_views(ops):
     assert torch.equal(raw, raw2)
 
 
+@pytest.mark.parametrize("use_time", [False, True])
+def test_rgb_ray_bias_vs_fp64(ops, use_time):
+    """stnerf_rgb_ray_bias: the direction / time columns of rgb_net.1 evaluated once per ray,
+    out[j] = bias + W[:, 256:] relu([PE_4(dir_j), PE_10(time_j)]) (modeling/spacenet.py:80-86,141-151), against an fp64
+    evaluation; rays a list leaves out are not written."""
+    torch.manual_seed(3)
+    rs = np.random.RandomState(11)
+    sd = syn.spacenet_state("net", rs, use_time)
+    n = 777
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
+    times = torch.where(torch.rand(n) < 0.5, torch.floor(torch.rand(n) * 30), torch.rand(n) * 30) + 1
+    net = ops.pack_spacenet(sd, "net")
+    enc = [O.positional_encoding(dirs.double(), 4)]
+    if use_time:
+        enc.append(O.positional_encoding(times.double().reshape(n, 1), 10))
+    e = torch.relu(torch.cat(enc, -1))
+    W, b = sd["net.rgb_net.1.weight"].double(), sd["net.rgb_net.1.bias"].double()
+    want = b + e @ W[:, 256:].T
+    got = ops.rgb_ray_bias(net, dev(dirs), dev(times) if use_time else None).cpu().double()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 4e-6 * scale, float((got - want).abs().max())
+    mask = (torch.rand(n, 2) < 0.4).to(torch.uint8)
+    lst, cnt = ops.compact_rays(dev(mask))
+    part = ops.rgb_ray_bias(net, dev(dirs), dev(times) if use_time else None, ray_list=lst[1], ray_count=cnt[1:2]).cpu().double()
+    hit = mask[:, 1].bool()
+    assert torch.equal(part[hit], got[hit]) and bool((part[~hit] == 0).all())
+
+
 @pytest.mark.parametrize("stage_kernel", ["wave", "lds"])
 @pytest.mark.parametrize("deep, bkgd_deform, ns", [(False, False, 13), (False, False, 64), (True, True, 9), (False, True, 128), (False, True, 90)])
 def test_mlp_stage_is_bit_identical_to_the_per_network_launches(ops, deep, bkgd_deform, ns, stage_kernel, monkeypatch):

@@ -66,6 +66,9 @@ SCENARIOS = [
     ("deformed timed bkgd + performers + motion, ns=128", dict(n=600, ns=128, deep=False, bkgd_deform=True, with_perf=True, with_motion=True)),
     ("deep_rgb, deformed bkgd, ns=9", dict(n=1100, ns=9, deep=True, bkgd_deform=True, with_perf=True, with_motion=True)),
     ("ragged: ns=90, n=517", dict(n=517, ns=90, deep=False, bkgd_deform=False, with_perf=True, with_motion=True)),
+    ("few items: ns=16, n=768", dict(n=768, ns=16, deep=False, bkgd_deform=False, with_perf=True, with_motion=True)),
+    ("few items: ns=24, n=768", dict(n=768, ns=24, deep=False, bkgd_deform=False, with_perf=True, with_motion=True)),
+    ("tiny: ns=16, n=40", dict(n=40, ns=16, deep=False, bkgd_deform=False, with_perf=True, with_motion=True)),
 ]
 
 
@@ -77,7 +80,7 @@ def check():
         out = {}
         for kern in os.environ.get("ORDER", "lds,wave").split(","):
             raw = torch.full((n, l, ns, 4), 7.0, device="cuda")
-            run(kern, sc["layers_for"](raw), sc["dirs"], ns, deep_rgb=sc["deep"])
+            run(kern, sc["layers_for"](raw), sc["dirs"], ns, deep_rgb=sc["deep"], sigmoid_rgb=bool(os.environ.get("SIGMOID")))
             out[kern] = raw
         a, b = out["lds"], out["wave"]
         diff = (a != b)
@@ -100,7 +103,7 @@ def check():
         print(line, flush=True)
         # twice the same bits (dynamic scheduling does not touch the arithmetic)
         raw2 = torch.full((n, l, ns, 4), 7.0, device="cuda")
-        run("wave", sc["layers_for"](raw2), sc["dirs"], ns, deep_rgb=sc["deep"])
+        run("wave", sc["layers_for"](raw2), sc["dirs"], ns, deep_rgb=sc["deep"], sigmoid_rgb=bool(os.environ.get("SIGMOID")))
         if not torch.equal(raw2, b):
             print(f"[{name}] wave kernel is not deterministic: {int((raw2 != b).any(-1).sum())} rows differ between two runs", flush=True)
             bad_total += 1
@@ -135,7 +138,6 @@ def space_reference(sd, pos, dirs, times, use_time):
     if use_time:
         enc.append(pe(times.double().reshape(-1, 1), 10))
     e = torch.relu(torch.cat(enc, -1))
-    acts[101] = e
     x = torch.cat([h, e], -1)
     acts[7] = torch.relu(x @ W("rgb_net.1").T + B("rgb_net.1"))
     return acts
