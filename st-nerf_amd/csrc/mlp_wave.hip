@@ -357,6 +357,12 @@ __device__ __forceinline__ void stage_bias_store(const BiasStage<NB>& st, float*
 // Layer boundary: in = relu(acc) (one v_max_i32 per value); as soon as a block is consumed, the bias of the NEXT
 // layer's block (next_bias = that vector in the wave's LDS window, nullptr-free: NFB_NEXT = 0 after the last layer) is
 // read into the freed accumulator registers.  Register 4 q + r of block fb <-> feature 32 fb + 8 q + 4 h + r.
+// Layer loops are ROTATED around this pass -- { relu_rebias of the previous layer; K segment } -- so that what crosses the
+// loop's back edge is the MFMAs' own output.  With the pass at the END of the body the freshly loaded bias crosses it,
+// and the register allocator parks 76 of the 128 values in arch VGPRs to copy them into the accumulators at the loop
+// head: 76 v_accvgpr_write per layer on the matrix pipe's time (-0.3 % for the whole kernel).  The barrier between a
+// block's reads and its bias load keeps the ds_read from being hoisted (= from needing other registers than the ones
+// just read).
 template <int NFB, int NFB_NEXT>
 __device__ __forceinline__ void relu_rebias(f32x16 (&acc)[8], f32x16 (&in)[8], const float* next_bias, int lane) {
     const float4* nb4 = reinterpret_cast<const float4*>(next_bias) + (lane >> 5);
@@ -366,6 +372,7 @@ __device__ __forceinline__ void relu_rebias(f32x16 (&acc)[8], f32x16 (&in)[8], c
 #pragma unroll
             for (int i = 0; i < 16; ++i) in[fb][i] = relu_bits(acc[fb][i]);
         }
+        __builtin_amdgcn_sched_barrier(0);  // (the bias goes into the registers just read: no earlier)
         if (fb < NFB_NEXT) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -547,8 +554,6 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
     WV_DBG(100, pe, 2);
     WP(WP_S_PE);
     segment_r<8, 2, 8, 0, 8>(acc, pe, wa, wb, rsrc, wl256, (uint32_t)L.w[0] * 4u, WSTEP256, nx256, (uint32_t)L.w[1] * 4u);
-    relu_rebias<8, 8>(acc, in, biasw, lane);
-    WV_DBG(0, in, 8);
     WP(WP_S_L0);
     // ---- stage1.2 .. stage2.4: six 256-wide layers, stage2.0 (li == 4) with the PE(pos) skip segment behind its 256
     // features (modeling/spacenet.py:45-57,136-138)
@@ -560,16 +565,20 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
         const uint32_t after = boff + 1024u;               // the next layer's weights (stage2.4: density_net follows)
         const uint32_t next_w = li == 6 ? (uint32_t)L.w_rgb1 * 4u : after;
         const NextOfs next_wl{li == 6 ? nx128p.base : nx256.base, li == 6, WSTEP128};  // (rgb_net.1 runs in step pairs)
+        // the previous layer's ReLU, this layer's bias (rotated: see relu_rebias)
+        relu_rebias<8, 8>(acc, in, biasw + (li - 1) * 256, lane);
+        WV_DBG(li - 1, in, 8);
+        WP(WP_L_EPI);
         // (one copy of the 32-step body: behind stage2.0's 256 features the skip segment simply continues in the blob)
         segment_r<8, 8, 32, 0, 8>(acc, in, wa, wb, rsrc, wl256, soff, WSTEP256, next_wl,  // (li == 4: next_wl == wl256)
                                   li == 4 ? soff + 32u * WSTEP256 : next_w);
         if (li == 4) segment_r<8, 2, 8, 0, 8>(acc, pe, wa, wb, rsrc, wl256, soff + 32u * WSTEP256, WSTEP256, next_wl, next_w);
         WP(WP_L_SEG);
-        relu_rebias<8, 8>(acc, in, biasw + li * 256, lane);  // (behind stage2.4 the bias read is overwritten just below)
-        WP(WP_L_EPI);
-        WV_DBG(li, in, 8);
         soff = after;
     }
+    relu_rebias<8, 0>(acc, in, biasw, lane);
+    WV_DBG(6, in, 8);
+    WP(WP_L_EPI);
     // ---- rgb_net.1's C operands: this sample's row of the ray-bias table straight into the accumulators.  (Fetching them
     // inside the preceding ReLU pass, block by block, would cover their latency, but keeps the row pointer live through
     // the layer loop -- the loop's lane offsets then go to scratch and every phase slows down.)
@@ -656,22 +665,21 @@ __device__ __forceinline__ void motion_wave(const float* net, float* encw, float
     WP(WP_M_ENC);
     // motion_net.0: 11 K steps (22 quads) = 5 step pairs + a half pair (every layer here runs in step pairs)
     segment_p<3, 11, 0, 8>(acc, me, wa, wb, rsrc, wl128p, (uint32_t)L.w[0] * 4u, WSTEP128, nx128p, (uint32_t)L.w[1] * 4u);
-    relu_rebias<4, 4>(acc, in, biasw, lane);
-    WV_DBG(200, in, 4);
     Head3W hf;  // the flow head's weights: fetched here, used behind the four hidden layers
     load_head3(hf, rsrc, blane, (uint32_t)L.w_out * 4u);
 #pragma unroll 1
     for (int li = 1; li <= 4; ++li) {
+        relu_rebias<4, 4>(acc, in, biasw + (li - 1) * 256, lane);  // the previous layer's ReLU, this layer's bias
+        WV_DBG(199 + li, in, 4);
         const uint32_t soff = (uint32_t)L.w[1] * 4u + (uint32_t)(li - 1) * (32u * 128u * 16u + 512u);
         const uint32_t next_w = soff + 32u * 128u * 16u + 512u;
         // (behind motion_net.8 nothing follows: the fetch is discarded, so it re-reads this layer's first rows -- a full
         // operand fetch at the output layer's 1.5 KB would run past the end of the blob.  6 and 8 pairs per layer: every
         // layer starts in wa)
         segment_p<8, 16, 0, 8>(acc, in, wa, wb, rsrc, wl128p, soff, WSTEP128, nx128p, li < 4 ? next_w : soff);
-        if (li < 4) relu_rebias<4, 4>(acc, in, biasw + li * 256, lane);
-        else relu_rebias<4, 0>(acc, in, biasw, lane);
-        WV_DBG(200 + li, in, 4);
     }
+    relu_rebias<4, 0>(acc, in, biasw, lane);
+    WV_DBG(204, in, 4);
     WP(WP_M_LAYERS);
     float fl[3];
     head3(in, hf, net + L.b_out, lane, fl);
@@ -803,8 +811,12 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_wave_stage_kernel(StageArgs
         if (slot_of(it0) == 0 && cur.valid) dbg.row = (int64_t)(it0 - base_of(it0)) * WV_ITEM + wave * WV_ROWS + (lane & 31);
 #endif
         WP(WP_TOP);
-        if (ly.motion) motion_wave(ly.motion, encw, p, cur.tv, ly.motion_flags, lane, acc, in, wa, wb WV_DBG_ARG WP_ARG);
-        float4 o = space_wave<DEEP>(ly.space, ly.use_time != 0, encw, p, ly.raybias, cur.ray, lane, acc, in, wa, wb,
+        // (deep_rgb variant: the lane index the networks see is opaque per item -- hoisted out of the item loop, the
+        // per-lane LDS addresses derived from it do not fit beside this variant's live values and go to scratch)
+        int ln = lane;
+        if constexpr (DEEP) asm volatile("" : "+v"(ln));
+        if (ly.motion) motion_wave(ly.motion, encw, p, cur.tv, ly.motion_flags, ln, acc, in, wa, wb WV_DBG_ARG WP_ARG);
+        float4 o = space_wave<DEEP>(ly.space, ly.use_time != 0, encw, p, ly.raybias, cur.ray, ln, acc, in, wa, wb,
                                     [&]() { fetch(it1, rr_next, nxt); } WV_DBG_ARG WP_ARG);
         if (cur.valid && lane < 32) {
             if (a.sigmoid_rgb) {  // torch.sigmoid(rgb): 1-ulp v_exp_f32 / v_rcp_f32, the same expression the compositor uses
