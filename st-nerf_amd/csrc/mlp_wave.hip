@@ -12,7 +12,9 @@
 //     s >> 2.  The activations of the whole network therefore never leave the register file: no LDS traffic, no
 //     barrier, no epilogue stores between layers; a layer boundary is 128 ReLUs (v_max_i32) and nothing else.
 //   * 256 features x 32 samples = 128 registers in + 128 accumulators out: one wave per SIMD with the unified
-//     512-entry register file (accumulators in AGPRs), 4 waves = 128 samples per CU.
+//     512-entry register file (accumulators in AGPRs), 4 waves = 128 samples per CU.  (A second wave per SIMD would
+//     not buy overlap: f32 MFMAs run on the SIMD's own f32 lanes, a vector instruction costs the MFMA stream its 5 - 6
+//     cycles whichever wave issues it -- tools/micro/mfma_two_waves.hip.  What counts is the vector instruction COUNT.)
 //   * Weights: the A operand of a K step is 8 x 16 B per lane straight from the packed blob (buffer loads, SGPR
 //     offsets, one step ahead); the four waves of a CU run the same network in step, so each line comes out of L2
 //     once per CU and the other three waves hit the vector L1.
