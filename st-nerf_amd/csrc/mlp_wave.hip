@@ -41,7 +41,8 @@ constexpr int WV_THREADS = WV_NW * 64;
 constexpr int WV_ITEM = WV_NW * WV_ROWS;          // rows per work item
 constexpr int WV_ENC_QUADS = 22;                  // widest staged encoding: MotionNet's 84 (+4) features
 constexpr int WV_ENC_FLOATS = WV_ENC_QUADS * WV_ROWS * 4;
-constexpr int WV_BIAS_SLOTS = 10;                 // bias vectors of one network staged per wave (256 floats each)
+constexpr int WV_BIAS_SLOTS = 11;                 // 256-float slots per wave: bias vectors of one network + its head weights
+constexpr int WV_HEAD_SLOT = 8;                   // first head slot: density_net.0 (1 slot), then the 3 x 128 head (2 slots)
 constexpr int WV_BIAS_FLOATS = WV_BIAS_SLOTS * 256;
 constexpr int WV_WAVE_FLOATS = WV_ENC_FLOATS + WV_BIAS_FLOATS;   // a wave's private LDS window
 constexpr int WV_LDS = WV_NW * WV_WAVE_FLOATS * 4 + 16 + STNERF_MAX_LAYERS * 8;   // + queue slots + rows per layer
@@ -345,9 +346,12 @@ struct BiasStage {
     float4 v[NB];
 };
 template <int NB>
-__device__ __forceinline__ void stage_bias_issue(BiasStage<NB>& st, __amdgpu_buffer_rsrc_t rsrc, int lane, const uint32_t (&boff)[NB]) {
+__device__ __forceinline__ void stage_bias_issue(BiasStage<NB>& st, __amdgpu_buffer_rsrc_t rsrc, int lane, const uint32_t (&boff)[NB],
+                                                 int last_lanes = 64) {
+    // floats 4 lane .. of vector i; the LAST vector may end with the blob: lanes >= last_lanes re-read its start
 #pragma unroll
-    for (int i = 0; i < NB; ++i) st.v[i] = load_weight(rsrc, (uint32_t)lane * 16u, boff[i]);  // floats 4 lane .. of vector i
+    for (int i = 0; i < NB; ++i)
+        st.v[i] = load_weight(rsrc, (uint32_t)((i + 1 == NB && lane >= last_lanes) ? 0 : lane) * 16u, boff[i]);
 }
 template <int NB>
 __device__ __forceinline__ void stage_bias_store(const BiasStage<NB>& st, float* biasw, int lane) {
@@ -425,27 +429,23 @@ __device__ __forceinline__ float pair_sum(float ca, float cb) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Heads.  Three phases each, placed apart by the callers: the weights are fetched into registers EARLY (behind a stretch
-// of arithmetic that covers their latency), the fma chains run on registers only, and the two lanes of a sample swap
-// their chains with v_permlane32_swap.  (Written as load -> use per part, a head is a chain of 4 .. 12
-// dependent L2 round trips plus as many LDS-crossbar round trips with nothing else for the single wave of the SIMD to
-// do: measured 3.6 % of the kernel for 0.2 % worth of arithmetic.)
+// Heads.  The weights come out of the wave's LDS window (staged there with the biases), the fma chains run on registers,
+// and the two lanes of a sample swap their chains with v_permlane32_swap.  (Written as load from the blob -> use ->
+// ds_bpermute per part, a head is a chain of 4 .. 12 dependent L2 round trips plus as many LDS-crossbar round trips with
+// nothing else for the single wave of the SIMD to do: measured 3.6 % of the kernel for 0.2 % worth of arithmetic.
+// Fetched from the blob into registers EARLY instead, the weights hold 64 .. 192 registers across a layer and the
+// allocator shuffles ~200 values between the register files around them: +0.45 .. 0.75 % for the LDS form.)
 // ---------------------------------------------------------------------------------------------
 // sigma head (256 -> 1) in the grouping of head_partial<TM, 1> with four parts of 16 quads: part pp, chain u runs over
 // the quads 16 pp + u + 4 m, m = 0..3, four fmas each; S_pp = (c0 + c1) + (c2 + c3); sigma = (((b + S_0) + S_1) + S_2) + S_3.
 // This lane holds the quads 2 s + h: its chains are u = h (s = 8 pp + 2 m) and u = h + 2 (s = 8 pp + 2 m + 1).
-// The head is written in two halves (parts 0, 1 over the feature blocks 0..3, parts 2, 3 over blocks 4..7), each with 64
-// registers of weights.
-struct HeadSigmaW {
-    float4 w[16];  // the weights of quad 2 s + h, s = 16 half .. 16 half + 15
-};
-__device__ __forceinline__ void load_head_sigma(HeadSigmaW& hw, __amdgpu_buffer_rsrc_t rsrc, uint32_t blane, uint32_t w_off, int half) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) hw.w[j] = load_weight(rsrc, blane, w_off + 32u * (uint32_t)(16 * half + j));
-}
-// sigma_in = the bias (half 0) or the result of half 0 (half 1)
+// The head is written in two halves (parts 0, 1 over the feature blocks 0..3, parts 2, 3 over blocks 4..7).
+// The head weights are copied into the wave's LDS window together with the bias vectors (stage_bias_*) and read back
+// with ds_read_b128 right where they are used: fetched from the blob at that point they cost an exposed L2 round trip
+// per head (a single wave per SIMD has nothing else to do), fetched early they hold 64 .. 192 registers across a layer.
 template <int HALF>
-__device__ __forceinline__ float head_sigma(const f32x16 (&in)[8], const HeadSigmaW& hw, float sigma_in, int lane) {
+__device__ __forceinline__ float head_sigma(const f32x16 (&in)[8], const float* wlds /* the 256 weights */, float sigma_in, int lane) {
+    const float4* w4 = reinterpret_cast<const float4*>(wlds) + (lane >> 5);  // quad 2 s + h
     float ca[2], cb[2];
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
@@ -454,14 +454,15 @@ __device__ __forceinline__ float head_sigma(const f32x16 (&in)[8], const HeadSig
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int sa = 8 * pp + 2 * m, sb = sa + 1;
-            ca[pl] = fmaf(in[sa >> 2][4 * (sa & 3) + 0], hw.w[sa - 16 * HALF].x, ca[pl]);
-            ca[pl] = fmaf(in[sa >> 2][4 * (sa & 3) + 1], hw.w[sa - 16 * HALF].y, ca[pl]);
-            ca[pl] = fmaf(in[sa >> 2][4 * (sa & 3) + 2], hw.w[sa - 16 * HALF].z, ca[pl]);
-            ca[pl] = fmaf(in[sa >> 2][4 * (sa & 3) + 3], hw.w[sa - 16 * HALF].w, ca[pl]);
-            cb[pl] = fmaf(in[sb >> 2][4 * (sb & 3) + 0], hw.w[sb - 16 * HALF].x, cb[pl]);
-            cb[pl] = fmaf(in[sb >> 2][4 * (sb & 3) + 1], hw.w[sb - 16 * HALF].y, cb[pl]);
-            cb[pl] = fmaf(in[sb >> 2][4 * (sb & 3) + 2], hw.w[sb - 16 * HALF].z, cb[pl]);
-            cb[pl] = fmaf(in[sb >> 2][4 * (sb & 3) + 3], hw.w[sb - 16 * HALF].w, cb[pl]);
+            const float4 wa4 = w4[2 * sa], wb4 = w4[2 * sb];
+            ca[pl] = fmaf(in[sa >> 2][4 * (sa & 3) + 0], wa4.x, ca[pl]);
+            ca[pl] = fmaf(in[sa >> 2][4 * (sa & 3) + 1], wa4.y, ca[pl]);
+            ca[pl] = fmaf(in[sa >> 2][4 * (sa & 3) + 2], wa4.z, ca[pl]);
+            ca[pl] = fmaf(in[sa >> 2][4 * (sa & 3) + 3], wa4.w, ca[pl]);
+            cb[pl] = fmaf(in[sb >> 2][4 * (sb & 3) + 0], wb4.x, cb[pl]);
+            cb[pl] = fmaf(in[sb >> 2][4 * (sb & 3) + 1], wb4.y, cb[pl]);
+            cb[pl] = fmaf(in[sb >> 2][4 * (sb & 3) + 2], wb4.z, cb[pl]);
+            cb[pl] = fmaf(in[sb >> 2][4 * (sb & 3) + 3], wb4.w, cb[pl]);
         }
     }
     float sigma = sigma_in;
@@ -471,18 +472,10 @@ __device__ __forceinline__ float head_sigma(const f32x16 (&in)[8], const HeadSig
 }
 
 // 128 -> 3 head (rgb_net's last layer, MotionNet's flow) in the grouping of head_partial<TM, 3> with four parts of 8
-// quads: part pp, chain u over the quads 8 pp + u + 4 m, m = 0, 1.  Weights [3][128] at w_off, bias b3.
-struct Head3W {
-    float4 w[3][16];  // [output][s]: the weights of quad 2 s + h, s = 0..15
-};
-__device__ __forceinline__ void load_head3(Head3W& hw, __amdgpu_buffer_rsrc_t rsrc, uint32_t blane, uint32_t w_off) {
-#pragma unroll
-    for (int o = 0; o < 3; ++o)
-#pragma unroll
-        for (int s = 0; s < 16; ++s) hw.w[o][s] = load_weight(rsrc, blane, w_off + (uint32_t)(o * 128 + 8 * s) * 4u);
-}
-__device__ __forceinline__ void head3(const f32x16 (&in)[8], const Head3W& hw, const float* __restrict__ b3, int lane,
-                                      float (&out)[3]) {
+// quads: part pp, chain u over the quads 8 pp + u + 4 m, m = 0, 1.  Weights [3][128] in the LDS window, bias b3.
+__device__ __forceinline__ void head3(const f32x16 (&in)[8], const float* wlds /* the 3 x 128 weights */, const float* __restrict__ b3,
+                                      int lane, float (&out)[3]) {
+    const float4* w4 = reinterpret_cast<const float4*>(wlds) + (lane >> 5);
     float ca[4][3], cb[4][3];
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
@@ -492,14 +485,15 @@ __device__ __forceinline__ void head3(const f32x16 (&in)[8], const Head3W& hw, c
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int sa = 4 * pp + 2 * m, sb = sa + 1;
-                ca[pp][o] = fmaf(in[sa >> 2][4 * (sa & 3) + 0], hw.w[o][sa].x, ca[pp][o]);
-                ca[pp][o] = fmaf(in[sa >> 2][4 * (sa & 3) + 1], hw.w[o][sa].y, ca[pp][o]);
-                ca[pp][o] = fmaf(in[sa >> 2][4 * (sa & 3) + 2], hw.w[o][sa].z, ca[pp][o]);
-                ca[pp][o] = fmaf(in[sa >> 2][4 * (sa & 3) + 3], hw.w[o][sa].w, ca[pp][o]);
-                cb[pp][o] = fmaf(in[sb >> 2][4 * (sb & 3) + 0], hw.w[o][sb].x, cb[pp][o]);
-                cb[pp][o] = fmaf(in[sb >> 2][4 * (sb & 3) + 1], hw.w[o][sb].y, cb[pp][o]);
-                cb[pp][o] = fmaf(in[sb >> 2][4 * (sb & 3) + 2], hw.w[o][sb].z, cb[pp][o]);
-                cb[pp][o] = fmaf(in[sb >> 2][4 * (sb & 3) + 3], hw.w[o][sb].w, cb[pp][o]);
+                const float4 wa4 = w4[o * 32 + 2 * sa], wb4 = w4[o * 32 + 2 * sb];
+                ca[pp][o] = fmaf(in[sa >> 2][4 * (sa & 3) + 0], wa4.x, ca[pp][o]);
+                ca[pp][o] = fmaf(in[sa >> 2][4 * (sa & 3) + 1], wa4.y, ca[pp][o]);
+                ca[pp][o] = fmaf(in[sa >> 2][4 * (sa & 3) + 2], wa4.z, ca[pp][o]);
+                ca[pp][o] = fmaf(in[sa >> 2][4 * (sa & 3) + 3], wa4.w, ca[pp][o]);
+                cb[pp][o] = fmaf(in[sb >> 2][4 * (sb & 3) + 0], wb4.x, cb[pp][o]);
+                cb[pp][o] = fmaf(in[sb >> 2][4 * (sb & 3) + 1], wb4.y, cb[pp][o]);
+                cb[pp][o] = fmaf(in[sb >> 2][4 * (sb & 3) + 2], wb4.z, cb[pp][o]);
+                cb[pp][o] = fmaf(in[sb >> 2][4 * (sb & 3) + 3], wb4.w, cb[pp][o]);
             }
         }
     }
@@ -553,9 +547,18 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
     read_enc_blocks<2, 8>(encw, lane, pe);
     wave_lds_sync();
     stage_bias_store<NBS>(bst, biasw, lane);
+    // the head weights follow through slots 8 (density_net.0) and 9 / 10 (the colour head), in flight behind stage1.0
+    // (whose input is the encoding: the eight activation blocks are not live yet, registers to spare)
+    BiasStage<3> hst;
+    {
+        const uint32_t ho[3] = {(uint32_t)L.w_sigma * 4u, (uint32_t)L.w_rgb2 * 4u,
+                                (uint32_t)L.w_rgb2 * 4u + 1024u};  // floats 256..383 of the 3 x 128 head: 32 lanes, then the blob ends
+        stage_bias_issue<3>(hst, rsrc, lane, ho, 32);
+    }
     WV_DBG(100, pe, 2);
     WP(WP_S_PE);
     segment_r<8, 2, 8, 0, 8>(acc, pe, wa, wb, rsrc, wl256, (uint32_t)L.w[0] * 4u, WSTEP256, nx256, (uint32_t)L.w[1] * 4u);
+    stage_bias_store<3>(hst, biasw + WV_HEAD_SLOT * 256, lane);
     WP(WP_S_L0);
     // ---- stage1.2 .. stage2.4: six 256-wide layers, stage2.0 (li == 4) with the PE(pos) skip segment behind its 256
     // features (modeling/spacenet.py:45-57,136-138)
@@ -598,25 +601,17 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
             }
     }
     // ---- sigma = density_net(h) (:139), raw, then rgb_net: relu -> Linear(283|304, 128) -> relu -> Linear(128, 3)
-    // (:80-86); h is already >= 0, and only the 256 backbone columns are left of the first layer.  The sigma weights go
-    // out first, then the next item's HBM loads (`mid`); the chains cover the latter.  (Weaving the two halves of the head
-    // into the layer -- weights behind one half of the K loop, chains after it -- hides the weight latency too, but measured
-    // 0.6 % slower: more values live across the K loop, less room for the allocator.)  The colour head's weights travel
-    // behind the second half of the layer (its first four input blocks are dead by then: registers to spare).
-    HeadSigmaW hs0, hs1;
-    load_head_sigma(hs0, rsrc, blane, (uint32_t)L.w_sigma * 4u, 0);
-    load_head_sigma(hs1, rsrc, blane, (uint32_t)L.w_sigma * 4u, 1);
+    // (:80-86); h is already >= 0, and only the 256 backbone columns are left of the first layer.  The next item's HBM
+    // loads go out first (`mid`); the sigma chains (weights from the LDS window) cover them and the C-operand fetch above.
     const float b_sigma = net[L.b_sigma];
     const uint32_t wr = (uint32_t)L.w_rgb1 * 4u;
     const LaneOfs wl128p = lane_offsets_paired(nx128p.base, WSTEP128);  // (not live through the layer loop)
     mid();
-    float sigma = head_sigma<0>(in, hs0, b_sigma, lane);
-    sigma = head_sigma<1>(in, hs1, sigma, lane);
+    float sigma = head_sigma<0>(in, biasw + WV_HEAD_SLOT * 256, b_sigma, lane);
+    sigma = head_sigma<1>(in, biasw + WV_HEAD_SLOT * 256, sigma, lane);
     WP(WP_S_MID);
     segment_p<4, 16, 0, 8>(acc, reinterpret_cast<const f32x16 (&)[4]>(in[0]), wa, wb, rsrc, wl128p, wr, WSTEP128, nx128p,
                            wr + 16u * WSTEP128);
-    Head3W hr;
-    load_head3(hr, rsrc, blane, (uint32_t)L.w_rgb2 * 4u);
     const uint32_t w_after = DEEP ? (uint32_t)L.w_deep[0] * 4u : wr;  // (not deep: nothing follows; the fetch is discarded)
     segment_p<4, 16, 0, 8>(acc, reinterpret_cast<const f32x16 (&)[4]>(in[4]), wa, wb, rsrc, wl128p, wr + 16u * WSTEP128, WSTEP128,
                            nx128p, w_after);
@@ -630,7 +625,7 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
     relu_rebias<4, 0>(acc, in, biasw, lane);
     WV_DBG(7, in, 4);
     float rgb[3];
-    head3(in, hr, net + L.b_rgb2, lane, rgb);
+    head3(in, biasw + (WV_HEAD_SLOT + 1) * 256, net + L.b_rgb2, lane, rgb);
     WP(WP_S_HEAD);
     return make_float4(rgb[0], rgb[1], rgb[2], sigma);
 }
@@ -663,12 +658,16 @@ __device__ __forceinline__ void motion_wave(const float* net, float* encw, float
     read_enc_blocks<3, 11>(encw, lane, me);
     wave_lds_sync();
     stage_bias_store<4>(bst, biasw, lane);
+    BiasStage<2> hst;  // the flow head's 3 x 128 weights -> slots 4, 5, in flight behind motion_net.0
+    {
+        const uint32_t ho[2] = {(uint32_t)L.w_out * 4u, (uint32_t)L.w_out * 4u + 1024u};  // (32 lanes, then the blob ends)
+        stage_bias_issue<2>(hst, rsrc, lane, ho, 32);
+    }
     WV_DBG(199, me, 3);
     WP(WP_M_ENC);
     // motion_net.0: 11 K steps (22 quads) = 5 step pairs + a half pair (every layer here runs in step pairs)
     segment_p<3, 11, 0, 8>(acc, me, wa, wb, rsrc, wl128p, (uint32_t)L.w[0] * 4u, WSTEP128, nx128p, (uint32_t)L.w[1] * 4u);
-    Head3W hf;  // the flow head's weights: fetched here, used behind the four hidden layers
-    load_head3(hf, rsrc, blane, (uint32_t)L.w_out * 4u);
+    stage_bias_store<2>(hst, biasw + 4 * 256, lane);
 #pragma unroll 1
     for (int li = 1; li <= 4; ++li) {
         relu_rebias<4, 4>(acc, in, biasw + (li - 1) * 256, lane);  // the previous layer's ReLU, this layer's bias
@@ -684,7 +683,7 @@ __device__ __forceinline__ void motion_wave(const float* net, float* encw, float
     WV_DBG(204, in, 4);
     WP(WP_M_LAYERS);
     float fl[3];
-    head3(in, hf, net + L.b_out, lane, fl);
+    head3(in, biasw + 4 * 256, net + L.b_out, lane, fl);
 #pragma unroll
     for (int c3 = 0; c3 < 3; ++c3) p[c3] = p[c3] + fl[c3];
     WP(WP_M_HEAD);
