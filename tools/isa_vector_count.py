@@ -5,7 +5,8 @@ With one wave per SIMD a vector instruction costs the f32 MFMA stream 5 - 6 cycl
 (tools/micro/mfma_two_waves.hip), so the count of vector instructions per item IS the kernel's non-MFMA time; this
 script is how changes are judged before they go to the GPU (no GPU needed: hipcc -S).
 
-    python tools/isa_vector_count.py [extra hipcc flags, e.g. -DSTNERF_WAVE_PROF] [--deep] [--asm file.s]
+    python tools/isa_vector_count.py [extra hipcc flags] [--deep] [--asm file.s]
+    python tools/isa_vector_count.py --phases     (profiler build: counts between its clock reads = per phase of an item)
 
 Regions: item loop head .. MotionNet layer loop | its body | MotionNet tail, SpaceNet encoding, stage1.0 | SpaceNet layer
 loop body (x 6 per item, includes the skip segment's copy) | sigma, rgb_net.1, colour head, store.  `vec` = VALU +
@@ -51,6 +52,9 @@ def classify(line):
 def main():
     args = sys.argv[1:]
     deep = "--deep" in args
+    phases = "--phases" in args
+    if phases:
+        args = [a for a in args if a != "--phases"] + ["-DSTNERF_WAVE_PROF"]
     asm = None
     if "--asm" in args:
         asm = args[args.index("--asm") + 1]
@@ -70,6 +74,16 @@ def main():
         if re.search(r"; (NumVgprs|NumAgprs|ScratchSize|Occupancy)", l):
             print(l.strip("; "))
     item = next(i for i, l in enumerate(body) if "This Loop Header: Depth=1" in l)
+    if phases:
+        # straight-line listing order of the item loop: a phase = the code between two clock reads (loop bodies counted once)
+        marks = [i for i in range(item, len(body)) if re.match(r"\s*s_memtime", body[i])]
+        prev = item
+        for n, m in enumerate(marks + [len(body)]):
+            c = collections.Counter(k for k in map(classify, body[prev:m]) if k)
+            print(f"segment {n:2d} (lines {prev:5d}..{m:5d})  vec {c['VALU'] + c['acc_rw']:5d}   " +
+                  "  ".join(f"{k} {c[k]}" for k in ("VALU", "acc_rw", "MFMA", "DS", "VMEM", "SALU", "wait", "nop")))
+            prev = m
+        return
     inner = [i for i, l in enumerate(body) if "Parent Loop" in l]
     if len(inner) < 2:
         raise SystemExit("expected two inner loops (MotionNet layers, SpaceNet layers)")
