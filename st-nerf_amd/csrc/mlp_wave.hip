@@ -481,9 +481,7 @@ __device__ __forceinline__ float pair_sum(float ca, float cb) {
 // the quads 16 pp + u + 4 m, m = 0..3, four fmas each; S_pp = (c0 + c1) + (c2 + c3); sigma = (((b + S_0) + S_1) + S_2) + S_3.
 // This lane holds the quads 2 s + h: its chains are u = h (s = 8 pp + 2 m) and u = h + 2 (s = 8 pp + 2 m + 1).
 // The head is written in two halves (parts 0, 1 over the feature blocks 0..3, parts 2, 3 over blocks 4..7).
-// The head weights are copied into the wave's LDS window together with the bias vectors (stage_bias_*) and read back
-// with ds_read_b128 right where they are used: fetched from the blob at that point they cost an exposed L2 round trip
-// per head (a single wave per SIMD has nothing else to do), fetched early they hold 64 .. 192 registers across a layer.
+// sigma_in = the bias (half 0) or the result of half 0 (half 1)
 template <int HALF>
 __device__ __forceinline__ float head_sigma(const f32x16 (&in)[8], const float* wlds /* the 256 weights */, float sigma_in, int lane) {
     const float4* w4 = reinterpret_cast<const float4*>(wlds) + (lane >> 5);  // quad 2 s + h
