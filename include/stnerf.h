@@ -196,20 +196,35 @@ int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32
                          const float* times, int64_t times_ray_stride, float* flow,
                          int64_t flow_ray_stride, int add_to_xyz, stnerf_stream_t stream);
 
+/* "bf16x3": the packed form of a network for the split-bf16 arithmetic of stnerf_mlp_stage (STNERF_STAGE_BF16X3;
+ * csrc/mlp_bf16x3.hip).  modeling/spacenet.py:45-86, modeling/motion_net.py:20-32 are plain fp32 nn.Linear layers: every
+ * weight (host side, here) and every activation (in the kernel) is split into three bf16 numbers, x = x0 + x1 + x2 --
+ * 8 + 8 + 8 significand bits, i.e. EXACT, with fp32's exponent range: no |W| limit, no activation limit, no overflow
+ * flag -- and a product is evaluated with its six leading cross terms on the bf16 MFMA (dropped terms <= 2^-24 |a b|),
+ * fp32 accumulate.  Same tensors as stnerf_pack_net; the blob = [the exact-f32 blob of stnerf_pack_net | bias vectors and
+ * head weights in the kernel's LDS order | the MFMA layers' weights as bf16 triples in consumption order].  All net
+ * kinds.  The device copy must be 1 KB aligned. */
+int64_t stnerf_packed_bytes_bf16x3(int kind);
+int stnerf_pack_net_bf16x3(int kind, const float* const* weights_host, const float* const* biases_host,
+                           int n_tensors, void* dst_host, int64_t dst_bytes);
+
 /* a8 + a9 for a whole network stage of the pipeline (coarse or fine, modeling/layered_rfrender.py:340-418 / :495-576):
  * ONE persistent launch evaluates every listed layer -- one workgroup per CU pops work items (128 rows of a layer; the
  * MotionNet of a deformed layer runs in front of its SpaceNet on the same rows, the flow stays on chip) from a device-side
- * queue.  Two organisations of the tile arithmetic, selected by the environment variable STNERF_STAGE_KERNEL (read on
- * every call): "wave" (default; csrc/mlp_wave.hip: a wave owns 32 samples, the activations never leave its registers)
- * and "lds" (csrc/mlp_stage.hip: feature-split waves, activations in LDS).  Either way the results are bit-identical to
- * stnerf_motionnet_fwd(ADD_TO_XYZ) followed by stnerf_spacenet_fwd per layer, except that the deformed points are NOT
- * written back to xyz.  Exact-f32 arithmetic only.  `queue`: one zeroed uint32 on the device.  `ray_bias`: workspace of
- * n_layers x n_rays x 128 floats (16-byte aligned) for the per-ray part of rgb_net.1 (stnerf_rgb_ray_bias).
+ * queue (csrc/stage_entry.hip).  A wave owns 32 samples and the activations never leave its registers.  Two arithmetics:
+ * exact f32 (csrc/mlp_wave.hip, the default; results bit-identical to stnerf_motionnet_fwd(ADD_TO_XYZ) followed by
+ * stnerf_spacenet_fwd per layer, except that the deformed points are NOT written back to xyz) and, with
+ * STNERF_STAGE_BF16X3, split-bf16 (csrc/mlp_bf16x3.hip: every fp32 operand as three bf16 pieces, six bf16 MFMAs per
+ * product, two fp32 accumulators -- fp32's exponent range, no range limits, closer to an fp64 evaluation than an fp32
+ * fma chain is; every net must then be a blob of stnerf_pack_net_bf16x3, 1 KB aligned).  `queue`: one zeroed uint32 on
+ * the device.  `ray_bias`: workspace of n_layers x n_rays x 128 floats (16-byte aligned) for the per-ray part of
+ * rgb_net.1 (stnerf_rgb_ray_bias).
  * flags: STNERF_STAGE_DEEP_RGB = the SpaceNets are of a *_DEEP kind; STNERF_STAGE_SIGMOID_RGB = store sigmoid(rgb)
  * instead of the raw colour head output (torch.sigmoid of layers/render_layer.py:47 moved into the network epilogue,
- * where it is free; pair it with stnerf_composite_params.rgb_activated = 1). */
+ * where it is free; pair it with stnerf_composite_params.rgb_activated = 1); STNERF_STAGE_BF16X3 as above. */
 #define STNERF_STAGE_DEEP_RGB 1
 #define STNERF_STAGE_SIGMOID_RGB 2
+#define STNERF_STAGE_BF16X3 4
 typedef struct stnerf_stage_layer {
     const void* space;         /* packed SpaceNet (kind given by use_time and the deep_rgb argument)                 */
     const void* motion;        /* packed MotionNet evaluated first on the same rows (xyz + flow), or NULL            */
@@ -308,7 +323,8 @@ typedef struct stnerf_render_params {
     int32_t only_coarse;
     int32_t use_deform_time, use_space_time;
     int32_t precision;            /* 0: exact f32 MFMA, one persistent stnerf_mlp_stage launch per stage; 1: fp16x3 (one launch
-                                     per network); 2: exact f32, one launch per network (round-1 scheduling, for A/B runs)  */
+                                     per network); 2: exact f32, one launch per network (round-1 scheduling, for A/B runs);
+                                     3: bf16x3 (split-bf16, stnerf_mlp_stage with STNERF_STAGE_BF16X3; nets packed by stnerf_pack_net_bf16x3) */
     int32_t has_edits;            /* edits_* / pivot are meaningful                                          */
     int32_t bkgd_use_deform_time; /* BKGD_USE_DEFORM_TIME: nets.motion[0] warps the background samples (:358-367) */
     int32_t bkgd_use_space_time;  /* BKGD_USE_SPACE_TIME: background SpaceNets take the frame id (needs use_space_time, :382-390) */

@@ -23,10 +23,11 @@ SOURCES = [
     ("render.hip", ["-ffp-contract=off"]),
     ("mlp.hip", []),
     ("mlp_raybias.hip", []),
-    ("mlp_stage.hip", []),
     # (no -mllvm -amdgpu-mfma-vgpr-form=1 here: it saves the v_accvgpr_read of every ReLU (+0.3 %), but with it two of
     # three instrumented variants of this file computed wrong, run-to-run varying results on the MI355X -- hipcc 7.2)
     ("mlp_wave.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"] if os.environ.get("STNERF_WAVE_VGPR_FORM") else []),
+    ("mlp_bf16x3.hip", []),
+    ("stage_entry.hip", []),
     ("mlp_f16x3.hip", []),
     ("pipeline.hip", []),
 ]

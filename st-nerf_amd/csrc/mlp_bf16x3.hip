@@ -1,0 +1,845 @@
+// Persistent stage kernel, split-bf16 arithmetic ("bf16x3"): fp32-faithful matrix products on the bf16 MFMA pipe.
+//
+// gfx950 has no tf32/xf32 MFMA and its f32 MFMA runs at the f32 vector rate (157 TF/s), 1/16 of the bf16 rate.  Here every
+// fp32 operand is split into THREE bf16 pieces, x = x0 + x1 + x2 (8 + 8 + 8 significand bits: the split is exact and keeps
+// fp32's exponent range -- no scaling, no range limit), and a product a*b is evaluated with its six leading cross terms
+//     a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0)            (dropped: a1 b2, a2 b1, a2 b2 <= 2^-24 |a b|)
+// on v_mfma_f32_32x32x16_bf16 (bf16 products are exact in fp32; f32 accumulate).  The a0 b0 terms go to one accumulator,
+// the five small terms (<= 2^-8 of it) to a second one: the hardware rounds the running sum after every 8 products, and
+// with one accumulator the 96 MFMAs of a 256-deep layer put 192 roundings at the scale of the full sum -- measured
+// 1.09 x the error of an fp32 fma chain (tools/micro/bf16x3_proto.hip); split, the large accumulator sees 32 of them and
+// the small one's are 2^-8 smaller: ~0.45 x the fp32 chain's error.
+//
+// Organisation = csrc/mlp_wave.hip's: a wave owns 32 samples and all features, the accumulator layout of a layer is the
+// B-operand layout of the next one (K step t of 16 = registers 8 (t & 1) .. + 7 of block t >> 1, both lane halves), so the
+// activations never leave the register file: a layer boundary is { big + small, ReLU, split into three bf16 planes }.
+// What differs:
+//   * 256-wide layers run as two PASSES of 128 output features (4 blocks x {big, small} = 128 accumulator registers);
+//     the first pass's outputs are parked in AGPRs until the second pass has consumed the layer's input.
+//   * Weights: 6 B per value and 2.7 x the f32 kernel's MFMA rate -- four waves streaming the blob through the vector L1
+//     would need ~60 B/clk/CU (measured ceiling 53).  They are fetched ONCE per CU by LDS-DMA (global_load_lds_dwordx4,
+//     no registers involved) into a ring of four 24 KB slots in consumption order and read by every wave with
+//     ds_read_b128 straight into AGPRs (1 KB contiguous per instruction: conflict-free), one read behind each of the
+//     first MFMAs of a unit; one raw s_barrier per slot (= 48 MFMAs) orders "slot landed" and "slot free" at once.
+//   * Bias vectors and head weights: one copy per workgroup in LDS (LDS-DMA at the start of a work item).
+//   * PE, bias, ReLU, heads, outputs: fp32, as in the exact-f32 kernels; rgb_net.1's direction / time columns come per
+//     ray from mlp_raybias.hip (exact f32) as the layer's C operand.
+//
+// Reference: modeling/spacenet.py:16-160, modeling/motion_net.py:7-71, modeling/layered_rfrender.py:340-418,495-576.
+#include <stdlib.h>
+#include <string.h>
+
+#include "mlp_wave_common.h"
+#include "mlp_bf16x3.h"
+
+namespace stnerf {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr int BX_LDS_RING = BX_RING * BX_SLOT;
+constexpr int BX_LDS_ENC = WV_NW * WV_ENC_FLOATS * 4;
+constexpr int BX_LDS_CONST = (BX_CONST_SPACE + BX_CONST_MOTION) * 4;
+constexpr int BX_LDS = BX_LDS_RING + BX_LDS_ENC + BX_LDS_CONST + 16 + STNERF_MAX_LAYERS * 8;
+static_assert(BX_LDS <= 160 * 1024, "bf16x3 stage kernel: LDS budget");
+
+#define BX_SB() __builtin_amdgcn_sched_barrier(0)
+// s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt = [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8])
+#define BX_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 0xf) | (((n) >> 4) << 14) | 0x0f70)
+
+// ---------------------------------------------------------------------------------------------
+// fp32 -> three bf16 pieces (round to nearest even at every step: x = p0 + p1 + p2 exactly)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    f32x2_ v = {a, b};
+    bf16x2 h = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32
+    return *reinterpret_cast<unsigned*>(&h);
+}
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    u32x4 w0, w1, w2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = v[2 * i], x1 = v[2 * i + 1];
+        const unsigned u = pk_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(u << 16), r1 = x1 - __uint_as_float(u & 0xffff0000u);
+        const unsigned m = pk_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+        w0[i] = u;
+        w1[i] = m;
+        w2[i] = pk_bf16(s0, s1);
+    }
+    p0 = *reinterpret_cast<bf16x8*>(&w0);
+    p1 = *reinterpret_cast<bf16x8*>(&w1);
+    p2 = *reinterpret_cast<bf16x8*>(&w2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The weight stream: which global slot the workgroup fetches next (wave-uniform), the ring, the A-operand buffers.
+// ---------------------------------------------------------------------------------------------
+struct Seg {
+    const char* p;
+    uint32_t left;  // slots
+};
+struct ABuf {
+    bf16x8 p[3];  // the three pieces of one unit's A operand (AGPRs)
+};
+struct Ctx {
+    Seg seg[4];         // this work item's networks (deformation net, SpaceNet), then the next item's
+    const char* idle;   // a valid source when nothing is left to fetch
+    uint32_t gi;        // slots issued so far
+    uint32_t lds_lane;  // LDS byte address of the ring + lane * 16
+    uint32_t rcur, rnext;  // this lane's LDS byte address inside the slot being consumed / the next one
+    uint32_t gc;        // slots consumed so far
+    char* ring;
+    int wave, lane;
+    ABuf A[2];
+};
+
+__device__ __forceinline__ const char* feed_next(Ctx& cx) {
+    const char* p = cx.idle;
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool take = !done && cx.seg[i].left != 0;
+        p = take ? cx.seg[i].p : p;
+        cx.seg[i].p += take ? BX_SLOT : 0;
+        cx.seg[i].left -= take ? 1u : 0u;
+        done = done || take;
+    }
+    return p;
+}
+
+// this wave's quarter (6 x 1 KB) of the next slot of the stream on its way into ring slot gi & 3
+__device__ __forceinline__ void dma_issue(Ctx& cx) {
+    const char* s = feed_next(cx) + cx.wave * (6 * BX_CHUNK) + cx.lane * 16;
+    auto d = (__attribute__((address_space(3))) char*)(cx.ring) + (cx.gi & (BX_RING - 1)) * BX_SLOT + cx.wave * (6 * BX_CHUNK);
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+        __builtin_amdgcn_global_load_lds(s + c * BX_CHUNK, (__attribute__((address_space(3))) void*)(d + c * BX_CHUNK), 16, 0, 0);
+    cx.gi += 1;
+}
+
+// A operands: ds_read_b128 straight into AGPRs, as asm -- the compiler does not count these reads; a_wait() is their
+// s_waitcnt and names every destination, so no consumer can be scheduled above it.  `keep` = reads of LATER units that may
+// stay outstanding (LDS returns in order; anything else in flight only makes the wait more conservative).
+template <int OFF>
+__device__ __forceinline__ void a_read(bf16x8& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst) : "v"(addr), "i"(OFF) : "memory");
+}
+template <int KEEP>
+__device__ __forceinline__ void a_wait(ABuf& A) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+a"(A.p[0]), "+a"(A.p[1]), "+a"(A.p[2]) : "i"(KEEP));
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// One unit = the six MFMAs of (K step, feature block): five into `small` (the first of a pass starts it from 0), a0 b0
+// into `big`.  U = position in the slot (K step U >> 2, block U & 3); the reads of unit U + 2 go out behind the first three
+// MFMAs (the buffer they fill was consumed by unit U - 2).
+template <int U, bool FIRST, bool BIG0 = false>
+__device__ __forceinline__ void unit(Ctx& cx, f32x16& big, f32x16& small, const bf16x8& b0, const bf16x8& b1, const bf16x8& b2) {
+    ABuf& cur = cx.A[U & 1];
+    ABuf& nx = cx.A[(U + 1) & 1];
+    constexpr int OFF = ((U + 1) & 7) * BX_UNIT;
+    const uint32_t ra = (U + 1) < 8 ? cx.rcur : cx.rnext;
+    a_wait<0>(cur);
+    BX_SB();
+    if (FIRST) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        small = mfma_bf16(cur.p[2], b0, z);
+    } else {
+        small = mfma_bf16(cur.p[2], b0, small);
+    }
+    BX_SB();
+    a_read<OFF>(nx.p[0], ra);
+    a_read<OFF + BX_CHUNK>(nx.p[1], ra);
+    a_read<OFF + 2 * BX_CHUNK>(nx.p[2], ra);
+    BX_SB();
+    small = mfma_bf16(cur.p[0], b2, small);
+    small = mfma_bf16(cur.p[1], b1, small);
+    small = mfma_bf16(cur.p[1], b0, small);
+    small = mfma_bf16(cur.p[0], b1, small);
+    if (FIRST && BIG0) {  // (rgb_net.1: its C operand is added behind the K loop, see space_bx)
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        big = mfma_bf16(cur.p[0], b0, z);
+    } else {
+        big = mfma_bf16(cur.p[0], b0, big);
+    }
+    BX_SB();
+}
+
+// Between units 5 and 6 of a slot: the next slot has landed everywhere and the previous one is free everywhere (every wave
+// has issued -- and, to get here, completed -- its reads of it); the fetch three slots ahead goes into its place.
+__device__ __forceinline__ void slot_turn(Ctx& cx) {
+    BX_VMCNT(6);
+    __builtin_amdgcn_s_barrier();
+    dma_issue(cx);
+    BX_SB();
+}
+__device__ __forceinline__ void slot_done(Ctx& cx) {
+    cx.gc += 1;
+    cx.rcur = cx.rnext;
+    cx.rnext = cx.lds_lane + ((cx.gc + 1) & (BX_RING - 1)) * BX_SLOT;
+}
+
+// one ring slot: K steps k0, k1 (their B operands: the three planes of the input) for the pass's four blocks
+template <bool FIRST, bool BIG0 = false>
+__device__ __forceinline__ void slot(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], const bf16x8& k0p0, const bf16x8& k0p1,
+                                     const bf16x8& k0p2, const bf16x8& k1p0, const bf16x8& k1p1, const bf16x8& k1p2) {
+    unit<0, FIRST, BIG0>(cx, big[0], small[0], k0p0, k0p1, k0p2);
+    unit<1, FIRST, BIG0>(cx, big[1], small[1], k0p0, k0p1, k0p2);
+    unit<2, FIRST, BIG0>(cx, big[2], small[2], k0p0, k0p1, k0p2);
+    unit<3, FIRST, BIG0>(cx, big[3], small[3], k0p0, k0p1, k0p2);
+    unit<4, false>(cx, big[0], small[0], k1p0, k1p1, k1p2);
+    unit<5, false>(cx, big[1], small[1], k1p0, k1p1, k1p2);
+    unit<6, false>(cx, big[2], small[2], k1p0, k1p1, k1p2);
+    slot_turn(cx);
+    unit<7, false>(cx, big[3], small[3], k1p0, k1p1, k1p2);
+    slot_done(cx);
+}
+
+// K steps KS0 .. KS0 + 2 NSLOT - 1 of the activation planes
+template <int KS0, int NSLOT, bool FIRST, bool BIG0 = false>
+__device__ __forceinline__ void pass_act(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], const bf16x8 (&act)[3][16]) {
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+        const int k = KS0 + 2 * sl;
+        if (sl == 0)
+            slot<FIRST, BIG0>(cx, big, small, act[0][k], act[1][k], act[2][k], act[0][k + 1], act[1][k + 1], act[2][k + 1]);
+        else
+            slot<false>(cx, big, small, act[0][k], act[1][k], act[2][k], act[0][k + 1], act[1][k + 1], act[2][k + 1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Layer boundaries (vector ALU).  Register 4 q + r of block fb <-> feature 32 fb + 8 q + 4 h + r of the pass.
+// ---------------------------------------------------------------------------------------------
+// big = this lane's 64 values of a 128-float vector in LDS (the next pass's bias = the C operand of its a0 b0 chain)
+__device__ __forceinline__ void load_c(f32x16 (&big)[4], const float* v128, int lane) {
+    const float4* b4 = reinterpret_cast<const float4*>(v128) + (lane >> 5);
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = b4[fb * 8 + 2 * q];
+            big[fb][4 * q + 0] = b.x;
+            big[fb][4 * q + 1] = b.y;
+            big[fb][4 * q + 2] = b.z;
+            big[fb][4 * q + 3] = b.w;
+            BX_SB();
+        }
+}
+__device__ __forceinline__ float out_relu(const f32x16& big, const f32x16& small, int i) { return relu_bits(big[i] + small[i]); }
+
+// the first pass's outputs wait in AGPRs while the second pass still reads the layer's input
+struct Park {
+    float v[64];
+};
+__device__ __forceinline__ void park_put(float& dst, float v) { asm("v_accvgpr_write_b32 %0, %1" : "=a"(dst) : "v"(v)); }
+__device__ __forceinline__ float park_get(const float& src) {
+    float v;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(src));
+    return v;
+}
+
+// The heads (density_net.0: 256 -> 1; the 128 -> 3 colour / flow layers) accumulate in FP64 on the vector ALU: 128 + 192
+// v_fma_f64 per lane and work item are nothing next to 4.3 k MFMAs, and they take the heads out of the error budget -- with
+// the split accumulators the backbone's h is ~2.3 x closer to fp64 than an fp32 fma chain's, and a 256-term fp32 dot
+// product on top of it (however it is grouped) was most of the error left in sigma.
+__device__ __forceinline__ double pair_sum_d(double x) {  // x + the other lane's (lane ^ 32) x, in every lane
+    return x + __shfl_xor(x, 32, 64);
+}
+struct SigAcc {
+    double c[4];
+};
+__device__ __forceinline__ void sig_take(SigAcc& sg, const float (&v)[8], const float* w, int lane, int feat0 /* of v[0], h = 0 */) {
+    const float4* w4 = reinterpret_cast<const float4*>(w + feat0) + (lane >> 5);
+    const float4 wa = w4[0], wb = w4[2];
+    sg.c[0] = fma((double)v[0], (double)wa.x, sg.c[0]);
+    sg.c[1] = fma((double)v[1], (double)wa.y, sg.c[1]);
+    sg.c[2] = fma((double)v[2], (double)wa.z, sg.c[2]);
+    sg.c[3] = fma((double)v[3], (double)wa.w, sg.c[3]);
+    sg.c[0] = fma((double)v[4], (double)wb.x, sg.c[0]);
+    sg.c[1] = fma((double)v[5], (double)wb.y, sg.c[1]);
+    sg.c[2] = fma((double)v[6], (double)wb.z, sg.c[2]);
+    sg.c[3] = fma((double)v[7], (double)wb.w, sg.c[3]);
+}
+
+// pass A of a 256-wide layer: relu(big + small) -> park
+__device__ __forceinline__ void finish_park(const f32x16 (&big)[4], const f32x16 (&small)[4], Park& pk) {
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) park_put(pk.v[16 * fb + 8 * t + j], out_relu(big[fb], small[fb], 8 * t + j));
+            BX_SB();  // (group by group: keeps the live values of this straight-line code bounded)
+        }
+}
+// the pass's outputs -> K steps KS0 .. KS0 + 7 of the activation planes
+template <int KS0>
+__device__ __forceinline__ void finish_act(const f32x16 (&big)[4], const f32x16 (&small)[4], bf16x8 (&act)[3][16]) {
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = out_relu(big[fb], small[fb], 8 * t + j);
+            split8(v, act[0][KS0 + 2 * fb + t], act[1][KS0 + 2 * fb + t], act[2][KS0 + 2 * fb + t]);
+            BX_SB();
+        }
+}
+// sigma head (density_net.0, 256 -> 1) on the last backbone layer's outputs, before they are converted: features 0..127 wait
+// in the park, 128..255 in the accumulators.  (A pass of its own over the values -- 2 x 128 reads once per work item --
+// rather than a flavour of finish_act: the layer loop's body must define the activation planes on ONE path; with two
+// the planes' 192 registers meet in phi nodes the register coalescer cannot resolve, and half of them get copied.)
+__device__ __forceinline__ float sigma_head(const f32x16 (&big)[4], const f32x16 (&small)[4], const Park& pk, const float* wsig, float bias,
+                                            int lane) {
+    SigAcc sg;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sg.c[i] = 0.0;
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = park_get(pk.v[16 * fb + 8 * t + j]);
+            sig_take(sg, v, wsig, lane, 32 * fb + 16 * t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = out_relu(big[fb], small[fb], 8 * t + j);
+            sig_take(sg, v, wsig, lane, 128 + 32 * fb + 16 * t);
+            BX_SB();
+        }
+    return (float)((double)bias + pair_sum_d((sg.c[0] + sg.c[1]) + (sg.c[2] + sg.c[3])));
+}
+__device__ __forceinline__ void unpark_act(const Park& pk, bf16x8 (&act)[3][16]) {
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = park_get(pk.v[16 * fb + 8 * t + j]);
+            split8(v, act[0][2 * fb + t], act[1][2 * fb + t], act[2][2 * fb + t]);
+            BX_SB();
+        }
+}
+
+// 128 -> 3 head (rgb_net's last layer, MotionNet's flow) on relu(big + small): w = [3][128] in LDS; fp64 accumulation, two
+// chains per output and lane
+__device__ __forceinline__ void head3(const f32x16 (&big)[4], const f32x16 (&small)[4], const float* w, const float* __restrict__ b3,
+                                      int lane, float (&out)[3]) {
+    const float4* w4 = reinterpret_cast<const float4*>(w) + (lane >> 5);
+    double c[3][2];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) c[o][0] = c[o][1] = 0.0;
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (double)out_relu(big[fb], small[fb], 4 * q + r);
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float4 wv = w4[o * 32 + fb * 8 + 2 * q];
+                double& cc = c[o][q & 1];
+                cc = fma(v[0], (double)wv.x, cc);
+                cc = fma(v[1], (double)wv.y, cc);
+                cc = fma(v[2], (double)wv.z, cc);
+                cc = fma(v[3], (double)wv.w, cc);
+            }
+            BX_SB();
+        }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) out[o] = (float)((double)b3[o] + pair_sum_d(c[o][0] + c[o][1]));
+}
+
+// K steps 0 .. STEPS - 1 of the activation planes from the wave's staged encoding (feature 16 t + 8 h + j; NQ quads staged)
+template <int STEPS, int NQ>
+__device__ __forceinline__ void enc_to_act(const float* encw, int lane, bf16x8 (&act)[3][16]) {
+    const float4* e4 = reinterpret_cast<const float4*>(encw);
+    const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) {
+        float v[8];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * t + 2 + qq < NQ) {  // (static) both lane halves inside the staged quads
+                x = e4[(4 * t + 2 * h + qq) * WV_ROWS + c];
+            } else if (4 * t + qq < NQ) {  // only the lower half
+                const float4 y = e4[(4 * t + qq) * WV_ROWS + c];
+                x = h == 0 ? y : x;
+            }
+            v[4 * qq + 0] = x.x;
+            v[4 * qq + 1] = x.y;
+            v[4 * qq + 2] = x.z;
+            v[4 * qq + 3] = x.w;
+        }
+        split8(v, act[0][t], act[1][t], act[2][t]);
+        BX_SB();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MotionNet on the wave's 32 samples: p += flow (modeling/layered_rfrender.py:356,510).  19 slots.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void motion_bx(Ctx& cx, const float* net, const float* cm, float* encw, float (&p)[3], float tv, int flags,
+                                          f32x16 (&big)[4], f32x16 (&small)[4], bf16x8 (&act)[3][16]) {
+    const MotionLayout L = motion_layout();
+    const int lane = cx.lane;
+    encode_motion(encw, lane, p, tv, flags);
+    wave_lds_sync();
+    enc_to_act<6, WV_ENC_QUADS>(encw, lane, act);
+    load_c(big, cm + BXM_B, lane);
+    pass_act<0, 3, true>(cx, big, small, act);  // motion_net.0: 84 (+4) inputs, 6 K steps
+#pragma unroll 1
+    for (int li = 1; li <= 4; ++li) {
+        finish_act<0>(big, small, act);
+        load_c(big, cm + BXM_B + 128 * li, lane);
+        pass_act<0, 4, true>(cx, big, small, act);
+    }
+    float fl[3];
+    head3(big, small, cm + BXM_W_OUT, net + L.b_out, lane, fl);
+#pragma unroll
+    for (int c3 = 0; c3 < 3; ++c3) p[c3] = p[c3] + fl[c3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpaceNet on the wave's 32 samples; returns {r, g, b, sigma} (raw) in every lane.  `mid` is called once, in front of the
+// last backbone layer's boundary arithmetic (the caller issues the next work item's HBM loads there).
+// ---------------------------------------------------------------------------------------------
+template <bool DEEP, class Mid>
+__device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool use_time, const float* cs, float* encw, const float (&p)[3],
+                                           const float* __restrict__ raybias, int32_t ray, f32x16 (&big)[4], f32x16 (&small)[4],
+                                           bf16x8 (&act)[3][16], Mid mid) {
+    const SpaceLayout L = space_layout(use_time, DEEP);
+    const int lane = cx.lane;
+    const int h = lane >> 5;
+    Park pk;
+    encode_pos(encw, lane, p);
+    wave_lds_sync();
+    enc_to_act<4, 16>(encw, lane, act);
+    // ---- stage1.0: 63 (+1) -> 256
+    load_c(big, cs + BXC_B, lane);
+    pass_act<0, 2, true>(cx, big, small, act);
+    finish_park(big, small, pk);
+    load_c(big, cs + BXC_B + 128, lane);
+    pass_act<0, 2, true>(cx, big, small, act);
+    finish_act<8>(big, small, act);
+    unpark_act(pk, act);
+    // ---- stage1.2 .. stage2.4: six 256-wide layers, two passes each; stage2.0 (li == 4) takes PE(pos) again behind its 256
+    // features (modeling/spacenet.py:45-57,136-138): four more K steps per pass, their B operands split on the spot from the
+    // staged encoding (the activation planes are full)
+    auto pe_slots = [&]() {
+        const float4* e4 = reinterpret_cast<const float4*>(encw);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            bf16x8 pe[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float v[8];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const float4 x = e4[(4 * (2 * sl + t) + 2 * h + qq) * WV_ROWS + (lane & 31)];
+                    v[4 * qq + 0] = x.x;
+                    v[4 * qq + 1] = x.y;
+                    v[4 * qq + 2] = x.z;
+                    v[4 * qq + 3] = x.w;
+                }
+                split8(v, pe[t][0], pe[t][1], pe[t][2]);
+            }
+            slot<false>(cx, big, small, pe[0][0], pe[0][1], pe[0][2], pe[1][0], pe[1][1], pe[1][2]);
+        }
+    };
+    // (stage2.0 is peeled out of the layer loop: inside it, as a conditional block, its extra K steps redefine the
+    // accumulators on one of two paths and the register allocator answers with ~200 spills)
+    auto layer = [&](int li, auto with_pe) {
+        load_c(big, cs + BXC_B + 256 * li, lane);
+        pass_act<0, 8, true>(cx, big, small, act);
+        if constexpr (decltype(with_pe)::value) pe_slots();
+        finish_park(big, small, pk);
+        load_c(big, cs + BXC_B + 256 * li + 128, lane);
+        pass_act<0, 8, true>(cx, big, small, act);
+        if constexpr (decltype(with_pe)::value) pe_slots();
+    };
+    auto layer_end = [&]() {
+        finish_act<8>(big, small, act);
+        unpark_act(pk, act);
+    };
+#pragma unroll 1
+    for (int li = 1; li <= 3; ++li) {
+        layer(li, std::false_type{});
+        layer_end();
+    }
+    layer(4, std::true_type{});
+    layer_end();
+    float sigma = 0.f;
+#pragma unroll 1
+    for (int li = 5; li <= 6; ++li) {
+        layer(li, std::false_type{});
+        if (li == 6) {  // sigma = density_net(h) (:139), raw; the next work item's HBM loads go out in front of it
+            mid();
+            sigma = sigma_head(big, small, pk, cs + BXC_W_SIGMA, net[L.b_sigma], lane);
+        }
+        layer_end();
+    }
+    // ---- rgb_net: relu -> Linear(283|304, 128) -> relu -> Linear(128, 3) (:80-86); the 256 backbone columns here, the
+    // bias + direction / time columns = this sample's row of the ray-bias table (mlp_raybias.hip).  The exact-f32 kernels take
+    // that row as the C operand; here it is added BEHIND the K loop: it is an order of magnitude larger than the backbone
+    // part, and as the C operand it would put every rounding of the a0 b0 chain at its scale (measured: the colour output at
+    // 1.3 x the fp32 CPU chain's error instead of 0.5 x).  Its 16 loads go out in front of the pass's last slot (14 of the 16
+    // K steps' activation registers are dead by then).
+    pass_act<0, 7, true, true>(cx, big, small, act);
+    {
+        float4 crow[4][4];
+        const float* row = raybias + (int64_t)ray * 128 + 4 * h;
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) crow[fb][q] = *reinterpret_cast<const float4*>(row + fb * 32 + 8 * q);
+        pass_act<14, 1, false>(cx, big, small, act);
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                big[fb][4 * q + 0] = (big[fb][4 * q + 0] + small[fb][4 * q + 0]) + crow[fb][q].x;
+                big[fb][4 * q + 1] = (big[fb][4 * q + 1] + small[fb][4 * q + 1]) + crow[fb][q].y;
+                big[fb][4 * q + 2] = (big[fb][4 * q + 2] + small[fb][4 * q + 2]) + crow[fb][q].z;
+                big[fb][4 * q + 3] = (big[fb][4 * q + 3] + small[fb][4 * q + 3]) + crow[fb][q].w;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) small[fb][i] = 0.f;
+            BX_SB();
+        }
+    }
+    if constexpr (DEEP) {  // deep_rgb (:68-79): two more 128-wide hidden layers
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+            finish_act<0>(big, small, act);
+            load_c(big, cs + BXC_B_DEEP + 128 * i, lane);
+            pass_act<0, 4, true>(cx, big, small, act);
+        }
+    }
+    float rgb[3];
+    head3(big, small, cs + BXC_W_RGB2, net + L.b_rgb2, lane, rgb);
+    return make_float4(rgb[0], rgb[1], rgb[2], sigma);
+}
+
+template <bool DEEP>
+__global__ __launch_bounds__(WV_THREADS, 1) void mlp_bf16x3_stage_kernel(StageArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bx[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* ring = smem_bx;
+    float* encw = reinterpret_cast<float*>(smem_bx + BX_LDS_RING) + wave * WV_ENC_FLOATS;
+    float* cs = reinterpret_cast<float*>(smem_bx + BX_LDS_RING + BX_LDS_ENC);
+    float* cm = cs + BX_CONST_SPACE;
+    uint32_t* qslot = reinterpret_cast<uint32_t*>(smem_bx + BX_LDS_RING + BX_LDS_ENC + BX_LDS_CONST);
+    int64_t* lrows = reinterpret_cast<int64_t*>(qslot + 4);
+    // ---- the queue (as in mlp_wave.hip): items (128 rows) of layer slot j are [pre[j], pre[j+1])
+    uint32_t pre[STNERF_MAX_LAYERS + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int j = 0; j < STNERF_MAX_LAYERS; ++j) {
+        uint32_t items = 0;
+        if (j < a.n_layers) {
+            const int64_t rows = layer_rows(a.layer[j], a.n_rays, a.ns);
+            items = (uint32_t)((rows + WV_ITEM - 1) / WV_ITEM);
+            if (tid == 0) lrows[j] = rows;
+        }
+        pre[j + 1] = pre[j] + items;
+    }
+    const uint32_t total = pre[STNERF_MAX_LAYERS];
+    auto slot_of = [&](uint32_t item) {
+        int s = 0;
+#pragma unroll
+        for (int j = 1; j < STNERF_MAX_LAYERS; ++j) s += (item >= pre[j]) ? 1 : 0;
+        return s;
+    };
+    auto base_of = [&](uint32_t item) {
+        uint32_t b = 0;
+#pragma unroll
+        for (int j = 1; j < STNERF_MAX_LAYERS; ++j) b = (item >= pre[j]) ? pre[j] : b;
+        return b;
+    };
+    auto row_of = [&](uint32_t item, RowRef& rr) {
+        rr = RowRef{0, 0, false};
+        if (item >= total) return;
+        const int s = slot_of(item);
+        const int64_t rows = lrows[s];
+        const int64_t row = (int64_t)(item - base_of(item)) * WV_ITEM + wave * WV_ROWS + (lane & 31);
+        rr.valid = row < rows;
+        if (rr.valid) {
+            int64_t rslot;
+            if (rows <= 0x7fffffffll) {
+                const uint32_t q = (uint32_t)row / (uint32_t)a.ns;
+                rslot = q;
+                rr.k = (int)((uint32_t)row - q * (uint32_t)a.ns);
+            } else {
+                rslot = row / a.ns;
+                rr.k = (int)(row - rslot * a.ns);
+            }
+            const int32_t* rl = a.layer[s].ray_list;
+            rr.ray = rl ? (int64_t)rl[rslot] : rslot;
+        }
+    };
+    auto fetch = [&](uint32_t item, const RowRef& rr, WaveInputs& in) {
+        in.valid = rr.valid;
+        in.raw_off = 0;
+        in.ray = 0;
+        in.tv = 0.f;
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) in.p[c3] = 0.f;
+        if (rr.valid) {
+            const StageLayer& ly = a.layer[slot_of(item)];
+            const float* src = ly.xyz + rr.ray * a.xyz_ray_stride + 3 * rr.k;
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) in.p[c3] = src[c3];
+            if (ly.motion) in.tv = ly.times[rr.ray * a.times_ray_stride];
+            in.raw_off = rr.ray * a.raw_ray_stride + 4 * rr.k;
+            in.ray = (int32_t)rr.ray;
+        }
+    };
+    // the weight streams of an item's networks
+    const int64_t sp_kind_stream[2] = {bx_layout(DEEP ? STNERF_NET_SPACE_DEEP : STNERF_NET_SPACE).stream_off,
+                                       bx_layout(DEEP ? STNERF_NET_SPACE_TIME_DEEP : STNERF_NET_SPACE_TIME).stream_off};
+    const int64_t mo_stream = bx_layout(STNERF_NET_MOTION).stream_off;
+    auto segs_of = [&](uint32_t item, Seg& m, Seg& s) {
+        m = Seg{nullptr, 0u};
+        s = Seg{nullptr, 0u};
+        if (item >= total) return;
+        const StageLayer& ly = a.layer[slot_of(item)];
+        s.p = reinterpret_cast<const char*>(ly.space) + sp_kind_stream[ly.use_time ? 1 : 0];
+        s.left = (uint32_t)bx_space_slots(DEEP);
+        if (ly.motion) {
+            m.p = reinterpret_cast<const char*>(ly.motion) + mo_stream;
+            m.left = (uint32_t)bx_motion_slots();
+        }
+    };
+
+    // ---- prime the pipeline: two items popped, the first one's inputs loaded, three slots of its stream in flight
+    if (tid == 0) {
+        qslot[0] = atomicAdd(a.queue, 1u);
+        qslot[1] = atomicAdd(a.queue, 1u);
+    }
+    __syncthreads();
+    uint32_t it0 = __builtin_amdgcn_readfirstlane(qslot[0]);
+    uint32_t it1 = __builtin_amdgcn_readfirstlane(qslot[1]);
+    __syncthreads();
+    if (it0 >= total) return;  // (uniform)
+    WaveInputs cur, nxt;
+    {
+        RowRef rr;
+        row_of(it0, rr);
+        fetch(it0, rr, cur);
+    }
+    Ctx cx;
+    cx.ring = ring;
+    cx.wave = wave;
+    cx.lane = lane;
+    cx.gi = 0;
+    cx.gc = 0;
+    cx.lds_lane = (uint32_t)(uintptr_t)ring + (uint32_t)lane * 16u;
+    cx.rcur = cx.lds_lane;
+    cx.rnext = cx.lds_lane + BX_SLOT;
+    segs_of(it0, cx.seg[0], cx.seg[1]);
+    segs_of(it1, cx.seg[2], cx.seg[3]);
+    cx.idle = cx.seg[1].p;
+    dma_issue(cx);
+    dma_issue(cx);
+    dma_issue(cx);
+    BX_VMCNT(12);
+    __builtin_amdgcn_s_barrier();
+    a_read<0>(cx.A[0].p[0], cx.rcur);
+    a_read<BX_CHUNK>(cx.A[0].p[1], cx.rcur);
+    a_read<2 * BX_CHUNK>(cx.A[0].p[2], cx.rcur);
+    int par = 0;
+    f32x16 big[4], small[4];
+    bf16x8 act[3][16];
+    while (it0 < total) {
+        // the item after next (consumed at the end of this one) and the ray index of the next item's sample
+        uint32_t pending = 0;
+        if (tid == 0) pending = atomicAdd(a.queue, 1u);
+        RowRef rr_next;
+        row_of(it1, rr_next);
+        const StageLayer& ly = a.layer[slot_of(it0)];
+        // ---- this item's bias vectors / head weights: blob consts -> LDS (12 + 4 chunks of 1 KB over the four waves).  The
+        // previous item's last reads of the region are behind the barrier that ended it.
+        {
+            const char* sc = reinterpret_cast<const char*>(ly.space) + (sp_kind_stream[ly.use_time ? 1 : 0] - BX_CONST_SPACE * 4) + lane * 16;
+            auto d = (__attribute__((address_space(3))) char*)(cs);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                __builtin_amdgcn_global_load_lds(sc + (wave + 4 * i) * BX_CHUNK, (__attribute__((address_space(3))) void*)(d + (wave + 4 * i) * BX_CHUNK), 16, 0, 0);
+            if (ly.motion) {
+                const char* mc = reinterpret_cast<const char*>(ly.motion) + (mo_stream - BX_CONST_MOTION * 4) + lane * 16;
+                auto dm = (__attribute__((address_space(3))) char*)(cm);
+                __builtin_amdgcn_global_load_lds(mc + wave * BX_CHUNK, (__attribute__((address_space(3))) void*)(dm + wave * BX_CHUNK), 16, 0, 0);
+            }
+        }
+        float p[3];
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) p[c3] = cur.p[c3];
+        BX_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (ly.motion) motion_bx(cx, ly.motion, cm, encw, p, cur.tv, ly.motion_flags, big, small, act);
+        float4 o = space_bx<DEEP>(cx, ly.space, ly.use_time != 0, cs, encw, p, ly.raybias, cur.ray, big, small, act,
+                                  [&]() { fetch(it1, rr_next, nxt); });
+        if (cur.valid && lane < 32) {
+            if (a.sigmoid_rgb) {  // torch.sigmoid(rgb): 1-ulp v_exp_f32 / v_rcp_f32, the same expression the compositor uses
+                o.x = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(o.x * -1.44269504088896340736f));
+                o.y = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(o.y * -1.44269504088896340736f));
+                o.z = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(o.z * -1.44269504088896340736f));
+            }
+            *reinterpret_cast<float4*>(ly.raw + cur.raw_off) = o;
+        }
+        if (tid == 0) qslot[par] = pending;
+        __syncthreads();
+        const uint32_t it2 = __builtin_amdgcn_readfirstlane(qslot[par]);
+        par ^= 1;
+        it0 = it1;
+        it1 = it2;
+        cur = nxt;
+        // the stream: the next item's networks move up, the one after it joins
+        cx.seg[0] = cx.seg[2];
+        cx.seg[1] = cx.seg[3];
+        segs_of(it1, cx.seg[2], cx.seg[3]);
+    }
+    BX_VMCNT(0);  // (no LDS-DMA may outlive the workgroup)
+}
+
+int launch_bf16x3_stage(const StageArgs& a, bool deep_rgb, int cus, hipStream_t stream) {
+    const int64_t max_items = ((a.n_rays * a.ns + WV_ITEM - 1) / WV_ITEM) * a.n_layers;
+    const int grid = (int)(max_items < cus ? max_items : cus);  // one persistent workgroup per CU
+    const void* kfn = deep_rgb ? reinterpret_cast<const void*>(mlp_bf16x3_stage_kernel<true>)
+                               : reinterpret_cast<const void*>(mlp_bf16x3_stage_kernel<false>);
+    if (const int rc = reserve_dynamic_lds(kfn, BX_LDS, "mlp_stage (bf16x3)")) return rc;
+    if (deep_rgb)
+        hipLaunchKernelGGL(mlp_bf16x3_stage_kernel<true>, dim3(grid), dim3(WV_THREADS), BX_LDS, stream, a);
+    else
+        hipLaunchKernelGGL(mlp_bf16x3_stage_kernel<false>, dim3(grid), dim3(WV_THREADS), BX_LDS, stream, a);
+    STNERF_CHECK_LAUNCH("mlp_stage (bf16x3)");
+    return STNERF_OK;
+}
+
+}  // namespace stnerf
+
+// ---------------------------------------------------------------------------------------------
+// Host: the packer
+// ---------------------------------------------------------------------------------------------
+using namespace stnerf;
+
+namespace {
+inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);  // inf / nan: as is
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+inline float bf16_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+inline void split3(float w, uint16_t (&p)[3]) {
+    p[0] = bf16_rne(w);
+    const float r1 = w - bf16_f32(p[0]);
+    p[1] = bf16_rne(r1);
+    const float r2 = r1 - bf16_f32(p[1]);
+    p[2] = bf16_rne(r2);
+}
+
+// One pass = 128 output rows n0 .. n0 + 127 of W[out][in] (row-major, `in` columns), `ksteps` K steps; col(t, h, j) = input
+// column of B position (t, h, j) or -1 (zero).  Appends ksteps * 4 units of 3 KB at dst; returns the bytes written.
+template <class ColFn>
+int64_t emit_pass(uint16_t* dst, const float* W, int in, int n0, int ksteps, ColFn col) {
+    uint16_t* d = dst;
+    for (int t = 0; t < ksteps; ++t)
+        for (int fb = 0; fb < 4; ++fb) {
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int h = lane >> 5, c = lane & 31;
+                    const int k = col(t, h, j);
+                    uint16_t p[3] = {0, 0, 0};
+                    if (k >= 0) split3(W[(int64_t)(n0 + 32 * fb + c) * in + k], p);
+                    for (int pc = 0; pc < 3; ++pc) d[pc * (BX_CHUNK / 2) + lane * 8 + j] = p[pc];
+                }
+            d += BX_UNIT / 2;
+        }
+    return (int64_t)(d - dst) * 2;
+}
+}  // namespace
+
+extern "C" int64_t stnerf_packed_bytes_bf16x3(int kind) {
+    if (!STNERF_NET_IS_SPACE(kind) && kind != STNERF_NET_MOTION) {
+        set_error("packed_bytes_bf16x3: unknown net kind %d", kind);
+        return STNERF_EINVAL;
+    }
+    return bx_layout(kind).total_bytes;
+}
+
+extern "C" int stnerf_pack_net_bf16x3(int kind, const float* const* W, const float* const* B, int n_tensors, void* dst_host,
+                                      int64_t dst_bytes) {
+    STNERF_REQUIRE(W && B && dst_host, "pack_net_bf16x3: null pointer");
+    STNERF_REQUIRE(STNERF_NET_IS_SPACE(kind) || kind == STNERF_NET_MOTION, "pack_net_bf16x3: unknown net kind %d", kind);
+    const BxLayout X = bx_layout(kind);
+    STNERF_REQUIRE(dst_bytes >= X.total_bytes, "pack_net_bf16x3: dst too small (%lld < %lld)", (long long)dst_bytes, (long long)X.total_bytes);
+    memset(dst_host, 0, (size_t)X.total_bytes);
+    // ---- the f32 section = the exact-f32 blob (also validates the tensor count)
+    if (const int rc = stnerf_pack_net(kind, W, B, n_tensors, dst_host, X.f32_floats * 4)) return rc;
+    char* base = static_cast<char*>(dst_host);
+    float* cst = reinterpret_cast<float*>(base + X.consts_off);
+    uint16_t* st = reinterpret_cast<uint16_t*>(base + X.stream_off);
+    int64_t off = 0;  // bytes into the stream
+    auto hidden = [](int t, int h, int j) { return bx_kmap_hidden(t, h, j); };
+    if (STNERF_NET_IS_SPACE(kind)) {
+        const bool deep = STNERF_NET_IS_DEEP(kind);
+        const int nt = deep ? 12 : 10;
+        const int in_f[7] = {63, 256, 256, 256, 319, 256, 256};
+        for (int i = 0; i < 7; ++i) memcpy(cst + BXC_B + 256 * i, B[i], 256 * sizeof(float));
+        for (int i = 0; i < 2 && deep; ++i) memcpy(cst + BXC_B_DEEP + 128 * i, B[9 + i], 128 * sizeof(float));
+        memcpy(cst + BXC_W_SIGMA, W[7], 256 * sizeof(float));
+        memcpy(cst + BXC_W_RGB2, W[nt - 1], 3 * 128 * sizeof(float));
+        for (int i = 0; i < 7; ++i)
+            for (int half = 0; half < 2; ++half) {
+                if (i == 0) {
+                    off += emit_pass(st + off / 2, W[0], 63, 128 * half, 4, [](int t, int h, int j) {
+                        const int k = bx_kmap_enc(t, h, j);
+                        return k < 63 ? k : -1;
+                    });
+                } else if (i == 4) {  // stage2.0: the 256 features, then PE(pos)
+                    off += emit_pass(st + off / 2, W[4], 319, 128 * half, 20, [](int t, int h, int j) {
+                        if (t < 16) return bx_kmap_hidden(t, h, j);
+                        const int k = bx_kmap_enc(t - 16, h, j);
+                        return k < 63 ? 256 + k : -1;
+                    });
+                } else {
+                    off += emit_pass(st + off / 2, W[i], in_f[i], 128 * half, 16, hidden);
+                }
+            }
+        // rgb_net.1: the 256 backbone columns (direction / time columns: mlp_raybias.hip)
+        off += emit_pass(st + off / 2, W[8], 256 + 27 + (STNERF_NET_USES_TIME(kind) ? 21 : 0), 0, 16, hidden);
+        for (int i = 0; i < 2 && deep; ++i) off += emit_pass(st + off / 2, W[9 + i], 128, 0, 8, hidden);
+    } else {
+        for (int i = 0; i < 5; ++i) memcpy(cst + BXM_B + 128 * i, B[i], 128 * sizeof(float));
+        memcpy(cst + BXM_W_OUT, W[5], 3 * 128 * sizeof(float));
+        off += emit_pass(st + off / 2, W[0], 84, 0, 6, [](int t, int h, int j) {
+            const int k = bx_kmap_enc(t, h, j);
+            return k < 84 ? k : -1;
+        });
+        for (int i = 1; i < 5; ++i) off += emit_pass(st + off / 2, W[i], 128, 0, 8, hidden);
+    }
+    STNERF_REQUIRE(off == (int64_t)X.n_slots * BX_SLOT, "pack_net_bf16x3: internal: stream of %lld B, expected %lld", (long long)off,
+                   (long long)X.n_slots * BX_SLOT);
+    return STNERF_OK;
+}

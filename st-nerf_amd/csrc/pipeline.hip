@@ -68,7 +68,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
     const int l = p->l, n1 = p->n1, n2 = p->n2, S = n1 + n2, rs = p->ray_stride;
     STNERF_REQUIRE(n >= 0 && l >= 1 && l <= STNERF_MAX_LAYERS && n1 >= 3 && n2 >= 0, "render_rays: bad shape");
     STNERF_REQUIRE(rs >= (p->retiming ? 6 + l : 7), "render_rays: ray stride %d too small for the frame-id columns", rs);
-    STNERF_REQUIRE(p->precision >= 0 && p->precision <= 2, "render_rays: unknown precision %d", p->precision);
+    STNERF_REQUIRE(p->precision >= 0 && p->precision <= 3, "render_rays: unknown precision %d", p->precision);
     STNERF_REQUIRE(nets->bkgd && (p->only_coarse || nets->bkgd_fine), "render_rays: background network missing");
     STNERF_REQUIRE(!p->bkgd_use_deform_time || nets->motion[0], "render_rays: bkgd_time_deform_net missing");
     STNERF_REQUIRE(!p->bkgd_use_space_time || p->use_space_time,
@@ -115,9 +115,9 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
     // ---- one network stage: deform + evaluate every shown layer on its hit rays (:340-418 / :495-576)
     auto stage = [&](float* xyz, float* raw, int ns, bool fine) -> int {
         const int64_t xs = (int64_t)l * ns * 3, ws_ = (int64_t)l * ns * 4;
-        if (p->precision == 0) {
-            // exact f32: ONE persistent launch over every shown layer (csrc/mlp_stage.hip); deformed performers first
-            // (256-row items), the background last (128-row items: the finest grain drains the queue)
+        if (p->precision == 0 || p->precision == 3) {
+            // exact f32 / bf16x3: ONE persistent launch over every shown layer (csrc/stage_entry.hip); deformed performers
+            // first, the background last
             stnerf_stage_layer sl[STNERF_MAX_LAYERS];
             int ns_l = 0;
             for (int pass = 0; pass < 2; ++pass) {
@@ -140,7 +140,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
             }
             set_launch_tag(fine ? 1 : 0);
             const int r2 = stnerf_mlp_stage(sl, ns_l, n, ns, rays + 3, rs, rs, xs, ws_,
-                                            (p->deep_rgb ? STNERF_STAGE_DEEP_RGB : 0) | STNERF_STAGE_SIGMOID_RGB,
+                                            (p->deep_rgb ? STNERF_STAGE_DEEP_RGB : 0) | STNERF_STAGE_SIGMOID_RGB | (p->precision == 3 ? STNERF_STAGE_BF16X3 : 0),
                                             reinterpret_cast<uint32_t*>(ray_count + STNERF_MAX_LAYERS + (fine ? 1 : 0)), ray_bias, stream);
             set_launch_tag(-1);
             return r2;
@@ -192,7 +192,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
     cp.near = p->near;
     cp.fine = 0;
     cp.cut_negative_t = 1;
-    cp.rgb_activated = p->precision == 0;  // the persistent stage kernel stores sigmoid(rgb)
+    cp.rgb_activated = p->precision == 0 || p->precision == 3;  // the persistent stage kernels store sigmoid(rgb)
     for (int i = 0; i < STNERF_MAX_LAYERS; ++i) {
         cp.sigma_scale[i] = 1.f;
         cp.evaluated[i] = i < l ? (i == 0 ? 2 : p->shown[i]) : 1;  // background: every ray, mask or not (:382-392)

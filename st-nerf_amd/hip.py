@@ -88,6 +88,9 @@ _PROTOS = {
     "stnerf_packed_bytes_f16x3": (c_i64, [C.c_int]),
     "stnerf_pack_net_f16x3": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
                                         c_i64]),
+    "stnerf_packed_bytes_bf16x3": (c_i64, [C.c_int]),
+    "stnerf_pack_net_bf16x3": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
+                                         c_i64]),
     "stnerf_spacenet_fwd_f16x3": (C.c_int, [C.c_int, C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_i64,
                                             c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, C.c_void_p, C.c_void_p]),
     "stnerf_motionnet_fwd_f16x3": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_i64, c_f32p,

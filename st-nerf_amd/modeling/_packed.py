@@ -11,16 +11,26 @@ def _params_fingerprint(module: nn.Module):
 class _PackedMixin:
     """Lazily (re)packs a module's nn.Linear weights into the kernel layout."""
 
-    precision = "fp32"   # "fp32": exact f32 MFMA;  "fp16x3": fp32-accurate split-fp16 MFMA (ops.PRECISIONS)
+    precision = "fp32"   # "fp32": exact f32 MFMA;  "fp16x3" / "bf16x3": split low-precision MFMA (ops.PRECISIONS)
 
-    def _packed(self):
-        fp = _params_fingerprint(self) + (self.precision,)
-        if getattr(self, "_pack_fp", None) != fp:
+    def _packed(self, precision=None):
+        """The kernel-layout blob for `precision` (default: the module's own).  One blob per precision is kept as long
+        as the parameters do not change, so that a launch which has to fall back to another arithmetic (the fp16x3 range
+        guard -> exact f32) does not repack on every call."""
+        precision = precision or self.precision
+        fp = _params_fingerprint(self)
+        cache = getattr(self, "_pack_cache", None)
+        if cache is None or cache[0] != fp:
+            cache = self._pack_cache = (fp, {})
+        if precision not in cache[1]:
             dev = next(self.parameters()).device
             if dev.type != "cuda":
                 raise RuntimeError("this network lives on %s: call .cuda() first -- the render path runs on the "
                                    "MI355X only (no CPU fallback)" % dev)
             sd = {k: v for k, v in self.state_dict().items()}
-            self._pack_net = self._pack(sd, dev)
-            self._pack_fp = fp
-        return self._pack_net
+            keep, self.precision = self.precision, precision
+            try:
+                cache[1][precision] = self._pack(sd, dev)
+            finally:
+                self.precision = keep
+        return cache[1][precision]

@@ -85,13 +85,19 @@ class LayeredRFRender(nn.Module):
         self.ray_window = (0, 0, 0)        # (first, stripe, period): which rays of the view `rays` are (include/stnerf.h);
                                            # keeps the RNG stream of a view under multi-GPU sharding
 
+    F16_LATCH_AFTER = 8    # fp16x3 range-guard fallbacks after which the model stays in exact f32
+
     def set_precision(self, precision: str):
-        """"fp32" (default: exact f32 MFMA) or "fp16x3" (fp32-accurate 3-term split-fp16 MFMA, ~2.8x faster)."""
+        """"fp32" (default: exact f32 MFMA), "bf16x3" (three bf16 pieces per operand, six MFMAs per product, two
+        accumulators: fp32's significand and range, closer to an fp64 evaluation than an fp32 fma chain) or "fp16x3" (two
+        fp16 pieces, three MFMAs: 22 significand bits, |W| < 234, activations < 65520 -- a launch that leaves the range is
+        re-run in exact f32)."""
         if precision not in ops.PRECISIONS:
             raise ValueError(f"precision must be one of {ops.PRECISIONS}")
         for m in self.modules():
             if isinstance(m, (SpaceNet, MotionNet)):
                 m.precision = precision
+        self.f16_fallbacks, self.f16_latched = 0, False
         return self
 
     # ---- reference API -----------------------------------------------------------------------
@@ -192,14 +198,14 @@ class LayeredRFRender(nn.Module):
             for i in range(1, l):
                 if not self.is_shown_layer(i):
                     continue  # a hidden layer's points are never consumed
-                ops.motionnet_fwd(self.time_deform_nets[i - 1]._packed(), xyz[:, i], rays[:, times_col(i)],
+                ops.motionnet_fwd(self.time_deform_nets[i - 1]._packed("fp32"), xyz[:, i], rays[:, times_col(i)],
                                   add_to_xyz=True, ray_list=lst[i], ray_count=cnt[i:i + 1])
-        ops.spacenet_fwd(bk._packed(), xyz[:, 0], rays[:, 3:6], None, raw[:, 0])
+        ops.spacenet_fwd(bk._packed("fp32"), xyz[:, 0], rays[:, 3:6], None, raw[:, 0])
         for i in range(1, l):
             if not self.is_shown_layer(i):
                 continue
             tm = rays[:, times_col(i)] if self.use_space_time else None
-            ops.spacenet_fwd(nets[i - 1]._packed(), xyz[:, i], rays[:, 3:6], tm, raw[:, i], ray_list=lst[i],
+            ops.spacenet_fwd(nets[i - 1]._packed("fp32"), xyz[:, i], rays[:, 3:6], tm, raw[:, i], ray_list=lst[i],
                              ray_count=cnt[i:i + 1])
 
     def _render_launch(self, rays, boxes, pivot, retiming, only_coarse, thr, bthr, window, replay, force_fp32=False):
@@ -213,11 +219,11 @@ class LayeredRFRender(nn.Module):
         p.use_deform_time, p.use_space_time = int(self.use_deform_time), int(self.use_space_time)
         p.bkgd_use_deform_time, p.bkgd_use_space_time = int(self.bkgd_use_deform_time), int(self.bkgd_use_space_time)
         p.deep_rgb = int(self.deep_rgb)
-        # 0: exact f32, one persistent launch per network stage; 1: fp16x3; 2: exact f32, one launch per network
-        f16 = self.bkgd_spacenet.precision == "fp16x3"
-        if force_fp32:      # the fp16x3 range guard fired: this launch again in exact f32 (packs the f32 blobs on first use)
-            self.set_precision("fp32")
-        p.precision = 1 if (f16 and not force_fp32) else (0 if self.mlp_schedule == "stage" else 2)
+        # 0: exact f32, one persistent launch per network stage; 1: fp16x3; 2: exact f32, one launch per network; 3: bf16x3
+        prec = self.bkgd_spacenet.precision
+        if force_fp32 or (prec == "fp16x3" and getattr(self, "f16_latched", False)):
+            prec = "fp32"   # the fp16x3 range guard fired: this launch (again) in exact f32 -- its blobs are cached per precision
+        p.precision = {"fp16x3": 1, "bf16x3": 3}.get(prec, 0 if self.mlp_schedule == "stage" else 2)
         for i in range(l):
             p.shown[i] = int(self.is_shown_layer(i))
         p.border, p.near, p.alpha = float(self.boarder_weight), float(self.near), float(self.alpha)
@@ -233,7 +239,7 @@ class LayeredRFRender(nn.Module):
         nets = hip.Nets()
         keep = []                                                    # packed blobs must outlive the enqueue
         def ptr(module):
-            pk = module._packed()
+            pk = module._packed(prec)
             keep.append(pk)
             return pk.blob.data_ptr()
         nets.bkgd, nets.bkgd_fine = ptr(self.bkgd_spacenet), ptr(self.bkgd_spacenet_fine)
@@ -255,14 +261,17 @@ class LayeredRFRender(nn.Module):
             if guard is None or guard.device != rays.device:
                 self._f16_guard = guard = torch.zeros(1, dtype=torch.int32, device=rays.device)
             guard.zero_()
-        try:
-            out = ops.render_rays(rays, boxes, nets, p, ws, jitter=replay["jitter"] if replay else None,
-                                  u=(replay.get("u") if replay else None), overflow=guard)
-        finally:
-            if force_fp32:
-                self.set_precision("fp16x3")
+        out = ops.render_rays(rays, boxes, nets, p, ws, jitter=replay["jitter"] if replay else None,
+                              u=(replay.get("u") if replay else None), overflow=guard)
         if guard is not None and int(guard.item()) != 0:   # (one 4-byte D2H per launch sequence, fp16x3 mode only)
             self.f16_fallbacks = getattr(self, "f16_fallbacks", 0) + 1
+            if self.f16_fallbacks >= self.F16_LATCH_AFTER and not getattr(self, "f16_latched", False):
+                # a scene whose activations keep leaving the fp16 range pays the fp16x3 pass, a sync and the f32 pass per
+                # launch: stop trying
+                self.f16_latched = True
+                import warnings
+                warnings.warn(f"fp16x3: {self.f16_fallbacks} launches left the fp16 range and were re-run in exact f32; "
+                              "rendering in fp32 from now on (set_precision('bf16x3') has no range limit)")
             return self._render_launch(rays, boxes, pivot, retiming, only_coarse, thr, bthr, window, replay, force_fp32=True)
         return out
 

@@ -33,6 +33,7 @@ class MotionNet(nn.Module, _PackedMixin):
         x = input_0.reshape(-1, 1, 4)
         xyz = x[..., :3].contiguous()
         flow = torch.empty_like(xyz)
-        ops.motionnet_fwd(self._packed(), xyz, x[:, 0, 3].contiguous(), flow=flow, add_to_xyz=False,
+        # (bf16x3 has no stand-alone MotionNet launch -- it runs fused in front of a SpaceNet: the op-level call is exact f32)
+        ops.motionnet_fwd(self._packed("fp32" if self.precision == "bf16x3" else None), xyz, x[:, 0, 3].contiguous(), flow=flow, add_to_xyz=False,
                           plain_time=not self.input_time)
         return flow.reshape(*input_0.shape[:-1], 3) if bins else flow.reshape(-1, 3)

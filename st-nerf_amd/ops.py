@@ -136,7 +136,7 @@ SPACENET_KEYS = ["stage1.0", "stage1.2", "stage1.4", "stage1.6", "stage2.0", "st
 MOTIONNET_KEYS = [f"motion_net.{j}" for j in (0, 2, 4, 6, 8, 10)]
 
 
-PRECISIONS = ("fp32", "fp16x3")
+PRECISIONS = ("fp32", "fp16x3", "bf16x3")
 
 
 class PackedNet:
@@ -151,13 +151,14 @@ class PackedNet:
 
 
 def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cuda", precision: str = "fp32") -> PackedNet:
-    """Repack reference-layout nn.Linear tensors (host copy) and upload.  precision: "fp32" (exact f32 MFMA)
-    or "fp16x3" (fp32-accurate split-fp16 MFMA; SpaceNet only)."""
+    """Repack reference-layout nn.Linear tensors (host copy) and upload.  precision: "fp32" (exact f32 MFMA),
+    "fp16x3" (two fp16 pieces per operand, three MFMAs; |W| < 234, activations < 65520) or "bf16x3" (three bf16 pieces
+    per operand, six MFMAs, two accumulators: the full fp32 significand and exponent range; the stage kernel only)."""
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
-    f16 = precision == "fp16x3"
-    size_fn = hip.lib().stnerf_packed_bytes_f16x3 if f16 else hip.lib().stnerf_packed_bytes
-    pack_fn = hip.lib().stnerf_pack_net_f16x3 if f16 else hip.lib().stnerf_pack_net
+    lib = hip.lib()
+    size_fn = {"fp32": lib.stnerf_packed_bytes, "fp16x3": lib.stnerf_packed_bytes_f16x3, "bf16x3": lib.stnerf_packed_bytes_bf16x3}[precision]
+    pack_fn = {"fp32": lib.stnerf_pack_net, "fp16x3": lib.stnerf_pack_net_f16x3, "bf16x3": lib.stnerf_pack_net_bf16x3}[precision]
     nbytes = size_fn(kind)
     if nbytes < 0:
         hip.check(int(nbytes), "stnerf_packed_bytes")
@@ -167,7 +168,13 @@ def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cud
     wp = (C.c_void_p * len(ws))(*(w.data_ptr() for w in ws))
     bp = (C.c_void_p * len(bs))(*(b.data_ptr() for b in bs))
     hip.check(pack_fn(kind, wp, bp, len(ws), C.c_void_p(host.data_ptr()), nbytes), "stnerf_pack_net")
-    return PackedNet(kind, host.to(device), precision)
+    blob = host.to(device)
+    if precision == "bf16x3" and blob.data_ptr() % 1024:   # (the stage kernel streams it by 16-byte LDS-DMA from 1 KB-aligned sections)
+        raw = torch.empty(nbytes + 1024, dtype=torch.uint8, device=device)
+        off = (-raw.data_ptr()) % 1024
+        blob = raw[off:off + nbytes].view(torch.float32)
+        blob.copy_(host)
+    return PackedNet(kind, blob, precision)
 
 
 def _pe_columns(w: Tensor, dim: int, n_freq: int, include_input: bool, present: bool = True) -> Tensor:
@@ -253,12 +260,16 @@ def spacenet_fwd(net: PackedNet, xyz: Tensor, dirs: Tensor, times: Optional[Tens
     """xyz (n,ns,3), dirs (n,3), times (n,) | None, raw (n,ns,4) out; all may be strided views whose
     dim 0 is the ray.  Writes raw {r,g,b,sigma} for the listed rays.  modeling/spacenet.py:101-160."""
     n, ns = xyz.shape[0], xyz.shape[1]
+    if net.use_time and times is None:
+        raise ValueError("this SpaceNet takes time: pass times (n,)")
+    if net.precision == "bf16x3":   # the split-bf16 arithmetic exists as the stage kernel: a one-layer stage
+        mlp_stage([dict(space=net, motion=None, xyz=xyz, raw=raw, times=times if net.use_time else None, ray_list=ray_list,
+                        ray_count=ray_count)], dirs, ns, deep_rgb=net.kind in (hip.NET_SPACE_DEEP, hip.NET_SPACE_TIME_DEEP))
+        return raw
     xp, xs = _strided_view_ptr(xyz, (ns, 3), "xyz")
     dp, ds = _strided_view_ptr(dirs, (3,), "dirs")
     rp, rs = _strided_view_ptr(raw, (ns, 4), "raw")
     if net.use_time:
-        if times is None:
-            raise ValueError("this SpaceNet takes time: pass times (n,)")
         tp, ts = _strided_view_ptr(times.reshape(n), (), "times")
     else:
         tp, ts = C.c_void_p(0), 0
@@ -301,6 +312,9 @@ def motionnet_fwd(net: PackedNet, xyz: Tensor, times: Tensor, flow: Optional[Ten
     modeling/motion_net.py:34-71 + layered_rfrender.py:355-356.  plain_time = MotionNet(input_time=False):
     the time column is encoded as given instead of lerping the encodings of floor(t) and floor(t)+1."""
     n, ns = xyz.shape[0], xyz.shape[1]
+    if net.precision == "bf16x3":
+        raise ValueError("a bf16x3 MotionNet runs fused in front of its SpaceNet (ops.mlp_stage); there is no stand-alone "
+                         "launch -- pack it 'fp32' for the op-level call")
     xp, xs = _strided_view_ptr(xyz, (ns, 3), "xyz")
     tp, ts = _strided_view_ptr(times.reshape(n), (), "times")
     if flow is not None:
@@ -322,10 +336,12 @@ def motionnet_fwd(net: PackedNet, xyz: Tensor, times: Tensor, flow: Optional[Ten
 def mlp_stage(layers: Sequence[dict], dirs: Tensor, ns: int, deep_rgb: bool = False, sigmoid_rgb: bool = False) -> None:
     """One persistent launch over every listed layer (stnerf_mlp_stage).  Each dict: space (PackedNet), motion
     (PackedNet | None), xyz (n,ns,3), raw (n,ns,4) out, times (n,) | None, ray_list / ray_count | None,
-    plain_time (bool).  Views may be strided as long as all layers share the ray strides."""
+    plain_time (bool).  Views may be strided as long as all layers share the ray strides.  The arithmetic follows the
+    nets' packing: all "fp32" (exact f32 MFMA) or all "bf16x3" (split-bf16 MFMA)."""
     n = dirs.shape[0]
     arr = (hip.StageLayer * len(layers))()
     strides = None
+    precs = set()
     dp, ds = _strided_view_ptr(dirs, (3,), "dirs")
     for i, ly in enumerate(layers):
         xp, xs = _strided_view_ptr(ly["xyz"], (ns, 3), "xyz")
@@ -337,17 +353,21 @@ def mlp_stage(layers: Sequence[dict], dirs: Tensor, ns: int, deep_rgb: bool = Fa
             strides[2] = ts
         if (xs, rs) != tuple(strides[:2]) or (ts and ts != strides[2]):
             raise ValueError("mlp_stage: every layer must share the xyz / raw / times ray strides")
-        if ly["space"].precision != "fp32" or (ly.get("motion") is not None and ly["motion"].precision != "fp32"):
-            raise ValueError("mlp_stage runs the exact-f32 kernels: pack the networks with precision='fp32'")
+        precs.add(ly["space"].precision)
+        if ly.get("motion") is not None:
+            precs.add(ly["motion"].precision)
         lp, cp = _worklist(ly.get("ray_list"), ly.get("ray_count"))
         a = arr[i]
         a.space, a.motion = ly["space"].blob.data_ptr(), (ly["motion"].blob.data_ptr() if ly.get("motion") is not None else None)
         a.ray_list, a.ray_count, a.xyz, a.raw, a.times = lp.value, cp.value, xp.value, rp.value, tp.value
         a.use_time, a.motion_flags = int(ly["space"].use_time), (hip.MOTION_PLAIN_TIME if ly.get("plain_time") else 0)
+    if precs not in ({"fp32"}, {"bf16x3"}):
+        raise ValueError(f"mlp_stage: every network of a launch must be packed 'fp32' or every one 'bf16x3' (got {sorted(precs)})")
+    bx = 4 if precs == {"bf16x3"} else 0
     queue = torch.zeros(1, dtype=torch.int32, device=dirs.device)
     ray_bias = torch.empty(len(layers), n, 128, dtype=torch.float32, device=dirs.device)   # rgb_net.1 per ray (stnerf_rgb_ray_bias)
     hip.check(hip.lib().stnerf_mlp_stage(arr, len(layers), n, ns, dp, ds, strides[2], strides[0], strides[1],
-                                         (1 if deep_rgb else 0) | (2 if sigmoid_rgb else 0),
+                                         (1 if deep_rgb else 0) | (2 if sigmoid_rgb else 0) | bx,
                                          C.c_void_p(queue.data_ptr()), hip.dptr(ray_bias), hip.stream_ptr()), "stnerf_mlp_stage")
 
 

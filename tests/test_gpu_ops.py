@@ -271,15 +271,12 @@ def test_rgb_ray_bias_vs_fp64(ops, use_time):
     assert torch.equal(part[hit], got[hit]) and bool((part[~hit] == 0).all())
 
 
-@pytest.mark.parametrize("stage_kernel", ["wave", "lds"])
 @pytest.mark.parametrize("deep, bkgd_deform, ns", [(False, False, 13), (False, False, 64), (True, True, 9), (False, True, 128), (False, True, 90)])
-def test_mlp_stage_is_bit_identical_to_the_per_network_launches(ops, deep, bkgd_deform, ns, stage_kernel, monkeypatch):
+def test_mlp_stage_is_bit_identical_to_the_per_network_launches(ops, deep, bkgd_deform, ns):
     """stnerf_mlp_stage (one persistent launch: work queue over every layer, MotionNet fused in front of its SpaceNet)
     == stnerf_motionnet_fwd(ADD_TO_XYZ) + stnerf_spacenet_fwd per layer, bit for bit; rows of rays a layer does not list
-    stay untouched.  Both organisations behind the entry point: "wave" (csrc/mlp_wave.hip: a wave owns 32 samples, the
-    activations never leave its registers; the default) and "lds" (csrc/mlp_stage.hip: feature-split waves, activations in
-    LDS) -- the env switch is read on every call."""
-    monkeypatch.setenv("STNERF_STAGE_KERNEL", stage_kernel)
+    stay untouched (csrc/mlp_wave.hip: a wave owns 32 samples, the activations never leave its registers; the stage
+    kernel is compared with the fp64 oracle directly in tests/test_gpu_stage.py)."""
     torch.manual_seed(41 + ns)
     rs = np.random.RandomState(9)
     n, l = 1100, 3

@@ -25,9 +25,9 @@ def _cut(path, signature):
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="no ROCm clang for the host build")
 def test_packed_sincos_equals_scalar_sincos_bitwise(tmp_path):
     scalar = _cut(os.path.join(ROOT, "st-nerf_amd", "csrc", "mlp_common.h"), "__device__ __forceinline__ void sincos_pe(float x")
-    wave = open(os.path.join(ROOT, "st-nerf_amd", "csrc", "mlp_wave.hip")).read()
+    wave = open(os.path.join(ROOT, "st-nerf_amd", "csrc", "mlp_wave_common.h")).read()
     typedef = re.search(r"typedef float f32x2 __attribute__\(\(ext_vector_type\(2\)\)\);", wave).group(0)
-    packed = _cut(os.path.join(ROOT, "st-nerf_amd", "csrc", "mlp_wave.hip"), "__device__ __forceinline__ void sincos_pe2(f32x2 x")
+    packed = _cut(os.path.join(ROOT, "st-nerf_amd", "csrc", "mlp_wave_common.h"), "__device__ __forceinline__ void sincos_pe2(f32x2 x")
     src = tmp_path / "pe_host.cpp"
     src.write_text(r"""
 #include <cmath>

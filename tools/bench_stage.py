@@ -42,6 +42,17 @@ cases = {
     "motion + space standalone": (lambda: (ops.motionnet_fwd(mo, xyz, times, add_to_xyz=True), ops.spacenet_fwd(sp, xyz, dirs, times, raw)), FLOP_MOTION + FLOP_SPACE_TIME),
     "stage: performer fused": (lambda: ops.mlp_stage([dict(space=sp, motion=mo, xyz=xyz, raw=raw, times=times)], dirs, ns), FLOP_MOTION + FLOP_SPACE_TIME),
 }
+if os.environ.get("STAGE_ONLY"):
+    cases = {k: v for k, v in cases.items() if k.startswith("stage")}
+# the split-bf16 arithmetic of the same launch (csrc/mlp_bf16x3.hip): algorithmic TF/s; executed bf16 MFMA = 6 x
+rs = np.random.RandomState(0)
+bk_x = ops.pack_spacenet(syn.spacenet_state("net", rs, False), "net", precision="bf16x3")
+sp_x = ops.pack_spacenet(syn.spacenet_state("net", rs, True), "net", precision="bf16x3")
+mo_x = ops.pack_motionnet(syn.motionnet_state("net", rs), "net", precision="bf16x3")
+cases.update({
+    "bf16x3 stage: bkgd only": (lambda: ops.mlp_stage([dict(space=bk_x, motion=None, xyz=xyz, raw=raw)], dirs, ns), FLOP_SPACE),
+    "bf16x3 stage: performer fused": (lambda: ops.mlp_stage([dict(space=sp_x, motion=mo_x, xyz=xyz, raw=raw, times=times)], dirs, ns), FLOP_MOTION + FLOP_SPACE_TIME),
+})
 for name, (fn, flop) in cases.items():
     ms = timeit(fn)
     print(f"{name:36s} {ms:9.3f} ms  {rows * flop / (ms * 1e-3) / 1e12:7.2f} TF/s")
