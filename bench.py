@@ -6,7 +6,7 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" = one pass of the hot path over one synthetic 1080p view per GPU: device ray generation
-(a1/a2) -> coarse sampler -> mask compaction -> MotionNet/SpaceNet (fp32 MFMA) -> composite + merge ->
+(a1/a2) -> coarse sampler -> mask compaction -> MotionNet/SpaceNet (exact f32 MFMA; --precision bf16x3: split-bf16 MFMA) -> composite + merge ->
 inverse-CDF resample -> fine MotionNet/SpaceNet -> composite + merge, followed (N > 1) by the RCCL
 all-gather of the rendered tiles.
 
@@ -160,8 +160,7 @@ def _oracle_ray_window(O, K, T, H, W, first, n):
 def cpu_baseline(workload, budget_rays, threads=0):
     """The CPU oracle (a restatement of the reference algorithm, oracle/stnerf_oracle.py) timed on this box's host
     cores on a bounded sample of the same workload: whole 3584-ray reference chunks spread
-    evenly over the image height -- border rows see the background only, centre rows hit the performers -- each
-    timed on its own; `value` = rays of all chunks / their total time = the whole-frame rate they extrapolate to."""
+    evenly over the image height (the performer boxes span it: every chunk crosses them), each timed on its own; `value` = rays of all chunks / their total time = the whole-frame rate they extrapolate to."""
     import platform
     from oracle import stnerf_oracle as O
     # a fair CPU figure needs a sensible thread count: on the 2 x 64-core host of the MI355X box the chunk-sized GEMMs of
@@ -199,7 +198,8 @@ def cpu_baseline(workload, budget_rays, threads=0):
         pass
     return dict(value=rate, unit="rays/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{n_chunks} reference chunks of {chunk} rays spread evenly over the rows of the {W}x{H} view "
-                       f"(border rows: background only; centre rows: performers), oracle/stnerf_oracle.py on torch "
+                       f"(the performer boxes span the image height: every chunk crosses them, see chunks[].performer_hit_fraction), "
+                       f"oracle/stnerf_oracle.py on torch "
                        f"{torch.__version__} CPU fp32, {total:.1f} s",
                 seconds=total, ray_samples_per_s=evals / total, extrapolated_frame_seconds=H * W / rate,
                 host=dict(nproc=os.cpu_count(), torch_threads=torch.get_num_threads(), cpu=cpu), chunks=per_chunk)
@@ -281,10 +281,12 @@ def main():
     ap.add_argument("--no-weak-leg", action="store_true", help="N>1: skip the secondary weak-scaling leg")
     ap.add_argument("--no-psnr-check", action="store_true",
                     help="skip the PSNR-vs-reference check of the device RNG mode (a 128x128 view, ~0.1 s)")
-    ap.add_argument("--eager-gpu-baseline-rays", type=int, default=0,
-                    help=">0: also time the oracle restatement through eager PyTorch-ROCm on this GPU (informative)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16x3"],
-                    help="arithmetic of the headline run: exact f32 MFMA (default) or fp32-accurate split-fp16 MFMA")
+    ap.add_argument("--eager-gpu-baseline-rays", type=int, default=3584,
+                    help=">0 (default: one reference chunk): also time the oracle restatement through eager PyTorch-ROCm on this GPU -- "
+                         "the 'stock ATen on the same GPU' figure of BASELINE.md 3.5 (informative); 0 skips it")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "fp16x3"],
+                    help="arithmetic of the headline run: exact f32 MFMA (default), split-bf16 (three bf16 pieces per fp32 operand, "
+                         "six MFMAs, two accumulators: fp32's significand and range) or split-fp16 (22-bit operands, range-limited)")
     ap.add_argument("--mlp-schedule", default="stage", choices=["stage", "per_net"],
                     help="exact-f32 MLP scheduling: one persistent launch per stage (default) or one launch per network (round 1)")
     ap.add_argument("--no-second-precision", action="store_true",
@@ -298,6 +300,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the render path has no CPU fallback)")
+    if not args.debug_single_device and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but this node exposes {torch.cuda.device_count()} GPU(s): one process per GPU needs "
+                         f"{world} visible devices (check HIP_VISIBLE_DEVICES / the compute partition mode)")
     if args.debug_single_device:
         local_rank = 0                  # every rank on cuda:0 (validates the N > 1 logic on a 1-GPU box; gloo, not RCCL)
     torch.cuda.set_device(local_rank)
@@ -411,11 +416,14 @@ def main():
 
     head = measure(args.precision, args.steps, args.warmup, mode)
     elapsed, ksum, evals, evals_all = head["elapsed"], head["ksum"], head["evals"], head["evals_all"]
-    other = None
+    others = []
     if not args.no_second_precision:
-        op = "fp16x3" if args.precision == "fp32" else "fp32"
-        other = measure(op, max(1, min(args.steps, 2)), 1, mode)
-        other["precision"] = op
+        # the arithmetics that are not the headline: bf16x3 first (the fp32-faithful fast mode), then fp16x3 / fp32
+        for op in [q for q in ("bf16x3", "fp32", "fp16x3") if q != args.precision][:2]:
+            o = measure(op, max(1, min(args.steps, 2)), 1, mode)
+            o["precision"] = op
+            others.append(o)
+    model.set_precision(args.precision)
     weak = None
     if world > 1 and mode == "stripes" and not args.no_weak_leg:
         weak = measure(args.precision, max(1, min(args.steps, 2)), 1, "views")
@@ -425,10 +433,8 @@ def main():
         staged = "mlp_stage" in ksum
         sp = ksum["mlp_stage"] if staged else ksum["spacenet"]
         achieved = sp["flop"] / (sp["ms"] * 1e-3) / 1e12
-        if args.precision == "fp16x3":   # executed MFMA work is 3 fp16 terms per algorithmic product
-            achieved, peak_used = 3.0 * achieved, PEAK_F16_MFMA_TFLOPS
-        else:
-            peak_used = PEAK_F32_MFMA_TFLOPS
+        mult_head = {"fp16x3": 3.0, "bf16x3": 6.0}.get(args.precision, 1.0)   # executed MFMA terms per algorithmic product
+        achieved, peak_used = mult_head * achieved, (PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_F16_MFMA_TFLOPS)
         # HBM traffic cannot be counted inside this process: it comes from the committed rocprofv3 PMC passes
         # of the same command (profiles/), per launch, with the gfx950 FETCH_SIZE correction applied.
         pmc = json.load(open(PMC_TRAFFIC_JSON)) if os.path.exists(PMC_TRAFFIC_JSON) else {}
@@ -465,7 +471,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong" if mode == "stripes" else "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f32-accurate products as 3 fp16 MFMA terms (22-bit split operands), f32 accumulate",
+            "dtype": {"fp32": "f32",
+                      "bf16x3": "f32 operands as 3 bf16 pieces each (24-bit significand, f32 exponent range), 6 bf16 MFMA terms per product, f32 accumulate",
+                      "fp16x3": "f32-accurate products as 3 fp16 MFMA terms (22-bit split operands), f32 accumulate"}[args.precision],
             "data": "synthetic",
             "config": {"workload": args.workload, "precision": args.precision, "height": H, "width": W, "performer_layers": L,
                        "coarse_samples": n1, "fine_samples": n2, "use_space_time": st, "use_deform_time": dt,
@@ -481,12 +489,13 @@ def main():
             "mask_fraction": head["mask_fraction"],
             "per_rank_compute_s": {"min": min(per_rank), "mean": sum(per_rank) / len(per_rank), "max": max(per_rank),
                                    "all": per_rank, "note": "render time of each rank's share over the timed steps, before the all-gather"},
-            "roofline": {"kernel": (("stnerf::mlp_wave_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, "
-                                     "a wave owns 32 samples and keeps their activations in registers, v_mfma_f32_32x32x2_f32)")
-                                    if os.environ.get("STNERF_STAGE_KERNEL", "wave") != "lds" else
-                                    ("stnerf::mlp_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, "
-                                     "feature-split waves with the activations in LDS, v_mfma_f32_32x32x2_f32)")) if staged else
-                                   "stnerf::spacenet_kernel (fused PE + 9-layer MLP, v_mfma_f32_32x32x2_f32)",
+            "roofline": {"kernel": (("stnerf::mlp_bf16x3_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, "
+                                     "a wave owns 32 samples and keeps their activations in registers as three bf16 planes, weights through an "
+                                     "LDS-DMA ring, v_mfma_f32_32x32x16_bf16; achieved = EXECUTED MFMA rate = 6 x algorithmic)")
+                                    if args.precision == "bf16x3" else
+                                    ("stnerf::mlp_wave_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, "
+                                     "a wave owns 32 samples and keeps their activations in registers, v_mfma_f32_32x32x2_f32)")) if staged else
+                                   "stnerf::spacenet_kernel (fused PE + 9-layer MLP)",
                          "bound": "mfma", "achieved": achieved, "peak": peak_used, "unit": "TFLOP/s",
                          "frac": achieved / peak_used, "traffic": traffic,
                          "traffic_source": ("profiles/" + os.path.basename(PMC_TRAFFIC_JSON)) if traffic else None,
@@ -502,16 +511,22 @@ def main():
             "psnr_vs_reference": psnr_check,
             "device": info,
         }
-        if other is not None:
+        for other in others:
             osp = other["ksum"]["mlp_stage"] if "mlp_stage" in other["ksum"] else other["ksum"]["spacenet"]
             o_ach = osp["flop"] / (osp["ms"] * 1e-3) / 1e12
-            peak_o = PEAK_F16_MFMA_TFLOPS if other["precision"] == "fp16x3" else PEAK_F32_MFMA_TFLOPS
-            mult = 3.0 if other["precision"] == "fp16x3" else 1.0
-            rec["other_precision"] = {
+            peak_o = PEAK_F32_MFMA_TFLOPS if other["precision"] == "fp32" else PEAK_F16_MFMA_TFLOPS
+            mult = {"fp16x3": 3.0, "bf16x3": 6.0}.get(other["precision"], 1.0)
+            notes = {
+                "bf16x3": "every fp32 operand = three bf16 pieces (8+8+8 significand bits: exact, fp32's exponent range, no limits), "
+                          "a*b = its six leading cross terms on v_mfma_f32_32x32x16_bf16, a0*b0 and the five small terms in separate "
+                          "f32 accumulators, heads in fp64: closer to an fp64 evaluation than the fp32 CPU chain (tests/test_gpu_stage.py); "
+                          "opt-in (model.set_precision('bf16x3')), not the headline until reviewed",
+                "fp16x3": "every product a*b as ah*bh + ah*bl + al*bh on the fp16 MFMA pipe (22-bit operands, |W| < 234, activations "
+                          "< 65520 with an overflow guard), per-network launches; opt-in",
+                "fp32": "exact f32 MFMA (the library default)"}
+            rec["other_precision" if other is others[0] else "other_precision_2"] = {
                 "precision": other["precision"],
-                "note": "same workload and poses, measured after the headline run; fp16x3 = every product a*b evaluated as "
-                        "ah*bh + ah*bl + al*bh on the fp16 MFMA pipe with f32 accumulation: passes the same parity tests "
-                        "as the exact-f32 kernels (tests/test_gpu_f16x3.py); opt-in, not the headline",
+                "note": "same workload and poses, measured after the headline run; " + notes[other["precision"]],
                 "value": other["rays"] / other["elapsed"], "unit": "rays/s",
                 "ms_per_step": 1e3 * other["elapsed"] / other["steps"], "steps": other["steps"],
                 "ray_samples_per_s": other["evals_all"] / other["elapsed"],

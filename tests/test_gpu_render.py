@@ -39,11 +39,13 @@ def fine_stage_bar(got, ref32, exact, tol, what):
     err_hip = (got.double() - exact.double()).abs().reshape(got.shape[0], -1).amax(-1)
     n = err_ref.numel()
     out_ref, out_hip = int((err_ref > tol).sum()), int((err_hip > tol).sum())
-    assert out_hip <= 1.5 * out_ref + max(2, n // 200), \
+    # (round 2 allowed 1.5 x + max(2, n / 200) outliers and 2 x on the quantiles; the kernels measure 162 vs 161 of 1024 and
+    # 33 vs 36 -- the bar is now what they need: 1.1 x + 2 rays, median / p90 within 1.25 x)
+    assert out_hip <= 1.1 * out_ref + 2, \
         f"{what}: {out_hip} of {n} rays above {tol} vs the exact result, the reference's fp32 evaluation has {out_ref}"
     for q in (0.5, 0.9):
         qh, qr = float(torch.quantile(err_hip, q)), float(torch.quantile(err_ref, q))
-        assert qh <= 2.0 * qr + tol / 50, f"{what}: p{int(100 * q)} error {qh:.2e} vs the reference's {qr:.2e}"
+        assert qh <= 1.25 * qr + tol / 50, f"{what}: p{int(100 * q)} error {qh:.2e} vs the reference's {qr:.2e}"
     return out_hip, out_ref, float(err_hip.max()), float(err_ref.max())
 
 

@@ -176,3 +176,60 @@ def test_mlp_stage_rejects_mixed_packings(ops):
                             xyz=x, raw=raw, times=t)], d, ns)
     with pytest.raises(ValueError):
         ops.motionnet_fwd(ops.pack_motionnet(sm, "net", precision="bf16x3"), x, t)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16x3 through the drop-in boundary: the reference's own outputs, same tolerances as the exact-f32 mode
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["fwd_c1", "fwd_c3", "fwd_c3_64_64", "fwd_c3_90_30", "fwd_edit", "fwd_hide", "fwd_nonretime",
+                                  "fwd_only_coarse", "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet",
+                                  "fwd_deep_rgb", "fwd_no_raw_no_dir", "fwd_grazing", "fwd_c4", "fwd_c5"])
+def test_whole_path_bf16x3_matches_reference_fixtures(name):
+    """LayeredRFRender.forward / layered_batchify_ray in bf16x3 precision against the fixtures the reference itself wrote
+    (tests/golden/make_golden.py), with the tolerances and the measured fine-stage bar of the exact-f32 mode."""
+    import test_gpu_render as R
+    R.run_forward_case(name, precision="bf16x3")
+
+
+def test_c2_full_view_bf16x3_agrees_with_fp32():
+    """C2 (512x512, 64+64) rendered in both arithmetics with the same device RNG stream."""
+    import test_gpu_render as R
+    from stnerf_amd.render.render_pose import render_pose
+    meta = dict(L=1, n1=64, n2=64, space_time=True, deform_time=False, weight_seed=40, edit={})
+    model = R.build_model(meta)
+    K, T = syn.camera(512, 512, 8.0)
+    model.seed = 3
+    imgs = {}
+    for prec in ("fp32", "bf16x3"):
+        model.set_precision(prec)
+        imgs[prec] = render_pose(model, T, K, 512, 512, [(0, 1), (1, 2.5)], far=20.0)[0]
+    a, b = imgs["fp32"], imgs["bf16x3"]
+    per_pix = (a - b).abs().max(-1)[0]
+    frac = float((per_pix <= R.COLOR_ATOL).float().mean())
+    quality = float(-10 * torch.log10(torch.mean((a - b) ** 2)))
+    print(f"bf16x3 vs fp32 at C2: {100 * frac:.3f} % of pixels within {R.COLOR_ATOL}, PSNR {quality:.1f} dB, max {float(per_pix.max()):.2e}")
+    assert frac >= 0.99 and quality >= 70.0
+
+
+def test_bf16x3_module_level_calls(ops):
+    """SpaceNet.forward / MotionNet.forward of a model set to bf16x3 (the op-level surface of the drop-in boundary): the
+    SpaceNet runs as a one-layer stage, the stand-alone MotionNet call stays exact f32."""
+    import test_gpu_render as R
+    meta = dict(L=1, n1=12, n2=6, space_time=True, deform_time=True, weight_seed=7, edit={})
+    model = R.build_model(meta).set_precision("bf16x3")
+    torch.manual_seed(1)
+    n, s = 50, 12
+    pos = (torch.rand(n, s, 3, device="cuda") - 0.5) * 4
+    rays = torch.cat([torch.zeros(n, 3), torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)], -1).cuda()
+    t = (torch.rand(n, 1, device="cuda") * 5 + 1)
+    net = model.spacenets[0]
+    with torch.no_grad():
+        rgb, sig = net(pos, rays, t)
+        flow = model.time_deform_nets[0](torch.cat([pos, t.view(n, 1, 1).repeat(1, s, 1)], -1))
+    sd64 = {"net." + k: v.detach().double().cpu() for k, v in net.state_dict().items()}
+    rgb64, sig64 = O.space_net(sd64, "net", pos.double().cpu(), rays[:, 3:6].double().cpu(), t.double().cpu())
+    _close(rgb.cpu(), rgb64, 4.0, "rgb")
+    _close(sig.cpu(), sig64, 60.0, "sigma")
+    sdm = {"net." + k: v.detach().double().cpu() for k, v in model.time_deform_nets[0].state_dict().items()}
+    f64 = O.motion_net(sdm, "net", torch.cat([pos, t.view(n, 1, 1).repeat(1, s, 1)], -1).double().cpu())
+    _close(flow.cpu(), f64, 1.0, "flow")
