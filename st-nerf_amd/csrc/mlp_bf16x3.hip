@@ -45,6 +45,24 @@ constexpr int BX_LDS = BX_LDS_RING + BX_LDS_ENC + BX_LDS_CONST + 16 + STNERF_MAX
 static_assert(BX_LDS <= 160 * 1024, "bf16x3 stage kernel: LDS budget");
 
 #define BX_SB() __builtin_amdgcn_sched_barrier(0)
+
+// Optional per-phase cycle accounting (development builds: -DSTNERF_BX_PROF, tools/bx_prof.py): every wave adds its clock
+// deltas per phase; read back with stnerf_debug_bx_phases().
+#ifdef STNERF_BX_PROF
+static __device__ unsigned long long g_bxphase[16];
+struct BxProf {
+    unsigned long long t, acc[16];
+};
+#define BXP_PARAM , BxProf& bp
+#define BXP_ARG , bp
+#define BXP(i) do { const unsigned long long n_ = clock64(); bp.acc[i] += n_ - bp.t; bp.t = n_; } while (0)
+#else
+#define BXP_PARAM
+#define BXP_ARG
+#define BXP(i) do { } while (0)
+#endif
+enum { BXP_TOP = 0, BXP_MOTION_ENC = 1, BXP_MOTION_PASS = 2, BXP_MOTION_FIN = 3, BXP_PE = 4, BXP_PASS = 5, BXP_PARK = 6, BXP_ACT = 7,
+       BXP_LOADC = 8, BXP_SIGMA = 9, BXP_RGB_TAIL = 10, BXP_END = 11, BXP_ITEMS = 12 };
 // s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt = [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8])
 #define BX_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 0xf) | (((n) >> 4) << 14) | 0x0f70)
 
@@ -94,7 +112,7 @@ struct Ctx {
     uint32_t gc;        // slots consumed so far
     char* ring;
     int wave, lane;
-    ABuf A[2];
+    ABuf A[4];
 };
 
 __device__ __forceinline__ const char* feed_next(Ctx& cx) {
@@ -111,14 +129,32 @@ __device__ __forceinline__ const char* feed_next(Ctx& cx) {
     return p;
 }
 
-// this wave's quarter (6 x 1 KB) of the next slot of the stream on its way into ring slot gi & 3
-__device__ __forceinline__ void dma_issue(Ctx& cx) {
-    const char* s = feed_next(cx) + cx.wave * (6 * BX_CHUNK) + cx.lane * 16;
-    auto d = (__attribute__((address_space(3))) char*)(cx.ring) + (cx.gi & (BX_RING - 1)) * BX_SLOT + cx.wave * (6 * BX_CHUNK);
-#pragma unroll
-    for (int c = 0; c < 6; ++c)
-        __builtin_amdgcn_global_load_lds(s + c * BX_CHUNK, (__attribute__((address_space(3))) void*)(d + c * BX_CHUNK), 16, 0, 0);
+// This wave's quarter (6 x 1 KB) of the next slot of the stream on its way into ring slot gi & 3.  Issued in a clump, the
+// six LDS-DMA instructions (each with its M0 write) hold the wave's issue port for ~240 cycles with one MFMA in flight to
+// cover them (tools/micro/bf16x3_proto.hip: 5 of 42 cycles per MFMA); dma_begin() does the scalar part at the slot turn,
+// dma_chunk<c>() goes out one behind each of the MFMAs of the slot's last two units that carry no operand read.
+struct Dma {
+    const char* src;                                  // this lane's source address of chunk 0
+    __attribute__((address_space(3))) char* dst;      // (wave-uniform) LDS destination of chunk 0
+};
+__device__ __forceinline__ void dma_begin(Ctx& cx, Dma& d) {
+    d.src = feed_next(cx) + cx.wave * (6 * BX_CHUNK) + cx.lane * 16;
+    d.dst = (__attribute__((address_space(3))) char*)(cx.ring) + (cx.gi & (BX_RING - 1)) * BX_SLOT + cx.wave * (6 * BX_CHUNK);
     cx.gi += 1;
+}
+template <int C>
+__device__ __forceinline__ void dma_chunk(const Dma& d) {
+    __builtin_amdgcn_global_load_lds(d.src + C * BX_CHUNK, (__attribute__((address_space(3))) void*)(d.dst + C * BX_CHUNK), 16, 0, 0);
+}
+__device__ __forceinline__ void dma_issue(Ctx& cx) {   // (all six at once: priming)
+    Dma d;
+    dma_begin(cx, d);
+    dma_chunk<0>(d);
+    dma_chunk<1>(d);
+    dma_chunk<2>(d);
+    dma_chunk<3>(d);
+    dma_chunk<4>(d);
+    dma_chunk<5>(d);
 }
 
 // A operands: ds_read_b128 straight into AGPRs, as asm -- the compiler does not count these reads; a_wait() is their
@@ -138,15 +174,18 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, co
 }
 
 // One unit = the six MFMAs of (K step, feature block): five into `small` (the first of a pass starts it from 0), a0 b0
-// into `big`.  U = position in the slot (K step U >> 2, block U & 3); the reads of unit U + 2 go out behind the first three
-// MFMAs (the buffer they fill was consumed by unit U - 2).
-template <int U, bool FIRST, bool BIG0 = false>
-__device__ __forceinline__ void unit(Ctx& cx, f32x16& big, f32x16& small, const bf16x8& b0, const bf16x8& b1, const bf16x8& b2) {
-    ABuf& cur = cx.A[U & 1];
-    ABuf& nx = cx.A[(U + 1) & 1];
-    constexpr int OFF = ((U + 1) & 7) * BX_UNIT;
-    const uint32_t ra = (U + 1) < 8 ? cx.rcur : cx.rnext;
-    a_wait<0>(cur);
+// into `big`.  U = position in the slot (K step U >> 2, block U & 3); the reads of unit U + 2 go out one behind each of the
+// first three MFMAs (four buffers; the one they fill was consumed by unit U - 2).  With the reads only one unit ahead --
+// 160 cycles -- the K passes ran at 1.33 x their MFMA time (tools/bx_prof.py): the LDS round trip under four waves' load is
+// longer than that.
+template <int U, bool FIRST, bool BIG0 = false, int DMA0 = -1>
+__device__ __forceinline__ void unit(Ctx& cx, f32x16& big, f32x16& small, const bf16x8& b0, const bf16x8& b1, const bf16x8& b2,
+                                     const Dma* dma = nullptr) {
+    ABuf& cur = cx.A[U & 3];
+    ABuf& nx = cx.A[(U + 2) & 3];
+    constexpr int OFF = ((U + 2) & 7) * BX_UNIT;
+    const uint32_t ra = (U + 2) < 8 ? cx.rcur : cx.rnext;
+    a_wait<3>(cur);   // (the three reads of unit U + 1 may stay in flight)
     BX_SB();
     if (FIRST) {
         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -156,28 +195,46 @@ __device__ __forceinline__ void unit(Ctx& cx, f32x16& big, f32x16& small, const 
     }
     BX_SB();
     a_read<OFF>(nx.p[0], ra);
-    a_read<OFF + BX_CHUNK>(nx.p[1], ra);
-    a_read<OFF + 2 * BX_CHUNK>(nx.p[2], ra);
     BX_SB();
     small = mfma_bf16(cur.p[0], b2, small);
+    BX_SB();
+    a_read<OFF + BX_CHUNK>(nx.p[1], ra);
+    BX_SB();
     small = mfma_bf16(cur.p[1], b1, small);
+    BX_SB();
+    a_read<OFF + 2 * BX_CHUNK>(nx.p[2], ra);
+    BX_SB();
     small = mfma_bf16(cur.p[1], b0, small);
+    if (DMA0 >= 0) {
+        BX_SB();
+        dma_chunk<DMA0 < 0 ? 0 : DMA0>(*dma);
+        BX_SB();
+    }
     small = mfma_bf16(cur.p[0], b1, small);
+    if (DMA0 >= 0) {
+        BX_SB();
+        dma_chunk<DMA0 < 0 ? 0 : DMA0 + 1>(*dma);
+        BX_SB();
+    }
     if (FIRST && BIG0) {  // (rgb_net.1: its C operand is added behind the K loop, see space_bx)
         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         big = mfma_bf16(cur.p[0], b0, z);
     } else {
         big = mfma_bf16(cur.p[0], b0, big);
     }
+    if (DMA0 >= 0) {
+        BX_SB();
+        dma_chunk<DMA0 < 0 ? 0 : DMA0 + 2>(*dma);
+    }
     BX_SB();
 }
 
 // Between units 5 and 6 of a slot: the next slot has landed everywhere and the previous one is free everywhere (every wave
 // has issued -- and, to get here, completed -- its reads of it); the fetch three slots ahead goes into its place.
-__device__ __forceinline__ void slot_turn(Ctx& cx) {
+__device__ __forceinline__ void slot_turn(Ctx& cx, Dma& d) {
     BX_VMCNT(6);
     __builtin_amdgcn_s_barrier();
-    dma_issue(cx);
+    dma_begin(cx, d);
     BX_SB();
 }
 __device__ __forceinline__ void slot_done(Ctx& cx) {
@@ -196,9 +253,10 @@ __device__ __forceinline__ void slot(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[
     unit<3, FIRST, BIG0>(cx, big[3], small[3], k0p0, k0p1, k0p2);
     unit<4, false>(cx, big[0], small[0], k1p0, k1p1, k1p2);
     unit<5, false>(cx, big[1], small[1], k1p0, k1p1, k1p2);
-    unit<6, false>(cx, big[2], small[2], k1p0, k1p1, k1p2);
-    slot_turn(cx);
-    unit<7, false>(cx, big[3], small[3], k1p0, k1p1, k1p2);
+    Dma d;
+    slot_turn(cx, d);
+    unit<6, false, false, 0>(cx, big[2], small[2], k1p0, k1p1, k1p2, &d);
+    unit<7, false, false, 3>(cx, big[3], small[3], k1p0, k1p1, k1p2, &d);
     slot_done(cx);
 }
 
@@ -392,24 +450,28 @@ __device__ __forceinline__ void enc_to_act(const float* encw, int lane, bf16x8 (
 // MotionNet on the wave's 32 samples: p += flow (modeling/layered_rfrender.py:356,510).  19 slots.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void motion_bx(Ctx& cx, const float* net, const float* cm, float* encw, float (&p)[3], float tv, int flags,
-                                          f32x16 (&big)[4], f32x16 (&small)[4], bf16x8 (&act)[3][16]) {
+                                          int lane, f32x16 (&big)[4], f32x16 (&small)[4], bf16x8 (&act)[3][16] BXP_PARAM) {
     const MotionLayout L = motion_layout();
-    const int lane = cx.lane;
     encode_motion(encw, lane, p, tv, flags);
     wave_lds_sync();
     enc_to_act<6, WV_ENC_QUADS>(encw, lane, act);
     load_c(big, cm + BXM_B, lane);
+    BXP(BXP_MOTION_ENC);
     pass_act<0, 3, true>(cx, big, small, act);  // motion_net.0: 84 (+4) inputs, 6 K steps
+    BXP(BXP_MOTION_PASS);
 #pragma unroll 1
     for (int li = 1; li <= 4; ++li) {
         finish_act<0>(big, small, act);
         load_c(big, cm + BXM_B + 128 * li, lane);
+        BXP(BXP_MOTION_FIN);
         pass_act<0, 4, true>(cx, big, small, act);
+        BXP(BXP_MOTION_PASS);
     }
     float fl[3];
     head3(big, small, cm + BXM_W_OUT, net + L.b_out, lane, fl);
 #pragma unroll
     for (int c3 = 0; c3 < 3; ++c3) p[c3] = p[c3] + fl[c3];
+    BXP(BXP_MOTION_FIN);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -418,23 +480,29 @@ __device__ __forceinline__ void motion_bx(Ctx& cx, const float* net, const float
 // ---------------------------------------------------------------------------------------------
 template <bool DEEP, class Mid>
 __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool use_time, const float* cs, float* encw, const float (&p)[3],
-                                           const float* __restrict__ raybias, int32_t ray, f32x16 (&big)[4], f32x16 (&small)[4],
-                                           bf16x8 (&act)[3][16], Mid mid) {
+                                           const float* __restrict__ raybias, int32_t ray, int lane, f32x16 (&big)[4], f32x16 (&small)[4],
+                                           bf16x8 (&act)[3][16], Mid mid BXP_PARAM) {
     const SpaceLayout L = space_layout(use_time, DEEP);
-    const int lane = cx.lane;
     const int h = lane >> 5;
     Park pk;
     encode_pos(encw, lane, p);
     wave_lds_sync();
     enc_to_act<4, 16>(encw, lane, act);
+    BXP(BXP_PE);
     // ---- stage1.0: 63 (+1) -> 256
     load_c(big, cs + BXC_B, lane);
+    BXP(BXP_LOADC);
     pass_act<0, 2, true>(cx, big, small, act);
+    BXP(BXP_PASS);
     finish_park(big, small, pk);
+    BXP(BXP_PARK);
     load_c(big, cs + BXC_B + 128, lane);
+    BXP(BXP_LOADC);
     pass_act<0, 2, true>(cx, big, small, act);
+    BXP(BXP_PASS);
     finish_act<8>(big, small, act);
     unpark_act(pk, act);
+    BXP(BXP_ACT);
     // ---- stage1.2 .. stage2.4: six 256-wide layers, two passes each; stage2.0 (li == 4) takes PE(pos) again behind its 256
     // features (modeling/spacenet.py:45-57,136-138): four more K steps per pass, their B operands split on the spot from the
     // staged encoding (the activation planes are full)
@@ -463,16 +531,22 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     // accumulators on one of two paths and the register allocator answers with ~200 spills)
     auto layer = [&](int li, auto with_pe) {
         load_c(big, cs + BXC_B + 256 * li, lane);
+        BXP(BXP_LOADC);
         pass_act<0, 8, true>(cx, big, small, act);
         if constexpr (decltype(with_pe)::value) pe_slots();
+        BXP(BXP_PASS);
         finish_park(big, small, pk);
+        BXP(BXP_PARK);
         load_c(big, cs + BXC_B + 256 * li + 128, lane);
+        BXP(BXP_LOADC);
         pass_act<0, 8, true>(cx, big, small, act);
         if constexpr (decltype(with_pe)::value) pe_slots();
+        BXP(BXP_PASS);
     };
     auto layer_end = [&]() {
         finish_act<8>(big, small, act);
         unpark_act(pk, act);
+        BXP(BXP_ACT);
     };
 #pragma unroll 1
     for (int li = 1; li <= 3; ++li) {
@@ -488,6 +562,7 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
         if (li == 6) {  // sigma = density_net(h) (:139), raw; the next work item's HBM loads go out in front of it
             mid();
             sigma = sigma_head(big, small, pk, cs + BXC_W_SIGMA, net[L.b_sigma], lane);
+            BXP(BXP_SIGMA);
         }
         layer_end();
     }
@@ -498,6 +573,7 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     // 1.3 x the fp32 CPU chain's error instead of 0.5 x).  Its 16 loads go out in front of the pass's last slot (14 of the 16
     // K steps' activation registers are dead by then).
     pass_act<0, 7, true, true>(cx, big, small, act);
+    BXP(BXP_PASS);
     {
         float4 crow[4][4];
         const float* row = raybias + (int64_t)ray * 128 + 4 * h;
@@ -506,6 +582,7 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
 #pragma unroll
             for (int q = 0; q < 4; ++q) crow[fb][q] = *reinterpret_cast<const float4*>(row + fb * 32 + 8 * q);
         pass_act<14, 1, false>(cx, big, small, act);
+        BXP(BXP_PASS);
 #pragma unroll
         for (int fb = 0; fb < 4; ++fb) {
 #pragma unroll
@@ -530,6 +607,7 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     }
     float rgb[3];
     head3(big, small, cs + BXC_W_RGB2, net + L.b_rgb2, lane, rgb);
+    BXP(BXP_RGB_TAIL);
     return make_float4(rgb[0], rgb[1], rgb[2], sigma);
 }
 
@@ -662,9 +740,17 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_bf16x3_stage_kernel(StageAr
     a_read<0>(cx.A[0].p[0], cx.rcur);
     a_read<BX_CHUNK>(cx.A[0].p[1], cx.rcur);
     a_read<2 * BX_CHUNK>(cx.A[0].p[2], cx.rcur);
+    a_read<BX_UNIT>(cx.A[1].p[0], cx.rcur);
+    a_read<BX_UNIT + BX_CHUNK>(cx.A[1].p[1], cx.rcur);
+    a_read<BX_UNIT + 2 * BX_CHUNK>(cx.A[1].p[2], cx.rcur);
     int par = 0;
     f32x16 big[4], small[4];
     bf16x8 act[3][16];
+#ifdef STNERF_BX_PROF
+    BxProf bp;
+    for (int i = 0; i < 16; ++i) bp.acc[i] = 0;
+    bp.t = clock64();
+#endif
     while (it0 < total) {
         // the item after next (consumed at the end of this one) and the ray index of the next item's sample
         uint32_t pending = 0;
@@ -691,9 +777,15 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_bf16x3_stage_kernel(StageAr
         for (int c3 = 0; c3 < 3; ++c3) p[c3] = cur.p[c3];
         BX_VMCNT(0);
         __builtin_amdgcn_s_barrier();
-        if (ly.motion) motion_bx(cx, ly.motion, cm, encw, p, cur.tv, ly.motion_flags, big, small, act);
-        float4 o = space_bx<DEEP>(cx, ly.space, ly.use_time != 0, cs, encw, p, ly.raybias, cur.ray, big, small, act,
-                                  [&]() { fetch(it1, rr_next, nxt); });
+        BXP(BXP_TOP);
+        // (the lane index the networks see is opaque per item: hoisted out of the item loop, the per-lane LDS addresses and
+        // constants derived from it -- ~40 registers of the encodings alone -- do not fit beside the loop's live values and
+        // come back from scratch, each reload behind a vmcnt(0) that also drains the weight ring's DMA queue)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        if (ly.motion) motion_bx(cx, ly.motion, cm, encw, p, cur.tv, ly.motion_flags, ln, big, small, act BXP_ARG);
+        float4 o = space_bx<DEEP>(cx, ly.space, ly.use_time != 0, cs, encw, p, ly.raybias, cur.ray, ln, big, small, act,
+                                  [&]() { fetch(it1, rr_next, nxt); } BXP_ARG);
         if (cur.valid && lane < 32) {
             if (a.sigmoid_rgb) {  // torch.sigmoid(rgb): 1-ulp v_exp_f32 / v_rcp_f32, the same expression the compositor uses
                 o.x = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(o.x * -1.44269504088896340736f));
@@ -713,8 +805,16 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_bf16x3_stage_kernel(StageAr
         cx.seg[0] = cx.seg[2];
         cx.seg[1] = cx.seg[3];
         segs_of(it1, cx.seg[2], cx.seg[3]);
+        BXP(BXP_END);
+#ifdef STNERF_BX_PROF
+        bp.acc[BXP_ITEMS] += 1;
+#endif
     }
     BX_VMCNT(0);  // (no LDS-DMA may outlive the workgroup)
+#ifdef STNERF_BX_PROF
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_bxphase[i], bp.acc[i]);
+#endif
 }
 
 int launch_bf16x3_stage(const StageArgs& a, bool deep_rgb, int cus, hipStream_t stream) {
@@ -732,6 +832,17 @@ int launch_bf16x3_stage(const StageArgs& a, bool deep_rgb, int cus, hipStream_t 
 }
 
 }  // namespace stnerf
+
+#ifdef STNERF_BX_PROF
+extern "C" int stnerf_debug_bx_phases(unsigned long long* host16, int reset) {
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(stnerf::g_bxphase), sizeof(unsigned long long) * 16) != hipSuccess) return STNERF_ELAUNCH;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(stnerf::g_bxphase), z, sizeof(z)) != hipSuccess) return STNERF_ELAUNCH;
+    }
+    return STNERF_OK;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Host: the packer

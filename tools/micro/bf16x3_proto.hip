@@ -31,7 +31,7 @@ constexpr int SLOT = 24576;   // one K step of 16 for 256 outputs: 8 feature blo
 constexpr int RING = 4;
 constexpr int NLMAX = 8;
 
-enum { F_CONV = 1, F_BAR = 2, F_LDS = 4, F_DMA = 8, F_ALL = 15 };
+enum { F_CONV = 1, F_BAR = 2, F_LDS = 4, F_DMA = 8, F_ALL = 15, F_NOWAITV = 16, F_SPREAD = 32, F_NOISSUE = 64 };
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     f32x2 v = {a, b};
@@ -66,14 +66,14 @@ __device__ __forceinline__ float relu_bits(float x) {
 #define VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 0xf) | (((n) >> 4) << 14) | 0x0f70)
 
 // the wave's quarter of ring slot `g` (6 x 1 KB) on its way
-template <int FLAGS>
+template <int FLAGS, int C0 = 0, int C1 = 6>
 __device__ __forceinline__ void dma_slot(const char* blob, unsigned g, unsigned nslots, char* ring, int wave, int lane) {
-    if (!(FLAGS & F_DMA)) return;
+    if (!(FLAGS & F_DMA) || (FLAGS & F_NOISSUE)) return;
     const unsigned src = g % nslots;
     const char* s = blob + (size_t)src * SLOT + wave * 6144 + lane * 16;
     auto d = (__attribute__((address_space(3))) char*)(ring) + (g % RING) * SLOT + wave * 6144;
 #pragma unroll
-    for (int c = 0; c < 6; ++c)
+    for (int c = C0; c < C1; ++c)
         __builtin_amdgcn_global_load_lds(s + c * 1024, (__attribute__((address_space(3))) void*)(d + c * 1024), 16, 0, 0);
 }
 
@@ -146,13 +146,36 @@ __device__ __forceinline__ void layer256(f32x16 (&acc)[8], const bf16x8 (&act)[3
         mma_pair(acc[4], acc[5], Ax, act[0][s], act[1][s], act[2][s]);
         __builtin_amdgcn_sched_barrier(0);
         // slot g + 1 landed everywhere, slot g - 1 is free everywhere
-        if (FLAGS & F_DMA) VMCNT(6);
+        if ((FLAGS & F_DMA) && !(FLAGS & F_NOWAITV)) VMCNT(6);
         if (FLAGS & F_BAR) __builtin_amdgcn_s_barrier();
-        dma_slot<FLAGS>(blob, g + 3, nslots, ring, wave, lane);
+        if (!(FLAGS & F_SPREAD)) dma_slot<FLAGS>(blob, g + 3, nslots, ring, wave, lane);
         __builtin_amdgcn_sched_barrier(0);
         wait_pair(Ay);
         read_pair<FLAGS>(Ax, nslot, 0, lane);
         __builtin_amdgcn_sched_barrier(0);
+        if (FLAGS & F_SPREAD) {
+            // the six DMA instructions one behind each of the first MFMAs of the pair
+            const bf16x8 &b0 = act[0][s], &b1 = act[1][s], &b2 = act[2][s];
+            f32x16 &c0 = acc[6], &c1 = acc[7];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay.a[0][2], b0, c0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0); dma_slot<FLAGS, 0, 1>(blob, g + 3, nslots, ring, wave, lane); __builtin_amdgcn_sched_barrier(0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay.a[1][2], b0, c1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0); dma_slot<FLAGS, 1, 2>(blob, g + 3, nslots, ring, wave, lane); __builtin_amdgcn_sched_barrier(0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay.a[0][0], b2, c0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0); dma_slot<FLAGS, 2, 3>(blob, g + 3, nslots, ring, wave, lane); __builtin_amdgcn_sched_barrier(0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay.a[1][0], b2, c1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0); dma_slot<FLAGS, 3, 4>(blob, g + 3, nslots, ring, wave, lane); __builtin_amdgcn_sched_barrier(0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay.a[0][1], b1, c0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0); dma_slot<FLAGS, 4, 5>(blob, g + 3, nslots, ring, wave, lane); __builtin_amdgcn_sched_barrier(0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay.a[1][1], b1, c1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0); dma_slot<FLAGS, 5, 6>(blob, g + 3, nslots, ring, wave, lane); __builtin_amdgcn_sched_barrier(0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay.a[0][1], b0, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay.a[1][1], b0, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay.a[0][0], b1, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay.a[1][0], b1, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay.a[0][0], b0, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ay.a[1][0], b0, c1, 0, 0, 0);
+        } else
         mma_pair(acc[6], acc[7], Ay, act[0][s], act[1][s], act[2][s]);
         g += 1;
         __builtin_amdgcn_sched_barrier(0);
@@ -499,6 +522,14 @@ int main(int argc, char** argv) {
     run_proto<F_CONV>("conversion only (no LDS/DMA/barrier)", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
     run_proto<0>("MFMAs only", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
     run_proto<F_ALL>("full, 64 workgroups", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, 64);
+    run_proto<(F_ALL & ~F_CONV)>("no conv", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
+    run_proto<(F_ALL & ~F_CONV) | F_NOWAITV>("no conv, DMA issued, no vmcnt wait (racy)", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
+    run_proto<(F_ALL & ~F_CONV) | F_NOISSUE>("no conv, vmcnt wait + barrier, DMA not issued", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
+    run_proto<(F_ALL & ~F_CONV) | F_SPREAD>("no conv, DMA spread behind MFMAs", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
+    run_proto<(F_ALL & ~F_CONV & ~F_BAR) | F_SPREAD>("no conv, DMA spread, no barrier (racy)", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
+    run_proto<(F_ALL & ~F_CONV & ~F_BAR) | F_SPREAD | F_NOWAITV>("no conv, DMA spread, no barrier, no wait (racy)", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
+    run_proto<(F_ALL & ~F_CONV & ~F_LDS)>("no conv, no ds_read", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
+    if (argc > 1) return 0;
     // ---- 3. shadow
     run_shadow<0, 8>(d_out, d_cyc);
     run_shadow<0, 4>(d_out, d_cyc);
