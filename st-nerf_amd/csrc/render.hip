@@ -1068,8 +1068,10 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
     if (n == 0) return STNERF_OK;
     STNERF_REQUIRE((int64_t)l * S <= 65535, "composite: more than 65535 samples per ray");
     const int64_t per_wave = (((int64_t)l * S * 22 + 15) / 16) * 16;
-    int wpb = (int)((150 * 1024) / per_wave);
-    STNERF_REQUIRE(wpb >= 1, "composite: %d samples per ray do not fit the 160 KiB LDS", l * S);
+    constexpr int64_t LDS_BUDGET = 150 * 1024;   // of the CU's 160 KiB: the rest stays with the kernel's static LDS
+    int wpb = (int)(LDS_BUDGET / per_wave);
+    STNERF_REQUIRE(wpb >= 1, "composite: %d samples per ray need %lld B of LDS per wave, more than the %lld B this kernel may use", l * S,
+                   (long long)per_wave, (long long)LDS_BUDGET);
     if (wpb > 4) wpb = 4;
     const int lds = (int)(per_wave * wpb);
     if (lds > 64 * 1024) {

@@ -5,9 +5,19 @@ The reference has no plugin interface: its callers bind the render-path symbols 
 render/layered_neural_renderer.py:7-8; ``from layers.RaySamplePoint import RaySamplePoint``,
 demo/taekwondo_demo.py:21).  ``patch_reference`` therefore imports the reference's OWN ``modeling``, ``utils`` and
 ``layers`` packages -- so everything this framework does not replace (``add_two_dim_dict``, ``make_loss``,
-``utils.logger``, ``vis_density``, the datasets, the trainer ...) stays exactly what it was -- and rebinds only the
+``utils.logger``, ``vis_density``, the datasets ...) stays exactly what it was -- and rebinds only the
 render-path symbols to the HIP implementation, in those packages and in every already-imported reference module
-that holds one of the originals.  Two lines at the top of a reference script::
+that holds one of the originals.
+
+**Patching makes the model inference-only.**  The replacements (LayeredRFRender, SpaceNet, MotionNet, RaySamplePoint,
+sample_pdf, Trigonometric_kernel, VolumeRenderer) run on the MI355X only -- CPU tensors are refused -- and have no
+backward pass: ``engine.layered_trainer`` would fail at ``loss.backward()``, so ``LayeredRFRender.forward`` raises a
+clear error as soon as it is called with autograd enabled on trainable parameters; NEAR_FAR sampling, USE_DEFORM_VIEW
+and POSE_REFINEMENT configurations are refused by the constructor.  Render / demo / evaluation scripts (which run under
+``torch.no_grad()``, render/layered_neural_renderer.py:377) are what this is for; train with the reference's own model
+(``patch.undo()`` restores it).  Models built after patching draw fresh jitter / resampling numbers on every forward
+call, as the reference's torch.rand does (``model.fresh_draws_per_call``; set ``model.seed`` and switch it off for
+reproducible frames).  Two lines at the top of a reference script::
 
     import stnerf_amd.dropin
     stnerf_amd.dropin.patch_reference("/path/to/st-nerf")
@@ -180,6 +190,11 @@ def patch_reference(reference_root: Optional[str] = None, device_ray_generation:
             if new is not None and val is not new:
                 patch.rebound.append((mod, name, val))
                 setattr(mod, name, new)
+    # models the reference's code builds from here on draw fresh jitter / resampling numbers per forward call, as its
+    # torch.rand does (layers/RaySamplePoint.py:98, utils/sample_pdf.py:31)
+    from stnerf_amd.modeling.layered_rfrender import LayeredRFRender as _LRF
+    patch.class_attrs.append((_LRF, "FRESH_DRAWS_DEFAULT", _LRF.FRESH_DRAWS_DEFAULT))
+    _LRF.FRESH_DRAWS_DEFAULT = True
     if device_ray_generation:
         try:
             ray_dataset = importlib.import_module("data.datasets.ray_dataset")

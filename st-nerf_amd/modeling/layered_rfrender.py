@@ -78,6 +78,11 @@ class LayeredRFRender(nn.Module):
         self.bboxes = None
         # MI355X-side knobs (not in the reference)
         self.seed = 0                      # Philox seed of the on-device jitter / resampling draws
+        self.fresh_draws_per_call = type(self).FRESH_DRAWS_DEFAULT  # True: every forward() advances `seed` (the reference draws fresh torch.rand
+                                           # numbers per call, layers/RaySamplePoint.py:98, utils/sample_pdf.py:31);
+                                           # False: a call is a pure function of (rays, weights, seed) -- what the
+                                           # sharded / chunked renders and the tests rely on.  dropin.patch_reference
+                                           # switches it on for models built through the reference's own code
         self.max_rays_per_launch = 1 << 19 # rays per kernel sequence (workspace bound ~20 KB/ray, not a semantic chunk)
         self.replay = None                 # {"jitter": (l,N,N1), "u": (l,N,N2)} to replay recorded uniforms
         self.mlp_schedule = "stage"        # "stage": one persistent MLP launch per stage (stnerf_mlp_stage); "per_net":
@@ -86,6 +91,7 @@ class LayeredRFRender(nn.Module):
                                            # keeps the RNG stream of a view under multi-GPU sharding
 
     F16_LATCH_AFTER = 8    # fp16x3 range-guard fallbacks after which the model stays in exact f32
+    FRESH_DRAWS_DEFAULT = False   # what a new model's fresh_draws_per_call starts as (dropin.patch_reference: True)
 
     def set_precision(self, precision: str):
         """"fp32" (default: exact f32 MFMA), "bf16x3" (three bf16 pieces per operand, six MFMAs per product, two
@@ -281,6 +287,10 @@ class LayeredRFRender(nn.Module):
         from row 0 of every ``ref_chunk``-ray piece) while launching kernels over far larger pieces."""
         if not rays.is_cuda:
             raise RuntimeError("rays must live on the GPU: the MI355X render path has no CPU fallback")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("LayeredRFRender (MI355X) is inference-only: the HIP render path has no backward pass.  Call it "
+                               "under torch.no_grad() (render/layered_neural_renderer.py:377 does) or freeze the parameters; "
+                               "training stays with the reference's own model")
         rays = rays.contiguous().float()
         N, L = rays.shape[0], self.layer_num
         width = rays.shape[1]
@@ -335,6 +345,8 @@ class LayeredRFRender(nn.Module):
         fine_layer = [trip(lo_f[:, i]) for i in range(l)]
         coarse_layer = [trip(lo_c[:, i]) for i in range(l)]
         ray_mask = [mask[:, i].bool() for i in range(l)]
+        if self.fresh_draws_per_call and self.replay is None:
+            self.seed = (int(self.seed) + 1) & 0xFFFFFFFFFFFFFFFF   # the next call draws new jitter / resampling numbers
         return trip(mix_f), trip(mix_c), fine_layer, coarse_layer, ray_mask
 
     def forward(self, rays, labels=None, bboxes=None, only_coarse=False, near_far=None, near_far_points=[],

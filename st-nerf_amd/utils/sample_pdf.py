@@ -1,16 +1,33 @@
 """Inverse-CDF importance resampling with the reference's signature (utils/sample_pdf.py:18-63), computed by the
 wave-scan resampler (csrc/render.hip: ``stnerf_resample``)."""
+import itertools
+
+import numpy as np
 import torch
 
 from stnerf_amd import ops
 
+_calls = itertools.count()   # seed of the device Philox stream when the caller names none: fresh draws per call (:31)
 
-def sample_pdf(z_vals, weights, N_samples, det=False, pytest=False, u=None, seed=0):
+
+def sample_pdf(z_vals, weights, N_samples, det=False, pytest=False, u=None, seed=None):
     """utils/sample_pdf.py:18-63: z_vals (n,N1), weights (n,N1-2) -> new samples (n,N_samples).
-    ``u`` (n,N_samples) replays uniform draws; default is the device Philox stream."""
-    if det or pytest:
-        n = z_vals.shape[0]
+    ``u`` (n,N_samples) replays uniform draws.  Otherwise, as the reference: ``det`` -> u = linspace(0, 1, N_samples) (:28-29);
+    ``pytest`` -> numpy's seed-0 stream, np.random.seed(0) + np.random.rand(n, N_samples) (:33-42; with ``det`` the
+    same linspace, broadcast); else fresh uniform draws -- the device Philox stream, keyed by ``seed`` if given and by
+    a per-process call counter if not."""
+    n = z_vals.shape[0]
+    if pytest:
+        np.random.seed(0)                       # (:36: the reference reseeds numpy's GLOBAL stream; so does this)
+        if det:
+            un = np.broadcast_to(np.linspace(0., 1., N_samples), (n, N_samples))
+        else:
+            un = np.random.rand(n, N_samples)
+        u = torch.as_tensor(np.ascontiguousarray(un), dtype=torch.float32, device=z_vals.device)   # torch.Tensor(u) (:41)
+    elif det:
         u = torch.linspace(0., 1., steps=N_samples, device=z_vals.device).expand(n, N_samples).contiguous()
+    if seed is None:
+        seed = next(_calls)
     n, n1 = z_vals.shape
     pad = torch.zeros(n, 1, device=z_vals.device)
     wfull = torch.cat([pad, weights, pad], -1).reshape(n, 1, n1).contiguous()

@@ -145,6 +145,35 @@ def test_reference_callers_import_after_patch(reference_env):
     assert not _is_ours(modeling.build_layered_model) and not _is_ours(lnr.layered_batchify_ray)
 
 
+def test_patched_models_are_inference_only_and_draw_fresh_numbers(reference_env):
+    """after patching, models built by the reference's code (a) advance their RNG seed on every forward, as the
+    reference's torch.rand does, (b) refuse to run with autograd enabled on trainable parameters (no backward pass exists);
+    undo() restores the class default."""
+    from stnerf_amd.modeling.layered_rfrender import LayeredRFRender
+    dropin = reference_env
+    assert LayeredRFRender.FRESH_DRAWS_DEFAULT is False
+    dropin.patch_reference(REFERENCE)
+    assert LayeredRFRender.FRESH_DRAWS_DEFAULT is True
+    import modeling
+    m = modeling.build_layered_model(_cfg(8, 4, 2), camera_num=1)
+    assert isinstance(m, LayeredRFRender) and m.fresh_draws_per_call is True
+    rays = torch.zeros(4, 9)
+    rays.is_cuda_ = True
+    with pytest.raises(RuntimeError, match="GPU"):               # CPU tensors are refused ...
+        m(rays)
+    dropin.unpatch_reference()
+    assert LayeredRFRender.FRESH_DRAWS_DEFAULT is False
+    assert LayeredRFRender(_our_cfg(8, 4, 2), camera_num=1).fresh_draws_per_call is False
+
+
+def _our_cfg(n1, n2, L):
+    from stnerf_amd.config.defaults import get_cfg_defaults
+    cfg = get_cfg_defaults()
+    cfg.MODEL.COARSE_RAY_SAMPLING, cfg.MODEL.FINE_RAY_SAMPLING, cfg.DATASETS.LAYER_NUM = n1, n2, L
+    cfg.MODEL.USE_DEFORM_TIME = cfg.MODEL.USE_SPACE_TIME = True
+    return cfg
+
+
 def test_device_ray_generation_patch(reference_env):
     dropin = reference_env
     dropin.patch_reference(REFERENCE, device_ray_generation=True)

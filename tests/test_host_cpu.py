@@ -163,3 +163,35 @@ def test_aten_cumsum_accumulates_in_double():
     p = torch.rand(300, 126) ** 8
     p = p / p.sum(-1, keepdim=True)
     assert torch.equal(torch.cumsum(p, -1), torch.cumsum(p.double(), -1).float())
+
+
+def test_sample_pdf_host_flags_follow_the_reference(monkeypatch):
+    """utils/sample_pdf.py:26-42: det -> linspace; pytest -> numpy's seed-0 stream (np.random.seed(0); np.random.rand(n, N)),
+    or the linspace broadcast when det is set too; otherwise fresh draws per call (:31) -- here: the device stream under a
+    seed that changes from call to call unless the caller names one.  Host logic only: the native call is intercepted."""
+    from stnerf_amd import ops
+    from stnerf_amd.utils import sample_pdf as mod
+    seen = []
+
+    def fake_resample(t, w, n2, rays, u=None, seed=0, **kw):
+        seen.append((None if u is None else u.clone(), seed))
+        n = t.shape[0]
+        return None, None, torch.zeros(n, 1, n2)
+    monkeypatch.setattr(ops, "resample", fake_resample)
+    n, n1, n2 = 5, 12, 7
+    z = torch.sort(torch.rand(n, n1), -1)[0]
+    w = torch.rand(n, n1 - 2)
+    mod.sample_pdf(z, w, n2, det=True)
+    assert torch.equal(seen[-1][0].reshape(n, n2), torch.linspace(0., 1., n2).expand(n, n2))
+    mod.sample_pdf(z, w, n2, pytest=True)
+    np.random.seed(0)
+    want = torch.as_tensor(np.random.rand(n, n2), dtype=torch.float32)
+    assert torch.equal(seen[-1][0].reshape(n, n2), want)                      # the reference's numbers, bit for bit
+    mod.sample_pdf(z, w, n2, det=True, pytest=True)
+    assert torch.equal(seen[-1][0].reshape(n, n2), torch.linspace(0., 1., n2).expand(n, n2))
+    mod.sample_pdf(z, w, n2)
+    mod.sample_pdf(z, w, n2)
+    assert seen[-1][0] is None and seen[-2][0] is None and seen[-1][1] != seen[-2][1]     # fresh draws per call
+    mod.sample_pdf(z, w, n2, seed=9)
+    mod.sample_pdf(z, w, n2, seed=9)
+    assert seen[-1][1] == seen[-2][1] == 9                                     # reproducible on request
