@@ -158,12 +158,13 @@ def test_patched_models_are_inference_only_and_draw_fresh_numbers(reference_env)
     m = modeling.build_layered_model(_cfg(8, 4, 2), camera_num=1)
     assert isinstance(m, LayeredRFRender) and m.fresh_draws_per_call is True
     rays = torch.zeros(4, 9)
-    rays.is_cuda_ = True
     with pytest.raises(RuntimeError, match="GPU"):               # CPU tensors are refused ...
         m(rays)
     dropin.unpatch_reference()
     assert LayeredRFRender.FRESH_DRAWS_DEFAULT is False
-    assert LayeredRFRender(_our_cfg(8, 4, 2), camera_num=1).fresh_draws_per_call is False
+    cfg = _our_cfg(8, 4, 2)
+    cfg.MODEL.SAMPLE_METHOD, cfg.MODEL.POSE_REFINEMENT, cfg.MODEL.DEEP_RGB = "BBOX", False, False
+    assert LayeredRFRender(cfg, camera_num=1).fresh_draws_per_call is False
 
 
 def _our_cfg(n1, n2, L):
