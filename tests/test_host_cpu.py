@@ -170,7 +170,8 @@ def test_sample_pdf_host_flags_follow_the_reference(monkeypatch):
     or the linspace broadcast when det is set too; otherwise fresh draws per call (:31) -- here: the device stream under a
     seed that changes from call to call unless the caller names one.  Host logic only: the native call is intercepted."""
     from stnerf_amd import ops
-    from stnerf_amd.utils import sample_pdf as mod
+    import importlib
+    mod = importlib.import_module("stnerf_amd.utils.sample_pdf")
     seen = []
 
     def fake_resample(t, w, n2, rays, u=None, seed=0, **kw):
