@@ -188,8 +188,8 @@ def test_sample_pdf_host_flags_follow_the_reference(monkeypatch):
     np.random.seed(0)
     want = torch.as_tensor(np.random.rand(n, n2), dtype=torch.float32)
     assert torch.equal(seen[-1][0].reshape(n, n2), want)                      # the reference's numbers, bit for bit
-    mod.sample_pdf(z, w, n2, det=True, pytest=True)
-    assert torch.equal(seen[-1][0].reshape(n, n2), torch.linspace(0., 1., n2).expand(n, n2))
+    mod.sample_pdf(z, w, n2, det=True, pytest=True)                            # (:37-39: numpy's float64 linspace, then torch.Tensor(u))
+    assert torch.equal(seen[-1][0].reshape(n, n2), torch.as_tensor(np.linspace(0., 1., n2), dtype=torch.float32).expand(n, n2))
     mod.sample_pdf(z, w, n2)
     mod.sample_pdf(z, w, n2)
     assert seen[-1][0] is None and seen[-2][0] is None and seen[-1][1] != seen[-2][1]     # fresh draws per call
