@@ -76,21 +76,19 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     return *reinterpret_cast<unsigned*>(&h);
 }
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
-    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    // (scalar source on purpose: the compiler pairs the subtractions into v_pk_add_f32 by itself; written on explicit
+    // 2-vectors the value array is not promoted to registers and the split goes through scratch memory)
     u32x4 w0, w1, w2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        // two values per step; the residuals on the packed-f32 subtract (v_pk_add_f32: one issue slot for both)
-        const f32x2_ x = {v[2 * i], v[2 * i + 1]};
-        const unsigned u = pk_bf16(x[0], x[1]);
-        const f32x2_ h = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
-        const f32x2_ r = x - h;
-        const unsigned m = pk_bf16(r[0], r[1]);
-        const f32x2_ g = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
-        const f32x2_ t = r - g;
+        const float x0 = v[2 * i], x1 = v[2 * i + 1];
+        const unsigned u = pk_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(u << 16), r1 = x1 - __uint_as_float(u & 0xffff0000u);
+        const unsigned m = pk_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
         w0[i] = u;
         w1[i] = m;
-        w2[i] = pk_bf16(t[0], t[1]);
+        w2[i] = pk_bf16(s0, s1);
     }
     p0 = *reinterpret_cast<bf16x8*>(&w0);
     p1 = *reinterpret_cast<bf16x8*>(&w1);
@@ -437,8 +435,12 @@ __device__ __forceinline__ void enc_to_act(const float* encw, int lane, bf16x8 (
             if (4 * t + 2 + qq < NQ) {  // (static) both lane halves inside the staged quads
                 x = e4[(4 * t + 2 * h + qq) * WV_ROWS + c];
             } else if (4 * t + qq < NQ) {  // only the lower half
+                // (component by component: a select between two float4 values is lowered to a scratch array indexed by h)
                 const float4 y = e4[(4 * t + qq) * WV_ROWS + c];
-                x = h == 0 ? y : x;
+                x.x = h == 0 ? y.x : 0.f;
+                x.y = h == 0 ? y.y : 0.f;
+                x.z = h == 0 ? y.z : 0.f;
+                x.w = h == 0 ? y.w : 0.f;
             }
             v[4 * qq + 0] = x.x;
             v[4 * qq + 1] = x.y;

@@ -34,3 +34,61 @@ def test_wave_stage_kernel_uses_no_scratch_and_one_wave_per_simd(tmp_path):
     # the hot loop is what it is supposed to be: f32 MFMAs fed from registers, accumulators loaded by LDS reads directly
     assert text.count("v_mfma_f32_32x32x2_f32") >= 2 * 2400
     assert "scratch_load" not in text and "scratch_store" not in text
+
+
+def _compile(src_name, tmp_path, extra=()):
+    src = os.path.join(ROOT, "st-nerf_amd", "csrc", src_name)
+    asm = tmp_path / (src_name + ".s")
+    cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-function", *extra,
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), "-S", "--cuda-device-only", "-o", str(asm), src]
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL, timeout=600)
+    return str(asm)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="no hipcc")
+def test_wave_stage_kernel_vector_instruction_ceiling(tmp_path):
+    """The exact-f32 kernel's distance from the MFMA pipe's own rate IS its vector-instruction count (every VALU /
+    v_accvgpr instruction takes 5 - 6 cycles out of the f32 MFMA stream): a ceiling per region of
+    the work-item loop, from tools/isa_vector_count.py's static count (measured: 1027 / 129 / 779 / 265 / 926), so that a
+    change of compiler or source that adds vector work shows up here and not as a lost percent on the GPU."""
+    out = subprocess.run(["python3", os.path.join(ROOT, "tools", "isa_vector_count.py"), "--asm", _compile("mlp_wave.hip", tmp_path)],
+                         check=True, capture_output=True, text=True, timeout=600).stdout
+    got = {m.group(1).strip(): int(m.group(2)) for m in re.finditer(r"^(.+?)\s+vec\s+(\d+)\s", out, re.M)}
+    ceilings = {"item head .. MotionNet loop": 1080, "MotionNet layer loop body (x 4)": 136, "MotionNet tail + encoding + stage1.0": 820,
+                "SpaceNet layer loop body (x 6)": 272, "sigma + rgb_net.1 + head + store": 975}
+    assert set(ceilings) <= set(got), out
+    for region, cap in ceilings.items():
+        assert got[region] <= cap, f"{region}: {got[region]} vector instructions (ceiling {cap})\n{out}"
+    total = int(re.search(r"background path .*?: (\d+) vector", out).group(1))
+    assert total <= 4500, out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="no hipcc")
+def test_bf16x3_stage_kernel_resources(tmp_path):
+    """csrc/mlp_bf16x3.hip: one wave per SIMD; no scratch traffic from the first MFMA of a work item on (two loop-invariant
+    values -- the 1 / ns reciprocal of the row lookup, a zero quad of the MotionNet encoding -- are reloaded once per item
+    in front of it; anything later would sit behind a vmcnt(0) that drains the weight ring's DMA queue inside the K
+    passes); the LDS-DMA / barrier / MFMA structure what the design says: 48 MFMAs and 24 operand reads per ring slot."""
+    text = open(_compile("mlp_bf16x3.hip", tmp_path)).read()
+    kernels = re.findall(r"^(_ZN6stnerf23mlp_bf16x3_stage_kernelILb[01]E\S*):", text, re.M)
+    assert len(kernels) == 2, kernels
+    for name in kernels:
+        body = text[text.index(name + ":"):]
+        body = body[:body.index("s_endpgm")]
+        lines = body.split("\n")
+        loop = next(i for i, l in enumerate(lines) if "This Loop Header: Depth=1" in l)      # the work-item loop
+        in_loop = "\n".join(lines[loop:])
+        first_mfma = next(i for i in range(loop, len(lines)) if "v_mfma" in lines[i])
+        late = [l for l in lines[first_mfma:] if "scratch_" in l]
+        assert not late, late[:5]
+        assert sum("scratch_" in l for l in lines[loop:first_mfma]) <= 4
+        n_mfma, n_read = in_loop.count("v_mfma_f32_32x32x16_bf16"), len(re.findall(r"ds_read_b128 a\[", in_loop))
+        n_bar, n_dma = in_loop.count("s_barrier"), in_loop.count("global_load_lds_dwordx4")
+        deep = "ILb1E" in name
+        slots = 3 + 4 + 4 + 3 * 16 + 20 + 8 + (8 if deep else 0)     # listed once per copy of a pass: motion, stage1.0, 3 layer-loop copies, PE slots, rgb_net.1
+        assert n_mfma == 48 * slots, (name, n_mfma, 48 * slots)
+        assert n_read == 24 * slots, (name, n_read)
+        assert n_bar >= slots and n_dma >= 6 * slots, (name, n_bar, n_dma)
+    occupancy = [int(v) for v in re.findall(r"; Occupancy: (\d+)", text)]
+    scratch = [int(v) for v in re.findall(r"; ScratchSize: (\d+)", text)]
+    assert occupancy == [1, 1] and all(s <= 128 for s in scratch), (occupancy, scratch)
