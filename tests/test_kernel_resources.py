@@ -85,7 +85,9 @@ def test_bf16x3_stage_kernel_resources(tmp_path):
         n_mfma, n_read = in_loop.count("v_mfma_f32_32x32x16_bf16"), len(re.findall(r"ds_read_b128 a\[", in_loop))
         n_bar, n_dma = in_loop.count("s_barrier"), in_loop.count("global_load_lds_dwordx4")
         deep = "ILb1E" in name
-        slots = 3 + 4 + 4 + 3 * 16 + 20 + 8 + (8 if deep else 0)     # listed once per copy of a pass: motion, stage1.0, 3 layer-loop copies, PE slots, rgb_net.1
+        # ring slots as LISTED (loop bodies once): MotionNet 3 + 4, stage1.0 2 x 2, three copies of a 256-wide layer (2 x 8),
+        # stage2.0's PE slots 2 x 2, rgb_net.1 7 + 1, the deep_rgb loop body 4
+        slots = 3 + 4 + 4 + 3 * 16 + 4 + 8 + (4 if deep else 0)
         assert n_mfma == 48 * slots, (name, n_mfma, 48 * slots)
         assert n_read == 24 * slots, (name, n_read)
         assert n_bar >= slots and n_dma >= 6 * slots, (name, n_bar, n_dma)
