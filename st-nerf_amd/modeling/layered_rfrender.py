@@ -287,10 +287,6 @@ class LayeredRFRender(nn.Module):
         from row 0 of every ``ref_chunk``-ray piece) while launching kernels over far larger pieces."""
         if not rays.is_cuda:
             raise RuntimeError("rays must live on the GPU: the MI355X render path has no CPU fallback")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError("LayeredRFRender (MI355X) is inference-only: the HIP render path has no backward pass.  Call it "
-                               "under torch.no_grad() (render/layered_neural_renderer.py:377 does) or freeze the parameters; "
-                               "training stays with the reference's own model")
         rays = rays.contiguous().float()
         N, L = rays.shape[0], self.layer_num
         width = rays.shape[1]
@@ -304,6 +300,10 @@ class LayeredRFRender(nn.Module):
             raise RuntimeError("set_bkgd_bbox / set_bboxes must be called before rendering")
         if N == 0:  # the reference dereferences row 0 (rays_frame_id[0, i+1], layered_rfrender.py:200)
             raise IndexError("empty ray batch: LayeredRFRender needs at least one ray")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("LayeredRFRender (MI355X) is inference-only: the HIP render path has no backward pass.  Call it "
+                               "under torch.no_grad() (render/layered_neural_renderer.py:377 does) or freeze the parameters; "
+                               "training stays with the reference's own model")
         step = N if ref_chunk is None else ref_chunk
         groups = []  # (start, end, boxes, pivot)
         if retiming:

@@ -89,7 +89,7 @@ def test_bf16x3_stage_kernel_resources(tmp_path):
         # stage2.0's PE slots 2 x 2, rgb_net.1 7 + 1, the deep_rgb loop body 4
         slots = 3 + 4 + 4 + 3 * 16 + 4 + 8 + (4 if deep else 0)
         assert n_mfma == 48 * slots, (name, n_mfma, 48 * slots)
-        assert n_read == 24 * slots, (name, n_read)
+        assert 24 * slots <= n_read <= 24 * slots + 16 * 12, (name, n_read)    # + the C-operand (bias) reads: 16 per pass start
         assert n_bar >= slots and n_dma >= 6 * slots, (name, n_bar, n_dma)
     occupancy = [int(v) for v in re.findall(r"; Occupancy: (\d+)", text)]
     scratch = [int(v) for v in re.findall(r"; ScratchSize: (\d+)", text)]
