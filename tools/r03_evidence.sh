@@ -32,5 +32,9 @@ timeout 900 python bench.py --workload synthetic-4k-L8-128+64 --steps 1 --warmup
 STAGE_ONLY=1 timeout 200 python tools/bench_stage.py > $out/bench_stage.txt 2>&1
 timeout 100 tools/micro/bf16x3_proto > $out/bf16x3_proto.txt 2>&1
 timeout 100 tools/micro/hbm_copy > $out/hbm_copy.json 2>/dev/null
-tail -3 $out/pytest.log; tail -3 $out/smoke.log; tail -c 400 $out/bench.json; for f in c2 c3_90_30 c4 c5; do tail -c 200 $out/bench_$f.err; done
-find $out -name "*.db" | head -20; du -sh $out
+# ---- 6. summarise here (the rocprofv3 databases are too large to travel: gpurun merges at most 64 MiB back), then drop them
+python tools/r03_summarise.py $out > $out/summarise.log 2>&1; echo rc=$? >> $out/summarise.log
+find $out -name "*.db" -delete; find $out -type d -empty -delete
+rm -rf $out/trace_fp32 $out/trace_bf16x3 $out/pmc_*_fp32 $out/pmc_*_bf16x3 2>/dev/null
+tail -3 $out/pytest.log; tail -3 $out/smoke.log; tail -30 $out/summarise.log; for f in c2 c3_90_30 c4 c5; do tail -c 200 $out/bench_$f.err; done
+du -sh $out

@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Turn the outputs of tools/r03_evidence.sh (gpurun_out/<tag>/) into the small files committed under profiles/:
+    r03_final.md            suite / smoke, the driver line's key figures, rocprofv3 kernel traces (f32 and bf16x3, pose 0),
+                            PMC passes (FETCH_SIZE, WRITE_SIZE, MfmaUtil, SQ_*) per kernel
+    r03_workloads.md        C2 / C3 64+64 / C3 90+30 / C4 / C5: bench line + per-kernel ms, both arithmetics
+    r03_pmc_hbm_traffic.json   what bench.py reads for roofline.traffic / hbm_kernels.*.counter_bytes_per_step
+    r03_bench*.json         the bench lines themselves
+Runs ON THE GPU BOX at the end of the evidence pass (the .db files are too large to travel) and writes into
+gpurun_out/<tag>/summary/.      python tools/r03_summarise.py gpurun_out/<tag>"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+src = sys.argv[1]
+dst = os.path.join(src, "summary")
+os.makedirs(dst, exist_ok=True)
+KERN = {"mlp_stage (f32 wave)": "%mlp_wave_stage_kernel%", "mlp_stage (bf16x3)": "%mlp_bf16x3_stage_kernel%", "ray_bias": "%ray_bias_kernel%",
+        "composite_single": "%composite_single_kernel%", "composite": "%composite_kernel%", "resample": "%resample_kernel%",
+        "sample_coarse": "%sample_coarse_kernel%", "compact_rays": "%compact_rays_kernel%", "generate_rays": "%generate_rays_kernel%"}
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0] if "stnerf::" in name else (name[:60] + "...") if len(name) > 60 else name
+
+
+def last_json(path):
+    try:
+        lines = [l for l in open(path).read().strip().splitlines() if l.startswith("{")]
+        return json.loads(lines[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def trace_table(db, out):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, count(*), sum(duration), avg(duration), max(vgpr_count), max(accum_vgpr_count), max(lds_size), "
+                       "max(grid_x), max(workgroup_x) from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    out.append("| kernel | calls | total ms | avg ms | % | VGPR | AGPR | LDS B | grid x wg |")
+    out.append("|---|---|---|---|---|---|---|---|---|")
+    for nm, c, s, a, vg, ag, lds, gx, wx in rows[:12]:
+        out.append(f"| `{short(nm)}` | {c} | {s / 1e6:.3f} | {a / 1e6:.4f} | {100 * s / tot:.2f} | {vg} | {ag} | {lds} | {gx} x {wx} |")
+    out.append(f"\ntotal GPU kernel time {tot / 1e6:.1f} ms over {sum(r[1] for r in rows)} dispatches\n")
+
+
+def pmc_rows(db, counters):
+    cur = sqlite3.connect(db).cursor()
+    res = {}
+    for c in counters:
+        for nm, n, s in cur.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name=? group by kernel_name", (c,)):
+            res.setdefault(short(nm), {})[c] = (n, s)
+    return res
+
+
+md = ["# r03: evidence for HEAD (one build, one GPU box)\n", "```", open(os.path.join(src, "env.txt")).read().strip(), "```\n"]
+md.append("## parity suite, smoke\n```")
+for f in ("pytest.log", "smoke.log"):
+    md += open(os.path.join(src, f)).read().strip().splitlines()[-3:]
+md.append("```\n")
+b = last_json(os.path.join(src, "bench.json"))
+json.dump(b, open(os.path.join(dst, "r03_bench.json"), "w"), indent=1)
+if "value" in b:
+    r = b["roofline"]
+    md.append("## the driver's command: `python bench.py` (C3, taekwondo-1080p-64+64, 3 timed poses)\n")
+    md.append(f"* headline (exact f32): **{b['value']:.4g} rays/s, {b['ray_samples_per_s']:.4g} ray-samples/s, {b['ms_per_step']:.1f} ms per frame**; "
+              f"stage kernel {r['launches']} launches, avg {r['avg_launch_ms']:.2f} ms, {r['achieved']:.2f} TF/s = **{r['frac']:.4f}** of {r['peak']} TF/s")
+    for k in ("other_precision", "other_precision_2"):
+        o = b.get(k)
+        if o:
+            md.append(f"* {k}: {o['precision']}: {o['value']:.4g} rays/s, {o['ms_per_step']:.1f} ms per frame, {o['roofline']['algorithmic_tflops']:.1f} algorithmic TF/s, "
+                      f"{o['roofline']['executed_mfma_tflops']:.0f} executed MFMA TF/s = {o['roofline']['frac']:.3f} of {o['roofline']['peak']:.0f}")
+    for k, e in b.get("hbm_kernels", {}).items():
+        md.append(f"* {k}: {e['ms_per_step']:.2f} ms per frame, {e['algorithmic_GBps']:.0f} GB/s of its algorithmic bytes = {e['frac']:.3f} of 8 TB/s"
+                  + (f" ({e['frac_of_measured_peak']:.3f} of the measured {e['measured_peak_GBps']:.0f} GB/s)" if "frac_of_measured_peak" in e else ""))
+    cb, eg = b.get("cpu_baseline"), b.get("eager_gpu_baseline")
+    if cb:
+        md.append(f"* cpu_baseline: {cb['value']:.1f} rays/s on {cb['cores']} threads ({cb['host']['cpu']}); frame extrapolates to {cb['extrapolated_frame_seconds']:.0f} s")
+    if eg:
+        md.append(f"* eager PyTorch-ROCm on the same GPU (oracle restatement, one reference chunk): {eg['value']:.0f} rays/s")
+    if b.get("psnr_vs_reference"):
+        p = b["psnr_vs_reference"]
+        md.append(f"* PSNR device-RNG render vs reference seed A: {p['hip_device_rng_vs_reference_seed_a_dB']:.2f} dB (reference seed B vs A: {p['reference_seed_b_vs_seed_a_dB']:.2f} dB)")
+    md.append("")
+traffic = {"workload": "taekwondo-1080p-64+64", "pose": "pose 0 of the bench's sweep (orbit 10 deg), one step", "gfx950_fetch_correction": 2.0,
+           "note": "hbm bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE), MI355X_MICROARCH.md section HBM; separate rocprofv3 --pmc runs", "kernels": {}, "kernels_bf16x3": {}}
+for prec in ("fp32", "bf16x3"):
+    db = os.path.join(src, f"trace_{prec}", "p_results.db")
+    md.append(f"## rocprofv3 --kernel-trace --stats, ONE step (pose 0), --precision {prec}\n")
+    if os.path.exists(db):
+        trace_table(db, md)
+    else:
+        md.append("(missing)\n")
+    rows = {}
+    for ctr, names in (("FETCH_SIZE", ["FETCH_SIZE"]), ("WRITE_SIZE", ["WRITE_SIZE"]), ("MfmaUtil", ["MfmaUtil"]),
+                       ("SQ", ["SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS"])):
+        p = os.path.join(src, f"pmc_{ctr}_{prec}", "p_results.db")
+        if os.path.exists(p):
+            for k, v in pmc_rows(p, names).items():
+                rows.setdefault(k, {}).update(v)
+    md.append(f"### PMC passes (own runs), --precision {prec}: per kernel, summed over its dispatches of the step\n")
+    md.append("| kernel | dispatches | FETCH_SIZE KB | WRITE_SIZE KB | HBM GB (2 x fetch + write) | MfmaUtil avg % | SQ_INSTS_VALU | SQ_INSTS_MFMA | SQ_INSTS_LDS | active / wave cycles |")
+    md.append("|---|---|---|---|---|---|---|---|---|---|")
+    for k, v in sorted(rows.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", (0, 0))[1]):
+        if "stnerf::" not in k:
+            continue
+        f, w = v.get("FETCH_SIZE", (0, 0)), v.get("WRITE_SIZE", (0, 0))
+        mu = v.get("MfmaUtil")
+        act, wc = v.get("SQ_ACTIVE_INST_ANY", (0, 0))[1], v.get("SQ_WAVE_CYCLES", (0, 1))[1]
+        md.append(f"| `{k}` | {f[0] or w[0]} | {f[1]:.0f} | {w[1]:.0f} | {1024 * (2 * f[1] + w[1]) / 1e9:.3f} | "
+                  f"{(mu[1] / mu[0]) if mu else float('nan'):.1f} | {v.get('SQ_INSTS_VALU', (0, 0))[1]:.3g} | {v.get('SQ_INSTS_MFMA', (0, 0))[1]:.3g} | "
+                  f"{v.get('SQ_INSTS_LDS', (0, 0))[1]:.3g} | {act / max(wc, 1):.3f} |")
+    md.append("")
+    # traffic json
+    fdb, wdb = os.path.join(src, f"pmc_FETCH_SIZE_{prec}", "p_results.db"), os.path.join(src, f"pmc_WRITE_SIZE_{prec}", "p_results.db")
+    if os.path.exists(fdb) and os.path.exists(wdb):
+        cf, cw = sqlite3.connect(fdb).cursor(), sqlite3.connect(wdb).cursor()
+        for name, like in (("spacenet", "%spacenet_kernel%"), ("motionnet", "%motionnet_kernel%"), ("mlp_stage", "%mlp%stage_kernel%"), ("composite", "%composite%kernel%"),
+                           ("resample", "%resample_kernel%"), ("sample_coarse", "%sample_coarse_kernel%")):
+            nf, fkb = cf.execute("select count(*), sum(value) from counters_collection where counter_name='FETCH_SIZE' and kernel_name like ?", (like,)).fetchone()
+            nw, wkb = cw.execute("select count(*), sum(value) from counters_collection where counter_name='WRITE_SIZE' and kernel_name like ?", (like,)).fetchone()
+            if not nf and not nw:
+                continue
+            hbm = 1024.0 * (2.0 * (fkb or 0) + (wkb or 0))
+            traffic["kernels" if prec == "fp32" else "kernels_bf16x3"][name] = {
+                "launches_per_step": nf, "fetch_size_kb_per_step": fkb or 0, "write_size_kb_per_step": wkb or 0, "hbm_bytes_per_step": hbm,
+                "hbm_bytes_per_launch": hbm / max(nf, 1)}
+json.dump(traffic, open(os.path.join(dst, "r03_pmc_hbm_traffic.json"), "w"), indent=1)
+open(os.path.join(dst, "r03_final.md"), "w").write("\n".join(md) + "\n")
+
+wl = ["# r03: every BASELINE configuration on the round's build (1 x MI355X, `tools/r03_evidence.sh`)\n",
+      "| config | workload | arithmetic | rays/s | ray-samples/s | s per frame | stage kernel TF/s (algorithmic) | frac of its MFMA peak (executed) | composite ms | resample ms | sample_coarse ms |",
+      "|---|---|---|---|---|---|---|---|---|---|---|"]
+for cfg, fn in (("C2", "bench_c2.json"), ("C3", "bench.json"), ("C3 (yml 90+30)", "bench_c3_90_30.json"), ("C4", "bench_c4.json"), ("C5 (one GPU)", "bench_c5.json")):
+    b = last_json(os.path.join(src, fn))
+    json.dump(b, open(os.path.join(dst, "r03_" + fn), "w"), indent=1)
+    if "value" not in b:
+        wl.append(f"| {cfg} | {fn} | failed: {b.get('error')} | | | | | | | | |")
+        continue
+    hk = b.get("hbm_kernels", {})
+    ms = lambda k: f"{hk[k]['ms_per_step']:.2f} ({hk[k]['frac']:.2f} of 8 TB/s)" if k in hk else ""
+    mult = {"fp32": 1.0, "bf16x3": 6.0, "fp16x3": 3.0}[b["config"]["precision"]]
+    wl.append(f"| {cfg} | {b['config']['workload']} | {b['config']['precision']} | {b['value']:.4g} | {b['ray_samples_per_s']:.4g} | {b['ms_per_step'] / 1e3:.3f} | "
+              f"{b['roofline']['achieved'] / mult:.1f} | {b['roofline']['frac']:.3f} | {ms('composite')} | {ms('resample')} | {ms('sample_coarse')} |")
+    for k in ("other_precision", "other_precision_2"):
+        o = b.get(k)
+        if o:
+            wl.append(f"| | | {o['precision']} | {o['value']:.4g} | {o['ray_samples_per_s']:.4g} | {o['ms_per_step'] / 1e3:.3f} | {o['roofline']['algorithmic_tflops']:.1f} | "
+                      f"{o['roofline']['frac']:.3f} | | | |")
+wl.append("")
+for f in ("bench_stage.txt", "bf16x3_proto.txt"):
+    p = os.path.join(src, f)
+    if os.path.exists(p):
+        wl += [f"## {f}\n", "```", open(p).read().strip(), "```\n"]
+open(os.path.join(dst, "r03_workloads.md"), "w").write("\n".join(wl) + "\n")
+for f in ("hbm_copy.json",):
+    p = os.path.join(src, f)
+    if os.path.exists(p) and os.path.getsize(p):
+        open(os.path.join(dst, "r03_hbm_copy_microbench.json"), "w").write(open(p).read())
+print(open(os.path.join(dst, "r03_final.md")).read()[:6000])
+print(open(os.path.join(dst, "r03_workloads.md")).read()[:3000])
