@@ -41,7 +41,7 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 constexpr int BX_LDS_RING = BX_RING * BX_SLOT;
 constexpr int BX_LDS_ENC = WV_NW * WV_ENC_FLOATS * 4;
 constexpr int BX_LDS_CONST = (BX_CONST_SPACE + BX_CONST_MOTION) * 4;
-constexpr int BX_LDS = BX_LDS_RING + BX_LDS_ENC + BX_LDS_CONST + 16 + STNERF_MAX_LAYERS * 8;
+constexpr int BX_LDS = BX_LDS_RING + BX_LDS_ENC + BX_LDS_CONST + 16 + STNERF_MAX_LAYERS * 8 + (STNERF_MAX_LAYERS + 1) * 4 + 12;
 static_assert(BX_LDS <= 160 * 1024, "bf16x3 stage kernel: LDS budget");
 
 #define BX_SB() __builtin_amdgcn_sched_barrier(0)
@@ -109,7 +109,6 @@ struct Ctx {
     Seg seg[4];         // this work item's networks (deformation net, SpaceNet), then the next item's
     const char* idle;   // a valid source when nothing is left to fetch
     uint32_t gi;        // slots issued so far
-    uint32_t lds_lane;  // LDS byte address of the ring + lane * 16
     uint32_t rcur, rnext;  // this lane's LDS byte address inside the slot being consumed / the next one
     uint32_t gc;        // slots consumed so far
     char* ring;
@@ -242,7 +241,9 @@ __device__ __forceinline__ void slot_turn(Ctx& cx, Dma& d) {
 __device__ __forceinline__ void slot_done(Ctx& cx) {
     cx.gc += 1;
     cx.rcur = cx.rnext;
-    cx.rnext = cx.lds_lane + ((cx.gc + 1) & (BX_RING - 1)) * BX_SLOT;
+    // the slot after it, wrapping at the end of the ring (from rnext itself: a third per-lane address kept through the item
+    // only to be added to here was spilled, and its reload waits behind vmcnt(0) -- the DMA queue)
+    cx.rnext = cx.rnext + (((cx.gc + 1) & (BX_RING - 1)) == 0 ? BX_SLOT - BX_RING * BX_SLOT : BX_SLOT);
 }
 
 // one ring slot: K steps k0, k1 (their B operands: the three planes of the input) for the pass's four blocks
@@ -293,6 +294,19 @@ __device__ __forceinline__ void load_c(f32x16 (&big)[4], const float* v128, int 
             BX_SB();
         }
 }
+// block fb of load_c: issued as soon as the block's accumulators have been consumed by a boundary pass, so that the LDS
+// round trip runs under the vector work of the following blocks (as relu_rebias of mlp_wave.hip)
+__device__ __forceinline__ void load_c_block(f32x16& bigfb, const float* v128, int fb, int lane) {
+    const float4* b4 = reinterpret_cast<const float4*>(v128) + (lane >> 5);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 b = b4[fb * 8 + 2 * q];
+        bigfb[4 * q + 0] = b.x;
+        bigfb[4 * q + 1] = b.y;
+        bigfb[4 * q + 2] = b.z;
+        bigfb[4 * q + 3] = b.w;
+    }
+}
 __device__ __forceinline__ float out_relu(const f32x16& big, const f32x16& small, int i) { return relu_bits(big[i] + small[i]); }
 
 // the first pass's outputs wait in AGPRs while the second pass still reads the layer's input
@@ -330,21 +344,25 @@ __device__ __forceinline__ void sig_take(SigAcc& sg, const float (&v)[8], const 
 }
 
 // pass A of a 256-wide layer: relu(big + small) -> park
-__device__ __forceinline__ void finish_park(const f32x16 (&big)[4], const f32x16 (&small)[4], Park& pk) {
+// next_c: the 128 C-operand values (bias) of the pass that follows
+__device__ __forceinline__ void finish_park(f32x16 (&big)[4], const f32x16 (&small)[4], Park& pk, const float* next_c, int lane) {
 #pragma unroll
-    for (int fb = 0; fb < 4; ++fb)
+    for (int fb = 0; fb < 4; ++fb) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) park_put(pk.v[16 * fb + 8 * t + j], out_relu(big[fb], small[fb], 8 * t + j));
             BX_SB();  // (group by group: keeps the live values of this straight-line code bounded)
         }
+        load_c_block(big[fb], next_c, fb, lane);
+        BX_SB();
+    }
 }
 // the pass's outputs -> K steps KS0 .. KS0 + 7 of the activation planes
 template <int KS0>
-__device__ __forceinline__ void finish_act(const f32x16 (&big)[4], const f32x16 (&small)[4], bf16x8 (&act)[3][16]) {
+__device__ __forceinline__ void finish_act(f32x16 (&big)[4], const f32x16 (&small)[4], bf16x8 (&act)[3][16], const float* next_c, int lane) {
 #pragma unroll
-    for (int fb = 0; fb < 4; ++fb)
+    for (int fb = 0; fb < 4; ++fb) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float v[8];
@@ -353,6 +371,11 @@ __device__ __forceinline__ void finish_act(const f32x16 (&big)[4], const f32x16 
             split8(v, act[0][KS0 + 2 * fb + t], act[1][KS0 + 2 * fb + t], act[2][KS0 + 2 * fb + t]);
             BX_SB();
         }
+        if (next_c) {  // (uniform; nullptr where the next pass starts from 0: rgb_net.1)
+            load_c_block(big[fb], next_c, fb, lane);
+            BX_SB();
+        }
+    }
 }
 // sigma head (density_net.0, 256 -> 1) on the last backbone layer's outputs, before they are converted: features 0..127 wait
 // in the park, 128..255 in the accumulators.  (A pass of its own over the values -- 2 x 128 reads once per work item --
@@ -458,17 +481,16 @@ __device__ __forceinline__ void enc_to_act(const float* encw, int lane, bf16x8 (
 __device__ __forceinline__ void motion_bx(Ctx& cx, const float* net, const float* cm, float* encw, float (&p)[3], float tv, int flags,
                                           int lane, f32x16 (&big)[4], f32x16 (&small)[4], bf16x8 (&act)[3][16] BXP_PARAM) {
     const MotionLayout L = motion_layout();
+    load_c(big, cm + BXM_B, lane);   // (in front of the encoding arithmetic: its LDS round trip is covered)
     encode_motion(encw, lane, p, tv, flags);
     wave_lds_sync();
     enc_to_act<6, WV_ENC_QUADS>(encw, lane, act);
-    load_c(big, cm + BXM_B, lane);
     BXP(BXP_MOTION_ENC);
     pass_act<0, 3, true>(cx, big, small, act);  // motion_net.0: 84 (+4) inputs, 6 K steps
     BXP(BXP_MOTION_PASS);
 #pragma unroll 1
     for (int li = 1; li <= 4; ++li) {
-        finish_act<0>(big, small, act);
-        load_c(big, cm + BXM_B + 128 * li, lane);
+        finish_act<0>(big, small, act, cm + BXM_B + 128 * li, lane);
         BXP(BXP_MOTION_FIN);
         pass_act<0, 4, true>(cx, big, small, act);
         BXP(BXP_MOTION_PASS);
@@ -491,22 +513,20 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     const SpaceLayout L = space_layout(use_time, DEEP);
     const int h = lane >> 5;
     Park pk;
+    load_c(big, cs + BXC_B, lane);   // (in front of the encoding arithmetic)
     encode_pos(encw, lane, p);
     wave_lds_sync();
     enc_to_act<4, 16>(encw, lane, act);
     BXP(BXP_PE);
-    // ---- stage1.0: 63 (+1) -> 256
-    load_c(big, cs + BXC_B, lane);
-    BXP(BXP_LOADC);
+    // ---- stage1.0: 63 (+1) -> 256.  Every pass's C operand (its bias) is read block by block inside the boundary pass in
+    // front of it, as soon as a block's accumulators have been consumed.
     pass_act<0, 2, true>(cx, big, small, act);
     BXP(BXP_PASS);
-    finish_park(big, small, pk);
+    finish_park(big, small, pk, cs + BXC_B + 128, lane);
     BXP(BXP_PARK);
-    load_c(big, cs + BXC_B + 128, lane);
-    BXP(BXP_LOADC);
     pass_act<0, 2, true>(cx, big, small, act);
     BXP(BXP_PASS);
-    finish_act<8>(big, small, act);
+    finish_act<8>(big, small, act, cs + BXC_B + 256, lane);
     unpark_act(pk, act);
     BXP(BXP_ACT);
     // ---- stage1.2 .. stage2.4: six 256-wide layers, two passes each; stage2.0 (li == 4) takes PE(pos) again behind its 256
@@ -536,31 +556,27 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     // (stage2.0 is peeled out of the layer loop: inside it, as a conditional block, its extra K steps redefine the
     // accumulators on one of two paths and the register allocator answers with ~200 spills)
     auto layer = [&](int li, auto with_pe) {
-        load_c(big, cs + BXC_B + 256 * li, lane);
-        BXP(BXP_LOADC);
         pass_act<0, 8, true>(cx, big, small, act);
         if constexpr (decltype(with_pe)::value) pe_slots();
         BXP(BXP_PASS);
-        finish_park(big, small, pk);
+        finish_park(big, small, pk, cs + BXC_B + 256 * li + 128, lane);
         BXP(BXP_PARK);
-        load_c(big, cs + BXC_B + 256 * li + 128, lane);
-        BXP(BXP_LOADC);
         pass_act<0, 8, true>(cx, big, small, act);
         if constexpr (decltype(with_pe)::value) pe_slots();
         BXP(BXP_PASS);
     };
-    auto layer_end = [&]() {
-        finish_act<8>(big, small, act);
+    auto layer_end = [&](int li) {   // (+ the next layer's first C operand; behind stage2.4 comes rgb_net.1, which starts from 0)
+        finish_act<8>(big, small, act, li < 6 ? cs + BXC_B + 256 * (li + 1) : nullptr, lane);
         unpark_act(pk, act);
         BXP(BXP_ACT);
     };
 #pragma unroll 1
     for (int li = 1; li <= 3; ++li) {
         layer(li, std::false_type{});
-        layer_end();
+        layer_end(li);
     }
     layer(4, std::true_type{});
-    layer_end();
+    layer_end(4);
     float sigma = 0.f;
 #pragma unroll 1
     for (int li = 5; li <= 6; ++li) {
@@ -570,7 +586,7 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
             sigma = sigma_head(big, small, pk, cs + BXC_W_SIGMA, net[L.b_sigma], lane);
             BXP(BXP_SIGMA);
         }
-        layer_end();
+        layer_end(li);
     }
     // ---- rgb_net: relu -> Linear(283|304, 128) -> relu -> Linear(128, 3) (:80-86); the 256 backbone columns here, the
     // bias + direction / time columns = this sample's row of the ray-bias table (mlp_raybias.hip).  The exact-f32 kernels take
@@ -606,8 +622,7 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     if constexpr (DEEP) {  // deep_rgb (:68-79): two more 128-wide hidden layers
 #pragma unroll 1
         for (int i = 0; i < 2; ++i) {
-            finish_act<0>(big, small, act);
-            load_c(big, cs + BXC_B_DEEP + 128 * i, lane);
+            finish_act<0>(big, small, act, cs + BXC_B_DEEP + 128 * i, lane);
             pass_act<0, 4, true>(cx, big, small, act);
         }
     }
@@ -629,31 +644,44 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_bf16x3_stage_kernel(StageAr
     float* cm = cs + BX_CONST_SPACE;
     uint32_t* qslot = reinterpret_cast<uint32_t*>(smem_bx + BX_LDS_RING + BX_LDS_ENC + BX_LDS_CONST);
     int64_t* lrows = reinterpret_cast<int64_t*>(qslot + 4);
-    // ---- the queue (as in mlp_wave.hip): items (128 rows) of layer slot j are [pre[j], pre[j+1])
-    uint32_t pre[STNERF_MAX_LAYERS + 1];
-    pre[0] = 0;
-#pragma unroll
-    for (int j = 0; j < STNERF_MAX_LAYERS; ++j) {
-        uint32_t items = 0;
-        if (j < a.n_layers) {
-            const int64_t rows = layer_rows(a.layer[j], a.n_rays, a.ns);
-            items = (uint32_t)((rows + WV_ITEM - 1) / WV_ITEM);
-            if (tid == 0) lrows[j] = rows;
+    // ---- the queue (as in mlp_wave.hip): items (128 rows) of layer slot j are [pre[j], pre[j+1]).  The prefix table lives in
+    // LDS, not in 17 SGPRs: this kernel's scalar registers are short (the stream state, the kernel arguments), and what does
+    // not fit is kept in VGPR lanes -- of which it has none to spare either.
+    uint32_t* lpre = reinterpret_cast<uint32_t*>(lrows + STNERF_MAX_LAYERS);
+    uint32_t total = 0;
+#pragma unroll 1
+    for (int j = 0; j < a.n_layers; ++j) {
+        const int64_t rows = layer_rows(a.layer[j], a.n_rays, a.ns);
+        if (tid == 0) {
+            lrows[j] = rows;
+            lpre[j] = total;
         }
-        pre[j + 1] = pre[j] + items;
+        total += (uint32_t)((rows + WV_ITEM - 1) / WV_ITEM);
     }
-    const uint32_t total = pre[STNERF_MAX_LAYERS];
+    // (layer slot, first item of that slot) of an item: wave-uniform
+    auto locate = [&](uint32_t item, int& slot, uint32_t& base) {
+        slot = 0;
+        base = 0;
+#pragma unroll 1
+        for (int j = 1; j < a.n_layers; ++j) {
+            const uint32_t pj = (uint32_t)__builtin_amdgcn_readfirstlane((int)lpre[j]);
+            if (item >= pj) {
+                slot = j;
+                base = pj;
+            }
+        }
+    };
     auto slot_of = [&](uint32_t item) {
-        int s = 0;
-#pragma unroll
-        for (int j = 1; j < STNERF_MAX_LAYERS; ++j) s += (item >= pre[j]) ? 1 : 0;
-        return s;
+        int s_;
+        uint32_t b_;
+        locate(item, s_, b_);
+        return s_;
     };
     auto base_of = [&](uint32_t item) {
-        uint32_t b = 0;
-#pragma unroll
-        for (int j = 1; j < STNERF_MAX_LAYERS; ++j) b = (item >= pre[j]) ? pre[j] : b;
-        return b;
+        int s_;
+        uint32_t b_;
+        locate(item, s_, b_);
+        return b_;
     };
     auto row_of = [&](uint32_t item, RowRef& rr) {
         rr = RowRef{0, 0, false};
@@ -732,9 +760,8 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_bf16x3_stage_kernel(StageAr
     cx.lane = lane;
     cx.gi = 0;
     cx.gc = 0;
-    cx.lds_lane = (uint32_t)(uintptr_t)ring + (uint32_t)lane * 16u;
-    cx.rcur = cx.lds_lane;
-    cx.rnext = cx.lds_lane + BX_SLOT;
+    cx.rcur = (uint32_t)(uintptr_t)ring + (uint32_t)lane * 16u;   // LDS byte address of the ring + lane * 16
+    cx.rnext = cx.rcur + BX_SLOT;
     segs_of(it0, cx.seg[0], cx.seg[1]);
     segs_of(it1, cx.seg[2], cx.seg[3]);
     cx.idle = cx.seg[1].p;
