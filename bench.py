@@ -40,8 +40,8 @@ from stnerf_amd.utils import layered_batchify_ray     # noqa: E402
 from stnerf_amd.parallel import gather_tiles, make_row_renderer, render_view_striped  # noqa: E402
 
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
-MEASURED_HBM_JSON = os.path.join(REPO, "profiles", "r02_hbm_copy_microbench.json")   # tools/micro/hbm_copy on the GPU box
-PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r02_pmc_hbm_traffic.json")         # tools/pmc_traffic.py
+MEASURED_HBM_JSON = os.path.join(REPO, "profiles", "r03_hbm_copy_microbench.json")   # tools/micro/hbm_copy on the GPU box
+PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r03_pmc_hbm_traffic.json")         # tools/r03_summarise.py (pose 0 of the sweep)
 
 # Algorithmic work per network evaluation: 2 * MACs of every nn.Linear.
 FLOP_SPACE, FLOP_SPACE_TIME, FLOP_MOTION = 924_672, 930_048, 153_344
@@ -440,7 +440,8 @@ def main():
         pmc = json.load(open(PMC_TRAFFIC_JSON)) if os.path.exists(PMC_TRAFFIC_JSON) else {}
         pmc_ok = pmc.get("workload") == args.workload and world == 1
         dom = "mlp_stage" if "mlp_stage" in ksum else "spacenet"
-        traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"] if pmc_ok and dom in pmc.get("kernels", {}) else None
+        pk = pmc.get("kernels_bf16x3" if args.precision == "bf16x3" else "kernels", {}) if args.precision != "fp16x3" else {}
+        traffic = pk[dom]["hbm_bytes_per_launch"] if pmc_ok and dom in pk else None
         measured = json.load(open(MEASURED_HBM_JSON)) if os.path.exists(MEASURED_HBM_JSON) else {}
         hbm_meas = {"composite": measured.get("read_GBps"), "resample": measured.get("copy_GBps"),
                     "sample_coarse": measured.get("write_GBps")}
@@ -498,7 +499,8 @@ def main():
                                    "stnerf::spacenet_kernel (fused PE + 9-layer MLP)",
                          "bound": "mfma", "achieved": achieved, "peak": peak_used, "unit": "TFLOP/s",
                          "frac": achieved / peak_used, "traffic": traffic,
-                         "traffic_source": ("profiles/" + os.path.basename(PMC_TRAFFIC_JSON)) if traffic else None,
+                         "traffic_source": ("profiles/" + os.path.basename(PMC_TRAFFIC_JSON) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over ONE "
+                                            "step of this workload at pose 0 of the sweep (the timed steps sweep the orbit: +- 10 % evaluations)") if traffic else None,
                          "algorithmic_bytes_per_launch": 28 * sp["evals"] / sp["launches"],   # 12 B point in + 16 B raw out per SpaceNet evaluation
                          "launches": sp["launches"], "avg_launch_ms": sp["ms"] / sp["launches"],
                          "algorithmic_flop_per_launch": sp["flop"] / sp["launches"],
