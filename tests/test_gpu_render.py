@@ -189,11 +189,13 @@ def run_forward_case(name, precision):
           + (f"; fine-stage rays above tol vs fp64 (HIP / reference): {sum(b[0] for b in bars)} / {sum(b[1] for b in bars)}" if bars else ""))
 
 
-def test_chunking_and_launch_size_do_not_change_the_image():
-    """Device RNG is keyed by the global ray index: the render is invariant to max_rays_per_launch."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_chunking_and_launch_size_do_not_change_the_image(precision):
+    """Device RNG is keyed by the global ray index: the render is invariant to max_rays_per_launch (in both arithmetics: a
+    sample's evaluation does not depend on which 128-row work item it lands in)."""
     from stnerf_amd.utils import layered_batchify_ray
     meta, a = load_golden("fwd_c3")
-    model = build_model(meta)
+    model = build_model(meta).set_precision(precision)
     K, T = syn.camera(40, 64, 10.0)
     from stnerf_amd import ops
     rays = ops.generate_rays(K, T, 40, 64, frame_ids=[1.0, 2.5, 2.5])

@@ -304,14 +304,15 @@ def test_reference_checkpoint_round_trip(tmp_path):
                      R.COLOR_ATOL, "fine mixed colour after the checkpoint round trip")
 
 
-def test_striped_ray_windows_render_a_ranks_stripes_in_one_call():
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_striped_ray_windows_render_a_ranks_stripes_in_one_call(precision):
     """Interleaved-stripe sharding of ONE view (BASELINE configs[3]/[4]): rank r of G renders stripes r, r+G, ... as ONE
     launch sequence over a striped ray window (include/stnerf.h); unstriped, the G pieces are bit-identical to the
     view rendered whole (pixels and RNG are keyed by the global ray index), also with ragged stripes."""
     from stnerf_amd import ops
     from stnerf_amd.parallel import make_row_renderer, stripe_spans, unstripe
     meta, _ = load_golden("fwd_c3")
-    model = R.build_model(meta)
+    model = R.build_model(meta).set_precision(precision)
     model.seed = 13
     h, w = 50, 72
     K, T = syn.camera(h, w, -9.0)
