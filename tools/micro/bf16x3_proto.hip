@@ -31,7 +31,7 @@ constexpr int SLOT = 24576;   // one K step of 16 for 256 outputs: 8 feature blo
 constexpr int RING = 4;
 constexpr int NLMAX = 8;
 
-enum { F_CONV = 1, F_BAR = 2, F_LDS = 4, F_DMA = 8, F_ALL = 15, F_NOWAITV = 16, F_SPREAD = 32, F_NOISSUE = 64 };
+enum { F_CONV = 1, F_BAR = 2, F_LDS = 4, F_DMA = 8, F_ALL = 15, F_NOWAITV = 16, F_SPREAD = 32, F_NOISSUE = 64, F_FLAGS = 128 };
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     f32x2 v = {a, b};
@@ -184,6 +184,127 @@ __device__ __forceinline__ void layer256(f32x16 (&acc)[8], const bf16x8 (&act)[3
     __builtin_amdgcn_sched_barrier(0);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Ring synchronisation WITHOUT the per-slot workgroup barrier: ring buffer b belongs to wave b, which fetches every slot
+// g = b (mod 4) whole (24 x 1 KB).  ready[b] = (slot landed in buffer b) + 1, done[w] = slots wave w has read completely.
+//   slot g, wave (g + 3) % 4: once min(done) >= g (everyone is through slot g - 1), refill buffer (g - 1) % 4 with slot g + 3
+//   slot g, wave (g + 1) % 4: its fetch of slot g + 1 (issued during slot g - 2) has landed: vmcnt(0), ready[(g+1)%4] = g + 2
+//   every wave, before its first read of slot g + 1: ready[(g + 1) % 4] >= g + 2;  after its last read of slot g: done[w] = g + 1
+// ---------------------------------------------------------------------------------------------------------------------
+// (asm: a compiler-visible LDS access behind an LDS-DMA in flight is given an s_waitcnt vmcnt(0) -- the DMA might alias it --,
+// which would make every poll wait for the poller's own fetches)
+__device__ __forceinline__ unsigned lds_u32(const unsigned* p) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(uintptr_t)p) : "memory");
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void lds_put(unsigned* p, unsigned v) {
+    asm volatile("ds_write_b32 %0, %1" : : "v"((unsigned)(uintptr_t)p), "v"(v) : "memory");
+}
+template <int C0, int NC>
+__device__ __forceinline__ void mma_pair_dma(f32x16& c0, f32x16& c1, const Apair& A, const bf16x8& b0, const bf16x8& b1, const bf16x8& b2,
+                                             bool issue, const char* src, __attribute__((address_space(3))) char* dst) {
+#define PROTO_DMA(c) do { if ((c) < NC) { __builtin_amdgcn_sched_barrier(0); if (issue) __builtin_amdgcn_global_load_lds(src + (C0 + c) * 1024, (__attribute__((address_space(3))) void*)(dst + (C0 + c) * 1024), 16, 0, 0); __builtin_amdgcn_sched_barrier(0); } } while (0)
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[0][2], b0, c0, 0, 0, 0);
+    PROTO_DMA(0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[1][2], b0, c1, 0, 0, 0);
+    PROTO_DMA(1);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[0][0], b2, c0, 0, 0, 0);
+    PROTO_DMA(2);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[1][0], b2, c1, 0, 0, 0);
+    PROTO_DMA(3);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[0][1], b1, c0, 0, 0, 0);
+    PROTO_DMA(4);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[1][1], b1, c1, 0, 0, 0);
+    PROTO_DMA(5);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[0][1], b0, c0, 0, 0, 0);
+    PROTO_DMA(6);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[1][1], b0, c1, 0, 0, 0);
+    PROTO_DMA(7);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[0][0], b1, c0, 0, 0, 0);
+    PROTO_DMA(8);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[1][0], b1, c1, 0, 0, 0);
+    PROTO_DMA(9);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[0][0], b0, c0, 0, 0, 0);
+    PROTO_DMA(10);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[1][0], b0, c1, 0, 0, 0);
+    PROTO_DMA(11);
+#undef PROTO_DMA
+}
+
+// Every wave fetches its quarter of every slot (as in the barrier version: a single wave's LDS-DMAs complete one after the
+// other, 24 from one wave take ~6 slot times); ready[w] = slots of which wave w's quarter has landed, done[w] = slots wave w
+// has read completely; both polled one phase after they are read (the read is issued early, its value used later).
+using Quad = u32x4;
+__device__ __forceinline__ void lds_get4(Quad& q, const unsigned* p) {   // issue only
+    asm volatile("ds_read_b128 %0, %1" : "=v"(q) : "v"((unsigned)(uintptr_t)p) : "memory");
+}
+__device__ __forceinline__ unsigned quad_min(Quad& q) {                  // after its wait
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q));
+    const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)q[0]), b = (unsigned)__builtin_amdgcn_readfirstlane((int)q[1]);
+    const unsigned c = (unsigned)__builtin_amdgcn_readfirstlane((int)q[2]), d = (unsigned)__builtin_amdgcn_readfirstlane((int)q[3]);
+    const unsigned ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+__device__ __forceinline__ void poll4(const unsigned* p, unsigned want, Quad& early, unsigned* spins) {
+    if (quad_min(early) >= want) return;   // the early read already shows it (the usual case)
+    unsigned tries = 0;
+    Quad q;
+    do {
+        lds_get4(q, p);
+    } while (quad_min(q) < want && ++tries <= (1u << 20));
+    if ((threadIdx.x & 63) == 0) atomicAdd(spins, tries + 1);
+}
+
+template <int VAR>
+__device__ __forceinline__ void layer256_flags(f32x16 (&acc)[8], const bf16x8 (&act)[3][16], Apair& Ax, Apair& Ay, const char* blob,
+                                               unsigned& g, unsigned nslots, char* ring, unsigned* ready, unsigned* done, int wave, int lane,
+                                               unsigned* spins) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const char* slot = ring + (s % RING) * SLOT;
+        const char* nslot = ring + ((s + 1) % RING) * SLOT;
+        __builtin_amdgcn_sched_barrier(0);
+        Quad qd, qr;
+        lds_get4(qd, done);                         // (used behind pair 0: everyone through slot g - 1?)
+        // my quarter of slot g + 1 (issued at the start of slot g - 2) has landed: in flight behind it at most slot g + 2's six
+        if (!(VAR & 1)) VMCNT(6);
+        lds_put(ready + wave, g + 2);
+        const unsigned src_slot = (g + 3) % nslots;
+        const char* src = blob + (size_t)src_slot * SLOT + wave * 6144 + lane * 16;
+        auto dst = (__attribute__((address_space(3))) char*)(ring) + ((s + 3) & 3) * SLOT + wave * 6144;
+        __builtin_amdgcn_sched_barrier(0);
+        read_pair<F_ALL>(Ay, slot, 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_pair_dma<0, 0>(acc[0], acc[1], Ax, act[0][s], act[1][s], act[2][s], false, src, dst);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_pair(Ay);
+        if (!(VAR & 4)) poll4(done, g, qd, spins);                  // buffer (g - 1) % 4 is free everywhere: my six chunks of slot g + 3 go out
+        read_pair<F_ALL>(Ax, slot, 2, lane);
+        lds_get4(qr, ready);                        // (used at the turn: slot g + 1 landed everywhere?)
+        __builtin_amdgcn_sched_barrier(0);
+        mma_pair_dma<0, 6>(acc[2], acc[3], Ay, act[0][s], act[1][s], act[2][s], true, src, dst);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_pair(Ax);
+        read_pair<F_ALL>(Ay, slot, 3, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_pair_dma<0, 0>(acc[4], acc[5], Ax, act[0][s], act[1][s], act[2][s], false, src, dst);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_pair(Ay);   // my last read of slot g is complete
+        lds_put(done + wave, g + 1);
+        if (!(VAR & 2)) poll4(ready, g + 2, qr, spins + 1);         // slot g + 1 landed everywhere
+        __builtin_amdgcn_sched_barrier(0);
+        read_pair<F_ALL>(Ax, nslot, 0, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_pair_dma<0, 0>(acc[6], acc[7], Ay, act[0][s], act[1][s], act[2][s], false, src, dst);
+        g += 1;
+        __builtin_amdgcn_sched_barrier(0);
+        wait_pair(Ax);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // in place: act = split(relu(acc)), acc = bias of the next layer (lbias: 256 floats in LDS)
 template <int FLAGS>
 __device__ __forceinline__ void convert(f32x16 (&acc)[8], bf16x8 (&act)[3][16], const float* lbias, int lane) {
@@ -215,22 +336,37 @@ __device__ __forceinline__ void convert(f32x16 (&acc)[8], bf16x8 (&act)[3][16], 
 // x: [128][256] fp32 (>= 0), feature-major per sample; out: [blocks][128][256] pre-activation of the last layer
 template <int FLAGS>
 __global__ __launch_bounds__(256, 1) void proto_kernel(const char* blob, const float* bias, int nl, const float* x, float* out,
-                                                       int items, unsigned long long* cycles) {
+                                                       int items, unsigned long long* cycles, unsigned* spins = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
     float* lbias = reinterpret_cast<float*>(smem + RING * SLOT);
+    unsigned* ready = reinterpret_cast<unsigned*>(smem + RING * SLOT + NLMAX * 1024);
+    unsigned* done = ready + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     for (int i = tid; i < nl * 256; i += 256) lbias[i] = bias[i];
     __syncthreads();
     const unsigned nslots = nl * 16;
     unsigned g = 0;
+    if (FLAGS & F_FLAGS) {
+        // prime: every wave its quarter of slots 0, 1, 2; slot 0 landed everywhere, nothing read yet
+        dma_slot<F_ALL>(blob, 0, nslots, ring, wave, lane);
+        dma_slot<F_ALL>(blob, 1, nslots, ring, wave, lane);
+        dma_slot<F_ALL>(blob, 2, nslots, ring, wave, lane);
+        if (tid < 4) {
+            ready[tid] = 1;
+            done[tid] = 0;
+        }
+        VMCNT(12);
+        __syncthreads();
+    } else {
     // prime: slots 0, 1, 2
     dma_slot<FLAGS>(blob, 0, nslots, ring, wave, lane);
     dma_slot<FLAGS>(blob, 1, nslots, ring, wave, lane);
     dma_slot<FLAGS>(blob, 2, nslots, ring, wave, lane);
     if (FLAGS & F_DMA) VMCNT(12);
     __builtin_amdgcn_s_barrier();
+    }
     f32x16 acc[8];
     bf16x8 act[3][16];
     Apair Ax, Ay;
@@ -254,7 +390,10 @@ __global__ __launch_bounds__(256, 1) void proto_kernel(const char* blob, const f
 #pragma unroll 1
         for (int l = 0; l < nl; ++l) {
             if (l > 0) convert<FLAGS>(acc, act, lbias + l * 256, lane);
-            layer256<FLAGS>(acc, act, Ax, Ay, blob, g, nslots, ring, wave, lane);
+            if (FLAGS & F_FLAGS)
+                layer256_flags<(FLAGS >> 8) & 7>(acc, act, Ax, Ay, blob, g, nslots, ring, ready, done, wave, lane, spins);
+            else
+                layer256<FLAGS>(acc, act, Ax, Ay, blob, g, nslots, ring, wave, lane);
         }
     }
     const unsigned long long t1 = clock64();
@@ -384,18 +523,22 @@ static int kperm(int s, int h, int j) { return 32 * (s >> 1) + 8 * (2 * (s & 1) 
 
 static double frand() { return (double)rand() / RAND_MAX; }
 
+static unsigned* g_spins = nullptr;
 template <int FLAGS>
 static void run_proto(const char* name, const char* d_blob, const float* d_bias, int nl, const float* d_x, float* d_out, int items,
                       unsigned long long* d_cyc, int blocks) {
-    const int lds = RING * SLOT + NLMAX * 1024;
+    const int lds = RING * SLOT + NLMAX * 1024 + 64;
+    if (!g_spins) { CK(hipMalloc(&g_spins, 8)); }
+    CK(hipMemset(g_spins, 0, 8));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(proto_kernel<FLAGS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    proto_kernel<FLAGS><<<blocks, 256, lds>>>(d_blob, d_bias, nl, d_x, d_out, 4, d_cyc);
+    proto_kernel<FLAGS><<<blocks, 256, lds>>>(d_blob, d_bias, nl, d_x, d_out, 4, d_cyc, g_spins);
     CK(hipDeviceSynchronize());
+    CK(hipMemset(g_spins, 0, 8));
     CK(hipEventRecord(e0));
-    proto_kernel<FLAGS><<<blocks, 256, lds>>>(d_blob, d_bias, nl, d_x, d_out, items, d_cyc);
+    proto_kernel<FLAGS><<<blocks, 256, lds>>>(d_blob, d_bias, nl, d_x, d_out, items, d_cyc, g_spins);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms;
@@ -404,8 +547,15 @@ static void run_proto(const char* name, const char* d_blob, const float* d_bias,
     CK(hipMemcpy(&cyc, d_cyc, 8, hipMemcpyDeviceToHost));
     const double mfma = (double)items * nl * 768;
     const double alg = (double)blocks * items * 128.0 * nl * 2.0 * 256 * 256;
-    printf("%-34s %8.3f ms  %7.1f alg TF/s  %7.1f exec TF/s  %6.2f cyc/MFMA (ideal 32)  %6.1f MHz(clock64)\n", name, ms, alg / ms * 1e-9,
+    unsigned sp[2];
+    CK(hipMemcpy(sp, g_spins, 8, hipMemcpyDeviceToHost));
+    printf("%-34s %8.3f ms  %7.1f alg TF/s  %7.1f exec TF/s  %6.2f cyc/MFMA (ideal 32)  %6.1f MHz(clock64)", name, ms, alg / ms * 1e-9,
            6.0 * alg / ms * 1e-9, (double)cyc / mfma, (double)cyc / (ms * 1e3));
+    if (FLAGS & F_FLAGS) {
+        // correctness of the flag protocol: the outputs must be those of the barrier version (checked by the caller through d_out)
+        printf("  spins: refill %u, ready %u", sp[0], sp[1]);
+    }
+    printf("\n");
     fflush(stdout);
 }
 
@@ -529,6 +679,19 @@ int main(int argc, char** argv) {
     run_proto<(F_ALL & ~F_CONV & ~F_BAR) | F_SPREAD>("no conv, DMA spread, no barrier (racy)", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
     run_proto<(F_ALL & ~F_CONV & ~F_BAR) | F_SPREAD | F_NOWAITV>("no conv, DMA spread, no barrier, no wait (racy)", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
     run_proto<(F_ALL & ~F_CONV & ~F_LDS)>("no conv, no ds_read", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
+    // ---- the flag protocol instead of the barrier; its outputs against the barrier version's
+    {
+        std::vector<float> A((size_t)128 * 256), Bv((size_t)128 * 256);
+        run_proto<F_ALL | F_SPREAD>("full, DMA spread (barrier)", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
+        CK(hipMemcpy(A.data(), d_out + (size_t)17 * 128 * 256, A.size() * 4, hipMemcpyDeviceToHost));
+        run_proto<F_ALL | F_FLAGS>("full, ownership + flags (no barrier)", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
+        CK(hipMemcpy(Bv.data(), d_out + (size_t)17 * 128 * 256, Bv.size() * 4, hipMemcpyDeviceToHost));
+        printf("flag protocol outputs == barrier outputs (workgroup 17): %s\n", memcmp(A.data(), Bv.data(), A.size() * 4) ? "NO" : "yes");
+        run_proto<(F_ALL & ~F_CONV) | F_FLAGS>("no conv, ownership + flags", d_blob, d_bias, nl, d_x, d_out, items, d_cyc, blocks);
+        // (measured: correct, and 2 - 3 x SLOWER than the barrier -- 93 .. 120 cycles per MFMA against 45, with the fetch
+        // spread over all four waves as here, 140 .. 260 with one wave fetching whole slots: a wave's LDS-DMAs complete one
+        // after the other, and every poll's wait sits behind them.  The barrier stays.)
+    }
     if (argc > 1) return 0;
     // ---- 3. shadow
     run_shadow<0, 8>(d_out, d_cyc);
