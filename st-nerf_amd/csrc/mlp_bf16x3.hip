@@ -29,6 +29,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "mlp_wave_common.h"
 #include "mlp_bf16x3.h"
 
@@ -179,9 +181,15 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8& a, const bf16x8& b, co
 // first three MFMAs (four buffers; the one they fill was consumed by unit U - 2).  With the reads only one unit ahead --
 // 160 cycles -- the K passes ran at 1.33 x their MFMA time (tools/bx_prof.py): the LDS round trip under four waves' load is
 // longer than that.
-template <int U, bool FIRST, bool BIG0 = false, int DMA0 = -1>
+// What may ride in the shadow of a unit's last three MFMAs (the ones without an operand read behind them): ~4 vector
+// instructions each are free (tools/micro/bf16x3_proto.hip: 2 per MFMA cost 0.5 cycles of 32).
+struct NoHook {
+    template <int U, int I>
+    __device__ __forceinline__ void at() {}
+};
+template <int U, bool FIRST, bool BIG0 = false, int DMA0 = -1, class Hook = NoHook>
 __device__ __forceinline__ void unit(Ctx& cx, f32x16& big, f32x16& small, const bf16x8& b0, const bf16x8& b1, const bf16x8& b2,
-                                     const Dma* dma = nullptr) {
+                                     const Dma* dma = nullptr, Hook* hook = nullptr) {
     ABuf& cur = cx.A[U & 3];
     ABuf& nx = cx.A[(U + 2) & 3];
     constexpr int OFF = ((U + 2) & 7) * BX_UNIT;
@@ -211,10 +219,20 @@ __device__ __forceinline__ void unit(Ctx& cx, f32x16& big, f32x16& small, const 
         dma_chunk<DMA0 < 0 ? 0 : DMA0>(*dma);
         BX_SB();
     }
+    if constexpr (!std::is_same<Hook, NoHook>::value) {
+        BX_SB();
+        hook->template at<U, 0>();
+        BX_SB();
+    }
     small = mfma_bf16(cur.p[0], b1, small);
     if (DMA0 >= 0) {
         BX_SB();
         dma_chunk<DMA0 < 0 ? 0 : DMA0 + 1>(*dma);
+        BX_SB();
+    }
+    if constexpr (!std::is_same<Hook, NoHook>::value) {
+        BX_SB();
+        hook->template at<U, 1>();
         BX_SB();
     }
     if (FIRST && BIG0) {  // (rgb_net.1: its C operand is added behind the K loop, see space_bx)
@@ -226,6 +244,10 @@ __device__ __forceinline__ void unit(Ctx& cx, f32x16& big, f32x16& small, const 
     if (DMA0 >= 0) {
         BX_SB();
         dma_chunk<DMA0 < 0 ? 0 : DMA0 + 2>(*dma);
+    }
+    if constexpr (!std::is_same<Hook, NoHook>::value) {
+        BX_SB();
+        hook->template at<U, 2>();
     }
     BX_SB();
 }
@@ -247,19 +269,19 @@ __device__ __forceinline__ void slot_done(Ctx& cx) {
 }
 
 // one ring slot: K steps k0, k1 (their B operands: the three planes of the input) for the pass's four blocks
-template <bool FIRST, bool BIG0 = false>
+template <bool FIRST, bool BIG0 = false, class Hook = NoHook>
 __device__ __forceinline__ void slot(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], const bf16x8& k0p0, const bf16x8& k0p1,
-                                     const bf16x8& k0p2, const bf16x8& k1p0, const bf16x8& k1p1, const bf16x8& k1p2) {
-    unit<0, FIRST, BIG0>(cx, big[0], small[0], k0p0, k0p1, k0p2);
-    unit<1, FIRST, BIG0>(cx, big[1], small[1], k0p0, k0p1, k0p2);
-    unit<2, FIRST, BIG0>(cx, big[2], small[2], k0p0, k0p1, k0p2);
-    unit<3, FIRST, BIG0>(cx, big[3], small[3], k0p0, k0p1, k0p2);
-    unit<4, false>(cx, big[0], small[0], k1p0, k1p1, k1p2);
-    unit<5, false>(cx, big[1], small[1], k1p0, k1p1, k1p2);
+                                     const bf16x8& k0p2, const bf16x8& k1p0, const bf16x8& k1p1, const bf16x8& k1p2, Hook* hook = nullptr) {
+    unit<0, FIRST, BIG0, -1, Hook>(cx, big[0], small[0], k0p0, k0p1, k0p2, nullptr, hook);
+    unit<1, FIRST, BIG0, -1, Hook>(cx, big[1], small[1], k0p0, k0p1, k0p2, nullptr, hook);
+    unit<2, FIRST, BIG0, -1, Hook>(cx, big[2], small[2], k0p0, k0p1, k0p2, nullptr, hook);
+    unit<3, FIRST, BIG0, -1, Hook>(cx, big[3], small[3], k0p0, k0p1, k0p2, nullptr, hook);
+    unit<4, false, false, -1, Hook>(cx, big[0], small[0], k1p0, k1p1, k1p2, nullptr, hook);
+    unit<5, false, false, -1, Hook>(cx, big[1], small[1], k1p0, k1p1, k1p2, nullptr, hook);
     Dma d;
     slot_turn(cx, d);
-    unit<6, false, false, 0>(cx, big[2], small[2], k1p0, k1p1, k1p2, &d);
-    unit<7, false, false, 3>(cx, big[3], small[3], k1p0, k1p1, k1p2, &d);
+    unit<6, false, false, 0, Hook>(cx, big[2], small[2], k1p0, k1p1, k1p2, &d, hook);
+    unit<7, false, false, 3, Hook>(cx, big[3], small[3], k1p0, k1p1, k1p2, &d, hook);
     slot_done(cx);
 }
 
@@ -414,6 +436,49 @@ __device__ __forceinline__ void unpark_act(const Park& pk, bf16x8 (&act)[3][16])
         }
 }
 
+// The same conversion as unpark_act's, for ONE block, spread over the MFMA shadows of one ring slot (a pair of values per
+// unit, in three steps).  Runs inside the second pass of a 256-wide layer, in slots 4 .. 7: K steps 0 .. 7 of the input planes
+// are dead by then and take the first pass's outputs directly -- 416 of a layer's 1344 boundary instructions under MFMAs.
+template <int FB>
+struct UnparkHook {
+    const Park& pk;
+    bf16x8 (&act)[3][16];
+    float x0, x1, r0, r1;
+    unsigned w0, w1;
+    template <int U, int I>
+    __device__ __forceinline__ void at() {
+        constexpr int T = 2 * FB + (U >> 2), W = U & 3;
+        if (I == 0) {
+            x0 = park_get(pk.v[16 * FB + 2 * U]);
+            x1 = park_get(pk.v[16 * FB + 2 * U + 1]);
+            w0 = pk_bf16(x0, x1);
+        } else if (I == 1) {
+            r0 = x0 - __uint_as_float(w0 << 16);
+            r1 = x1 - __uint_as_float(w0 & 0xffff0000u);
+            w1 = pk_bf16(r0, r1);
+        } else {
+            const float s0 = r0 - __uint_as_float(w1 << 16), s1 = r1 - __uint_as_float(w1 & 0xffff0000u);
+            reinterpret_cast<u32x4&>(act[0][T])[W] = w0;
+            reinterpret_cast<u32x4&>(act[1][T])[W] = w1;
+            reinterpret_cast<u32x4&>(act[2][T])[W] = pk_bf16(s0, s1);
+        }
+    }
+};
+template <int FB>
+__device__ __forceinline__ void slot_unpark(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], bf16x8 (&act)[3][16], const Park& pk) {
+    constexpr int k = 8 + 2 * FB;
+    UnparkHook<FB> hook{pk, act, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+    slot<false, false, UnparkHook<FB>>(cx, big, small, act[0][k], act[1][k], act[2][k], act[0][k + 1], act[1][k + 1], act[2][k + 1], &hook);
+}
+// second pass of a 256-wide layer: 16 K steps, the parked first pass converted on the way
+__device__ __forceinline__ void pass_b_unpark(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], bf16x8 (&act)[3][16], const Park& pk) {
+    pass_act<0, 4, true>(cx, big, small, act);
+    slot_unpark<0>(cx, big, small, act, pk);
+    slot_unpark<1>(cx, big, small, act, pk);
+    slot_unpark<2>(cx, big, small, act, pk);
+    slot_unpark<3>(cx, big, small, act, pk);
+}
+
 // 128 -> 3 head (rgb_net's last layer, MotionNet's flow) on relu(big + small): w = [3][128] in LDS; fp64 accumulation, two
 // chains per output and lane
 __device__ __forceinline__ void head3(const f32x16 (&big)[4], const f32x16 (&small)[4], const float* w, const float* __restrict__ b3,
@@ -561,13 +626,12 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
         BXP(BXP_PASS);
         finish_park(big, small, pk, cs + BXC_B + 256 * li + 128, lane);
         BXP(BXP_PARK);
-        pass_act<0, 8, true>(cx, big, small, act);
+        pass_b_unpark(cx, big, small, act, pk);
         if constexpr (decltype(with_pe)::value) pe_slots();
         BXP(BXP_PASS);
     };
     auto layer_end = [&](int li) {   // (+ the next layer's first C operand; behind stage2.4 comes rgb_net.1, which starts from 0)
         finish_act<8>(big, small, act, li < 6 ? cs + BXC_B + 256 * (li + 1) : nullptr, lane);
-        unpark_act(pk, act);
         BXP(BXP_ACT);
     };
 #pragma unroll 1
