@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
-"""A/B of the two persistent stage kernels behind stnerf_mlp_stage (GPU box):
-STNERF_STAGE_KERNEL=lds (csrc/mlp_stage.hip, activations in LDS) vs wave (csrc/mlp_wave.hip, activations in registers).
+"""A/B of two BUILDS of the exact-f32 stage kernel (csrc/mlp_wave.hip) behind stnerf_mlp_stage (GPU box).  Round 2 used
+this against the LDS-organised kernel (csrc/mlp_stage.hip, removed in round 3: tests/test_gpu_stage.py checks the stage
+against the oracle directly); what is left is the comparison of the tree's build with a variant build of the same source
+(STNERF_LIB=.../libstnerf_hip_<tag>.so, built with STNERF_LIB_TAG=<tag>), one library per process:
 
-    python tools/ab_wave.py check      bitwise comparison on a set of scenarios (exit code 1 on any difference)
+    STNERF_LIB=.../libstnerf_hip_base.so python tools/ab_wave.py check --save /tmp/base.pt
+    python tools/ab_wave.py check --against /tmp/base.pt     bitwise comparison on a set of scenarios (exit code 1 on
+                                                             any difference); without --against: determinism only
     python tools/ab_wave.py layers     development build (STNERF_LIB=.../libstnerf_hip_dbg.so): the wave kernel's
                                        activations after every stage against an fp64 evaluation -> which layer is wrong
-    python tools/ab_wave.py time       TF/s of both kernels on 131072 x 64 rows per scenario
+    python tools/ab_wave.py time       TF/s on 131072 x 64 rows per scenario
 """
 import os
 import sys
@@ -20,8 +24,7 @@ from stnerf_amd import hip, ops, synthetic as syn
 FLOP_SPACE, FLOP_SPACE_TIME, FLOP_MOTION = 924_672, 930_048, 153_344
 
 
-def run(kernel, layers, dirs, ns, **kw):
-    os.environ["STNERF_STAGE_KERNEL"] = kernel
+def run(layers, dirs, ns, **kw):
     ops.mlp_stage(layers, dirs, ns, **kw)
     torch.cuda.synchronize()
 
@@ -72,41 +75,44 @@ SCENARIOS = [
 ]
 
 
-def check():
+def check(save=None, against=None):
     bad_total = 0
+    saved = torch.load(against) if against else {}
+    keep = {}
     for name, kw in SCENARIOS:
         sc = scenario(name, **kw)
         n, l, ns = sc["n"], sc["l"], sc["ns"]
-        out = {}
-        for kern in os.environ.get("ORDER", "lds,wave").split(","):
-            raw = torch.full((n, l, ns, 4), 7.0, device="cuda")
-            run(kern, sc["layers_for"](raw), sc["dirs"], ns, deep_rgb=sc["deep"], sigmoid_rgb=bool(os.environ.get("SIGMOID")))
-            out[kern] = raw
-        a, b = out["lds"], out["wave"]
-        diff = (a != b)
-        nbad = int(diff.any(-1).sum())
-        bad_total += nbad
-        line = f"[{name}] rows differing: {nbad} of {n * l * ns}"
-        if nbad:
-            d = (a - b).abs()
-            comp = [int(diff[..., c].sum()) for c in range(4)]
-            line += f"; per component r,g,b,sigma: {comp}; max |d| {float(d.max()):.3e}; finite wave: {bool(torch.isfinite(b).all())}"
-            for layer in range(l):
-                dl = diff[:, layer].any(-1)
-                if bool(dl.any()):
-                    idx = dl.nonzero()[:6].tolist()
-                    line += f"\n    layer {layer}: {int(dl.sum())} rows, first (ray, sample): {idx}"
-                    r, s_ = idx[0]
-                    line += f"\n      lds  {a[r, layer, s_].tolist()}\n      wave {b[r, layer, s_].tolist()}"
-            untouched = (b.cpu()[~sc["mask"].bool()] == 7.0).all() if kw["with_perf"] else True
-            line += f"\n    rows of unlisted rays untouched: {bool(untouched)}"
-        print(line, flush=True)
+        b = torch.full((n, l, ns, 4), 7.0, device="cuda")
+        run(sc["layers_for"](b), sc["dirs"], ns, deep_rgb=sc["deep"], sigmoid_rgb=bool(os.environ.get("SIGMOID")))
+        keep[name] = b.cpu()
+        if name in saved:
+            a = saved[name].cuda()
+            diff = (a != b)
+            nbad = int(diff.any(-1).sum())
+            bad_total += nbad
+            line = f"[{name}] rows differing from {against}: {nbad} of {n * l * ns}"
+            if nbad:
+                d = (a - b).abs()
+                comp = [int(diff[..., c].sum()) for c in range(4)]
+                line += f"; per component r,g,b,sigma: {comp}; max |d| {float(d.max()):.3e}; finite: {bool(torch.isfinite(b).all())}"
+                for layer in range(l):
+                    dl = diff[:, layer].any(-1)
+                    if bool(dl.any()):
+                        idx = dl.nonzero()[:6].tolist()
+                        line += f"\n    layer {layer}: {int(dl.sum())} rows, first (ray, sample): {idx}"
+                        r, s_ = idx[0]
+                        line += f"\n      saved {a[r, layer, s_].tolist()}\n      this  {b[r, layer, s_].tolist()}"
+                untouched = (b.cpu()[~sc["mask"].bool()] == 7.0).all() if kw["with_perf"] else True
+                line += f"\n    rows of unlisted rays untouched: {bool(untouched)}"
+            print(line, flush=True)
         # twice the same bits (dynamic scheduling does not touch the arithmetic)
         raw2 = torch.full((n, l, ns, 4), 7.0, device="cuda")
-        run("wave", sc["layers_for"](raw2), sc["dirs"], ns, deep_rgb=sc["deep"], sigmoid_rgb=bool(os.environ.get("SIGMOID")))
+        run(sc["layers_for"](raw2), sc["dirs"], ns, deep_rgb=sc["deep"], sigmoid_rgb=bool(os.environ.get("SIGMOID")))
         if not torch.equal(raw2, b):
-            print(f"[{name}] wave kernel is not deterministic: {int((raw2 != b).any(-1).sum())} rows differ between two runs", flush=True)
+            print(f"[{name}] not deterministic: {int((raw2 != b).any(-1).sum())} rows differ between two runs", flush=True)
             bad_total += 1
+    if save:
+        torch.save(keep, save)
     print("CHECK", "OK" if bad_total == 0 else f"FAILED ({bad_total})", flush=True)
     return bad_total == 0
 
@@ -192,7 +198,7 @@ def layers():
         for stage in sorted(ref):
             buf = torch.full((n * ns, 256), float("nan"), device="cuda")
             lib.stnerf_debug_wave_dump(C.c_void_p(buf.data_ptr()), stage)
-            run("wave", [dict(space=sp, motion=mo if with_motion else None, xyz=dx, raw=raw, times=dt)], dd, ns)
+            run([dict(space=sp, motion=mo if with_motion else None, xyz=dx, raw=raw, times=dt)], dd, ns)
             lib.stnerf_debug_wave_dump(None, -1)
             want = ref[stage]
             got = buf[:, :want.shape[1]].cpu().double()
@@ -246,16 +252,16 @@ def time_():
     for name, (ls, flop) in cases.items():
         if only and not any(name.startswith(o) for o in only.split(",")):
             continue
-        for kern in os.environ.get("KERNELS", "lds,wave").split(","):
-            os.environ["STNERF_STAGE_KERNEL"] = kern
-            ms = timeit(lambda: ops.mlp_stage(ls, dirs, ns, sigmoid_rgb=True), iters)
-            print(f"{name:30s} {kern:5s} {ms:9.3f} ms  {rows * flop / (ms * 1e-3) / 1e12:7.2f} TF/s", flush=True)
+        ms = timeit(lambda: ops.mlp_stage(ls, dirs, ns, sigmoid_rgb=True), iters)
+        if True:
+            print(f"{name:30s} {ms:9.3f} ms  {rows * flop / (ms * 1e-3) / 1e12:7.2f} TF/s", flush=True)
 
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "check"
     if what == "check":
-        sys.exit(0 if check() else 1)
+        opt = dict(zip(sys.argv[2::2], sys.argv[3::2]))
+        sys.exit(0 if check(opt.get("--save"), opt.get("--against")) else 1)
     elif what == "layers":
         sys.exit(0 if layers() else 1)
     elif what == "time":

@@ -4,7 +4,8 @@
 out=gpurun_out/${1:-waveab}
 mkdir -p $out
 export PYTHONDONTWRITEBYTECODE=1
-timeout 200 python tools/ab_wave.py check > $out/check.log 2>&1; echo "rc=$?" >> $out/check.log
+STNERF_LIB=$PWD/st-nerf_amd/libstnerf_hip_base.so timeout 200 python tools/ab_wave.py check --save /tmp/base.pt > $out/check_base.log 2>&1
+timeout 200 python tools/ab_wave.py check --against /tmp/base.pt > $out/check.log 2>&1; echo "rc=$?" >> $out/check.log
 for v in main base main base; do
   echo "== $v" >> $out/time.log
   if [ $v = base ]; then export STNERF_LIB=$PWD/st-nerf_amd/libstnerf_hip_base.so; else unset STNERF_LIB; fi

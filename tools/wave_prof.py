@@ -4,7 +4,6 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from stnerf_amd import hip, ops, synthetic as syn
-os.environ["STNERF_STAGE_KERNEL"] = "wave"
 lib = hip.lib()
 lib.stnerf_debug_wave_phases.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 n, ns = int(os.environ.get("RAYS", 131072)), 64
