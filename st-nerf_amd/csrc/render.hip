@@ -9,6 +9,8 @@
 // Reference: layers/render_layer.py:8-58, utils/sample_pdf.py:18-63,
 //            modeling/layered_rfrender.py:414-475, :538-606.
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 
 // Occupancy targets (waves per SIMD) of the three kernels: the VGPR budget follows from them (512 / waves).
 #ifndef STNERF_WAVES_COMPOSITE
@@ -45,23 +47,31 @@ __device__ __forceinline__ float dpp_move(float identity, float v) {
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
 constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138;
 
+// The fp32 scans run IN PLACE: `v_mul_f32_dpp v, v, v row_shr:1` multiplies every lane whose source lane exists by that lane's
+// value and leaves the others untouched (bound_ctrl off: a lane without a source is not executed) -- one vector
+// instruction per step.  Written through the update_dpp builtin the same step is three (identity into a scratch
+// register, DPP move over it, multiply), and the compositor is bound by its vector-instruction count.
+// The two wait states a DPP read needs behind the write of its source are the s_nop 1 in front of every step.
+#define STNERF_DPP_STEP(op, ctrl) "s_nop 1\n\t" op " %0, %0, %0 " ctrl "\n\t"
 __device__ __forceinline__ float wave_scan_mul(float v) {  // inclusive
-    v *= dpp_move<DPP_ROW_SHR1>(1.f, v);
-    v *= dpp_move<DPP_ROW_SHR2>(1.f, v);
-    v *= dpp_move<DPP_ROW_SHR4>(1.f, v);
-    v *= dpp_move<DPP_ROW_SHR8>(1.f, v);
-    v *= dpp_move<DPP_ROW_BCAST15, 0xa>(1.f, v);
-    v *= dpp_move<DPP_ROW_BCAST31, 0xc>(1.f, v);
+    asm(STNERF_DPP_STEP("v_mul_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
+        STNERF_DPP_STEP("v_mul_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+        STNERF_DPP_STEP("v_mul_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+        STNERF_DPP_STEP("v_mul_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+        STNERF_DPP_STEP("v_mul_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+        STNERF_DPP_STEP("v_mul_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(v));
     return v;
 }
 
 __device__ __forceinline__ float wave_scan_add(float v) {  // inclusive
-    v += dpp_move<DPP_ROW_SHR1>(0.f, v);
-    v += dpp_move<DPP_ROW_SHR2>(0.f, v);
-    v += dpp_move<DPP_ROW_SHR4>(0.f, v);
-    v += dpp_move<DPP_ROW_SHR8>(0.f, v);
-    v += dpp_move<DPP_ROW_BCAST15, 0xa>(0.f, v);
-    v += dpp_move<DPP_ROW_BCAST31, 0xc>(0.f, v);
+    asm(STNERF_DPP_STEP("v_add_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
+        STNERF_DPP_STEP("v_add_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+        STNERF_DPP_STEP("v_add_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+        STNERF_DPP_STEP("v_add_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+        STNERF_DPP_STEP("v_add_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+        STNERF_DPP_STEP("v_add_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(v));
     return v;
 }
 
@@ -338,12 +348,14 @@ struct CompositeArgs {
     int waves_per_block;
     int p2;  // floor_pow2(S)
     uint8_t* handled;  // [n] or nullptr: rays composite_single_kernel has already finished (it writes 0 / 1 for every ray)
+    int lds_layers;    // composite_merge_kernel: layers its merged list holds (rays with more live layers are left to the next launch)
 };
 
-// FASTPATH: also composite rays with one live layer from registers (the kernel then serves every ray on its own: callers
-// without scratch); without it the kernel is the lean second pass behind composite_single_kernel (58 VGPRs: 8 waves per SIMD).
-template <bool FASTPATH>
-__global__ void __attribute__((amdgpu_waves_per_eu(FASTPATH ? STNERF_WAVES_COMPOSITE : 8, 8))) composite_kernel(CompositeArgs a) {
+// The LDS-staged compositor: every ray on its own, the whole ray (all l * S samples) in LDS, rank merge by binary
+// searches.  Since round 3 it serves the `order` parity output and layers of more than 192 samples only; production
+// calls take composite_single_kernel + composite_merge_kernel below (same numbers, bit for bit).
+__global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) composite_kernel(CompositeArgs a) {
+    constexpr bool FASTPATH = true;  // rays with one live layer are composited from registers
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (uniform: ray index and addresses on the scalar unit)
@@ -699,7 +711,7 @@ struct SingleBuf {
 };
 
 template <int MAXB, int MAXCHK>
-__global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_SINGLE, 8))) composite_single_kernel(CompositeArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXB > 2 ? 4 : STNERF_WAVES_SINGLE, 8))) composite_single_kernel(CompositeArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t first = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -817,6 +829,445 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_SINGLE, 8))) com
         cur = nxt;
         m1 = m2;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rays with SEVERAL live layers (round 3): layers in registers, merge by insertion.
+//
+// composite_kernel stages the whole ray in LDS (22 B per sample: 8.4 KB per wave at 3 x 128 samples, 38 KB at 9 x 192 --
+// one wave per SIMD) and ranks every sample against every other layer (log2 S dependent LDS reads per sample and layer:
+// cost ~ l^2).  This kernel keeps a layer in registers while it is composited (the arithmetic of composite_regs, as the
+// single-layer kernel above), and builds the merged order one layer at a time in a 6 B / sample LDS list
+// (depth + source index):
+//   * the samples of the NEW layer search the list merged so far (one upper_bound each: ties go behind the earlier
+//     layers, the order of a stable sort of the concatenation) and mark their output slots in a bit mask (ds_or);
+//   * every output slot then knows from the mask alone what it receives: bit set -> the next sample of the new layer,
+//     clear -> list element (slot - set bits below it); the prefix count is s_bcnt1 + v_mbcnt on the mask words, no scan.
+//     The list is rewritten in place from the top block down (a list element only ever moves up).
+//   Search steps per ray: S log2(m) per inserted layer instead of S (l-1) log2(S) per layer -- 2.7 x fewer at l = 3,
+//   10 x at l = 9 -- and the LDS footprint is 2.9 KB (3 x 128) / 11.4 KB (9 x 192) per wave.
+//   * the merged composite gathers each sample's float4 from global memory by source index (the rows were read by this
+//     wave a moment ago: L2 / L1 hits) and re-applies the layer's density edits per lane (two LDS table reads).
+// Same merged order, same lanes, same arithmetic as composite_kernel: bit-identical outputs (the `order` parity call
+// still takes composite_kernel; tests/test_gpu_ops.py::test_composite_production_shortcuts_are_bitwise_neutral compares
+// the two).  A layer that is neither ascending nor strictly descending sends the ray to a brute-force rank (tests only).
+// ---------------------------------------------------------------------------------------------
+constexpr int DPP_WAVE_SHL1 = 0x130;
+constexpr int MERGE_TAB_BYTES = 128;  // per workgroup: effective threshold[16] | sigma_scale[16]
+
+__host__ __device__ __forceinline__ int64_t merge_lds_per_wave(int l, int S) {   // l: layers the merged list holds
+    const int64_t LS = (int64_t)l * S, SP = (S + 63) / 64 * 64, words = (LS + 63) / 64 * 2;
+    return ((4 * LS + 4 * SP + 4 * words + 2 * LS + 15) / 16) * 16;
+}
+
+template <int MAXB>
+struct LayerRegs {
+    float tk[MAXB];
+    float4 rw[MAXB];
+};
+
+// Running state of one alpha-composite (gen_weight + VolumeRenderer.forward, see composite_run): the transmittance
+// carried from block to block and the five weighted sums.
+struct CompositeAcc {
+    float carry = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
+};
+
+// One block of 64 samples (lane = sample): weight of the lane's sample, sums updated.  The arithmetic, operation for
+// operation, of composite_run / composite_regs (the kernels are compared bit for bit).  `ok`: the lane holds a sample.
+template <bool ALL>
+__device__ __forceinline__ float composite_block(CompositeAcc& A, float sigma, float delta, float r, float g, float b, float t, bool ok) {
+    float alpha = 1.f - exp_neg(fmaxf(sigma, 0.f) * delta);
+    float tr = (1.f - alpha) + 1e-10f;
+    if (!ALL) {
+        alpha = ok ? alpha : 0.f;
+        tr = ok ? tr : 1.f;
+    }
+    const float incl = wave_scan_mul(tr);
+    const float excl = wave_prev(incl, 1.f);
+    float w = alpha * (A.carry * excl);
+    A.carry = A.carry * wave_last(incl);
+    if (!ALL) w = ok ? w : 0.f;   // (alpha = 0 does not make it zero when the transmittance has overflowed)
+    A.cr += w * r;
+    A.cg += w * g;
+    A.cb += w * b;
+    A.cd += w * t;
+    A.ca += w;
+    return w;
+}
+
+// the five sums over the wave, stored by lane 63 (which holds the totals of the in-place scans)
+__device__ __forceinline__ void composite_store5(const CompositeAcc& A, float* dst, float* dst2, unsigned lane) {
+    const float o0 = wave_scan_add(A.cr), o1 = wave_scan_add(A.cg), o2 = wave_scan_add(A.cb), o3 = wave_scan_add(A.cd),
+                o4 = wave_scan_add(A.ca);
+    if (lane == 63u) {
+        if (dst) { dst[0] = o0; dst[1] = o1; dst[2] = o2; dst[3] = o3; dst[4] = o4; }
+        if (dst2) { dst2[0] = o0; dst2[1] = o1; dst2[2] = o2; dst2[3] = o3; dst2[4] = o4; }
+    }
+}
+
+// FULL: S == 64 * MAXB (64 / 128 / 192 samples per layer: every BASELINE configuration) -- no lane is ever idle, the
+// `k < S` predicates and their exec-mask bookkeeping disappear.
+template <int MAXB, bool FULL>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MAXB > 2 || !FULL) ? 5 : 6, 8))) composite_merge_kernel(CompositeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned S = FULL ? 64u * MAXB : (unsigned)a.S, L = (unsigned)a.l, LS = L * S;
+    const unsigned LC = (unsigned)a.lds_layers * S;   // capacity of the merged list (samples)
+    float* tab = reinterpret_cast<float*>(smem_raw);
+    unsigned ev1 = 0, ev2 = 0;
+#pragma unroll
+    for (int i = 0; i < STNERF_MAX_LAYERS; ++i) {
+        if (i < a.l) {
+            if (a.p.evaluated[i] == 2) ev2 |= 1u << i;
+            else if (a.p.evaluated[i] != 0) ev1 |= 1u << i;
+            if ((int)threadIdx.x == i) {
+                tab[i] = a.p.use_threshold[i] != 0 ? a.p.threshold[i] : -INFINITY;   // (sigma < -inf never holds)
+                tab[16 + i] = a.p.sigma_scale[i];
+            }
+        }
+    }
+    __syncthreads();
+    unsigned char* mine = smem_raw + MERGE_TAB_BYTES + (size_t)wave * merge_lds_per_wave(a.lds_layers, (int)S);
+    float* mkey = reinterpret_cast<float*>(mine);            // [LC] merged depths, ascending
+    float* ckey = mkey + LC;                                  // [SP] the layer being inserted, ascending (ckey = mkey + LC is used below)
+    unsigned* bits = reinterpret_cast<unsigned*>(ckey + (S + 63u) / 64u * 64u);   // [2 ceil(LC / 64)] output slots of the new layer
+    unsigned short* mpay = reinterpret_cast<unsigned short*>(bits + (LC + 63u) / 64u * 2u);   // [LC] source sample of a list entry
+    const unsigned lmask = L >= 32u ? ~0u : (1u << L) - 1u;
+    const float invS = 1.f / (float)S, nearv = a.p.near, border = a.p.border;
+    const bool fine = a.p.fine != 0, activated = a.p.rgb_activated != 0;
+    auto ok_lane = [&](int b) -> bool { return FULL || (unsigned)b * 64u + lane < S; };
+
+    // A wave takes the rays wave_id + k * (number of waves), k = 0, 1, ... (neighbouring rays -- same performers, same cost --
+    // go to different waves), GR of them at a time: one round trip fetches the `handled` bytes and hit masks of the whole
+    // group (lane i < GR: the group's ray i; its mask packed into one word), one group ahead of the one being worked on.
+    // The rays composite_single_kernel has finished (about 60 % of a view) then cost nothing here -- taken one at a time,
+    // every one of them is a dependent HBM round trip with nothing behind it.
+    constexpr unsigned GR = 16;
+    const int64_t nwaves = (int64_t)gridDim.x * a.waves_per_block, wave_id = (int64_t)blockIdx.x * a.waves_per_block + wave;
+    auto group_flags = [&](int64_t k0, unsigned& mk) -> int {
+        int hnd = 1;
+        mk = 0u;
+        const int64_t ray = wave_id + (k0 + lane) * nwaves;
+        if (lane < GR && ray < a.n) {
+            hnd = a.handled ? (int)a.handled[ray] : 0;
+            if (a.mask) {
+#pragma unroll
+                for (int i = 0; i < STNERF_MAX_LAYERS; ++i)
+                    if (i < a.l) mk |= a.mask[ray * a.l + i] ? 1u << i : 0u;
+            }
+        }
+        return hnd;
+    };
+    using Regs = LayerRegs<MAXB>;
+    unsigned mk_next = 0u;
+    int hnd_next = group_flags(0, mk_next);
+    CP_DECL
+    for (int64_t k0 = 0; wave_id + k0 * nwaves < a.n; k0 += GR) {
+      const unsigned mk = mk_next;
+      unsigned todo_rays = (unsigned)__ballot(hnd_next == 0);
+      hnd_next = group_flags(k0 + GR, mk_next);
+      CP(0);
+      while (todo_rays) {  // (wave-uniform; no workgroup barrier inside the loops)
+        const int jr = __ffs(todo_rays) - 1;
+        todo_rays &= todo_rays - 1u;
+        const int64_t ray = wave_id + (k0 + jr) * nwaves;
+        const unsigned mask_bits = (unsigned)__builtin_amdgcn_readlane((int)mk, jr);
+        const unsigned have_m = (ev2 | (ev1 & (a.mask ? mask_bits : ~0u))) & lmask;
+        const float* __restrict__ tsrc = a.t + ray * LS;
+        const float4* __restrict__ rsrc = a.raw + ray * LS;
+        // (idle lanes of a ragged last block read the layer's last sample: no branch around the loads, nothing uses the value)
+        auto sample_of = [&](int b) -> unsigned { const unsigned k = (unsigned)b * 64u + lane; return FULL ? k : (k < S ? k : S - 1u); };
+        auto load = [&](Regs& r, unsigned layer) {   // raw is read for a layer without output as well (zeroed when used)
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) {
+                r.tk[b] = tsrc[layer * S + sample_of(b)];
+                r.rw[b] = rsrc[layer * S + sample_of(b)];
+            }
+        };
+        // the first layer with network output is (almost always) the first live layer: its loads go out together with the
+        // depth checks below instead of one round trip behind them
+        const int first_have = have_m ? __ffs(have_m) - 1 : -1;
+        Regs cur;
+        load(cur, first_have >= 0 ? (unsigned)first_have : 0u);
+        // ---- which layers take part: those with network output, and those without whose depths are real (a hidden layer,
+        // a grazing hit: they shape their neighbours' deltas; see composite_kernel).  Four layers' depths per round trip.
+        unsigned live = have_m;
+        constexpr int CB = 4;
+        for (unsigned cand = ~have_m & lmask; cand;) {
+            int ly[CB];
+            float v[CB][MAXB];
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                ly[j] = cand ? __ffs(cand) - 1 : -1;
+                cand &= cand - 1u;   // (0 stays 0)
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b) v[j][b] = ly[j] >= 0 ? tsrc[(unsigned)ly[j] * S + sample_of(b)] : -1000.f;
+            }
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                bool missed = true;
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b) missed = missed && v[j][b] == -1000.f;
+                if (ly[j] >= 0 && !__all(missed)) live |= 1u << ly[j];
+            }
+        }
+        const unsigned nlive = (unsigned)__popc(live);
+        CP(1);
+        if (nlive * S > LC) continue;   // more live layers than this launch's list holds: the next launch takes the ray
+        // ---- the layers the ray misses: zero weights and outputs
+        for (unsigned dead = ~live & lmask; dead; dead &= dead - 1u) {
+            const unsigned other = (unsigned)__ffs(dead) - 1u;
+            if (a.weights) {
+                float* wz = a.weights + (ray * L + other) * S;
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b)
+                    if (ok_lane(b)) wz[(unsigned)b * 64u + lane] = 0.f;
+            }
+            if (a.layer_out && lane < 5u) a.layer_out[(ray * L + other) * 5 + lane] = 0.f;
+        }
+        if (a.handled && lane == 0u) a.handled[ray] = 1;
+        if (nlive == 0u) {
+            if (a.mixed_out && lane < 5u) a.mixed_out[ray * 5 + lane] = 0.f;
+            continue;
+        }
+        unsigned m = 0;                    // length of the merged list
+        bool any_unsorted = false, merged_done = false;
+        unsigned todo = live;
+        int layer = __ffs(todo) - 1;
+        todo &= todo - 1u;
+        if (layer != first_have) load(cur, (unsigned)layer);   // (a layer without output in front of it takes part: hidden / grazing)
+        Regs nxt = cur;
+        while (layer >= 0) {
+            const int nlayer = todo ? __ffs(todo) - 1 : -1;
+            todo &= todo - 1u;
+            if (nlayer >= 0) load(nxt, (unsigned)nlayer);
+            __builtin_amdgcn_sched_barrier(0);  // the next layer's loads go out ahead of this layer's arithmetic
+            // ---- density edits (a10), as composite_kernel's staging
+            {
+                const bool have = (have_m >> layer & 1u) != 0;
+                const bool cut_neg = !fine && a.p.cut_negative_t && layer > 0;             // :414
+                const bool cut_near = !fine && layer == 0;                                 // :422
+                const float thr = tab[layer], sscale = tab[16 + layer];
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b) {
+                    float4 v = cur.rw[b];
+                    if (!have) v = make_float4(0.f, 0.f, 0.f, 0.f);     // zero tensors (:398-399); sigma = 0 makes the colour moot
+                    else {
+                        if (cut_neg && cur.tk[b] < 0.f) v.w = 0.f;
+                        if (v.w < thr) v.w = 0.f;                                           // :416-418, :538-547, :564-566
+                        v.w = v.w * sscale;                                                 // :575-576
+                        if (cut_near && cur.tk[b] < nearv) v.w = 0.f;
+                        if (!activated) {
+                            v.x = sigmoidf(v.x);
+                            v.y = sigmoidf(v.y);
+                            v.z = sigmoidf(v.z);
+                        }
+                    }
+                    cur.rw[b] = v;
+                }
+            }
+            // ---- successor depths inside the layer (lane + 1; lane 63 takes the next block's lane 0) and the list's direction
+            float tn[MAXB];
+            bool desc = false, not_desc = false;
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) {
+                float first_next = 0.f;
+                if (b + 1 < MAXB) first_next = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cur.tk[b + 1 < MAXB ? b + 1 : b])));
+                const float shifted = dpp_move<DPP_WAVE_SHL1>(0.f, cur.tk[b]);
+                tn[b] = lane == 63u ? first_next : shifted;
+                const bool has_next = FULL ? (b + 1 < MAXB || lane != 63u) : ((unsigned)b * 64u + lane + 1u < S);
+                desc = desc || (has_next && tn[b] < cur.tk[b]);
+                not_desc = not_desc || (has_next && !(tn[b] < cur.tk[b]));
+            }
+            const bool some_desc = __any(desc), some_asc = __any(not_desc);
+            const bool rev = some_desc && !some_asc, unsorted = some_desc && some_asc;
+            // ---- the layer's own composite (:435-444 / :598-603), from registers
+            float* wdst = a.weights ? a.weights + (ray * L + (unsigned)layer) * S : nullptr;
+            const bool single_asc = a.mixed_out && nlive == 1u && !some_desc;
+            {
+                CompositeAcc A;
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b) {
+                    if (FULL || (unsigned)b * 64u < S) {  // (uniform)
+                        const unsigned k = (unsigned)b * 64u + lane;
+                        const bool last = FULL ? (b + 1 == MAXB && lane == 63u) : (k + 1u >= S);
+                        const float delta = last ? border : tn[b] - cur.tk[b];
+                        const float w = composite_block<FULL>(A, cur.rw[b].w, delta, cur.rw[b].x, cur.rw[b].y, cur.rw[b].z, cur.tk[b], ok_lane(b));
+                        if (wdst && ok_lane(b)) wdst[k] = w;
+                    }
+                }
+                const float t_first = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cur.tk[0])));
+                // one live, ascending layer: the union IS the layer; the mix differs from its composite only by the fine
+                // stage's `t < near` cut (:605)
+                const bool mix_is_layer = single_asc && !(fine && t_first < nearv);
+                composite_store5(A, a.layer_out ? a.layer_out + (ray * L + (unsigned)layer) * 5 : nullptr,
+                                 mix_is_layer ? a.mixed_out + ray * 5 : nullptr, lane);
+                if (single_asc && !mix_is_layer) {
+                    CompositeAcc M;
+#pragma unroll
+                    for (int b = 0; b < MAXB; ++b) {
+                        if (FULL || (unsigned)b * 64u < S) {
+                            const unsigned k = (unsigned)b * 64u + lane;
+                            const bool last = FULL ? (b + 1 == MAXB && lane == 63u) : (k + 1u >= S);
+                            const float delta = last ? border : tn[b] - cur.tk[b];
+                            const float sg = cur.tk[b] < nearv ? 0.f : cur.rw[b].w;
+                            composite_block<FULL>(M, sg, delta, cur.rw[b].x, cur.rw[b].y, cur.rw[b].z, cur.tk[b], ok_lane(b));
+                        }
+                    }
+                    composite_store5(M, a.mixed_out + ray * 5, nullptr, lane);
+                }
+                merged_done = single_asc;
+            }
+            CP(2);
+            if (a.mixed_out && !single_asc) {
+                if (unsorted) {
+                    any_unsorted = true;
+                } else if (!any_unsorted) {
+                    // ---- insert the layer into the merged list (:425-429 / :587-592)
+                    const unsigned base_e = (unsigned)layer * S;
+                    if (m == 0u) {
+#pragma unroll
+                        for (int b = 0; b < MAXB; ++b) {
+                            const unsigned k = (unsigned)b * 64u + lane;
+                            if (ok_lane(b)) {
+                                const unsigned r = rev ? S - 1u - k : k;
+                                mkey[r] = cur.tk[b];
+                                mpay[r] = (unsigned short)(base_e + k);
+                            }
+                        }
+                    } else {
+                        const unsigned tot = m + S, nblk = (tot + 63u) >> 6;
+                        for (unsigned w = lane; w < 2u * nblk; w += 64u) bits[w] = 0u;
+#pragma unroll
+                        for (int b = 0; b < MAXB; ++b) {
+                            const unsigned k = (unsigned)b * 64u + lane;
+                            if (ok_lane(b)) ckey[rev ? S - 1u - k : k] = cur.tk[b];
+                        }
+                        wave_sync();
+                        // #{list entries <= v} for the MAXB samples of a lane in lockstep (independent LDS chains)
+                        unsigned pos[MAXB];
+#pragma unroll
+                        for (int b = 0; b < MAXB; ++b) pos[b] = 0u;
+                        for (unsigned step = (unsigned)__builtin_amdgcn_readfirstlane((int)(1u << (31 - __clz((int)m)))); step > 0u; step >>= 1) {
+#pragma unroll
+                            for (int b = 0; b < MAXB; ++b) {
+                                const unsigned np = pos[b] + step;
+                                const float x = mkey[(np < m ? np : m) - 1u];
+                                pos[b] = ((np <= m) & (x <= cur.tk[b])) ? np : pos[b];
+                            }
+                        }
+#pragma unroll
+                        for (int b = 0; b < MAXB; ++b) {
+                            const unsigned k = (unsigned)b * 64u + lane;
+                            if (ok_lane(b)) {
+                                const unsigned p = (rev ? S - 1u - k : k) + pos[b];
+                                __hip_atomic_fetch_or(&bits[p >> 5], 1u << (p & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                        wave_sync();
+                        unsigned above = 0;  // samples of the new layer in the blocks already written (higher slots)
+                        for (int B = (int)nblk - 1; B >= 0; --B) {
+                            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)bits[2 * B]);
+                            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)bits[2 * B + 1]);
+                            const unsigned cnt_in = (unsigned)(__popc(lo) + __popc(hi));
+                            const unsigned below = S - above - cnt_in + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+                            const bool is_new = ((lane < 32u ? lo >> lane : hi >> (lane - 32u)) & 1u) != 0u;
+                            const unsigned p = (unsigned)B * 64u + lane;
+                            if (p < tot) {
+                                const unsigned j = p - below;                        // list entries in front of slot p
+                                const float key = mkey[is_new ? LC + below : j];     // (ckey = mkey + LC)
+                                const unsigned short old = mpay[j];
+                                const unsigned short pay = is_new ? (unsigned short)(base_e + (rev ? S - 1u - below : below)) : old;
+                                mkey[p] = key;
+                                mpay[p] = pay;
+                            }
+                            above += cnt_in;
+                        }
+                    }
+                    m = (unsigned)__builtin_amdgcn_readfirstlane((int)(m + S));
+                    wave_sync();
+                }
+            }
+            CP(3);
+            cur = nxt;
+            layer = nlayer;
+        }
+        if (!a.mixed_out || merged_done) continue;
+        if (any_unsorted) {  // general rank over the live samples: (depth, source index) lexicographic, O(n^2) (tests only)
+            for (unsigned la_m = live; la_m; la_m &= la_m - 1u) {
+                const unsigned la = (unsigned)__ffs(la_m) - 1u;
+                for (unsigned k = lane; k < S; k += 64u) {
+                    const unsigned e = la * S + k;
+                    const float v = tsrc[e];
+                    unsigned rank = 0;
+                    for (unsigned lb_m = live; lb_m; lb_m &= lb_m - 1u) {
+                        const unsigned lb = (unsigned)__ffs(lb_m) - 1u;
+                        for (unsigned x = 0; x < S; ++x) {
+                            const float xv = tsrc[lb * S + x];
+                            rank += (xv < v || (xv == v && lb * S + x < e)) ? 1u : 0u;
+                        }
+                    }
+                    mkey[rank] = v;
+                    mpay[rank] = (unsigned short)e;
+                }
+            }
+            m = nlive * S;
+            wave_sync();
+        }
+        // ---- merged composite (:448 / :605-606): two blocks of the list per round trip of the float4 gather (four cost 13 registers = one wave per SIMD)
+        {
+            constexpr int G = 2;
+            const bool cut_neg_on = !fine && a.p.cut_negative_t;
+            CompositeAcc A;
+            for (unsigned base = 0; base < m; base += 64u * G) {
+                float key[G], keyn[G];
+                float4 rw[G];
+                unsigned src[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const unsigned mm = base + (unsigned)g * 64u + lane;
+                    const unsigned mc = FULL ? mm : (mm < m ? mm : m - 1u);
+                    if (base + (unsigned)g * 64u < m) {  // (uniform)
+                        key[g] = mkey[mc];
+                        keyn[g] = mkey[mc + 1u];          // (one past the list's end for its last sample: inside the LDS window, unused)
+                        src[g] = mpay[mc];
+                        rw[g] = rsrc[src[g]];
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (base + (unsigned)g * 64u < m) {  // (uniform)
+                        const unsigned mm = base + (unsigned)g * 64u + lane;
+                        const bool ok = FULL || mm < m;
+                        float4 v = rw[g];
+                        const unsigned ly = (unsigned)(((float)src[g] + 0.5f) * invS);
+                        const float tk = key[g];
+                        if (!(have_m >> ly & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        else {
+                            if (cut_neg_on && ly > 0u && tk < 0.f) v.w = 0.f;
+                            if (v.w < tab[ly]) v.w = 0.f;
+                            v.w = v.w * tab[16 + ly];
+                            if (!fine && ly == 0u && tk < nearv) v.w = 0.f;
+                            if (!activated) {
+                                v.x = sigmoidf(v.x);
+                                v.y = sigmoidf(v.y);
+                                v.z = sigmoidf(v.z);
+                            }
+                        }
+                        if (fine && tk < nearv) v.w = 0.f;                        // :605
+                        const float delta = (mm + 1u < m) ? keyn[g] - tk : border;
+                        composite_block<FULL>(A, v.w, delta, v.x, v.y, v.z, tk, ok);
+                    }
+                }
+            }
+            composite_store5(A, a.mixed_out + ray * 5, nullptr, lane);
+        }
+        CP(4);
+        wave_sync();
+      }
+    }
+    CP_FLUSH;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1058,6 +1509,17 @@ extern "C" int stnerf_gen_weight(const float* sigma, const float* delta, int64_t
     return STNERF_OK;
 }
 
+static bool tiered_possible(int l, int S) { return l > 3 && merge_lds_per_wave(l, S) > 6 * 1024; }
+
+// Development switch: STNERF_COMPOSITE_KERNEL=staged sends every call to the LDS-staged kernel (A/B timing, bitwise checks).
+static bool legacy_composite() {
+    static const bool v = [] {
+        const char* e = getenv("STNERF_COMPOSITE_KERNEL");
+        return e && !strcmp(e, "staged");
+    }();
+    return v;
+}
+
 extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t* mask, int64_t n, int l, int S,
                                 const stnerf_composite_params* params_host, float* layer_out, float* mixed_out,
                                 float* weights, int32_t* order, uint8_t* scratch, stnerf_stream_t stream) {
@@ -1067,39 +1529,78 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
     STNERF_REQUIRE(((uintptr_t)raw & 15) == 0, "composite: raw must be 16-byte aligned");
     if (n == 0) return STNERF_OK;
     STNERF_REQUIRE((int64_t)l * S <= 65535, "composite: more than 65535 samples per ray");
-    const int64_t per_wave = (((int64_t)l * S * 22 + 15) / 16) * 16;
     constexpr int64_t LDS_BUDGET = 150 * 1024;   // of the CU's 160 KiB: the rest stays with the kernel's static LDS
+    LaunchTimer timer(PROF_COMPOSITE, 0, n, S,
+                      20ll * l * S + l + 20ll * (l + 1) + (weights ? 4ll * l * S : 0) + (order ? 4ll * l * S : 0),
+                      as_stream(stream));
+    const int nblk = (S + 63) / 64;
+    constexpr int MERGE_MAXB = 3;
+    if (!order && nblk <= MERGE_MAXB && !legacy_composite()) {
+        // ---- production path: rays with one live layer first when the caller lends n bytes of scratch (pipelined over
+        // the rays of a wave, no LDS), the others -- or all of them -- in the register / insertion-merge kernel
+        CompositeArgs a{t, reinterpret_cast<const float4*>(raw), mask, n, l, S, *params_host, layer_out, mixed_out,
+                        weights, nullptr, 4, floor_pow2(S), nullptr};
+        if (scratch && (layer_out || mixed_out || weights)) {
+            int64_t waves = n < 256 * 32 ? n : 256 * 32;  // 8 waves per SIMD, every wave strides over the rays
+            const dim3 grid((unsigned)((waves + 3) / 4));
+            if (nblk <= 2 && (l - 1) * nblk <= 6) {
+                a.handled = scratch;
+                hipLaunchKernelGGL((composite_single_kernel<2, 6>), grid, dim3(256), 0, as_stream(stream), a);
+            } else if ((l - 1) * nblk <= 24) {
+                a.handled = scratch;
+                hipLaunchKernelGGL((composite_single_kernel<3, 24>), grid, dim3(256), 0, as_stream(stream), a);
+            }
+            STNERF_CHECK_LAUNCH("composite (single-layer rays)");
+        }
+        // The merged list lives in LDS, 6 B per sample and layer: 11.4 KB per wave at 9 x 192 samples -- three waves per SIMD.
+        // Most rays of such a scene cross two or three boxes, so with scratch the rays are served in two launches: lists of
+        // three layers first (full occupancy; a ray with more live layers is left unmarked), the rest with lists of l layers.
+        if (scratch && !a.handled && tiered_possible(l, S)) {
+            if (hipMemsetAsync(scratch, 0, (size_t)n, as_stream(stream)) != hipSuccess) return STNERF_ELAUNCH;
+            a.handled = scratch;
+        }
+        const bool two_tiers = a.handled != nullptr && tiered_possible(l, S);
+        for (int tier = two_tiers ? 0 : 1; tier < 2; ++tier) {
+            a.lds_layers = tier == 0 ? 3 : l;
+            const int64_t per_wave = merge_lds_per_wave(a.lds_layers, S);
+            int wpb = (int)((LDS_BUDGET - MERGE_TAB_BYTES) / per_wave);
+            STNERF_REQUIRE(wpb >= 1, "composite: %d samples per ray need %lld B of LDS per wave, more than the %lld B this kernel may use", l * S,
+                           (long long)per_wave, (long long)LDS_BUDGET);
+            if (wpb > 4) wpb = 4;
+            a.waves_per_block = wpb;
+            const int lds = (int)(MERGE_TAB_BYTES + per_wave * wpb);
+            int64_t blocks = (n + wpb - 1) / wpb;
+            if (blocks > 256 * 16) blocks = 256 * 16;
+            const dim3 grid((unsigned)blocks), block(wpb * 64);
+            auto launch = [&](auto kernel) -> int {
+                if (lds > 64 * 1024)
+                    if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(kernel), lds, "composite")) return rc;
+                hipLaunchKernelGGL(kernel, grid, block, lds, as_stream(stream), a);
+                return STNERF_OK;
+            };
+            const bool full = S == 64 * nblk;
+            const int rc = nblk == 1 ? (full ? launch(composite_merge_kernel<1, true>) : launch(composite_merge_kernel<1, false>))
+                         : nblk == 2 ? (full ? launch(composite_merge_kernel<2, true>) : launch(composite_merge_kernel<2, false>))
+                                     : (full ? launch(composite_merge_kernel<3, true>) : launch(composite_merge_kernel<3, false>));
+            if (rc) return rc;
+            STNERF_CHECK_LAUNCH("composite");
+        }
+        return STNERF_OK;
+    }
+    // ---- the `order` parity output and layers of more than 192 samples: the LDS-staged kernel (every ray on its own)
+    const int64_t per_wave = (((int64_t)l * S * 22 + 15) / 16) * 16;
     int wpb = (int)(LDS_BUDGET / per_wave);
     STNERF_REQUIRE(wpb >= 1, "composite: %d samples per ray need %lld B of LDS per wave, more than the %lld B this kernel may use", l * S,
                    (long long)per_wave, (long long)LDS_BUDGET);
     if (wpb > 4) wpb = 4;
     const int lds = (int)(per_wave * wpb);
-    if (lds > 64 * 1024) {
-        if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(composite_kernel<true>), lds, "composite")) return rc;
-        if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(composite_kernel<false>), lds, "composite")) return rc;
-    }
+    if (lds > 64 * 1024)
+        if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(composite_kernel), lds, "composite")) return rc;
     CompositeArgs a{t, reinterpret_cast<const float4*>(raw), mask, n, l, S, *params_host, layer_out, mixed_out,
                     weights, order, wpb, floor_pow2(S), nullptr};
-    LaunchTimer timer(PROF_COMPOSITE, 0, n, S,
-                      20ll * l * S + l + 20ll * (l + 1) + (weights ? 4ll * l * S : 0) + (order ? 4ll * l * S : 0),
-                      as_stream(stream));
-    // two passes when the caller lends n bytes of scratch: the rays with one live layer first (pipelined, no LDS),
-    // the rest in the general kernel.  The `order` parity output and very deep layers take the general kernel alone.
-    constexpr int MAXB = 2, MAXCHK = 6;
-    const int nblk = (S + 63) / 64;
-    if (scratch && !order && nblk <= MAXB && (l - 1) * nblk <= MAXCHK && (layer_out || mixed_out || weights)) {
-        a.handled = scratch;
-        int64_t waves = n < 256 * 32 ? n : 256 * 32;  // 8 waves per SIMD, every wave strides over the rays
-        hipLaunchKernelGGL((composite_single_kernel<MAXB, MAXCHK>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
-                           as_stream(stream), a);
-        STNERF_CHECK_LAUNCH("composite (single-layer rays)");
-    }
     int64_t blocks = (n + wpb - 1) / wpb;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    if (a.handled)
-        hipLaunchKernelGGL(composite_kernel<false>, dim3((unsigned)blocks), dim3(wpb * 64), lds, as_stream(stream), a);
-    else
-        hipLaunchKernelGGL(composite_kernel<true>, dim3((unsigned)blocks), dim3(wpb * 64), lds, as_stream(stream), a);
+    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(wpb * 64), lds, as_stream(stream), a);
     STNERF_CHECK_LAUNCH("composite");
     return STNERF_OK;
 }
