@@ -860,6 +860,9 @@ __host__ __device__ __forceinline__ int64_t merge_lds_per_wave(int l, int S) {  
     return ((4 * LS + 4 * SP + 4 * words + 2 * LS + 15) / 16) * 16;
 }
 
+// occupancy target of composite_merge_kernel (waves per SIMD -> 512 / n registers); the host sizes the LDS tiers with it
+__host__ __device__ constexpr int merge_waves_per_simd(int maxb, bool full) { return !full ? 5 : maxb > 2 ? 6 : 7; }
+
 template <int MAXB>
 struct LayerRegs {
     float tk[MAXB];
@@ -908,7 +911,7 @@ __device__ __forceinline__ void composite_store5(const CompositeAcc& A, float* d
 // FULL: S == 64 * MAXB (64 / 128 / 192 samples per layer: every BASELINE configuration) -- no lane is ever idle, the
 // `k < S` predicates and their exec-mask bookkeeping disappear.
 template <int MAXB, bool FULL>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MAXB > 2 || !FULL) ? 5 : 6, 8))) composite_merge_kernel(CompositeArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(merge_waves_per_simd(MAXB, FULL), 8))) composite_merge_kernel(CompositeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const unsigned lane = threadIdx.x & 63u;
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -991,9 +994,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MAXB 
         Regs cur;
         load(cur, first_have >= 0 ? (unsigned)first_have : 0u);
         // ---- which layers take part: those with network output, and those without whose depths are real (a hidden layer,
-        // a grazing hit: they shape their neighbours' deltas; see composite_kernel).  Four layers' depths per round trip.
+        // a grazing hit: they shape their neighbours' deltas; see composite_kernel).  Eight layers' depths per round trip.
         unsigned live = have_m;
-        constexpr int CB = 4;
+        constexpr int CB = 8;
         for (unsigned cand = ~have_m & lmask; cand;) {
             int ly[CB];
             float v[CB][MAXB];
@@ -1509,8 +1512,6 @@ extern "C" int stnerf_gen_weight(const float* sigma, const float* delta, int64_t
     return STNERF_OK;
 }
 
-static bool tiered_possible(int l, int S) { return l > 3 && merge_lds_per_wave(l, S) > 6 * 1024; }
-
 // Development switch: STNERF_COMPOSITE_KERNEL=staged sends every call to the LDS-staged kernel (A/B timing, bitwise checks).
 static bool legacy_composite() {
     static const bool v = [] {
@@ -1552,16 +1553,21 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
             }
             STNERF_CHECK_LAUNCH("composite (single-layer rays)");
         }
-        // The merged list lives in LDS, 6 B per sample and layer: 11.4 KB per wave at 9 x 192 samples -- three waves per SIMD.
-        // Most rays of such a scene cross two or three boxes, so with scratch the rays are served in two launches: lists of
-        // three layers first (full occupancy; a ray with more live layers is left unmarked), the rest with lists of l layers.
-        if (scratch && !a.handled && tiered_possible(l, S)) {
+        // The merged list lives in LDS, 6 B per sample and layer: 11.4 KB per wave at 9 x 192 samples -- three waves per SIMD,
+        // where the registers allow five.  Few rays of such a scene cross every box, so with scratch the rays are served in
+        // two launches: first with lists of as many layers as full occupancy leaves room for (a ray with more live layers is
+        // left unmarked), then the rest with lists of l layers.
+        const bool full = S == 64 * nblk;
+        const int waves_per_simd = merge_waves_per_simd(nblk, full);   // (the kernels' amdgpu_waves_per_eu)
+        int cap = l;
+        while (cap > 2 && MERGE_TAB_BYTES + 4 * merge_lds_per_wave(cap, S) > LDS_BUDGET / waves_per_simd) --cap;
+        if (cap < l && scratch && !a.handled) {
             if (hipMemsetAsync(scratch, 0, (size_t)n, as_stream(stream)) != hipSuccess) return STNERF_ELAUNCH;
             a.handled = scratch;
         }
-        const bool two_tiers = a.handled != nullptr && tiered_possible(l, S);
+        const bool two_tiers = cap < l && a.handled != nullptr;
         for (int tier = two_tiers ? 0 : 1; tier < 2; ++tier) {
-            a.lds_layers = tier == 0 ? 3 : l;
+            a.lds_layers = tier == 0 ? cap : l;
             const int64_t per_wave = merge_lds_per_wave(a.lds_layers, S);
             int wpb = (int)((LDS_BUDGET - MERGE_TAB_BYTES) / per_wave);
             STNERF_REQUIRE(wpb >= 1, "composite: %d samples per ray need %lld B of LDS per wave, more than the %lld B this kernel may use", l * S,
@@ -1578,7 +1584,6 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
                 hipLaunchKernelGGL(kernel, grid, block, lds, as_stream(stream), a);
                 return STNERF_OK;
             };
-            const bool full = S == 64 * nblk;
             const int rc = nblk == 1 ? (full ? launch(composite_merge_kernel<1, true>) : launch(composite_merge_kernel<1, false>))
                          : nblk == 2 ? (full ? launch(composite_merge_kernel<2, true>) : launch(composite_merge_kernel<2, false>))
                                      : (full ? launch(composite_merge_kernel<3, true>) : launch(composite_merge_kernel<3, false>));
