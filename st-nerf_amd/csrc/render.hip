@@ -1273,9 +1273,98 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(merge_
     CP_FLUSH;
 }
 
+// ---- searches over an ascending LDS array padded with +inf up to (a power of two) - 1 entries: no bounds logic, the running
+// position is a byte address -- add, ds_read, compare, select per step (the bounded form above: eight instructions).
+// `half_bytes` = 4 * P / 2 for P = the smallest power of two > n (wave-uniform).  Returns #{x <= v} / #{x < v}.
+__host__ __device__ __forceinline__ int pow2_above(int n) {
+    int p = 1;
+    while (p <= n) p *= 2;
+    return p;
+}
+__device__ __forceinline__ int upper_bound_padded(const float* a, int half_bytes, float v) {
+    const char* base = reinterpret_cast<const char*>(a) - 4;
+    const char* q = base;
+    for (int step = half_bytes; step >= 4; step >>= 1) {
+        const char* c = q + step;
+        const float x = *reinterpret_cast<const float*>(c);
+        q = (x <= v) ? c : q;
+    }
+    return (int)(q - base) >> 2;
+}
+__device__ __forceinline__ int lower_bound_padded(const float* a, int half_bytes, float v) {
+    const char* base = reinterpret_cast<const char*>(a) - 4;
+    const char* q = base;
+    for (int step = half_bytes; step >= 4; step >>= 1) {
+        const char* c = q + step;
+        const float x = *reinterpret_cast<const float*>(c);
+        q = (x < v) ? c : q;
+    }
+    return (int)(q - base) >> 2;
+}
+
+// ---- ascending bitonic sort of one value per lane (64 lanes).  The partner of a compare-exchange at distance 1, 2 and 8 is
+// a DPP operand of the min / max themselves (quad_perm / row_ror:8), at distance 4 two bank-masked DPP moves, at 16 a
+// ds_swizzle, at 32 a ds_bpermute; which lanes keep the minimum is a lane pattern, i.e. a 64-bit constant per stage fed to
+// v_cndmask as a scalar mask.  3 - 5 vector instructions per stage (21 stages) against ~ 7 with __shfl_xor and a computed
+// direction.
+constexpr unsigned long long bitonic_keep_min_mask(int kk, int j) {
+    unsigned long long m = 0;
+    for (int lane = 0; lane < 64; ++lane)
+        if (((lane & j) == 0) == ((lane & kk) == 0)) m |= 1ull << lane;
+    return m;
+}
+template <int KK, int J>
+__device__ __forceinline__ float bitonic_stage(float v, int lane) {
+    constexpr unsigned long long KEEP_MIN = bitonic_keep_min_mask(KK, J);
+    float lo, hi;
+    if constexpr (J == 1) {
+        asm("s_nop 1\n\tv_min_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %1, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(lo), "=&v"(hi) : "v"(v));
+    } else if constexpr (J == 2) {
+        asm("s_nop 1\n\tv_min_f32_dpp %0, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %1, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(lo), "=&v"(hi) : "v"(v));
+    } else if constexpr (J == 8) {
+        asm("s_nop 1\n\tv_min_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32_dpp %1, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf" : "=&v"(lo), "=&v"(hi) : "v"(v));
+    } else {
+        float pv;
+        if constexpr (J == 4) {   // lanes 0-3 / 8-11 of a row take lane + 4, lanes 4-7 / 12-15 lane - 4
+            pv = v;
+            asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                "v_mov_b32_dpp %0, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(pv) : "v"(v));
+        } else if constexpr (J == 16) {
+            pv = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401f));   // bit mode: and 0x1f, or 0, xor 0x10
+        } else {
+            pv = __shfl_xor(v, J);
+        }
+        lo = fminf(v, pv);
+        hi = fmaxf(v, pv);
+    }
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "s"(KEEP_MIN));
+    (void)lane;
+    return r;
+}
+__device__ __forceinline__ float bitonic_sort64(float v, int lane) {
+    v = bitonic_stage<2, 1>(v, lane);
+    v = bitonic_stage<4, 2>(v, lane);   v = bitonic_stage<4, 1>(v, lane);
+    v = bitonic_stage<8, 4>(v, lane);   v = bitonic_stage<8, 2>(v, lane);   v = bitonic_stage<8, 1>(v, lane);
+    v = bitonic_stage<16, 8>(v, lane);  v = bitonic_stage<16, 4>(v, lane);  v = bitonic_stage<16, 2>(v, lane);  v = bitonic_stage<16, 1>(v, lane);
+    v = bitonic_stage<32, 16>(v, lane); v = bitonic_stage<32, 8>(v, lane);  v = bitonic_stage<32, 4>(v, lane);  v = bitonic_stage<32, 2>(v, lane);
+    v = bitonic_stage<32, 1>(v, lane);
+    v = bitonic_stage<64, 32>(v, lane); v = bitonic_stage<64, 16>(v, lane); v = bitonic_stage<64, 8>(v, lane);  v = bitonic_stage<64, 4>(v, lane);
+    v = bitonic_stage<64, 2>(v, lane);  v = bitonic_stage<64, 1>(v, lane);
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Resampler: one wave per (ray, layer).
 // ---------------------------------------------------------------------------------------------
+// floats of LDS per wave of resample_kernel
+__host__ __device__ __forceinline__ int resample_lds_floats(int n1, int n2) {
+    return pow2_above(n1) + pow2_above(n1 - 1) + pow2_above(n2) + 2 * n1 + n1 + n2;
+}
+
 struct ResampleArgs {
     const float* t;
     const float* weights;
@@ -1294,39 +1383,115 @@ struct ResampleArgs {
     float* cdf_out;
 };
 
-__global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_RESAMPLE, 8))) resample_kernel(ResampleArgs a) {
+// NB1 > 0: the coarse list fits NB1 blocks of 64 lanes and is software pipelined -- the depths, weights and ray of pair
+// i + 1 are in flight (in registers) while pair i is worked on.  The kernel is otherwise a chain of dependent round
+// trips per pair ("are all depths -1000?" -> "stage depths and weights" -> compute -> stores) with ~ 150 instructions
+// between them: measured, 80 % of a pair's cycles were waits for the first two (tools/resample_phase_prof.py).
+// NB1 = 0: lists of any length, loads where they are needed.
+// PLAIN: the production call -- device draws, no debug outputs, no box edits.  The arguments of the other flavours (u, z_new,
+// inds, cdf, the edit table) are then dead: a third of this kernel's vector instructions were v_readlane / v_writelane
+// traffic of scalar registers spilled into vector lanes, most of it kernel arguments it never uses on this path.
+template <int NB1, bool PLAIN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB1 >= 4 ? 6 : NB1 >= 2 ? 7 : STNERF_WAVES_RESAMPLE, 8))) resample_kernel(ResampleArgs a) {
+    const float* const u_in = PLAIN ? nullptr : a.u;
+    float* const z_out = PLAIN ? nullptr : a.z_new;
+    int32_t* const inds_out = PLAIN ? nullptr : a.inds;
+    float* const cdf_dbg = PLAIN ? nullptr : a.cdf_out;
+    const bool edited = PLAIN ? false : a.ed.any != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: the pair index, its 64-bit divisions and
                                                                         // the RNG key of the pair stay on the scalar unit
     const int n1 = a.n1, n2 = a.n2, S = n1 + n2, nb = n1 - 1;  // nb = #bins = len(cdf)
-    float* mine = reinterpret_cast<float*>(smem_raw) + (size_t)wave * (4 * n1 + n2 + S);
-    float* tc = mine;          // [n1]  coarse depths
-    float* cdf = tc + n1;      // [n1-1]
-    float* bins = cdf + n1;    // [n1-1]
+    // the three searched arrays are padded with +inf to (a power of two) - 1 entries, once (upper_bound_padded)
+    const int P1 = pow2_above(n1), PC = pow2_above(nb), P2 = pow2_above(n2);
+    float* mine = reinterpret_cast<float*>(smem_raw) + (size_t)wave * resample_lds_floats(n1, n2);
+    float* tc = mine;          // [n1 | pad to P1]  coarse depths
+    float* cdf = tc + P1;      // [n1-1 | pad to PC]
+    float* zs = cdf + PC;      // [n2 | pad to P2]
+    float* bins = zs + P2;     // [n1-1]
     float* wv = bins + n1;     // [n1-2] pdf numerators w + 1e-5
-    float* zs = wv + n1;       // [n2]
-    float* tf = zs + n2;       // [S]
-    const int p2_n1 = floor_pow2(n1), p2_nb = floor_pow2(nb), p2_n2 = floor_pow2(n2 > 0 ? n2 : 1);
+    float* tf = wv + n1;       // [S]
+    for (int k = n1 + lane; k < P1; k += 64) tc[k] = __builtin_inff();
+    for (int k = nb + lane; k < PC; k += 64) cdf[k] = __builtin_inff();
+    for (int k = n2 + lane; k < P2; k += 64) zs[k] = __builtin_inff();
+    const int p2_n1 = floor_pow2(n1);
     const int64_t pairs = a.n * a.l;
     const int64_t per_iter = (int64_t)gridDim.x * 4;
+    constexpr int NBR = NB1 > 0 ? NB1 : 1;
+    struct Pre {
+        float t[NBR], w[NBR], r;   // r: lane i < 6 holds component i of the ray (origin, direction)
+    };
+    auto issue = [&](Pre& q, int64_t pr, int64_t ray_of_pr) {
+        if (NB1 > 0 && pr < pairs) {
+            const float* tsrc = a.t + pr * n1;
+            const float* wsrc = a.weights + pr * n1;
+#pragma unroll
+            for (int b = 0; b < NBR; ++b) {
+                const int k = b * 64 + lane;
+                q.t[b] = tsrc[k < n1 ? k : n1 - 1];
+                q.w[b] = wsrc[k + 1 < n1 ? k + 1 : n1 - 1];   // (the caller's w[..., 1:-1]: numerator k is weight k + 1)
+            }
+            q.r = a.rays[ray_of_pr * a.ray_stride + (lane < 6 ? lane : 5)];
+        }
+    };
+    Pre nxt_in;
+#pragma unroll
+    for (int b = 0; b < NBR; ++b) nxt_in.t[b] = nxt_in.w[b] = 0.f;
+    nxt_in.r = 0.f;
+    // (ray, layer) of the wave's pair are carried along instead of divided out of the pair index every iteration: a 64-bit
+    // division is ~ 80 scalar + vector instructions, and there were two per pair
+    const int64_t dray = per_iter / a.l;
+    const int dlayer = (int)(per_iter - dray * a.l);
+    int64_t ray_n = ((int64_t)blockIdx.x * 4 + wave) / a.l;
+    int layer_n = (int)((int64_t)blockIdx.x * 4 + wave - ray_n * a.l);
+    issue(nxt_in, (int64_t)blockIdx.x * 4 + wave, ray_n);
+    CP_DECL
     for (int64_t p0 = (int64_t)blockIdx.x * 4; p0 < pairs; p0 += per_iter) {
         const int64_t pr = p0 + wave;
+        CP(7);
+        const Pre in = nxt_in;
+        const int64_t ray = ray_n;
+        const int layer = layer_n;
+        ray_n += dray;
+        layer_n += dlayer;
+        if (layer_n >= a.l) {
+            layer_n -= a.l;
+            ++ray_n;
+        }
+        issue(nxt_in, pr + per_iter, ray_n);
+        __builtin_amdgcn_sched_barrier(0);  // the next pair's loads go out ahead of this pair's arithmetic
         const bool active = pr < pairs;
         bool sorted_z = false;
-        const int64_t ray = active ? pr / a.l : 0;
-        const int layer = active ? (int)(pr - ray * a.l) : 0;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+        if (active) {
+            if (NB1 > 0) {
+                o0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(in.r), 0));
+                o1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(in.r), 1));
+                o2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(in.r), 2));
+                d0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(in.r), 3));
+                d1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(in.r), 4));
+                d2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(in.r), 5));
+            } else {
+                const float* r = a.rays + ray * a.ray_stride;
+                o0 = r[0], o1 = r[1], o2 = r[2], d0 = r[3], d1 = r[4], d2 = r[5];
+            }
+        }
         // ---- a layer the ray misses altogether: every coarse depth is -1000 (bin width 0), so every bin edge and every
         // resampled depth is exactly -1000 whatever the draws; write that and skip the work (60 % of the performer
         // pairs of a typical view).  The optional debug outputs take the general path.
-        if (active && !a.z_new && !a.inds && !a.cdf_out) {
+        if (active && !z_out && !inds_out && !cdf_dbg) {
             const float* tsrc = a.t + pr * n1;
             bool missed = true;
-            for (int k = lane; k < n1; k += 64) missed = missed && tsrc[k] == -1000.f;
+            if (NB1 > 0) {
+#pragma unroll
+                for (int b = 0; b < NBR; ++b) missed = missed && in.t[b] == -1000.f;   // (idle lanes hold the last depth)
+            } else {
+                for (int k = lane; k < n1; k += 64) missed = missed && tsrc[k] == -1000.f;
+            }
             if (__all(missed)) {
-                const float* r = a.rays + ray * a.ray_stride;
-                float x = -1000.f * r[3] + r[0], y = -1000.f * r[4] + r[1], w = -1000.f * r[5] + r[2];  // :465
-                if (a.ed.any) unedit_point(x, y, w, a.ed.e[layer], a.ed.pivot);
+                float x = -1000.f * d0 + o0, y = -1000.f * d1 + o1, w = -1000.f * d2 + o2;  // :465
+                if (edited) unedit_point(x, y, w, a.ed.e[layer], a.ed.pivot);
                 for (int m = lane; m < S; m += 64) {
                     a.t_fine[pr * S + m] = -1000.f;
                     if (a.xyz_fine) {
@@ -1336,17 +1501,29 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_RESAMPLE, 8))) r
                         dst[2] = w;
                     }
                 }
+                CP(0);
                 continue;
             }
         }
+        CP(0);
         // ---- pdf / cdf / bins   (sample_pdf.py:20-24; the caller passes w[..., 1:-1], layered_rfrender.py:460)
         if (active) {
-            const float* tsrc = a.t + pr * n1;
-            const float* wsrc = a.weights + pr * n1;
-            for (int k = lane; k < n1; k += 64) tc[k] = tsrc[k];
-            for (int k = lane; k < n1 - 2; k += 64) wv[k] = wsrc[k + 1] + 1e-5f;  // weights + 1e-5 (sample_pdf.py:21)
+            if (NB1 > 0) {
+#pragma unroll
+                for (int b = 0; b < NBR; ++b) {
+                    const int k = b * 64 + lane;
+                    if (k < n1) tc[k] = in.t[b];
+                    if (k < n1 - 2) wv[k] = in.w[b] + 1e-5f;  // weights + 1e-5 (sample_pdf.py:21)
+                }
+            } else {
+                const float* tsrc = a.t + pr * n1;
+                const float* wsrc = a.weights + pr * n1;
+                for (int k = lane; k < n1; k += 64) tc[k] = tsrc[k];
+                for (int k = lane; k < n1 - 2; k += 64) wv[k] = wsrc[k + 1] + 1e-5f;  // weights + 1e-5 (sample_pdf.py:21)
+            }
         }
         wave_sync();
+        CP(1);
         if (active) {
             // pdf = w / torch.sum(w) in ATen's CPU summation order; cdf = torch.cumsum(pdf): ATen's CPU cumsum
             // accumulates fp32 rows in DOUBLE and rounds every prefix to fp32 (cumsum_cpu_kernel: at::acc_type<float,
@@ -1366,19 +1543,21 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_RESAMPLE, 8))) r
             }
         }
         wave_sync();
+        CP(2);
         if (active) {
             for (int k = lane; k < nb; k += 64) bins[k] = 0.5f * (tc[k + 1] + tc[k]);
-            if (a.cdf_out)
-                for (int k = lane; k < nb; k += 64) a.cdf_out[pr * nb + k] = cdf[k];
+            if (cdf_dbg)
+                for (int k = lane; k < nb; k += 64) cdf_dbg[pr * nb + k] = cdf[k];
         }
         wave_sync();
+        CP(3);
         // ---- invert the cdf (sample_pdf.py:44-61)
         if (active) {
-            const uint64_t gray = a.u ? 0ull : (uint64_t)global_ray(a.win, ray);  // (wave-uniform)
+            const uint64_t gray = u_in ? 0ull : (uint64_t)global_ray(a.win, ray);  // (wave-uniform)
             for (int j = lane; j < n2; j += 64) {
-                const float u = a.u ? a.u[((int64_t)layer * a.n + ray) * n2 + j]
+                const float u = u_in ? u_in[((int64_t)layer * a.n + ray) * n2 + j]
                                     : philox_uniform(a.seed, gray, (uint32_t)layer, 1u, (uint32_t)j);
-                const int ind = upper_bound_lds(cdf, nb, p2_nb, u);   // searchsorted(right=True)
+                const int ind = upper_bound_padded(cdf, 2 * PC, u);   // searchsorted(right=True)
                 const int below = ind - 1 > 0 ? ind - 1 : 0;
                 const int above = ind < nb - 1 ? ind : nb - 1;
                 float den = cdf[above] - cdf[below];
@@ -1386,11 +1565,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_RESAMPLE, 8))) r
                 const float frac = (u - cdf[below]) / den;
                 const float z = bins[below] + frac * (bins[above] - bins[below]);
                 zs[j] = z;
-                if (a.z_new) a.z_new[pr * n2 + j] = z;
-                if (a.inds) a.inds[pr * n2 + j] = ind;
+                if (z_out) z_out[pr * n2 + j] = z;
+                if (inds_out) inds_out[pr * n2 + j] = ind;
             }
         }
         wave_sync();
+        CP(4);
         // ---- sort(cat[t, z])  (layered_rfrender.py:462) by ranks == a stable sort with t before z on ties.
         // The coarse list is ascending (unless a box edit made the bin width negative), so a t keeps its index
         // plus the number of smaller z, and a z its index among the sorted z plus the number of t <= z.  Up to 64
@@ -1416,19 +1596,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_RESAMPLE, 8))) r
                 asc = true;
             }
             if (asc && n2 <= 64) {
-                float v = lane < n2 ? zs[lane] : __builtin_inff();
-#pragma unroll
-                for (int kk = 2; kk <= 64; kk <<= 1) {
-#pragma unroll
-                    for (int j = kk >> 1; j > 0; j >>= 1) {
-                        const float pv = __shfl_xor(v, j);
-                        const bool keep_min = ((lane & j) == 0) == ((lane & kk) == 0);
-                        v = keep_min ? fminf(v, pv) : fmaxf(v, pv);
-                    }
-                }
+                const float v = bitonic_sort64(lane < n2 ? zs[lane] : __builtin_inff(), lane);
                 if (lane < n2) {
                     zs[lane] = v;  // now ascending
-                    tf[lane + upper_bound_lds(tc, n1, p2_n1, v)] = v;
+                    tf[lane + upper_bound_padded(tc, 2 * P1, v)] = v;
                 }
             }
             sorted_z = asc && n2 <= 64;
@@ -1438,7 +1609,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_RESAMPLE, 8))) r
             if (sorted_z) {
                 for (int k = lane; k < n1; k += 64) {
                     const float v = tc[k];
-                    tf[k + (n2 > 0 ? lower_bound_lds(zs, n2, p2_n2, v) : 0)] = v;
+                    tf[k + lower_bound_padded(zs, 2 * P2, v)] = v;
                 }
             } else {
                 bool desc = false;
@@ -1466,15 +1637,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_RESAMPLE, 8))) r
             }
         }
         wave_sync();
+        CP(5);
         if (active) {
-            const float* r = a.rays + ray * a.ray_stride;
-            const float o0 = r[0], o1 = r[1], o2 = r[2], d0 = r[3], d1 = r[4], d2 = r[5];
             for (int m = lane; m < S; m += 64) {
                 const float z = tf[m];
                 a.t_fine[pr * S + m] = z;
                 if (a.xyz_fine) {
                     float x = z * d0 + o0, y = z * d1 + o1, w = z * d2 + o2;  // :465
-                    if (a.ed.any) unedit_point(x, y, w, a.ed.e[layer], a.ed.pivot);
+                    if (edited) unedit_point(x, y, w, a.ed.e[layer], a.ed.pivot);
                     float* dst = a.xyz_fine + (pr * S + m) * 3;  // (staging these through LDS for 16-B stores measured slower)
                     dst[0] = x;
                     dst[1] = y;
@@ -1483,7 +1653,9 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_RESAMPLE, 8))) r
             }
         }
         wave_sync();
+        CP(6);
     }
+    CP_FLUSH;
 }
 
 }  // namespace stnerf
@@ -1625,13 +1797,19 @@ extern "C" int stnerf_resample(const float* t, const float* weights, int64_t n, 
     a.win = RayWindow{ray_index_base, ray_index_stripe, ray_index_period}; a.rays = rays; a.ray_stride = ray_stride;
     fill_edit_args(a.ed, edits_host, pivot_host, l);
     a.t_fine = t_fine; a.xyz_fine = xyz_fine; a.z_new = z_new; a.inds = inds; a.cdf_out = cdf;
-    const int lds = 4 * (4 * n1 + n2 + n1 + n2) * (int)sizeof(float);
+    const int lds = 4 * resample_lds_floats(n1, n2) * (int)sizeof(float);
     STNERF_REQUIRE(lds <= 64 * 1024, "resample: %d+%d samples per ray exceed the LDS budget", n1, n2);
     int64_t blocks = (n * l + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
     LaunchTimer timer(PROF_RESAMPLE, 0, n, n1 + n2, (int64_t)l * (8ll * n1 + (xyz_fine ? 16ll : 4ll) * (n1 + n2)) + 24,
                       as_stream(stream));
-    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(256), lds, as_stream(stream), a);
+    const bool plain = !u && !z_new && !inds && !cdf && !a.ed.any;
+    const dim3 grid((unsigned)blocks), block(256);
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, lds, as_stream(stream), a); };
+    if (n1 <= 64) plain ? launch(resample_kernel<1, true>) : launch(resample_kernel<1, false>);
+    else if (n1 <= 128) plain ? launch(resample_kernel<2, true>) : launch(resample_kernel<2, false>);
+    else if (n1 <= 256) plain ? launch(resample_kernel<4, true>) : launch(resample_kernel<4, false>);
+    else launch(resample_kernel<0, false>);
     STNERF_CHECK_LAUNCH("resample");
     return STNERF_OK;
 }
