@@ -549,11 +549,12 @@ def test_resample_random_layers_edits_and_device_rng(ops):
 
 
 @pytest.mark.parametrize("n1, n2", [(3, 2), (5, 4), (8, 4), (9, 5), (10, 64), (12, 6), (16, 8), (18, 7), (64, 64),
-                                    (90, 30), (128, 64), (200, 40)])
+                                    (90, 30), (128, 64), (200, 40), (300, 20)])
 def test_resample_bit_exact_vs_oracle_on_random_inputs(ops, n1, n2):
     """utils/sample_pdf.py on the CPU = torch.sum (ATen's fp32 reduction order) + torch.cumsum (fp64 accumulator);
     the kernel reproduces both orders, so cdf, inds and z are bit-equal for every row shape: rows shorter than one
-    8-float vector (scalar path), with and without leftover elements, one and two 64-lane blocks."""
+    8-float vector (scalar path), with and without leftover elements, one, two and four 64-lane blocks (the software-pipelined
+    kernel) and more than 256 samples (the general one)."""
     torch.manual_seed(1000 + n1)
     n, l = 700, 2
     t = torch.sort(torch.rand(n, l, n1) * 5.0, -1)[0]
@@ -572,6 +573,27 @@ def test_resample_bit_exact_vs_oracle_on_random_inputs(ops, n1, n2):
         assert torch.equal(inds[:, i].cpu().long(), inds_ref)
         assert torch.equal(z[:, i].cpu(), z_ref)
         assert torch.equal(tf[:, i].cpu(), torch.sort(torch.cat([t[:, i], z_ref], -1), -1)[0])
+
+
+@pytest.mark.parametrize("n1, n2", [(64, 64), (128, 64), (90, 30), (200, 40), (300, 20), (9, 5)])
+def test_resample_production_flavour_is_bit_identical_to_the_checked_one(ops, n1, n2):
+    """The production call (device draws, no debug outputs, no edits) runs the kernel's lean flavour and takes the
+    shortcut for layers a ray misses; with the debug outputs requested the same draws go through the flavour the oracle
+    tests above pin (and no shortcut).  Same seed -> the same depths and points, bit for bit."""
+    torch.manual_seed(77 + n1)
+    n, l = 1500, 3
+    t = torch.sort(torch.rand(n, l, n1) * 5.0 + 0.2, -1)[0]
+    w = torch.rand(n, l, n1) ** 8
+    miss = torch.rand(n, l) < 0.4
+    miss[:, 0] = False
+    t[miss] = -1000.0
+    w[miss] = 0.0
+    t[:40, 0] = t[:40, 0].flip(-1)                                # descending lists (a ray that misses the background box)
+    rays = torch.cat([torch.rand(n, 3), torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)], -1)
+    tf_a, xyz_a = ops.resample(dev(t), dev(w), n2, dev(rays), seed=1234, ray_index_base=17)
+    tf_b, xyz_b, _, _, _ = ops.resample(dev(t), dev(w), n2, dev(rays), seed=1234, ray_index_base=17, debug=True)
+    assert torch.equal(tf_a, tf_b) and torch.equal(xyz_a, xyz_b)
+    assert bool((tf_a[..., 1:] >= tf_a[..., :-1]).all()) and bool((tf_a[miss.cuda()] == -1000.0).all())
 
 
 @pytest.mark.parametrize("name", ["sample_pdf_90_30", "sample_pdf_128_64"])

@@ -96,3 +96,33 @@ def test_bf16x3_stage_kernel_resources(tmp_path):
     occupancy = [int(v) for v in re.findall(r"; Occupancy: (\d+)", text)]
     scratch = [int(v) for v in re.findall(r"; ScratchSize: (\d+)", text)]
     assert occupancy == [1, 1] and all(s <= 128 for s in scratch), (occupancy, scratch)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="no hipcc")
+def test_compositor_and_resampler_production_kernels_resources(tmp_path):
+    """csrc/render.hip: the compositor's merge kernel and the resampler are bound by vector-instruction issue and by how many
+    waves hide their LDS / HBM round trips (DESIGN.md sections 4.2 / 4.3), so the flavours the BASELINE shapes run (S a multiple
+    of 64; device draws) must keep their occupancy targets without scratch, use the one-instruction in-place DPP scan steps,
+    and the resampler's sort must not go through ds_bpermute except for its single distance-32 stage."""
+    text = open(_compile("render.hip", tmp_path)).read()
+
+    def kernel(mangled_part):
+        name = next(n for n in re.findall(r"^(_ZN6stnerf\w+):", text, re.M) if mangled_part in n)
+        body = text[text.index(name + ":"):]
+        end = body.index("s_endpgm")
+        meta = body[end:end + 6000]
+        get = lambda k: int(re.search(r"; " + k + r": (\d+)", meta).group(1))
+        return body[:end], get("NumVgprs"), get("ScratchSize"), get("Occupancy")
+
+    for part, occupancy in (("composite_merge_kernelILi1ELb1", 7), ("composite_merge_kernelILi2ELb1", 7), ("composite_merge_kernelILi3ELb1", 6),
+                            ("resample_kernelILi1ELb1", 8), ("resample_kernelILi2ELb1", 7)):
+        body, vgprs, scratch, occ = kernel(part)
+        assert occ >= occupancy, (part, vgprs, occ)
+        # (a few loop-invariant scalars parked in scratch outside the hot loops are tolerated for the 7-wave compositor flavours)
+        assert scratch <= (48 if "composite" in part else 0), (part, scratch)
+        assert "v_mul_f32_dpp" in body or "resample" in part, part
+        if "composite" in part:
+            assert body.count("v_mul_f32_dpp") >= 6 and body.count("v_add_f32_dpp") >= 30, part      # in-place scans
+            assert "ds_or_b32" in body and "v_mbcnt_hi_u32_b32" in body, part                         # slot mask + prefix count
+        else:
+            assert body.count("v_min_f32_dpp") >= 14 and body.count("ds_bpermute_b32") <= 2, part    # DPP bitonic stages

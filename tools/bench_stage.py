@@ -53,6 +53,9 @@ cases.update({
     "bf16x3 stage: bkgd only": (lambda: ops.mlp_stage([dict(space=bk_x, motion=None, xyz=xyz, raw=raw)], dirs, ns), FLOP_SPACE),
     "bf16x3 stage: performer fused": (lambda: ops.mlp_stage([dict(space=sp_x, motion=mo_x, xyz=xyz, raw=raw, times=times)], dirs, ns), FLOP_MOTION + FLOP_SPACE_TIME),
 })
+only = os.environ.get("CASES")   # comma-separated name prefixes
 for name, (fn, flop) in cases.items():
+    if only and not any(name.startswith(o) for o in only.split(",")):
+        continue
     ms = timeit(fn)
     print(f"{name:36s} {ms:9.3f} ms  {rows * flop / (ms * 1e-3) / 1e12:7.2f} TF/s")

@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Per-kernel sums of a rocprofv3 --pmc run written as csv (-f csv): python tools/pmc_sum.py <output dir>  (compositor / resampler kernels only)."""
 import csv, glob, collections, sys
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.defaultdict(set)

@@ -127,7 +127,70 @@ for prec in ("fp32", "bf16x3"):
             traffic["kernels" if prec == "fp32" else "kernels_bf16x3"][name] = {
                 "launches_per_step": nf, "fetch_size_kb_per_step": fkb or 0, "write_size_kb_per_step": wkb or 0, "hbm_bytes_per_step": hbm,
                 "hbm_bytes_per_launch": hbm / max(nf, 1)}
+# ---- compositor / resampler / sampler against the HBM rates measured on this box (tools/micro/hbm_copy): time from the kernel
+# trace, bytes from the FETCH_SIZE / WRITE_SIZE passes, one step (pose 0) per configuration
+try:
+    hb = json.load(open(os.path.join(src, "hbm_copy.json")))
+except Exception:  # noqa: BLE001
+    hb = {}
+md.append("## HBM-bound kernels on counter bytes (one step at pose 0; measured rates of this box: "
+          + ", ".join(f"{k} {hb[k]:.0f} GB/s" for k in ("read_GBps", "write_GBps", "copy_GBps") if k in hb) + ")\n")
+md.append("| config | kernel family | dispatches | ms per step | counter GB (2 x FETCH + WRITE) | TB/s | of 8 TB/s | of the measured rate |")
+md.append("|---|---|---|---|---|---|---|---|")
+hbm_table = {}
+for cfg, tag in (("C3 taekwondo-1080p-64+64 (f32)", "fp32"), ("C4 walking-1080p-L4-64+64 (bf16x3)", "c4"), ("C5 synthetic-4k-L8-128+64 (bf16x3)", "c5")):
+    tdb, fdb, wdb = (os.path.join(src, f"{k}_{tag}", "p_results.db") for k in ("trace", "pmc_FETCH_SIZE", "pmc_WRITE_SIZE"))
+    if not (os.path.exists(tdb) and os.path.exists(fdb) and os.path.exists(wdb)):
+        md.append(f"| {cfg} | (missing) | | | | | | |")
+        continue
+    ct, cf, cw = (sqlite3.connect(x).cursor() for x in (tdb, fdb, wdb))
+    for fam, like, ref in (("composite (single + merge)", "%composite%kernel%", "read_GBps"), ("resample", "%resample_kernel%", "copy_GBps"),
+                           ("sample_coarse", "%sample_coarse_kernel%", "write_GBps")):
+        nd, dur = ct.execute("select count(*), sum(duration) from kernels where name like ?", (like,)).fetchone()
+        fkb = cf.execute("select sum(value) from counters_collection where counter_name='FETCH_SIZE' and kernel_name like ?", (like,)).fetchone()[0] or 0
+        wkb = cw.execute("select sum(value) from counters_collection where counter_name='WRITE_SIZE' and kernel_name like ?", (like,)).fetchone()[0] or 0
+        if not nd:
+            continue
+        gb, ms = 1024.0 * (2 * fkb + wkb) / 1e9, dur / 1e6
+        rate = gb / ms   # TB/s
+        frac_m = rate * 1e3 / hb[ref] if ref in hb else float("nan")
+        md.append(f"| {cfg} | {fam} | {nd} | {ms:.2f} | {gb:.2f} | {rate:.2f} | {rate / 8:.3f} | {frac_m:.3f} of {ref.split('_')[0]} |")
+        hbm_table.setdefault(cfg, {})[fam] = {"dispatches": nd, "ms_per_step": ms, "counter_GB": gb, "TBps": rate, "frac_of_measured": frac_m, "measured": ref}
+md.append("")
+traffic["hbm_kernels_on_counter_bytes"] = hbm_table
 json.dump(traffic, open(os.path.join(dst, "r03_pmc_hbm_traffic.json"), "w"), indent=1)
+# ---- socket power / clock while the stage kernels run alone (rocm-smi samples, tools/power_trace.sh)
+pw = ["# r03: socket power and shader clock while the stage kernels run alone (rocm-smi, 20 Hz; `tools/power_trace.sh`)\n"]
+for tag, what in (("bf16x3", "split-bf16 stage kernel (csrc/mlp_bf16x3.hip)"), ("f32", "exact-f32 stage kernel (csrc/mlp_wave.hip)")):
+    pcsv, plog = os.path.join(src, f"power_{tag}.csv"), os.path.join(src, f"power_{tag}.log")
+    if not os.path.exists(pcsv):
+        continue
+    rows_p = []
+    for line in open(pcsv):
+        nums = []
+        for tok in line.replace("(", ",").replace(")", ",").replace("Mhz", "").split(","):
+            try:
+                nums.append(float(tok))
+            except ValueError:
+                pass
+        if nums:
+            rows_p.append(nums)
+    pw.append(f"## {what}\n")
+    pw += ["```"] + [l for l in open(plog).read().strip().splitlines() if "amdgpu.ids" not in l] + ["```"] if os.path.exists(plog) else []
+    pw.append(f"{len(rows_p)} samples; raw first lines of the csv:\n```")
+    pw += open(pcsv).read().strip().splitlines()[:3] + ["..."] + open(pcsv).read().strip().splitlines()[-3:] + ["```"]
+    if rows_p:
+        width = max(len(r) for r in rows_p)
+        cols = [[r[i] for r in rows_p if len(r) == width] for i in range(width)]
+        st = lambda c: f"{min(c):.0f} / {sorted(c)[len(c) // 2]:.0f} / {max(c):.0f}"
+        busy = [r for r in rows_p if len(r) == width and r[-1] > 0.6 * max(cols[-1])]       # samples taken while the kernel runs
+        pw.append(f"rocm-smi csv columns: fclk, mclk, sclk, socclk (MHz, each with its level), socket power (W).  min / median / max over all samples: "
+                  f"sclk {st(cols[4]) if width > 4 else '?'} MHz, power {st(cols[-1])} W; over the {len(busy)} samples above 60 % of the peak power: "
+                  f"sclk {st([r[4] for r in busy]) if busy and width > 4 else '?'} MHz, power {st([r[-1] for r in busy]) if busy else '?'} W\n")
+open(os.path.join(dst, "r03_power_clock_trace.md"), "w").write("\n".join(pw) + "\n")
+for f in ("power_bf16x3.csv", "power_f32.csv"):
+    if os.path.exists(os.path.join(src, f)):
+        open(os.path.join(dst, "r03_" + f), "w").write(open(os.path.join(src, f)).read())
 open(os.path.join(dst, "r03_final.md"), "w").write("\n".join(md) + "\n")
 
 wl = ["# r03: every BASELINE configuration on the round's build (1 x MI355X, `tools/r03_evidence.sh`)\n",
@@ -150,7 +213,7 @@ for cfg, fn in (("C2", "bench_c2.json"), ("C3", "bench.json"), ("C3 (yml 90+30)"
             wl.append(f"| | | {o['precision']} | {o['value']:.4g} | {o['ray_samples_per_s']:.4g} | {o['ms_per_step'] / 1e3:.3f} | {o['roofline']['algorithmic_tflops']:.1f} | "
                       f"{o['roofline']['frac']:.3f} | | | |")
 wl.append("")
-for f in ("bench_stage.txt", "bf16x3_proto.txt"):
+for f in ("bench_stage.txt", "bench_composite.txt", "bench_composite_staged.txt", "bench_resample.txt", "bf16x3_proto.txt"):
     p = os.path.join(src, f)
     if os.path.exists(p):
         wl += [f"## {f}\n", "```", open(p).read().strip(), "```\n"]
