@@ -278,9 +278,11 @@ typedef struct stnerf_composite_params {
  * Outputs (any may be NULL): layer_out[n][l][5] = {color(3), depth, acc}; mixed_out[n][5];
  * weights[n][l][S] per-layer weights (needed by stnerf_resample); order[n][l*S] int32 = source
  * index (layer*S + k) of each merged sample (torch.sort's index, ties broken by source index).
- * scratch: n bytes of device memory or NULL.  With scratch the rays that hit a single layer (about half of a view)
- * are composited first by a latency-pipelined kernel that needs no LDS, the others by the general kernel; without
- * it the general kernel takes every ray.  Same results bit for bit. */
+ * scratch: n bytes of device memory or NULL (contents on return unspecified).  With scratch the rays with a single live
+ * layer (about half of a view) are composited first by a latency-pipelined kernel that needs no LDS, the others by the
+ * register / insertion-merge kernel -- in two launches when a merged list of all l layers would not fit the LDS at full
+ * occupancy (e.g. 9 x 192 samples); without scratch that kernel takes every ray in one launch.  The `order` output and
+ * layers of more than 192 samples take the LDS-staged kernel.  Same images and weights bit for bit on every route. */
 int stnerf_composite(const float* t, const float* raw, const uint8_t* mask, int64_t n, int l, int S,
                      const stnerf_composite_params* params_host, float* layer_out, float* mixed_out,
                      float* weights, int32_t* order, uint8_t* scratch, stnerf_stream_t stream);

@@ -38,8 +38,8 @@ for cfg in "c4 walking-1080p-L4-64+64" "c5 synthetic-4k-L8-128+64 --rays-per-lau
   done
 done
 # ---- 5. stage kernels alone (with socket power / clock sampled by rocm-smi), compositor and resampler alone, microbenchmarks
-STAGE_ONLY=1 CASES="bf16x3" ITERS=40 timeout 120 bash tools/power_trace.sh $out/power_bf16x3.csv python tools/bench_stage.py > $out/power_bf16x3.log 2>&1
-STAGE_ONLY=1 CASES="stage" ITERS=25 timeout 120 bash tools/power_trace.sh $out/power_f32.csv python tools/bench_stage.py > $out/power_f32.log 2>&1
+STAGE_ONLY=1 CASES="bf16x3" ITERS=200 timeout 200 bash tools/power_trace.sh $out/power_bf16x3.csv python tools/bench_stage.py > $out/power_bf16x3.log 2>&1
+STAGE_ONLY=1 CASES="stage" ITERS=40 timeout 200 bash tools/power_trace.sh $out/power_f32.csv python tools/bench_stage.py > $out/power_f32.log 2>&1
 timeout 200 python tools/bench_composite.py > $out/bench_composite.txt 2>&1
 STNERF_COMPOSITE_KERNEL=staged timeout 200 python tools/bench_composite.py > $out/bench_composite_staged.txt 2>&1
 timeout 200 python tools/resample_phase_prof.py > $out/bench_resample.txt 2>&1
