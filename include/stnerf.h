@@ -287,6 +287,13 @@ int stnerf_composite(const float* t, const float* raw, const uint8_t* mask, int6
                      const stnerf_composite_params* params_host, float* layer_out, float* mixed_out,
                      float* weights, int32_t* order, uint8_t* scratch, stnerf_stream_t stream);
 
+/* The launch plan stnerf_composite follows for a shape (host arithmetic only, no GPU needed): plan[0] 1 = the LDS-staged
+ * kernel alone; [1] single-layer pre-pass (0 none, 1 / 2 = its two instantiations); [2] launches of the merge kernel (1 or
+ * 2); [3] layers the first launch's merged list holds; [4] 1 = scratch is cleared first; [5], [6] waves per workgroup and
+ * dynamic LDS bytes of the first launch (or of the staged kernel); [7], [8] of the second launch (0 without one).
+ * STNERF_EINVAL when a ray of l * S samples does not fit the LDS (the message says how much it needs). */
+int stnerf_composite_plan(int l, int S, int with_scratch, int with_order, int64_t* plan);
+
 /* a13 (+ the sort/merge and point generation of layered_rfrender.py:459-475): inverse-CDF
  * resampling of every layer.  utils/sample_pdf.py:18-63.
  * t[n][l][n1] coarse depths, weights[n][l][n1] coarse per-layer weights (interior [1:-1] used),

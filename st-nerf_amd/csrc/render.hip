@@ -1693,6 +1693,69 @@ static bool legacy_composite() {
     return v;
 }
 
+// Which kernels a stnerf_composite call launches, and with how much LDS (host arithmetic only; also exported as
+// stnerf_composite_plan so that the sizing is testable without a GPU).
+struct CompositePlan {
+    int staged;      // 1: the LDS-staged kernel alone (`order` output, more than 192 samples per layer, development switch)
+    int single;      // single-layer pre-pass: 0 none, 1 composite_single_kernel<2, 6>, 2 composite_single_kernel<3, 24>
+    int tiers;       // launches of composite_merge_kernel: 1, or 2 when a list of all l layers would cost occupancy
+    int cap;         // layers the first launch's merged list holds (= l with one launch)
+    int clear;       // 1: scratch is cleared first (two launches, no pre-pass to write it)
+    int wpb[2];      // waves per workgroup of the launch(es) (for the staged kernel: [0])
+    int64_t lds[2];  // dynamic LDS bytes per workgroup
+    int64_t need;    // LDS bytes per wave of the launch that needs most
+};
+constexpr int64_t COMPOSITE_LDS_BUDGET = 150 * 1024;   // of the CU's 160 KiB: the rest stays with the kernels' static LDS
+constexpr int MERGE_MAXB = 3;
+
+static bool plan_composite(int l, int S, bool scratch, bool order, bool any_output, bool staged_switch, CompositePlan& p) {
+    p = CompositePlan{};
+    const int nblk = (S + 63) / 64;
+    if (order || nblk > MERGE_MAXB || staged_switch) {
+        p.staged = 1;
+        p.need = (((int64_t)l * S * 22 + 15) / 16) * 16;
+        p.wpb[0] = (int)(COMPOSITE_LDS_BUDGET / p.need);
+        if (p.wpb[0] > 4) p.wpb[0] = 4;
+        p.lds[0] = p.need * p.wpb[0];
+        return p.wpb[0] >= 1;
+    }
+    if (scratch && any_output) p.single = (nblk <= 2 && (l - 1) * nblk <= 6) ? 1 : ((l - 1) * nblk <= 24) ? 2 : 0;
+    // The merged list lives in LDS, 6 B per sample and layer: 11.4 KB per wave at 9 x 192 samples -- three waves per SIMD,
+    // where the registers allow six.  Few rays of such a scene cross every box, so with scratch the rays are served in two
+    // launches: first with lists of as many layers as full occupancy leaves room for (a ray with more live layers is left
+    // unmarked), then the rest with lists of l layers.
+    const bool full = S == 64 * nblk;
+    const int waves_per_simd = merge_waves_per_simd(nblk, full);   // (the kernels' amdgpu_waves_per_eu)
+    int cap = l;
+    while (cap > 2 && MERGE_TAB_BYTES + 4 * merge_lds_per_wave(cap, S) > COMPOSITE_LDS_BUDGET / waves_per_simd) --cap;
+    const bool two = cap < l && scratch;
+    p.tiers = two ? 2 : 1;
+    p.cap = two ? cap : l;
+    p.clear = two && !p.single;
+    for (int tier = 0; tier < p.tiers; ++tier) {
+        const int64_t per_wave = merge_lds_per_wave(tier == p.tiers - 1 ? l : cap, S);
+        int wpb = (int)((COMPOSITE_LDS_BUDGET - MERGE_TAB_BYTES) / per_wave);
+        if (wpb > 4) wpb = 4;
+        p.wpb[tier] = wpb;
+        p.lds[tier] = MERGE_TAB_BYTES + per_wave * wpb;
+        p.need = per_wave;
+        if (wpb < 1) return false;
+    }
+    return true;
+}
+
+extern "C" int stnerf_composite_plan(int l, int S, int with_scratch, int with_order, int64_t* plan) {
+    STNERF_REQUIRE(plan, "composite_plan: null pointer");
+    STNERF_REQUIRE(l >= 1 && l <= STNERF_MAX_LAYERS && S >= 1 && (int64_t)l * S <= 65535, "composite_plan: bad shape l=%d S=%d", l, S);
+    CompositePlan p;
+    const bool ok = plan_composite(l, S, with_scratch != 0, with_order != 0, true, false, p);
+    const int64_t v[9] = {p.staged, p.single, p.tiers, p.cap, p.clear, p.wpb[0], p.lds[0], p.tiers == 2 ? p.wpb[1] : 0, p.tiers == 2 ? p.lds[1] : 0};
+    for (int i = 0; i < 9; ++i) plan[i] = v[i];
+    STNERF_REQUIRE(ok, "composite: %d samples per ray need %lld B of LDS per wave, more than the %lld B this kernel may use", l * S,
+                   (long long)p.need, (long long)COMPOSITE_LDS_BUDGET);
+    return STNERF_OK;
+}
+
 extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t* mask, int64_t n, int l, int S,
                                 const stnerf_composite_params* params_host, float* layer_out, float* mixed_out,
                                 float* weights, int32_t* order, uint8_t* scratch, stnerf_stream_t stream) {
@@ -1702,51 +1765,36 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
     STNERF_REQUIRE(((uintptr_t)raw & 15) == 0, "composite: raw must be 16-byte aligned");
     if (n == 0) return STNERF_OK;
     STNERF_REQUIRE((int64_t)l * S <= 65535, "composite: more than 65535 samples per ray");
-    constexpr int64_t LDS_BUDGET = 150 * 1024;   // of the CU's 160 KiB: the rest stays with the kernel's static LDS
+    CompositePlan plan;
+    const bool fits = plan_composite(l, S, scratch != nullptr, order != nullptr, layer_out || mixed_out || weights, legacy_composite(), plan);
+    STNERF_REQUIRE(fits, "composite: %d samples per ray need %lld B of LDS per wave, more than the %lld B this kernel may use", l * S,
+                   (long long)plan.need, (long long)COMPOSITE_LDS_BUDGET);
     LaunchTimer timer(PROF_COMPOSITE, 0, n, S,
                       20ll * l * S + l + 20ll * (l + 1) + (weights ? 4ll * l * S : 0) + (order ? 4ll * l * S : 0),
                       as_stream(stream));
     const int nblk = (S + 63) / 64;
-    constexpr int MERGE_MAXB = 3;
-    if (!order && nblk <= MERGE_MAXB && !legacy_composite()) {
+    if (!plan.staged) {
         // ---- production path: rays with one live layer first when the caller lends n bytes of scratch (pipelined over
         // the rays of a wave, no LDS), the others -- or all of them -- in the register / insertion-merge kernel
         CompositeArgs a{t, reinterpret_cast<const float4*>(raw), mask, n, l, S, *params_host, layer_out, mixed_out,
                         weights, nullptr, 4, floor_pow2(S), nullptr};
-        if (scratch && (layer_out || mixed_out || weights)) {
+        if (plan.single) {
             int64_t waves = n < 256 * 32 ? n : 256 * 32;  // 8 waves per SIMD, every wave strides over the rays
             const dim3 grid((unsigned)((waves + 3) / 4));
-            if (nblk <= 2 && (l - 1) * nblk <= 6) {
-                a.handled = scratch;
-                hipLaunchKernelGGL((composite_single_kernel<2, 6>), grid, dim3(256), 0, as_stream(stream), a);
-            } else if ((l - 1) * nblk <= 24) {
-                a.handled = scratch;
-                hipLaunchKernelGGL((composite_single_kernel<3, 24>), grid, dim3(256), 0, as_stream(stream), a);
-            }
+            a.handled = scratch;
+            if (plan.single == 1) hipLaunchKernelGGL((composite_single_kernel<2, 6>), grid, dim3(256), 0, as_stream(stream), a);
+            else hipLaunchKernelGGL((composite_single_kernel<3, 24>), grid, dim3(256), 0, as_stream(stream), a);
             STNERF_CHECK_LAUNCH("composite (single-layer rays)");
         }
-        // The merged list lives in LDS, 6 B per sample and layer: 11.4 KB per wave at 9 x 192 samples -- three waves per SIMD,
-        // where the registers allow five.  Few rays of such a scene cross every box, so with scratch the rays are served in
-        // two launches: first with lists of as many layers as full occupancy leaves room for (a ray with more live layers is
-        // left unmarked), then the rest with lists of l layers.
-        const bool full = S == 64 * nblk;
-        const int waves_per_simd = merge_waves_per_simd(nblk, full);   // (the kernels' amdgpu_waves_per_eu)
-        int cap = l;
-        while (cap > 2 && MERGE_TAB_BYTES + 4 * merge_lds_per_wave(cap, S) > LDS_BUDGET / waves_per_simd) --cap;
-        if (cap < l && scratch && !a.handled) {
+        if (plan.clear) {
             if (hipMemsetAsync(scratch, 0, (size_t)n, as_stream(stream)) != hipSuccess) return STNERF_ELAUNCH;
             a.handled = scratch;
         }
-        const bool two_tiers = cap < l && a.handled != nullptr;
-        for (int tier = two_tiers ? 0 : 1; tier < 2; ++tier) {
-            a.lds_layers = tier == 0 ? cap : l;
-            const int64_t per_wave = merge_lds_per_wave(a.lds_layers, S);
-            int wpb = (int)((LDS_BUDGET - MERGE_TAB_BYTES) / per_wave);
-            STNERF_REQUIRE(wpb >= 1, "composite: %d samples per ray need %lld B of LDS per wave, more than the %lld B this kernel may use", l * S,
-                           (long long)per_wave, (long long)LDS_BUDGET);
-            if (wpb > 4) wpb = 4;
+        const bool full = S == 64 * nblk;
+        for (int tier = 0; tier < plan.tiers; ++tier) {
+            a.lds_layers = tier == plan.tiers - 1 ? l : plan.cap;
+            const int wpb = plan.wpb[tier], lds = (int)plan.lds[tier];
             a.waves_per_block = wpb;
-            const int lds = (int)(MERGE_TAB_BYTES + per_wave * wpb);
             int64_t blocks = (n + wpb - 1) / wpb;
             if (blocks > 256 * 16) blocks = 256 * 16;
             const dim3 grid((unsigned)blocks), block(wpb * 64);
@@ -1765,12 +1813,7 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
         return STNERF_OK;
     }
     // ---- the `order` parity output and layers of more than 192 samples: the LDS-staged kernel (every ray on its own)
-    const int64_t per_wave = (((int64_t)l * S * 22 + 15) / 16) * 16;
-    int wpb = (int)(LDS_BUDGET / per_wave);
-    STNERF_REQUIRE(wpb >= 1, "composite: %d samples per ray need %lld B of LDS per wave, more than the %lld B this kernel may use", l * S,
-                   (long long)per_wave, (long long)LDS_BUDGET);
-    if (wpb > 4) wpb = 4;
-    const int lds = (int)(per_wave * wpb);
+    const int wpb = plan.wpb[0], lds = (int)plan.lds[0];
     if (lds > 64 * 1024)
         if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(composite_kernel), lds, "composite")) return rc;
     CompositeArgs a{t, reinterpret_cast<const float4*>(raw), mask, n, l, S, *params_host, layer_out, mixed_out,

@@ -182,3 +182,35 @@ def test_render_workspace_query_and_argument_errors(lib):
     assert lib.stnerf_render_workspace_bytes(10, 99, 64, 64, 0) == hip.EINVAL
     null = C.c_void_p(0)
     assert lib.stnerf_render_rays(null, 4, null, 0, None, None, null, null, null, 0, null, null, null, null, null, null, null) == hip.EINVAL
+
+
+def test_composite_launch_plan(lib):
+    """stnerf_composite_plan: the sizing arithmetic of the compositor's launches (render.hip: plan_composite) on the CPU.
+    Every BASELINE shape takes the register / insertion-merge kernels; the single-layer pre-pass needs scratch; a merged
+    list of all nine 192-sample layers would cost occupancy, so with scratch there are two launches and the first holds
+    four layers; the `order` output and layers of more than 192 samples take the LDS-staged kernel; nothing plans more than
+    the 160 KiB of a CU, and a ray that cannot fit is refused with the number of bytes it needs."""
+    def plan(l, S, scratch=True, order=False):
+        out = (C.c_int64 * 9)()
+        rc = lib.stnerf_composite_plan(l, S, int(scratch), int(order), out)
+        return rc, list(out)
+
+    for l, S in ((2, 64), (3, 64), (3, 128), (3, 90), (3, 120), (5, 64), (5, 128), (9, 128), (9, 192), (16, 192), (1, 1), (16, 1)):
+        for scratch in (True, False):
+            rc, (staged, single, tiers, cap, clear, wpb0, lds0, wpb1, lds1) = plan(l, S, scratch)
+            assert rc == 0 and not staged, (l, S, scratch)
+            assert (single != 0) == (scratch and (l - 1) * ((S + 63) // 64) <= 24), (l, S, scratch, single)
+            assert 1 <= wpb0 <= 4 and lds0 <= 150 * 1024 and lds1 <= 150 * 1024
+            assert tiers in (1, 2) and (tiers == 1 or (scratch and 2 <= cap < l and 1 <= wpb1 <= 4 and lds1 > lds0))
+            assert tiers == 2 or cap == l
+            assert clear == (1 if tiers == 2 and not single else 0)
+    assert plan(3, 128)[1][:5] == [0, 1, 1, 3, 0]                       # C3 fine: pre-pass <2, 6>, one merge launch
+    assert plan(5, 128)[1][:5] == [0, 2, 1, 5, 0]                       # C4 fine: pre-pass <3, 24>
+    assert plan(9, 192)[1][:5] == [0, 2, 2, 4, 0]                       # C5 fine: lists of four layers first, then nine
+    assert plan(9, 192, scratch=False)[1][:5] == [0, 0, 1, 9, 0]
+    assert plan(16, 192)[1][:5] == [0, 0, 2, 4, 1]                      # no pre-pass instantiation: scratch cleared instead
+    assert plan(3, 128, order=True)[1][0] == 1 and plan(3, 256)[1][0] == 1 and plan(3, 193)[1][0] == 1
+    rc, _ = plan(16, 4000, order=True)                                  # 64,000 samples x 22 B do not fit
+    assert rc == hip.EINVAL and "B of LDS per wave" in hip.last_error()
+    rc, _ = plan(17, 64)
+    assert rc == hip.EINVAL
