@@ -1340,8 +1340,11 @@ __device__ __forceinline__ float bitonic_stage(float v, int lane) {
         lo = fminf(v, pv);
         hi = fmaxf(v, pv);
     }
+    // (the mask is materialised next to its use: as an "s" operand the 21 constants are hoisted out of the pair loop -- 42 scalar
+    // registers, which the allocator then parks in vector lanes and fetches back with two v_readlane per stage)
     float r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "s"(KEEP_MIN));
+    asm("s_mov_b32 vcc_lo, %3\n\ts_mov_b32 vcc_hi, %4\n\tv_cndmask_b32_e32 %0, %1, %2, vcc"
+        : "=v"(r) : "v"(hi), "v"(lo), "n"((unsigned)(KEEP_MIN & 0xffffffffull)), "n"((unsigned)(KEEP_MIN >> 32)) : "vcc");
     (void)lane;
     return r;
 }
@@ -1388,10 +1391,13 @@ struct ResampleArgs {
 // trips per pair ("are all depths -1000?" -> "stage depths and weights" -> compute -> stores) with ~ 150 instructions
 // between them: measured, 80 % of a pair's cycles were waits for the first two (tools/resample_phase_prof.py).
 // NB1 = 0: lists of any length, loads where they are needed.
+// EXACT: n1 = 64 * NB1 and n2 = 64 (every BASELINE configuration: 64+64, 128+64) are compile-time constants -- the lane
+// predicates (k < n1, k < n1 - 2, lane < n2, ...) fold away instead of living as 64-bit masks in spilled scalar registers,
+// the searches unroll onto immediate LDS offsets: -30 % vector instructions (rocprofv3 SQ_INSTS_VALU), -25 % time.
 // PLAIN: the production call -- device draws, no debug outputs, no box edits.  The arguments of the other flavours (u, z_new,
 // inds, cdf, the edit table) are then dead: a third of this kernel's vector instructions were v_readlane / v_writelane
 // traffic of scalar registers spilled into vector lanes, most of it kernel arguments it never uses on this path.
-template <int NB1, bool PLAIN>
+template <int NB1, bool PLAIN, bool EXACT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB1 >= 4 ? 6 : NB1 >= 2 ? 7 : STNERF_WAVES_RESAMPLE, 8))) resample_kernel(ResampleArgs a) {
     const float* const u_in = PLAIN ? nullptr : a.u;
     float* const z_out = PLAIN ? nullptr : a.z_new;
@@ -1402,7 +1408,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB1 >=
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: the pair index, its 64-bit divisions and
                                                                         // the RNG key of the pair stay on the scalar unit
-    const int n1 = a.n1, n2 = a.n2, S = n1 + n2, nb = n1 - 1;  // nb = #bins = len(cdf)
+    const int n1 = EXACT ? 64 * NB1 : a.n1, n2 = EXACT ? 64 : a.n2, S = n1 + n2, nb = n1 - 1;  // nb = #bins = len(cdf)
     // the three searched arrays are padded with +inf to (a power of two) - 1 entries, once (upper_bound_padded)
     const int P1 = pow2_above(n1), PC = pow2_above(nb), P2 = pow2_above(n2);
     float* mine = reinterpret_cast<float*>(smem_raw) + (size_t)wave * resample_lds_floats(n1, n2);
@@ -1849,10 +1855,12 @@ extern "C" int stnerf_resample(const float* t, const float* weights, int64_t n, 
     const bool plain = !u && !z_new && !inds && !cdf && !a.ed.any;
     const dim3 grid((unsigned)blocks), block(256);
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, lds, as_stream(stream), a); };
-    if (n1 <= 64) plain ? launch(resample_kernel<1, true>) : launch(resample_kernel<1, false>);
-    else if (n1 <= 128) plain ? launch(resample_kernel<2, true>) : launch(resample_kernel<2, false>);
-    else if (n1 <= 256) plain ? launch(resample_kernel<4, true>) : launch(resample_kernel<4, false>);
-    else launch(resample_kernel<0, false>);
+    const bool exact = plain && n2 == 64 && (n1 == 64 || n1 == 128);
+    if (exact) n1 == 64 ? launch(resample_kernel<1, true, true>) : launch(resample_kernel<2, true, true>);
+    else if (n1 <= 64) plain ? launch(resample_kernel<1, true, false>) : launch(resample_kernel<1, false, false>);
+    else if (n1 <= 128) plain ? launch(resample_kernel<2, true, false>) : launch(resample_kernel<2, false, false>);
+    else if (n1 <= 256) plain ? launch(resample_kernel<4, true, false>) : launch(resample_kernel<4, false, false>);
+    else launch(resample_kernel<0, false, false>);
     STNERF_CHECK_LAUNCH("resample");
     return STNERF_OK;
 }
