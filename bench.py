@@ -1,21 +1,23 @@
 #!/usr/bin/env python3
 """Benchmark of the layered ray-march render path on MI355X (driver contract: one JSON line on rank 0).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: launches its own N ranks (torch.distributed.run, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path over one synthetic 1080p view per GPU: device ray generation
-(a1/a2) -> coarse sampler -> mask compaction -> MotionNet/SpaceNet (exact f32 MFMA; --precision bf16x3: split-bf16 MFMA) -> composite + merge ->
-inverse-CDF resample -> fine MotionNet/SpaceNet -> composite + merge, followed (N > 1) by the RCCL
-all-gather of the rendered tiles.
+A "step" = one pass of the hot path over ONE synthetic 1080p view: device ray generation (a1/a2) -> coarse sampler ->
+mask compaction -> MotionNet/SpaceNet (split-bf16 MFMA, the library default; the exact f32 MFMA arithmetic is timed as a
+second, co-equal leg) -> composite + merge -> inverse-CDF resample -> fine MotionNet/SpaceNet -> composite + merge,
+through the call surface a user of the reference calls: ``stnerf_amd.parallel.render_view`` = what ``render_pose`` runs
+(device ray generation + ``layered_batchify_ray``).
 
-N > 1 (the split BASELINE.json configs[3]/[4] describe): ONE view per step is cut into interleaved single-row
-stripes over the N ranks (the performers cover only part of the picture; contiguous tiles would differ ~2x in
-cost), every rank renders its 1/N of the rows as one launch sequence (striped ray window), one RCCL all-gather
-rebuilds the frame on every rank: `scaling` = "strong", value = rays of the view x steps / max-over-ranks time.
-A short secondary leg (`weak_scaling_views`) renders one whole view per rank per step.  `--partition views`
-makes that the headline instead.
+The SAME function is the step at every N.  N = 1: the whole view on the one GPU.  N > 1 (the split BASELINE.json
+configs[3]/[4] describe): the view is cut into interleaved single-row stripes over the N ranks (the performers cover only
+part of the picture; contiguous tiles would differ ~2x in cost), every rank generates and renders its 1/N of the rows
+as one launch sequence (striped ray window), one RCCL all-gather rebuilds the WHOLE 5-tuple (mixed + per-layer colour /
+depth / acc, fine and coarse, hit masks: 10 + 11 l floats per ray) on every rank.  `scaling` = "strong" at every N:
+value = rays of the view x steps / max-over-ranks time.  `--partition views` (one whole view per rank per step, weak
+scaling) stays available as an explicit alternative.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): Taekwondo-shaped
 scene, 2 performer layers + background, 1920x1080, 64 coarse + 64 fine samples (128/ray/layer),
@@ -37,7 +39,8 @@ sys.path.insert(0, REPO)
 from stnerf_amd import ops, synthetic as syn          # noqa: E402
 from stnerf_amd.modeling import build_layered_model   # noqa: E402
 from stnerf_amd.utils import layered_batchify_ray     # noqa: E402
-from stnerf_amd.parallel import gather_tiles, make_row_renderer, render_view_striped  # noqa: E402
+from stnerf_amd import parallel                         # noqa: E402
+from stnerf_amd.parallel import gather_tiles, render_view  # noqa: E402
 
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 MEASURED_HBM_JSON = os.path.join(REPO, "profiles", "r03_hbm_copy_microbench.json")   # tools/micro/hbm_copy on the GPU box
@@ -56,6 +59,7 @@ WORKLOADS = {
     "walking-1080p-L4-64+64": (1080, 1920, 4, 64, 64, False, True),
     "synthetic-4k-L8-128+64": (2160, 3840, 8, 128, 64, False, True),   # BASELINE configs[4] on one GPU (use --rays-per-launch 131072)
     "tiny-64-32+0": (64, 64, 1, 32, 0, True, False),
+    "taekwondo-192x256-32+32": (192, 256, 2, 32, 32, True, True),     # the C3 scene small enough for the N-rank bitwise tests
 }
 
 
@@ -205,11 +209,11 @@ def cpu_baseline(workload, budget_rays, threads=0):
                 host=dict(nproc=os.cpu_count(), torch_threads=torch.get_num_threads(), cpu=cpu), chunks=per_chunk)
 
 
-def psnr_vs_reference(model_unused, device):
-    """PSNR parity of the production (device Philox) RNG mode with the reference: tests/golden/psnr_view.npz holds the
-    REFERENCE rendered with two torch seeds on a 128 x 128 view of this scene (64+64, seed-0 weights; written by
-    tests/golden/make_golden.py from /root/reference).  PSNR(reference B, reference A) is its own run-to-run spread;
-    the HIP render must land on it."""
+def psnr_vs_reference(precision, device):
+    """PSNR parity of the production (device Philox) RNG mode with the reference, in the arithmetic of the headline leg:
+    tests/golden/psnr_view.npz holds the REFERENCE rendered with two torch seeds on a 128 x 128 view of this scene
+    (64+64, seed-0 weights; written by tests/golden/make_golden.py from /root/reference).  PSNR(reference B, reference A)
+    is its own run-to-run spread; the HIP render must land on it."""
     import numpy as np
     path = os.path.join(REPO, "tests", "golden", "psnr_view.npz")
     if not os.path.exists(path):
@@ -223,14 +227,19 @@ def psnr_vs_reference(model_unused, device):
     model.set_bkgd_bbox(bk)
     model.set_bboxes(per)
     model = model.to(device).eval()
+    model.shard_views = False
     K, T = syn.camera(meta["h"], meta["w"], meta["orbit"])
     rays = ops.generate_rays(K, T, meta["h"], meta["w"], frame_ids=[1.0] + [meta["frame"]] * meta["L"], device=device)
     psnr = lambda a, b: float(-10 * torch.log10(torch.mean((a - b) ** 2)))
-    model.seed = 5
-    with torch.no_grad():
-        img = layered_batchify_ray(model, rays, None, None)[0][0].cpu()
-    return {"hip_device_rng_vs_reference_seed_a_dB": psnr(img, A), "reference_seed_b_vs_seed_a_dB": psnr(B, A),
-            "view": f"{meta['w']}x{meta['h']}, L={meta['L']}, {meta['n1']}+{meta['n2']}", "fixture": "tests/golden/psnr_view.npz"}
+    out = {"reference_seed_b_vs_seed_a_dB": psnr(B, A), "view": f"{meta['w']}x{meta['h']}, L={meta['L']}, {meta['n1']}+{meta['n2']}",
+           "fixture": "tests/golden/psnr_view.npz"}
+    for prec in dict.fromkeys([precision, "bf16x3", "fp32"]):
+        model.set_precision(prec)
+        model.seed = 5
+        with torch.no_grad():
+            img = layered_batchify_ray(model, rays, None, None)[0][0].cpu()
+        out[f"hip_device_rng_{prec}_vs_reference_seed_a_dB"] = psnr(img, A)
+    return out
 
 
 def eager_gpu_baseline(workload, n_rays, device):
@@ -261,6 +270,41 @@ def eager_gpu_baseline(workload, n_rays, device):
                 sample=f"{n} rays ({n // chunk} reference chunks of {chunk}) from the centre rows, {dt_s:.2f} s")
 
 
+def _self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without torch.distributed.run's environment: become the launcher of N ranks of
+    this very command (one process per GPU, rendezvous on 127.0.0.1, a free port)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+PRECISION_NOTES = {
+    "bf16x3": "the library default: every fp32 operand = three bf16 pieces (8+8+8 significand bits: exact for finite values in "
+              "bf16's exponent range = fp32's), a*b = its six leading cross terms on v_mfma_f32_32x32x16_bf16, a0*b0 and the "
+              "five small terms in separate f32 accumulators, heads in fp64: closer to an fp64 evaluation than the fp32 CPU "
+              "chain on every layer (tests/test_gpu_stage.py)",
+    "fp16x3": "every product a*b as ah*bh + ah*bl + al*bh on the fp16 MFMA pipe (22-bit operands, |W| < 234, activations "
+              "< 65520 with an overflow guard), per-network launches; opt-in",
+    "fp32": "exact f32 MFMA (v_mfma_f32_32x32x2_f32), model.set_precision('fp32')"}
+DTYPE_NOTES = {"fp32": "f32",
+               "bf16x3": "f32 (operands as 3 bf16 pieces each: 24-bit significand, f32 exponent range; 6 bf16 MFMA terms per product, f32 accumulate)",
+               "fp16x3": "f32-accurate products as 3 fp16 MFMA terms (22-bit split operands), f32 accumulate"}
+EXECUTED_TERMS = {"fp32": 1.0, "fp16x3": 3.0, "bf16x3": 6.0}     # MFMA products executed per algorithmic product
+STAGE_KERNEL = {
+    "bf16x3": "stnerf::mlp_bf16x3_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, a wave owns 32 "
+              "samples and keeps their activations in registers as three bf16 planes, weights through an LDS-DMA ring, "
+              "v_mfma_f32_32x32x16_bf16; achieved = EXECUTED MFMA rate = 6 x algorithmic)",
+    "fp32": "stnerf::mlp_wave_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, a wave owns 32 "
+            "samples and keeps their activations in registers, v_mfma_f32_32x32x2_f32)",
+    "fp16x3": "stnerf::spacenet_f16x3_kernel (per-network launches, LDS-staged activations, v_mfma_f32_32x32x8_f16 x 3)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,100 +315,60 @@ def main():
                     help="0 disables the CPU baseline leg; default = 8 reference chunks spread over the image (BASELINE.md 3.3)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline leg (0 = min(32, host cores))")
     ap.add_argument("--rays-per-launch", type=int, default=1 << 19)
-    ap.add_argument("--partition", default=None, choices=["views", "stripes"],
-                    help="N>1 headline: 'stripes' (default) = ONE view per step in interleaved row stripes over the GPUs "
+    ap.add_argument("--partition", default="stripes", choices=["views", "stripes"],
+                    help="'stripes' (default, every N): ONE view per step, in interleaved row stripes over the GPUs when N > 1 "
                          "(strong scaling, the split BASELINE configs[3]/[4] describe); 'views' = one whole view per GPU "
                          "per step (weak scaling)")
     ap.add_argument("--stripe-rows", type=int, default=1, help="image rows per stripe of the striped partition")
     ap.add_argument("--debug-single-device", action="store_true",
                     help="N>1 with every rank on cuda:0 over gloo: exercises the multi-rank code path on a 1-GPU box (not a measurement)")
-    ap.add_argument("--no-weak-leg", action="store_true", help="N>1: skip the secondary weak-scaling leg")
     ap.add_argument("--no-psnr-check", action="store_true",
                     help="skip the PSNR-vs-reference check of the device RNG mode (a 128x128 view, ~0.1 s)")
     ap.add_argument("--eager-gpu-baseline-rays", type=int, default=3584,
                     help=">0 (default: one reference chunk): also time the oracle restatement through eager PyTorch-ROCm on this GPU -- "
                          "the 'stock ATen on the same GPU' figure of BASELINE.md 3.5 (informative); 0 skips it")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "fp16x3"],
-                    help="arithmetic of the headline run: exact f32 MFMA (default), split-bf16 (three bf16 pieces per fp32 operand, "
-                         "six MFMAs, two accumulators: fp32's significand and range) or split-fp16 (22-bit operands, range-limited)")
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "fp16x3"],
+                    help="arithmetic of the headline leg: split-bf16 (the library default: three bf16 pieces per fp32 operand, six MFMAs, "
+                         "two accumulators: fp32's significand and range), exact f32 MFMA, or split-fp16 (22-bit operands, range-limited)")
     ap.add_argument("--mlp-schedule", default="stage", choices=["stage", "per_net"],
                     help="exact-f32 MLP scheduling: one persistent launch per stage (default) or one launch per network (round 1)")
     ap.add_argument("--no-second-precision", action="store_true",
-                    help="skip the extra (untimed-for-`value`) leg that measures the other precision mode")
+                    help="skip the second, co-equal leg (same steps and warm-up) in the other arithmetic (fp32 <-> bf16x3)")
+    ap.add_argument("--no-config-legs", action="store_true",
+                    help="skip the short legs over the other BASELINE configs (C4 walking-1080p-L4, C2 single-512), N = 1 only")
+    ap.add_argument("--dump-outputs", default=None,
+                    help="rank 0 writes the LAST timed step's whole 5-tuple (every rank holds it after the all-gather) to this "
+                         "torch file: tests compare an N-rank run with the 1-rank run bit for bit")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args)                               # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the render path has no CPU fallback)")
-    if not args.debug_single_device and torch.cuda.device_count() < world:
-        raise SystemExit(f"--gpus {world} but this node exposes {torch.cuda.device_count()} GPU(s): one process per GPU needs "
-                         f"{world} visible devices (check HIP_VISIBLE_DEVICES / the compute partition mode)")
-    if args.debug_single_device:
-        local_rank = 0                  # every rank on cuda:0 (validates the N > 1 logic on a 1-GPU box; gloo, not RCCL)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    try:
+        parallel.init_from_env(single_device=args.debug_single_device)   # cuda:LOCAL_RANK, RCCL (gloo in the one-device debug mode)
+    except RuntimeError as e:
+        raise SystemExit(str(e))
+    device = torch.device("cuda", torch.cuda.current_device())
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.debug_single_device:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
 
     from stnerf_amd import hip
     info = hip.device_info()
-    model, (H, W, L, n1, n2, st, dt) = build_scene(args.workload, device)
-    model.max_rays_per_launch = args.rays_per_launch
-    model.mlp_schedule = args.mlp_schedule
-    l = L + 1
-    n_rays = H * W
-    frame_ids = [1.0] + [2.5] * L
+    frame_ids_of = lambda L: [1.0] + [2.5] * L
+    partition = args.partition
 
-    mode = args.partition or ("stripes" if world > 1 else "views")
-    stripe = W * args.stripe_rows                     # rays per stripe: whole image rows
-
-    def step(i, mode):
-        """-> (image tile (n_rays [x world if views], 5), this rank's per-layer hit masks, this rank's compute seconds).
-        Novel-view sweep, a new pose every step; every rank uses the same camera for step i."""
-        K, T = syn.camera(H, W, orbit_deg=10.0 + 1.5 * i)
-        t0 = time.perf_counter()
-        if mode == "stripes":
-            # strong scaling: ONE view per step; rank r renders image rows r, r+N, r+2N, ... (x stripe_rows) as one
-            # launch sequence over a striped ray window, then one RCCL all-gather of the stripes
-            model.seed = i
-            rows = make_row_renderer(model, K, T, H, W, frame_ids, device=device)
-            holder = {}
-
-            def timed_rows(first, n):
-                out = rows(first, n)
-                torch.cuda.synchronize()
-                holder["t"] = time.perf_counter() - t0
-                return out
-
-            def timed_striped(first, n, st_, period):
-                out = rows.striped(first, n, st_, period)
-                torch.cuda.synchronize()
-                holder["t"] = time.perf_counter() - t0
-                return out
-            timed_rows.striped = timed_striped
-            tile = render_view_striped(timed_rows, n_rays, stripe)
-            return tile, rows.last_masks, holder.get("t", 0.0)
-        # weak scaling: one whole view per GPU per step (distinct RNG streams), tiles all-gathered
-        rays = ops.generate_rays(K, T, H, W, frame_ids=frame_ids, device=device)
-        model.seed = i * world + rank
-        with torch.no_grad():
-            fine, coarse, fine_layers, _, masks = layered_batchify_ray(model, rays, None, None)
-        tile = torch.cat(list(fine), dim=1).contiguous()      # (H*W, 5): colour, depth, acc of the final image
-        torch.cuda.synchronize()
-        compute = time.perf_counter() - t0
-        if world > 1:
-            tile = gather_tiles(tile, world * n_rays)          # ONE RCCL all-gather of the rendered tiles
-        return tile, masks, compute
+    def scene(workload):
+        model, dims = build_scene(workload, device)
+        model.max_rays_per_launch = args.rays_per_launch
+        model.mlp_schedule = args.mlp_schedule
+        model.shard_views = partition == "stripes"
+        return model, dims
 
     def fence():
         torch.cuda.synchronize()
@@ -372,179 +376,203 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(precision, steps, warmup, mode):
-        """K timed steps (barrier + synchronize on both sides, MAX over ranks) in one precision mode."""
+    def measure(model, dims, precision, steps, warmup):
+        """`steps` timed steps (barrier + synchronize on both sides, MAX over ranks) in one arithmetic.  A step is
+        parallel.render_view -- the function render_pose runs -- at every N."""
+        H, W, L, n1, n2, st, dt = dims
+        l, n_rays, frame_ids = L + 1, H * W, frame_ids_of(L)
         model.set_precision(precision)
-        for i in range(warmup):
-            step(-1 - i, mode)
-        deep_extra = 0
-        timer = KernelTimer(n1, [FLOP_SPACE] + [(FLOP_SPACE_TIME if st else FLOP_SPACE) + (FLOP_MOTION if dt else 0) + deep_extra] * L)
-        timer.start()
-        fence()
-        t0 = time.perf_counter()
-        compute = 0.0
-        for i in range(steps):
-            tile, masks, c = step(i, mode)
-            compute += c
-        fence()
-        elapsed = time.perf_counter() - t0
-        timer.stop()
-        per_rank = [compute]
+        clock = {"compute": 0.0, "t0": 0.0}
+        inner = type(model).render_rays_raw.__get__(model)
+
+        def timed_raw(*a, **k):                           # this rank's share of the view, before the all-gather
+            out = inner(*a, **k)
+            torch.cuda.synchronize()
+            clock["compute"] += time.perf_counter() - clock["t0"]
+            return out
+        model.render_rays_raw = timed_raw
+
+        def step(i):
+            """Novel-view sweep, a new pose every step; every rank uses the same camera for step i."""
+            K, T = syn.camera(H, W, orbit_deg=10.0 + 1.5 * i)
+            model.seed = i if partition == "stripes" else i * world + rank
+            clock["t0"] = time.perf_counter()
+            out = render_view(model, K, T, H, W, frame_ids, stripe_rows=args.stripe_rows, device=device)
+            if partition == "views" and world > 1:          # weak scaling: every rank its own view, final tiles all-gathered
+                gather_tiles(torch.cat(list(out[0]), 1).contiguous(), world * n_rays)
+            return out
+
+        try:
+            for i in range(warmup):
+                step(-1 - i)
+            timer = KernelTimer(n1, [FLOP_SPACE] + [(FLOP_SPACE_TIME if st else FLOP_SPACE) + (FLOP_MOTION if dt else 0)] * L)
+            timer.start()
+            clock["compute"] = 0.0
+            fence()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                out = step(i)
+            fence()
+            elapsed = time.perf_counter() - t0
+            timer.stop()
+        finally:
+            del model.render_rays_raw
+        per_rank = [clock["compute"]]
         if world > 1:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
             allc = torch.zeros(world, dtype=torch.float64, device=device)
-            allc[rank] = compute
+            allc[rank] = clock["compute"]
             dist.all_reduce(allc)
             per_rank = allc.tolist()
         ksum = timer.summarise()  # this rank's launches over the timed steps
         evals = sum(d["evals"] for name, d in ksum.items() if name in ("spacenet", "mlp_stage"))
-        hit = torch.stack([m.float().mean() for m in masks]).double() if masks is not None else torch.zeros(l, dtype=torch.float64, device=device)
+        hit = torch.stack(out[4]).float().mean(1).double()       # the gathered masks of the last view (every rank holds them)
+        evals_all = float(evals)
         if world > 1:
             ev = torch.tensor([evals], dtype=torch.float64, device=device)
             dist.all_reduce(ev)
             evals_all = float(ev.item())
-            dist.all_reduce(hit)
-            hit = hit / world
-        else:
-            evals_all = float(evals)
-        assert bool(torch.isfinite(tile).all()), "non-finite pixels in the rendered tile"
-        return dict(elapsed=elapsed, ksum=ksum, evals=evals, evals_all=evals_all, tile=tile, mask_fraction=hit.tolist(),
-                    per_rank_compute_s=per_rank, steps=steps, mode=mode,
-                    rays=(n_rays if mode == "stripes" else world * n_rays) * steps)
+        flat = torch.cat(list(out[0]) + list(out[1]), 1)
+        assert bool(torch.isfinite(flat).all()), "non-finite pixels in the rendered view"
+        return dict(elapsed=elapsed, ksum=ksum, evals=evals, evals_all=evals_all, out=out, mask_fraction=hit.tolist(),
+                    per_rank_compute_s=per_rank, steps=steps, warmup=warmup, precision=precision, dims=dims,
+                    rays=(n_rays if partition == "stripes" else world * n_rays) * steps)
 
-    head = measure(args.precision, args.steps, args.warmup, mode)
-    elapsed, ksum, evals, evals_all = head["elapsed"], head["ksum"], head["evals"], head["evals_all"]
-    others = []
+    model, dims = scene(args.workload)
+    H, W, L, n1, n2, st, dt = dims
+    n_rays = H * W
+    head = measure(model, dims, args.precision, args.steps, args.warmup)
+    second = None
     if not args.no_second_precision:
-        # the arithmetics that are not the headline: bf16x3 first (the fp32-faithful fast mode), then fp16x3 / fp32
-        for op in [q for q in ("bf16x3", "fp32", "fp16x3") if q != args.precision][:2]:
-            o = measure(op, max(1, min(args.steps, 2)), 1, mode)
-            o["precision"] = op
-            others.append(o)
+        # the other arithmetic as a CO-EQUAL leg: same steps, same warm-up, same poses, full roofline block
+        second = measure(model, dims, "fp32" if args.precision != "fp32" else "bf16x3", args.steps, args.warmup)
     model.set_precision(args.precision)
-    weak = None
-    if world > 1 and mode == "stripes" and not args.no_weak_leg:
-        weak = measure(args.precision, max(1, min(args.steps, 2)), 1, "views")
-    psnr_check = psnr_vs_reference(model, device) if (rank == 0 and not args.no_psnr_check) else None
+    config_legs = []
+    if world == 1 and not args.no_config_legs and partition == "stripes":
+        for wl, k in (("walking-1080p-L4-64+64", 2), ("single-512-64+64", 2)):
+            if wl == args.workload:
+                continue
+            m2, d2 = scene(wl)
+            leg = measure(m2, d2, args.precision, k, 1)
+            leg["workload"] = wl
+            leg.pop("out")
+            config_legs.append(leg)
+            del m2
+            torch.cuda.empty_cache()
+    psnr_check = psnr_vs_reference(args.precision, device) if (rank == 0 and not args.no_psnr_check) else None
+
+    if args.dump_outputs and rank == 0:
+        o = head["out"]
+        torch.save({"mixed_fine": [t.cpu() for t in o[0]], "mixed_coarse": [t.cpu() for t in o[1]],
+                    "layer_fine": [[t.cpu() for t in trip] for trip in o[2]],
+                    "layer_coarse": [[t.cpu() for t in trip] for trip in o[3]], "masks": [t.cpu() for t in o[4]],
+                    "world": world, "partition": partition, "precision": args.precision}, args.dump_outputs)
 
     if rank == 0:
-        staged = "mlp_stage" in ksum
-        sp = ksum["mlp_stage"] if staged else ksum["spacenet"]
-        achieved = sp["flop"] / (sp["ms"] * 1e-3) / 1e12
-        mult_head = {"fp16x3": 3.0, "bf16x3": 6.0}.get(args.precision, 1.0)   # executed MFMA terms per algorithmic product
-        achieved, peak_used = mult_head * achieved, (PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_F16_MFMA_TFLOPS)
-        # HBM traffic cannot be counted inside this process: it comes from the committed rocprofv3 PMC passes
-        # of the same command (profiles/), per launch, with the gfx950 FETCH_SIZE correction applied.
         pmc = json.load(open(PMC_TRAFFIC_JSON)) if os.path.exists(PMC_TRAFFIC_JSON) else {}
-        pmc_ok = pmc.get("workload") == args.workload and world == 1
-        dom = "mlp_stage" if "mlp_stage" in ksum else "spacenet"
-        pk = pmc.get("kernels_bf16x3" if args.precision == "bf16x3" else "kernels", {}) if args.precision != "fp16x3" else {}
-        traffic = pk[dom]["hbm_bytes_per_launch"] if pmc_ok and dom in pk else None
         measured = json.load(open(MEASURED_HBM_JSON)) if os.path.exists(MEASURED_HBM_JSON) else {}
         hbm_meas = {"composite": measured.get("read_GBps"), "resample": measured.get("copy_GBps"),
                     "sample_coarse": measured.get("write_GBps")}
 
-        def hbm_entry(k, d):
+        def stage_of(leg):
+            return leg["ksum"]["mlp_stage"] if "mlp_stage" in leg["ksum"] else leg["ksum"]["spacenet"]
+
+        def roofline_of(leg, workload):
+            """MFMA roofline of the stage kernel of one leg: EXECUTED MFMA rate (what the matrix pipe does) over the dense peak
+            of the instruction it issues, and the algorithmic rate (network FLOPs of the reference's arithmetic) beside it."""
+            prec = leg["precision"]
+            sp = stage_of(leg)
+            alg = sp["flop"] / (sp["ms"] * 1e-3) / 1e12
+            executed = EXECUTED_TERMS[prec] * alg
+            peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_F16_MFMA_TFLOPS
+            # HBM traffic cannot be counted inside this process: it comes from the committed rocprofv3 PMC passes
+            # of the same command (profiles/), per launch, with the gfx950 FETCH_SIZE correction applied.
+            pk = pmc.get({"bf16x3": "kernels_bf16x3", "fp32": "kernels"}.get(prec, "-"), {})
+            dom = "mlp_stage" if "mlp_stage" in leg["ksum"] else "spacenet"
+            traffic = pk[dom]["hbm_bytes_per_launch"] if (pmc.get("workload") == workload and world == 1 and dom in pk) else None
+            return {"kernel": STAGE_KERNEL[prec] if dom == "mlp_stage" else "stnerf::spacenet_kernel (fused PE + 9-layer MLP)",
+                    "bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s", "frac": executed / peak,
+                    "executed_mfma_tflops": executed, "algorithmic_tflops": alg,
+                    "traffic": traffic,
+                    "traffic_source": ("profiles/" + os.path.basename(PMC_TRAFFIC_JSON) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over ONE "
+                                       "step of this workload at pose 0 of the sweep (the timed steps sweep the orbit: +- 10 % evaluations)") if traffic else None,
+                    "algorithmic_bytes_per_launch": 28 * sp["evals"] / sp["launches"],   # 12 B point in + 16 B raw out per SpaceNet evaluation
+                    "launches": sp["launches"], "avg_launch_ms": sp["ms"] / sp["launches"],
+                    "algorithmic_flop_per_launch": sp["flop"] / sp["launches"],
+                    "note": "algorithmic FLOPs = network evaluations x 924,672 (930,048 with time; + 153,344 per MotionNet evaluation in the fused "
+                            "stage kernel); executed = algorithmic x MFMA terms per product (1 for f32, 6 for bf16x3); HIP events recorded by the "
+                            "library on the launch stream around every launch of the timed steps (rank 0)"}
+
+        def hbm_entry(leg, k, d):
             sec = d["ms"] * 1e-3
-            e = {"launches": d["launches"], "ms_per_step": d["ms"] / head["steps"],
+            e = {"launches": d["launches"], "ms_per_step": d["ms"] / leg["steps"],
                  "algorithmic_GBps": d["bytes"] / sec / 1e9, "peak_GBps": PEAK_HBM_GBPS, "frac": d["bytes"] / sec / (PEAK_HBM_GBPS * 1e9),
-                 "algorithmic_bytes_per_step": d["bytes"] / head["steps"],
-                 "dense_bytes_per_step": d["bytes_dense"] / head["steps"],
-                 "bytes_note": "algorithmic = bytes the kernel has to move (t, raw and weights only of the layers a ray hits); "
-                               "dense = every layer charged (round-1 accounting)"}
+                 "algorithmic_bytes_per_step": d["bytes"] / leg["steps"],
+                 "dense_bytes_per_step": d["bytes_dense"] / leg["steps"]}
             if hbm_meas.get(k):
                 e["measured_peak_GBps"] = hbm_meas[k]
                 e["frac_of_measured_peak"] = d["bytes"] / sec / (hbm_meas[k] * 1e9)
-            if pmc_ok and k in pmc.get("kernels", {}):
-                cb = pmc["kernels"][k]["hbm_bytes_per_step"]
+            pk = pmc.get("kernels_bf16x3" if leg["precision"] == "bf16x3" else "kernels", {})
+            if pmc.get("workload") == args.workload and world == 1 and k in pk and leg.get("workload", args.workload) == args.workload:
+                cb = pk[k]["hbm_bytes_per_step"]
                 e["counter_bytes_per_step"] = cb
-                e["counter_GBps"] = cb / (d["ms"] / head["steps"] * 1e-3) / 1e9
+                e["counter_GBps"] = cb / (d["ms"] / leg["steps"] * 1e-3) / 1e9
+                e["counter_over_algorithmic"] = cb / (d["bytes"] / leg["steps"])
                 e["counter_source"] = "profiles/" + os.path.basename(PMC_TRAFFIC_JSON)
             return e
 
-        per_rank = head["per_rank_compute_s"]
+        def leg_record(leg, workload):
+            per_rank = leg["per_rank_compute_s"]
+            return {"precision": leg["precision"], "dtype": DTYPE_NOTES[leg["precision"]], "note": PRECISION_NOTES[leg["precision"]],
+                    "workload": workload, "value": leg["rays"] / leg["elapsed"], "unit": "rays/s", "steps": leg["steps"], "warmup": leg["warmup"],
+                    "ms_per_step": 1e3 * leg["elapsed"] / leg["steps"],
+                    "ray_samples_per_s": leg["evals_all"] / leg["elapsed"],
+                    "ray_samples_per_step_rank0": leg["evals"] / leg["steps"],
+                    "mask_fraction": leg["mask_fraction"],
+                    "per_rank_compute_s": {"min": min(per_rank), "mean": sum(per_rank) / len(per_rank), "max": max(per_rank), "all": per_rank,
+                                           "note": "render time of each rank's share over the timed steps, before the all-gather"},
+                    "roofline": roofline_of(leg, workload),
+                    "kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / leg["steps"],
+                                    "algorithmic_tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12} for k, d in leg["ksum"].items() if "flop" in d},
+                    "hbm_kernels": {k: hbm_entry(leg, k, d) for k, d in leg["ksum"].items() if "bytes" in d}}
+
+        hr = leg_record(head, args.workload)
         rec = {
             "metric": "rendered rays/s (and ray-samples/s) per GPU, 1080p x 128-sample layered render",
-            "value": head["rays"] / elapsed,
-            "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong" if mode == "stripes" else "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32",
-                      "bf16x3": "f32 operands as 3 bf16 pieces each (24-bit significand, f32 exponent range), 6 bf16 MFMA terms per product, f32 accumulate",
-                      "fp16x3": "f32-accurate products as 3 fp16 MFMA terms (22-bit split operands), f32 accumulate"}[args.precision],
-            "data": "synthetic",
+            "value": hr["value"], "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": hr["ms_per_step"],
+            "higher_is_better": True, "scaling": "strong" if partition == "stripes" else "weak", "vs_baseline": None,
+            "dtype": DTYPE_NOTES[args.precision], "data": "synthetic",
             "config": {"workload": args.workload, "precision": args.precision, "height": H, "width": W, "performer_layers": L,
                        "coarse_samples": n1, "fine_samples": n2, "use_space_time": st, "use_deform_time": dt,
                        "rays_per_view": n_rays, "rays_per_launch": args.rays_per_launch,
                        "weights": "random, density head scaled (synthetic.make_state_dict seed 0)",
-                       "parallelism": (f"ONE view per step in interleaved {args.stripe_rows}-row stripes over {world} GPUs (each rank: "
-                                       f"one launch sequence over its striped ray window), one RCCL all-gather per step"
-                                       if mode == "stripes" else
-                                       f"ray tiles: 1 view per GPU per step x {world} GPUs (same camera, own RNG stream), "
-                                       "one RCCL all-gather of the rendered tiles per step")},
-            "ray_samples_per_s": evals_all / elapsed,
-            "ray_samples_per_step_rank0": evals / args.steps,
-            "mask_fraction": head["mask_fraction"],
-            "per_rank_compute_s": {"min": min(per_rank), "mean": sum(per_rank) / len(per_rank), "max": max(per_rank),
-                                   "all": per_rank, "note": "render time of each rank's share over the timed steps, before the all-gather"},
-            "roofline": {"kernel": (("stnerf::mlp_bf16x3_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, "
-                                     "a wave owns 32 samples and keeps their activations in registers as three bf16 planes, weights through an "
-                                     "LDS-DMA ring, v_mfma_f32_32x32x16_bf16; achieved = EXECUTED MFMA rate = 6 x algorithmic)")
-                                    if args.precision == "bf16x3" else
-                                    ("stnerf::mlp_wave_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, "
-                                     "a wave owns 32 samples and keeps their activations in registers, v_mfma_f32_32x32x2_f32)")) if staged else
-                                   "stnerf::spacenet_kernel (fused PE + 9-layer MLP)",
-                         "bound": "mfma", "achieved": achieved, "peak": peak_used, "unit": "TFLOP/s",
-                         "frac": achieved / peak_used, "traffic": traffic,
-                         "traffic_source": ("profiles/" + os.path.basename(PMC_TRAFFIC_JSON) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over ONE "
-                                            "step of this workload at pose 0 of the sweep (the timed steps sweep the orbit: +- 10 % evaluations)") if traffic else None,
-                         "algorithmic_bytes_per_launch": 28 * sp["evals"] / sp["launches"],   # 12 B point in + 16 B raw out per SpaceNet evaluation
-                         "launches": sp["launches"], "avg_launch_ms": sp["ms"] / sp["launches"],
-                         "algorithmic_flop_per_launch": sp["flop"] / sp["launches"],
-                         "note": "algorithmic FLOPs = network evaluations x 924,672 (930,048 with time; + 153,344 per MotionNet evaluation in the fused stage kernel), "
-                                 "HIP events recorded by the library on the launch stream around every launch of the timed steps (rank 0)"},
-            "kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / args.steps,
-                            "tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12} for k, d in ksum.items() if "flop" in d},
-            "hbm_kernels": {k: hbm_entry(k, d) for k, d in ksum.items() if "bytes" in d},
+                       "parallelism": (f"ONE view per step through stnerf_amd.parallel.render_view (what render_pose calls) at every N; "
+                                       f"{world} GPU(s): interleaved {args.stripe_rows}-row stripes, each rank generates and renders its "
+                                       f"rows as one launch sequence, one RCCL all-gather of the whole 5-tuple "
+                                       f"({parallel.packed_width(L + 1)} floats per ray) per step"
+                                       if partition == "stripes" else
+                                       f"one whole view per GPU per step x {world} GPUs (same camera, own RNG stream), "
+                                       "one RCCL all-gather of the final tiles per step")},
+            "ray_samples_per_s": hr["ray_samples_per_s"], "ray_samples_per_step_rank0": hr["ray_samples_per_step_rank0"],
+            "mask_fraction": hr["mask_fraction"], "per_rank_compute_s": hr["per_rank_compute_s"],
+            "roofline": hr["roofline"], "kernels": hr["kernels"], "hbm_kernels": hr["hbm_kernels"],
+            "hbm_bytes_note": "algorithmic = bytes the kernel has to move (t, raw and weights only of the layers a ray hits); "
+                              "dense = every layer charged (round-1 accounting)",
+            "precision_legs": {"note": "the same workload, poses, steps and warm-up in both arithmetics, one after the other in this process; "
+                                       "`value` / `roofline` at the top level are those of config.precision",
+                               args.precision: hr},
             "hbm_microbench": measured or None,
             "psnr_vs_reference": psnr_check,
             "device": info,
         }
-        for other in others:
-            osp = other["ksum"]["mlp_stage"] if "mlp_stage" in other["ksum"] else other["ksum"]["spacenet"]
-            o_ach = osp["flop"] / (osp["ms"] * 1e-3) / 1e12
-            peak_o = PEAK_F32_MFMA_TFLOPS if other["precision"] == "fp32" else PEAK_F16_MFMA_TFLOPS
-            mult = {"fp16x3": 3.0, "bf16x3": 6.0}.get(other["precision"], 1.0)
-            notes = {
-                "bf16x3": "every fp32 operand = three bf16 pieces (8+8+8 significand bits: exact, fp32's exponent range, no limits), "
-                          "a*b = its six leading cross terms on v_mfma_f32_32x32x16_bf16, a0*b0 and the five small terms in separate "
-                          "f32 accumulators, heads in fp64: closer to an fp64 evaluation than the fp32 CPU chain (tests/test_gpu_stage.py); "
-                          "opt-in (model.set_precision('bf16x3')), not the headline until reviewed",
-                "fp16x3": "every product a*b as ah*bh + ah*bl + al*bh on the fp16 MFMA pipe (22-bit operands, |W| < 234, activations "
-                          "< 65520 with an overflow guard), per-network launches; opt-in",
-                "fp32": "exact f32 MFMA (the library default)"}
-            rec["other_precision" if other is others[0] else "other_precision_2"] = {
-                "precision": other["precision"],
-                "note": "same workload and poses, measured after the headline run; " + notes[other["precision"]],
-                "value": other["rays"] / other["elapsed"], "unit": "rays/s",
-                "ms_per_step": 1e3 * other["elapsed"] / other["steps"], "steps": other["steps"],
-                "ray_samples_per_s": other["evals_all"] / other["elapsed"],
-                "roofline": {"bound": "mfma", "algorithmic_tflops": o_ach, "executed_mfma_tflops": mult * o_ach,
-                             "peak": peak_o, "unit": "TFLOP/s", "frac": mult * o_ach / peak_o},
-                "kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / other["steps"],
-                                "algorithmic_tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12}
-                            for k, d in other["ksum"].items() if "flop" in d},
-            }
-        if weak is not None:
-            wr = weak["per_rank_compute_s"]
-            rec["weak_scaling_views"] = {
-                "note": "secondary leg: one whole view per GPU per step (same camera, own RNG stream), tiles all-gathered",
-                "value": weak["rays"] / weak["elapsed"], "unit": "rays/s", "steps": weak["steps"],
-                "ms_per_step": 1e3 * weak["elapsed"] / weak["steps"],
-                "per_rank_compute_s": {"min": min(wr), "mean": sum(wr) / len(wr), "max": max(wr)}}
+        if second is not None:
+            rec["precision_legs"][second["precision"]] = leg_record(second, args.workload)
+        if config_legs:
+            rec["config_legs"] = {leg["workload"]: {k: v for k, v in leg_record(leg, leg["workload"]).items()
+                                                    if k not in ("note", "dtype", "per_rank_compute_s")} for leg in config_legs}
         if world == 1 and args.eager_gpu_baseline_rays > 0:
             rec["eager_gpu_baseline"] = eager_gpu_baseline(args.workload, args.eager_gpu_baseline_rays, device)
         if world == 1 and args.cpu_baseline_rays > 0:
@@ -552,7 +580,9 @@ def main():
         else:
             rec["cpu_baseline"] = None
         print(json.dumps(rec))
+        sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -199,8 +199,9 @@ int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32
 /* "bf16x3": the packed form of a network for the split-bf16 arithmetic of stnerf_mlp_stage (STNERF_STAGE_BF16X3;
  * csrc/mlp_bf16x3.hip).  modeling/spacenet.py:45-86, modeling/motion_net.py:20-32 are plain fp32 nn.Linear layers: every
  * weight (host side, here) and every activation (in the kernel) is split into three bf16 numbers, x = x0 + x1 + x2 --
- * 8 + 8 + 8 significand bits, i.e. EXACT, with fp32's exponent range: no |W| limit, no activation limit, no overflow
- * flag -- and a product is evaluated with its six leading cross terms on the bf16 MFMA (dropped terms <= 2^-24 |a b|),
+ * 8 + 8 + 8 significand bits, i.e. exact for every finite fp32 value inside bf16's exponent range (|x| <= 3.39e38: above
+ * bf16's largest finite value the leading piece rounds to inf; residual pieces below 2^-133 flush, an error < 2^-16 of
+ * the smallest normal number), with fp32's exponent range: no |W| limit, no activation limit, no overflow flag -- and a product is evaluated with its six leading cross terms on the bf16 MFMA (dropped terms <= 2^-24 |a b|),
  * fp32 accumulate.  Same tensors as stnerf_pack_net; the blob = [the exact-f32 blob of stnerf_pack_net | bias vectors and
  * head weights in the kernel's LDS order | the MFMA layers' weights as bf16 triples in consumption order].  All net
  * kinds.  The device copy must be 1 KB aligned. */

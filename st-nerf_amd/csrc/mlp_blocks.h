@@ -1,5 +1,6 @@
-// Building blocks of the fused fp32 MLP kernels (mlp.hip: one network per launch; mlp_stage.hip: one persistent
-// launch per pipeline stage): the pipelined MFMA K loop, one dense layer on an LDS-resident tile, the VALU heads.
+// Building blocks of the fused fp32 MLP kernels with LDS-resident activations (mlp.hip: one network per launch -- the
+// op-level entry points stnerf_spacenet_fwd / stnerf_motionnet_fwd): the pipelined MFMA K loop, one dense layer on an
+// LDS-resident tile, the VALU heads.  (The stage kernels, mlp_wave.hip / mlp_bf16x3.hip, share only the head grouping.)
 // Design notes: mlp.hip header and DESIGN.md section 4.1.
 #pragma once
 #include <type_traits>

@@ -6,7 +6,7 @@
 // is therefore evaluated here, once per (layer, hit ray), and the MLP kernels take row c[ray] as the C operand of the
 // layer's first MFMA instead of the bias: 16 % of the layer's multiply-adds (1.3 % of the network's) and the 22 sin/cos
 // pairs per SAMPLE of the fused kernels go away.
-// This kernel defines the arithmetic for every exact-f32 MLP kernel (mlp.hip, mlp_stage.hip, mlp_wave.hip): c starts from
+// This kernel defines the arithmetic for every exact-f32 MLP kernel (mlp.hip, mlp_wave.hip): c starts from
 // the bias and takes the encoded features in index order with one fmaf each; the layer then adds the 256 backbone
 // features in the kernels' usual k order.  (The fp16x3 kernels keep the columns inside their own K loop.)
 #include "mlp_common.h"

@@ -1,5 +1,7 @@
-// Argument block and row bookkeeping shared by the two persistent stage kernels behind stnerf_mlp_stage:
-// mlp_stage.hip (feature-split waves, activations in LDS) and mlp_wave.hip (sample-split waves, activations in registers).
+// Argument block and row bookkeeping shared by the persistent stage kernels behind stnerf_mlp_stage (launched from
+// stage_entry.hip): mlp_wave.hip (exact f32) and mlp_bf16x3.hip (split bf16) -- sample-split waves, activations in registers;
+// their common prologue / epilogue code is mlp_wave_common.h.  (The round-2 organisation with feature-split waves and
+// activations in LDS, mlp_stage.hip, was removed in round 3.)
 #pragma once
 #include "mlp_blocks.h"
 

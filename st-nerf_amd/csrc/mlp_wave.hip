@@ -1,6 +1,7 @@
 // Persistent stage kernel, second organisation: SAMPLE-split waves with the activations in registers.
 //
-// mlp_stage.hip splits a layer's OUTPUT FEATURES over the 8 waves of a workgroup, so every layer is an all-to-all
+// The round-2 stage kernel (mlp_stage.hip, removed in round 3) split a layer's OUTPUT FEATURES over the 8 waves of a
+// workgroup, so every layer was an all-to-all
 // through LDS: 128 KiB of activations are written (ds_write_b128: ~79 B/clk/CU, ~1.1k cycles per layer with the matrix
 // pipe idle) and two workgroup barriers are taken per layer; that, the heads' LDS reductions and the issue slots of
 // the activation reads are the ~9 % the kernel stands below the f32 MFMA peak.  Here a wave owns 32 SAMPLES and all
@@ -23,9 +24,9 @@
 //     then each lane reads its half of the feature quads back) -- ordering inside a wave only, no barrier.
 //   * Heads: a lane holds every second feature quad of its sample; the partial-sum grouping of the LDS kernels
 //     (4 parts x 4 interleaved chains) is kept, the two lanes of a sample swap their chains with v_permlane32_swap.
-// Every output accumulates the same products in the same order as in mlp.hip / mlp_stage.hip (same instruction, same k
-// order, bias as the C operand of the first MFMA, same head grouping): results are bit-identical to those kernels
-// (tests/test_gpu_ops.py).
+// Every output accumulates the same products in the same order as in the per-network kernels of mlp.hip (same
+// instruction, same k order, bias as the C operand of the first MFMA, same head grouping): results are bit-identical to
+// them (tests/test_gpu_ops.py).
 //
 // Reference: modeling/spacenet.py:16-160, modeling/motion_net.py:7-71, modeling/layered_rfrender.py:340-418,495-576.
 #include <stdlib.h>

@@ -51,10 +51,15 @@ constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 
 // value and leaves the others untouched (bound_ctrl off: a lane without a source is not executed) -- one vector
 // instruction per step.  Written through the update_dpp builtin the same step is three (identity into a scratch
 // register, DPP move over it, multiply), and the compositor is bound by its vector-instruction count.
-// The two wait states a DPP read needs behind the write of its source are the s_nop 1 in front of every step.
+// The two wait states a DPP read needs behind the write of its source are the s_nop 1 in front of every step.  The FIRST
+// step of a block waits five: LLVM's hazard recognizer does not look inside inline asm, so a VALU write of EXEC (v_cmpx of
+// the predicated code these scans are called behind) directly in front of the block would otherwise leave the
+// "VALU writes EXEC -> DPP" hazard (5 wait states) uncovered.  tests/test_kernel_resources.py scans the ISA of every
+// other DPP instruction of this file for the same hazard.
 #define STNERF_DPP_STEP(op, ctrl) "s_nop 1\n\t" op " %0, %0, %0 " ctrl "\n\t"
+#define STNERF_DPP_FIRST(op, ctrl) "s_nop 4\n\t" op " %0, %0, %0 " ctrl "\n\t"
 __device__ __forceinline__ float wave_scan_mul(float v) {  // inclusive
-    asm(STNERF_DPP_STEP("v_mul_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
+    asm(STNERF_DPP_FIRST("v_mul_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
         STNERF_DPP_STEP("v_mul_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
         STNERF_DPP_STEP("v_mul_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
         STNERF_DPP_STEP("v_mul_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
@@ -65,7 +70,7 @@ __device__ __forceinline__ float wave_scan_mul(float v) {  // inclusive
 }
 
 __device__ __forceinline__ float wave_scan_add(float v) {  // inclusive
-    asm(STNERF_DPP_STEP("v_add_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
+    asm(STNERF_DPP_FIRST("v_add_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
         STNERF_DPP_STEP("v_add_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
         STNERF_DPP_STEP("v_add_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
         STNERF_DPP_STEP("v_add_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
@@ -1331,7 +1336,8 @@ __device__ __forceinline__ float bitonic_stage(float v, int lane) {
         if constexpr (J == 4) {   // lanes 0-3 / 8-11 of a row take lane + 4, lanes 4-7 / 12-15 lane - 4
             pv = v;
             asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-                "v_mov_b32_dpp %0, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(pv) : "v"(v));
+                "v_mov_b32_dpp %0, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "+&v"(pv) : "v"(v));   // early clobber: %0 is
+            // written by the first move before the second reads %1 -- the two must never share a register
         } else if constexpr (J == 16) {
             pv = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401f));   // bit mode: and 0x1f, or 0, xor 0x10
         } else {
@@ -1847,20 +1853,27 @@ extern "C" int stnerf_resample(const float* t, const float* weights, int64_t n, 
     fill_edit_args(a.ed, edits_host, pivot_host, l);
     a.t_fine = t_fine; a.xyz_fine = xyz_fine; a.z_new = z_new; a.inds = inds; a.cdf_out = cdf;
     const int lds = 4 * resample_lds_floats(n1, n2) * (int)sizeof(float);
-    STNERF_REQUIRE(lds <= 64 * 1024, "resample: %d+%d samples per ray exceed the LDS budget", n1, n2);
+    // (the +inf padding of the branch-free searches rounds three of the arrays up to powers of two: 512+512 samples need
+    // 73.7 KB for the block's four waves -- above the 64 KB a kernel gets without asking, inside the CU's 160 KB)
+    STNERF_REQUIRE(lds <= 160 * 1024, "resample: %d+%d samples per ray exceed the LDS budget", n1, n2);
     int64_t blocks = (n * l + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
     LaunchTimer timer(PROF_RESAMPLE, 0, n, n1 + n2, (int64_t)l * (8ll * n1 + (xyz_fine ? 16ll : 4ll) * (n1 + n2)) + 24,
                       as_stream(stream));
     const bool plain = !u && !z_new && !inds && !cdf && !a.ed.any;
     const dim3 grid((unsigned)blocks), block(256);
-    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, lds, as_stream(stream), a); };
+    int reserve_rc = STNERF_OK;
+    auto launch = [&](auto kernel) {
+        if (lds > 64 * 1024) reserve_rc = reserve_dynamic_lds(reinterpret_cast<const void*>(kernel), lds, "resample");
+        if (reserve_rc == STNERF_OK) hipLaunchKernelGGL(kernel, grid, block, lds, as_stream(stream), a);
+    };
     const bool exact = plain && n2 == 64 && (n1 == 64 || n1 == 128);
     if (exact) n1 == 64 ? launch(resample_kernel<1, true, true>) : launch(resample_kernel<2, true, true>);
     else if (n1 <= 64) plain ? launch(resample_kernel<1, true, false>) : launch(resample_kernel<1, false, false>);
     else if (n1 <= 128) plain ? launch(resample_kernel<2, true, false>) : launch(resample_kernel<2, false, false>);
     else if (n1 <= 256) plain ? launch(resample_kernel<4, true, false>) : launch(resample_kernel<4, false, false>);
     else launch(resample_kernel<0, false, false>);
+    if (reserve_rc) return reserve_rc;
     STNERF_CHECK_LAUNCH("resample");
     return STNERF_OK;
 }

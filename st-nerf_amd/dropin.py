@@ -26,6 +26,14 @@ or no edit at all, from the reference's root directory::
 
     python -m stnerf_amd.dropin demo/taekwondo_demo.py -c configs/config_taekwondo.yml
 
+**N GPUs, still no edit.**  Under ``python -m torch.distributed.run --nproc-per-node N -m stnerf_amd.dropin demo/...`` the
+launcher picks cuda:LOCAL_RANK and initialises the process group (RCCL) before the script starts; from then on every
+``layered_batchify_ray`` call of at least one chunk -- the reference's own ``render_pose`` makes one per frame,
+render/layered_neural_renderer.py:378 -- deals its chunks out to the ranks in turn and all-gathers the whole 5-tuple
+(stnerf_amd.parallel.render_rays_sharded), so every rank holds every image and the frame takes 1 / N of the time.  Ranks
+other than 0 have ``imageio``'s writers silenced (if imageio is installed) so that each file is written once.
+``STNERF_SHARD=0`` or ``model.shard_views = False`` turns the sharding off.
+
 Exercised against the real reference tree by tests/test_dropin.py.
 """
 from __future__ import annotations
@@ -212,6 +220,24 @@ def unpatch_reference() -> None:
         _active.undo()
 
 
+def join_process_group() -> Tuple[int, int]:
+    """Launched by torch.distributed.run (WORLD_SIZE > 1 in the environment): this process takes cuda:LOCAL_RANK and
+    joins the group, which is all the render path needs to split every view over the ranks (stnerf_amd.parallel).  On
+    ranks other than 0 the image / video writers of imageio (render/layered_neural_renderer.py:467-485,624-637) become
+    no-ops, if imageio is installed.  -> (rank, world); (0, 1) and nothing done for a plain ``python`` launch."""
+    from stnerf_amd import parallel
+    rank, world = parallel.init_from_env(single_device=os.environ.get("STNERF_SINGLE_DEVICE", "0") == "1")
+    if world > 1 and rank != 0:
+        try:
+            imageio = importlib.import_module("imageio")
+            for name in ("imwrite", "imsave", "mimwrite", "mimsave"):
+                if hasattr(imageio, name):
+                    setattr(imageio, name, lambda *a, **k: None)
+        except ImportError:
+            pass
+    return rank, world
+
+
 def main(argv=None) -> None:
     """``python -m stnerf_amd.dropin [--reference ROOT] [--device-rays] script.py [script args]``"""
     argv = list(sys.argv[1:] if argv is None else argv)
@@ -227,6 +253,7 @@ def main(argv=None) -> None:
     if not argv:
         raise SystemExit(main.__doc__)
     patch_reference(root if root is not None else os.getcwd(), device_ray_generation=device_rays)
+    join_process_group()
     sys.argv = argv
     runpy.run_path(argv[0], run_name="__main__")
 

@@ -89,6 +89,10 @@ class LayeredRFRender(nn.Module):
                                            # one launch per (layer, network) as in round 1 (A/B measurements)
         self.ray_window = (0, 0, 0)        # (first, stripe, period): which rays of the view `rays` are (include/stnerf.h);
                                            # keeps the RNG stream of a view under multi-GPU sharding
+        self.shard_views = True            # with an initialised torch.distributed group of > 1 ranks, layered_batchify_ray /
+                                           # render_pose cut the view into interleaved stripes over the ranks and all-gather
+                                           # the whole 5-tuple (stnerf_amd.parallel); False: every rank renders what it is given
+        self.shard_group = None            # the process group to shard over (None: the default group)
 
     F16_LATCH_AFTER = 8    # fp16x3 range-guard fallbacks after which the model stays in exact f32
     FRESH_DRAWS_DEFAULT = False   # what a new model's fresh_draws_per_call starts as (dropin.patch_reference: True)
@@ -285,6 +289,30 @@ class LayeredRFRender(nn.Module):
                     ref_chunk: Optional[int] = None):
         """Render all `rays`; ``ref_chunk`` reproduces the reference's chunk semantics (boxes are taken
         from row 0 of every ``ref_chunk``-ray piece) while launching kernels over far larger pieces."""
+        return self.as_reference_tuple(self.render_rays_raw(rays, only_coarse, density_threshold, bkgd_density_threshold,
+                                                            ref_chunk))
+
+    def as_reference_tuple(self, raw):
+        """(mixed_fine (n,5), mixed_coarse (n,5), layer_fine (n,l,5), layer_coarse (n,l,5), mask (n,l)) -> the
+        reference's 5-tuple of (color (n,3), depth (n,1), acc (n,1)) triples and bool masks (layered_rfrender.py:725-734)."""
+        mix_f, mix_c, lo_f, lo_c, mask = raw
+        l = self.layer_num + 1
+        trip = lambda x: (x[:, 0:3], x[:, 3:4], x[:, 4:5])
+        fine_layer = [trip(lo_f[:, i]) for i in range(l)]
+        coarse_layer = [trip(lo_c[:, i]) for i in range(l)]
+        ray_mask = [mask[:, i].bool() for i in range(l)]
+        return trip(mix_f), trip(mix_c), fine_layer, coarse_layer, ray_mask
+
+    def advance_seed(self):
+        """What a finished call does to ``seed`` (``fresh_draws_per_call``; a rank that owns no ray of a sharded view
+        calls this too, so that every rank's stream stays the same)."""
+        if self.fresh_draws_per_call and self.replay is None:
+            self.seed = (int(self.seed) + 1) & 0xFFFFFFFFFFFFFFFF   # the next call draws new jitter / resampling numbers
+
+    def render_rays_raw(self, rays, only_coarse=False, density_threshold=0.0001, bkgd_density_threshold=0.0,
+                        ref_chunk: Optional[int] = None):
+        """``render_rays`` before the outputs are cut into the reference's triples: the five tensors the library
+        wrote (what stnerf_amd.parallel packs into its one all-gather)."""
         if not rays.is_cuda:
             raise RuntimeError("rays must live on the GPU: the MI355X render path has no CPU fallback")
         rays = rays.contiguous().float()
@@ -339,15 +367,9 @@ class LayeredRFRender(nn.Module):
                 outs.append(self._render_launch(rays[s:e], bx, pivot, retiming, only_coarse, density_threshold,
                                                 bkgd_density_threshold, window_at(s), rp))
         cat = (lambda j: outs[0][j]) if len(outs) == 1 else (lambda j: torch.cat([o[j] for o in outs], 0))
-        mix_f, mix_c, lo_f, lo_c, mask = (cat(j) for j in range(5))
-        l = L + 1
-        trip = lambda x: (x[:, 0:3], x[:, 3:4], x[:, 4:5])
-        fine_layer = [trip(lo_f[:, i]) for i in range(l)]
-        coarse_layer = [trip(lo_c[:, i]) for i in range(l)]
-        ray_mask = [mask[:, i].bool() for i in range(l)]
-        if self.fresh_draws_per_call and self.replay is None:
-            self.seed = (int(self.seed) + 1) & 0xFFFFFFFFFFFFFFFF   # the next call draws new jitter / resampling numbers
-        return trip(mix_f), trip(mix_c), fine_layer, coarse_layer, ray_mask
+        raw = tuple(cat(j) for j in range(5))
+        self.advance_seed()
+        return raw
 
     def forward(self, rays, labels=None, bboxes=None, only_coarse=False, near_far=None, near_far_points=[],
                 density_threshold=0.0001, bkgd_density_threshold=0):

@@ -12,10 +12,19 @@ contiguous tiles of ONE view differ in cost by ~2x between its centre and its bo
 
 The helpers are device-agnostic (they run under gloo on CPU tensors in tests/test_parallel_cpu.py);
 only the ``render_rows`` callable passed in touches the GPU.
+
+The call surface shards by itself: as soon as a torch.distributed group of more than one rank
+is initialised, ``utils.layered_batchify_ray`` (-> ``render_rays_sharded``: the caller holds the whole ray tensor, as
+the reference's ``render_pose`` does, render/layered_neural_renderer.py:364-391) and ``render.render_pose`` (->
+``render_view``: rays generated on the device for the rank's stripes only) render interleaved stripes of the view and
+rebuild the WHOLE 5-tuple -- mixed fine / coarse, every layer's fine / coarse colour, depth, acc and the hit masks --
+on every rank with ONE all-gather (``pack_outputs``: 10 + 11 l floats per ray).  ``model.shard_views = False`` or
+``STNERF_SHARD=0`` switches that off (ranks that render different views).
 """
 from __future__ import annotations
 
-from typing import Callable, List, Tuple
+import os
+from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -154,3 +163,174 @@ def make_row_renderer(model, K, T, h: int, w: int, frame_ids, density_threshold:
     render_rows.striped = render_window     # (first, n, stripe, period): all of a rank's stripes in one launch sequence
     render_rows.last_masks = None           # per-layer hit masks of the latest call (bench.py counts evaluations)
     return render_rows
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The sharded call surface: layered_batchify_ray / render_pose under an initialised process group
+# ---------------------------------------------------------------------------------------------------------------
+def active_group(model=None) -> Optional[Tuple[int, int, object]]:
+    """(rank, world, group) when a view handed to the call surface is to be split over the ranks, else None:
+    an initialised process group of more than one rank, not switched off by ``STNERF_SHARD=0`` or
+    ``model.shard_views = False``, and no ray window already set on the model (a caller that windows its own rays --
+    ``make_row_renderer`` -- is doing the partition itself)."""
+    if os.environ.get("STNERF_SHARD", "1") == "0":
+        return None
+    if model is not None and (not getattr(model, "shard_views", True) or tuple(getattr(model, "ray_window", (0, 0, 0))) != (0, 0, 0)):
+        return None
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = getattr(model, "shard_group", None) if model is not None else None
+    world = dist.get_world_size(group)
+    if world < 2:
+        return None
+    return dist.get_rank(group), world, group
+
+
+def take_stripes(x: torch.Tensor, stripe: int, rank: int, world: int) -> torch.Tensor:
+    """Rows of ``x`` (dim 0 = ray) that lie in the stripes of ``rank`` (``stripe_spans``), in order, as one dense tensor:
+    the full rounds move as ONE strided copy."""
+    n = x.shape[0]
+    spans = stripe_spans(n, stripe, rank, world)
+    rounds = (n // stripe) // world
+    inner = tuple(x.shape[1:])
+    parts = []
+    if rounds:
+        parts.append(x[: rounds * world * stripe].reshape((rounds, world, stripe) + inner)[:, rank].reshape((rounds * stripe,) + inner))
+    parts += [x[s:e] for s, e in spans[rounds:]]
+    if not parts:
+        return x[:0].contiguous()
+    return parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, 0)
+
+
+def packed_width(l: int) -> int:
+    """Floats per ray of the packed 5-tuple: mixed fine + coarse (5 + 5), l layers fine + coarse (5 l + 5 l), l masks."""
+    return 10 + 11 * l
+
+
+def pack_outputs(raw) -> torch.Tensor:
+    """The five tensors of ``LayeredRFRender.render_rays_raw`` -> (n, 10 + 11 l) float32 (masks as 0.0 / 1.0): the payload
+    of the one all-gather."""
+    mix_f, mix_c, lo_f, lo_c, mask = raw
+    n = mix_f.shape[0]
+    return torch.cat([mix_f, mix_c, lo_f.reshape(n, -1), lo_c.reshape(n, -1), mask.to(torch.float32)], 1)
+
+
+def unpack_outputs(packed: torch.Tensor, l: int):
+    """Inverse of ``pack_outputs`` (dense tensors, the layout ``render_rays_raw`` returns)."""
+    n = packed.shape[0]
+    if packed.shape[1] != packed_width(l):
+        raise ValueError(f"packed outputs of {l} layers are {packed_width(l)} floats wide, got {packed.shape[1]}")
+    a, b, c = 10, 10 + 5 * l, 10 + 10 * l
+    return (packed[:, 0:5].contiguous(), packed[:, 5:10].contiguous(), packed[:, a:b].reshape(n, l, 5).contiguous(),
+            packed[:, b:c].reshape(n, l, 5).contiguous(), packed[:, c:].to(torch.uint8))
+
+
+def _all_gather_rows(local: torch.Tensor, per_rank: int, world: int, group=None) -> torch.Tensor:
+    """(per_rank-padded) all-gather of every rank's rows -> (world * per_rank, C).  backend nccl (= RCCL over xGMI) moves
+    device tensors directly; gloo (CPU tests, and the N-ranks-on-one-GPU debug mode) stages device tensors through the host."""
+    padded = local
+    if local.shape[0] != per_rank:
+        padded = local.new_zeros((per_rank,) + tuple(local.shape[1:]))
+        padded[: local.shape[0]] = local
+    padded = padded.contiguous()
+    if padded.is_cuda and dist.get_backend(group) == "gloo":
+        host = padded.cpu()
+        out = host.new_empty((world * per_rank,) + tuple(host.shape[1:]))
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out.to(padded.device)
+    out = padded.new_empty((world * per_rank,) + tuple(padded.shape[1:]))
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return out
+
+
+def gather_stripes(local: torch.Tensor, n_total: int, stripe: int, rank: int, world: int, group=None) -> torch.Tensor:
+    """Every rank's rendered stripes (``take_stripes`` order) -> the (n_total, C) view on every rank: ONE all-gather."""
+    sizes = [sum(e - s for s, e in stripe_spans(n_total, stripe, r, world)) for r in range(world)]
+    if local.shape[0] != sizes[rank]:
+        raise ValueError(f"rank {rank}: {local.shape[0]} rows rendered, its stripes hold {sizes[rank]}")
+    m = max(sizes)
+    return unstripe(_all_gather_rows(local, m, world, group), n_total, stripe, world, m)
+
+
+def _render_local(model, local_rays, window, n_total, stripe, rank, world, group, only_coarse, thr, bthr, chuncks, replay_full):
+    """This rank's stripes through the model (ray window set: the RNG stream is the view's), packed, gathered, unpacked."""
+    l = model.layer_num + 1
+    saved_window, saved_replay = model.ray_window, model.replay
+    try:
+        model.ray_window = window
+        if replay_full is not None:      # recorded uniforms (l, N, ns) follow their rays
+            model.replay = {k: take_stripes(v.transpose(0, 1), stripe, rank, world).transpose(0, 1).contiguous()
+                            for k, v in replay_full.items()}
+        if local_rays.shape[0]:
+            packed = pack_outputs(model.render_rays_raw(local_rays, only_coarse, thr, bthr, ref_chunk=chuncks))
+        else:                            # more ranks than stripes: only the collective (and the seed) on this rank
+            packed = local_rays.new_zeros((0, packed_width(l)))
+            model.advance_seed()
+    finally:
+        model.ray_window, model.replay = saved_window, saved_replay
+    whole = gather_stripes(packed, n_total, stripe, rank, world, group)
+    return model.as_reference_tuple(unpack_outputs(whole, l))
+
+
+def render_rays_sharded(model, rays, chuncks: int, density_threshold=0.0, bkgd_density_threshold=0.0, only_coarse=False,
+                        act=None):
+    """``layered_batchify_ray`` of a view every rank holds the rays of (N >= chuncks), split over the ranks: rank r takes
+    the reference's chunks r, r + G, r + 2G, ... (stripes of ``chuncks`` rays, so that row 0 of every reference chunk --
+    where the reference reads the frame ids, layered_rfrender.py:200 -- stays row 0 of a chunk), renders them as one
+    launch sequence and the whole 5-tuple is rebuilt on every rank by one all-gather.  Bitwise equal to the unsharded
+    render: the device RNG is keyed by the ray's index in the view."""
+    rank, world, group = act or active_group(model)
+    local = take_stripes(rays, chuncks, rank, world)
+    return _render_local(model, local, (rank * chuncks, chuncks, world * chuncks), rays.shape[0], chuncks, rank, world, group,
+                         only_coarse, density_threshold, bkgd_density_threshold, chuncks, model.replay)
+
+
+def render_view(model, K, T, h: int, w: int, frame_ids, density_threshold=0.0, bkgd_density_threshold=0.0,
+                chuncks: int = 512 * 7, stripe_rows: int = 1, device="cuda"):
+    """One view from its camera: rays generated on the device (no CPU ray tensor), ``layered_batchify_ray`` semantics, the
+    reference's 5-tuple on every rank.  Without a process group: the whole view on this GPU.  With one: interleaved
+    stripes of ``stripe_rows`` image rows over the ranks (rank r generates and renders rows r, r + G, ... only), one
+    all-gather.  The SAME function is bench.py's step at every N and what ``render.render_pose`` calls."""
+    from stnerf_amd import ops
+    from stnerf_amd.utils.batchify_rays import layered_batchify_ray
+    act = active_group(model)
+    n_total = h * w
+    if act is None or n_total < chuncks:
+        rays = ops.generate_rays(K, T, h, w, frame_ids=frame_ids, device=device)
+        with torch.no_grad():
+            return layered_batchify_ray(model, rays, None, None, chuncks=chuncks, density_threshold=density_threshold,
+                                        bkgd_density_threshold=bkgd_density_threshold)
+    rank, world, group = act
+    stripe = w * max(1, int(stripe_rows))
+    window = (rank * stripe, stripe, world * stripe)
+    n_local = ops.window_size(n_total, *window)
+    rays = ops.generate_rays(K, T, h, w, frame_ids=frame_ids, first_ray=window[0], n=n_local, device=device, stripe=stripe,
+                             period=window[2])
+    with torch.no_grad():
+        return _render_local(model, rays, window, n_total, stripe, rank, world, group, False, density_threshold,
+                             bkgd_density_threshold, chuncks, None)
+
+
+def init_from_env(backend: Optional[str] = None, single_device: bool = False):
+    """One process per GPU from the variables torch.distributed.run sets (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*):
+    picks cuda:LOCAL_RANK and initialises the group (backend "nccl" = RCCL over xGMI).  ``single_device`` puts every rank
+    on cuda:0 over gloo (the multi-rank code path on a 1-GPU box).  No-op without WORLD_SIZE > 1.  -> (rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world < 2:
+        return rank, world
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    backend = backend or os.environ.get("STNERF_DIST_BACKEND") or ("gloo" if single_device else "nccl")
+    local = 0 if single_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        if not single_device and torch.cuda.device_count() < world and backend == "nccl":
+            raise RuntimeError(f"WORLD_SIZE={world} but this node exposes {torch.cuda.device_count()} GPU(s): one process per GPU "
+                               "(check HIP_VISIBLE_DEVICES / the compute partition mode)")
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
+    return rank, world

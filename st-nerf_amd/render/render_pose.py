@@ -10,8 +10,7 @@ from typing import Sequence, Tuple
 
 import torch
 
-from stnerf_amd import ops
-from stnerf_amd.utils.batchify_rays import layered_batchify_ray
+from stnerf_amd.parallel import render_view
 
 
 def render_pose(model, pose, K, height: int, width: int, layer_frame_pair: Sequence[Tuple[int, float]], far: float,
@@ -21,17 +20,18 @@ def render_pose(model, pose, K, height: int, width: int, layer_frame_pair: Seque
     ``layer_frame_pair``: (layer_id, frame_id) pairs as in data/datasets/ray_dataset.py:276-281.
     Depth post-processing as in the reference: negative mixed depth -> 0, then / far (:382-383); the
     per-layer depths are divided by far; their ``depth_1[depth < 0] = 0`` (:388) tests the already
-    clamped mixed depth and therefore never fires -- reproduced as a no-op."""
+    clamped mixed depth and therefore never fires -- reproduced as a no-op.
+
+    One process per GPU under an initialised torch.distributed group: every rank generates and renders its interleaved
+    row stripes of the view only, one all-gather rebuilds all the images on every rank (stnerf_amd.parallel.render_view);
+    the return value is the single-GPU one, bit for bit."""
     L = model.layer_num
     frame_ids = [0.0] * (L + 1)
     for layer_id, frame_id in layer_frame_pair:
         frame_ids[layer_id] = float(frame_id)
-    rays = ops.generate_rays(torch.as_tensor(K, dtype=torch.float32), torch.as_tensor(pose, dtype=torch.float32),
-                             height, width, frame_ids=frame_ids, device=device)
-    with torch.no_grad():
-        stage2, _, stage2_layer, _, _ = layered_batchify_ray(model, rays, None, None, near_far=None,
-                                                             density_threshold=density_threshold,
-                                                             bkgd_density_threshold=bkgd_density_threshold)
+    stage2, _, stage2_layer, _, _ = render_view(model, torch.as_tensor(K, dtype=torch.float32),
+                                                torch.as_tensor(pose, dtype=torch.float32), height, width, frame_ids,
+                                                density_threshold, bkgd_density_threshold, device=device)
     color = stage2[0].reshape(height, width, 3)
     depth = stage2[1].reshape(height, width, 1).clamp_min(0) / far
     color_layer = [t[0].reshape(height, width, 3) for t in stage2_layer]

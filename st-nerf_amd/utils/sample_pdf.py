@@ -27,7 +27,9 @@ def sample_pdf(z_vals, weights, N_samples, det=False, pytest=False, u=None, seed
     elif det:
         u = torch.linspace(0., 1., steps=N_samples, device=z_vals.device).expand(n, N_samples).contiguous()
     if seed is None:
-        seed = next(_calls)
+        # only a call that really draws advances the per-process counter: det / pytest / an explicit u must not shift the
+        # random stream of later calls
+        seed = next(_calls) if u is None else 0
     n, n1 = z_vals.shape
     pad = torch.zeros(n, 1, device=z_vals.device)
     wfull = torch.cat([pad, weights, pad], -1).reshape(n, 1, n1).contiguous()

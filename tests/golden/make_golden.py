@@ -338,6 +338,122 @@ def g_forward(name, L, n1, n2, st, dt, seed, h, w, frame=2.5, per_ray_frames=Fal
     save(name, meta, rays=rays, **arrays)
 
 
+# ----------------------------------------------------------------------------- teacher-forced fine stage
+def g_teacher(name, L, n1, n2, st, dt, seed, h, w, frame=2.5, call_kwargs=None, edit=None):
+    """The reference's OWN intermediates of one forward call (one chunk), so that the fine stage of the HIP path can be fed
+    the reference's fine samples instead of its own (a last-ulp cdf difference moves a fine sample through the
+    ``den < 1e-5`` switch of utils/sample_pdf.py:59 and, times 2^9 in the encoding, moves a pixel: with the reference's
+    samples as the input every ray can be held to the fp32 tolerance).  Recorded, per layer i:
+
+    * ``pdf_t{i}`` / ``pdf_w{i}`` / ``pdf_z{i}``: what modeling/layered_rfrender.py:460 hands to sample_pdf (coarse depths,
+      ``weights[..., 1:-1]``) and what it gets back; ``u{i}`` the draw it made;
+    * ``z_vals_fine{i}``: the sorted union, the value of ``torch.sort`` at :462;
+    * ``xyz_fine_pre{i}``: the fine sample points before deformation -- what the time-deformation net is given at :505
+      (masked rays only; the background has no deformation here, so its SpaceNet input at :526-540 is recorded);
+    * ``raw_rgb_fine{i}`` / ``raw_sigma_fine{i}``: the fine SpaceNet's outputs as returned (before thresholds / alpha);
+    * ``xyz_fine_post{i}`` / ``density_fine_post{i}``: the stashes of :610-611 (after deformation / after the density edits);
+    * ``coarse_weights{i}``: the per-layer coarse weights (:437-444), whole rows;
+    plus the rays, every draw and all final outputs (same keys as the fwd_* fixtures)."""
+    import modeling.layered_rfrender as lr
+    model = build_ref_model(L, n1, n2, st, dt, seed)
+    edit = edit or {}
+    for k in ("scale", "shift", "alpha", "near"):
+        if k in edit:
+            setattr(model, k, edit[k])
+    rays = view_rays(h, w, L, frame=frame)
+    n, l, S = rays.shape[0], L + 1, n1 + n2
+    labels, bb, nf = torch.zeros(n), torch.zeros(n, 8, 3), torch.zeros(n, 2)
+    kw = dict(call_kwargs or {})
+    rec = dict(pdf=[], sorts=[], weights=[])
+    orig_pdf, orig_sort, orig_vr = lr.sample_pdf, torch.sort, model.volume_render.forward
+
+    def pdf(bins, weights, N_samples, det=False, pytest=False):
+        z = orig_pdf(bins, weights, N_samples=N_samples, det=det, pytest=pytest)
+        rec["pdf"].append((bins.clone(), weights.clone(), z.clone()))
+        return z
+
+    def sort(*a, **k):
+        out = orig_sort(*a, **k)
+        rec["sorts"].append(out[0].clone())
+        return out
+
+    def vr(depth, rgb, sigma, *a, **k):
+        out = orig_vr(depth, rgb, sigma, *a, **k)
+        rec["weights"].append(out[3].clone())
+        return out
+
+    calls = {}
+
+    def hook(tag):
+        def fn(module, inputs, output):
+            calls.setdefault(tag, []).append(([x.clone() if isinstance(x, torch.Tensor) else x for x in inputs],
+                                              tuple(o.clone() for o in output) if isinstance(output, tuple) else output.clone()))
+        return fn
+    handles = [model.bkgd_spacenet_fine.register_forward_hook(hook("space0"))]
+    for i in range(L):
+        handles.append(model.spacenets_fine[i].register_forward_hook(hook(f"space{i + 1}")))
+        if dt:
+            handles.append(model.time_deform_nets[i].register_forward_hook(hook(f"motion{i + 1}")))
+    torch.manual_seed(100 + seed)
+    lr.sample_pdf, torch.sort, model.volume_render.forward = pdf, sort, vr
+    try:
+        with RandRecorder() as rr, torch.no_grad():
+            out = model(rays, labels, bb, near_far=nf, **kw)
+    finally:
+        lr.sample_pdf, torch.sort, model.volume_render.forward = orig_pdf, orig_sort, orig_vr
+        for hd in handles:
+            hd.remove()
+    masks = out[4]
+    arrays = flatten_out(out)
+    for i, dr in enumerate(rr.draws):
+        arrays[f"draw{i}"] = dr
+    assert len(rec["pdf"]) == l and len(rr.draws) == 2 * l
+    fine_sorts = [x for x in rec["sorts"] if x.dim() == 2 and x.shape == (n, S)]
+    assert len(fine_sorts) == l, [tuple(x.shape) for x in rec["sorts"]]
+    assert len(rec["weights"]) == 2 * (l + 1)            # l per-layer + 1 merged composite per stage
+    for i in range(l):
+        t_c, w_c, z = rec["pdf"][i]
+        arrays[f"pdf_t{i}"], arrays[f"pdf_w{i}"], arrays[f"pdf_z{i}"] = t_c, w_c, z
+        arrays[f"u{i}"] = rr.draws[l + i]
+        arrays[f"z_vals_fine{i}"] = fine_sorts[i]
+        arrays[f"coarse_weights{i}"] = rec["weights"][i].reshape(n, n1)
+        assert torch.equal(arrays[f"coarse_weights{i}"][:, 1:-1], w_c)
+        arrays[f"xyz_fine_post{i}"] = model.xyz_fine_temp[i]
+        arrays[f"density_fine_post{i}"] = model.density_fine_temp[i]
+        idx = masks[i] if i > 0 else torch.ones(n, dtype=torch.bool)
+        pre = torch.zeros(n, S, 3)
+        rgb, sig = torch.zeros(n, S, 3), torch.zeros(n, S, 1)
+        if i == 0:
+            (inp, outp), = calls["space0"]
+            pre, (rgb, sig) = inp[0], outp
+        elif bool(idx.any()):
+            (inp, outp), = calls[f"space{i}"]
+            rgb[idx], sig[idx] = outp
+            if dt:
+                m_in = calls[f"motion{i}"][-1][0][0]                   # the fine-stage call: (hits, S, 4) = [xyz, frame id]
+                assert m_in.shape[1] == S
+                pre[idx] = m_in[..., :3]
+            else:
+                pre[idx] = inp[0]
+        arrays[f"xyz_fine_pre{i}"], arrays[f"raw_rgb_fine{i}"], arrays[f"raw_sigma_fine{i}"] = pre, rgb, sig
+    meta = dict(L=L, n1=n1, n2=n2, space_time=st, deform_time=dt, weight_seed=seed, h=h, w=w, edit=dict(edit), call_kwargs=kw,
+                chunk=None, only_coarse=False, n_draws=len(rr.draws), flags={}, frame=frame)
+    save(name, meta, rays=rays, **arrays)
+
+
+def g_teacher_cases():
+    """Same scenes, seeds and sizes as fwd_c3_64_64 / fwd_c3_90_30 / fwd_c4 / fwd_c5 (their final outputs are therefore
+    the same numbers), plus the edit case (shift / scale / alpha / near and both thresholds, as fwd_edit)."""
+    g_teacher("tf_c3_64_64", 2, 64, 64, True, True, 43, 6, 8)
+    g_teacher("tf_c3_90_30", 2, 90, 30, True, True, 41, 8, 8, call_kwargs=dict(density_threshold=0.05, bkgd_density_threshold=0.02))
+    g_teacher("tf_c4", 4, 10, 6, False, True, 35, 6, 12)
+    g_teacher("tf_c5", 8, 12, 4, False, True, 36, 4, 16, call_kwargs=dict(density_threshold=0.05))
+    g_teacher("tf_edit", 2, 12, 6, True, True, 23, 8, 8, frame=2.0,
+              edit=dict(scale=[1.0, 1.2, 0.8], shift=[None, None, [-0.1, 0.02, 0.05]], alpha=0.5, near=1.5),
+              call_kwargs=dict(density_threshold=0.2, bkgd_density_threshold=0.1))
+
+
+
 def g_more_layers():
     """BASELINE C4 / C5 shapes at fixture size: 4 performers with deformation only (configs/config_walking.yml has
     USE_SPACE_TIME off), 8 performers; rays hit 0-2 of the side-by-side performer slabs."""
@@ -447,6 +563,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--more-layers":
         g_more_layers()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--teacher":
+        g_teacher_cases()
+        return
     g_generate_rays()
     g_sampler()
     g_encoding()
@@ -475,6 +594,7 @@ def main():
     g_more_layers()
     g_round2()
     g_psnr_view()
+    g_teacher_cases()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,156 @@
+"""More than one rank on the ONE GPU of the test box (gloo instead of RCCL: RCCL refuses two ranks on one device): the
+multi-GPU code path exactly as a node runs it -- ``python bench.py --gpus N`` launching its own ranks, and the call
+surface (``layered_batchify_ray`` / ``render_pose`` / ``LayeredNeuralRenderer.render_pose``) sharding a view by itself
+once a process group exists -- must give, on every rank, every tensor of the single-rank render bit for bit
+(render/layered_neural_renderer.py:364-391 returns and :467-485 writes the per-layer images too, not just the mix)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+BENCH_COMMON = ["--steps", "2", "--warmup", "1", "--no-second-precision", "--no-config-legs", "--no-psnr-check",
+                "--cpu-baseline-rays", "0", "--eager-gpu-baseline-rays", "0"]
+
+
+def _run_bench(extra, dump):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):     # a plain `python bench.py`, as the driver runs it
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + BENCH_COMMON + ["--dump-outputs", dump] + extra,
+                       cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0]), torch.load(dump)
+
+
+def _flat(d):
+    out = d["mixed_fine"] + d["mixed_coarse"] + d["masks"]
+    for trip in d["layer_fine"] + d["layer_coarse"]:
+        out += trip
+    return out
+
+
+@pytest.mark.parametrize("workload, precision, world", [("taekwondo-192x256-32+32", "bf16x3", 2),
+                                                        ("taekwondo-192x256-32+32", "fp32", 3),
+                                                        ("single-512-64+64", "bf16x3", 2)])
+def test_bench_launches_its_own_ranks_and_matches_one_rank(tmp_path, workload, precision, world):
+    """`python bench.py --gpus N` (no torchrun) = N ranks of the same step function as N = 1; the gathered 5-tuple of the
+    last step is the 1-rank one, bit for bit; both lines carry the same partition and scaling label."""
+    one, a = _run_bench(["--gpus", "1", "--workload", workload, "--precision", precision], str(tmp_path / "one.pt"))
+    many, b = _run_bench(["--gpus", str(world), "--debug-single-device", "--workload", workload, "--precision", precision],
+                         str(tmp_path / "many.pt"))
+    assert one["n_gpus"] == 1 and many["n_gpus"] == world and b["world"] == world
+    assert one["scaling"] == many["scaling"] == "strong"
+    assert one["config"]["workload"] == many["config"]["workload"] == workload
+    fa, fb = _flat(a), _flat(b)
+    assert len(fa) == len(fb) and len(fa) > 10
+    for x, y in zip(fa, fb):
+        assert x.shape == y.shape and x.dtype == y.dtype and torch.equal(x, y)
+    assert float(a["mixed_fine"][0].std()) > 0.01                                  # a picture, not zeros
+    assert len(many["per_rank_compute_s"]["all"]) == world
+    assert abs(many["ray_samples_per_step_rank0"] * world - one["ray_samples_per_step_rank0"]) <= 0.35 * one["ray_samples_per_step_rank0"]
+    assert many["roofline"]["frac"] > 0 and many["cpu_baseline"] is None
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _surface_worker(rank, world, port, precision, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import types
+    import torch.distributed as dist
+    from stnerf_amd import parallel, synthetic as syn
+    from stnerf_amd.render import LayeredNeuralRenderer, render_pose
+    from stnerf_amd.utils import layered_batchify_ray
+    from oracle import stnerf_oracle as O
+    import test_gpu_render as R
+    parallel.init_from_env(single_device=True)
+    try:
+        L, n1, n2, H, W, far = 2, 16, 8, 48, 80, 20.0                  # 3840 rays: one full 3584-ray chunk + a ragged tail
+        meta = dict(L=L, n1=n1, n2=n2, space_time=True, deform_time=True, weight_seed=71, edit={})
+        model = R.build_model(meta).set_precision(precision)
+        K, T = syn.camera(H, W, 12.0)
+        pairs = [(0, 1), (1, 2.5), (2, 1)]
+        N = H * W
+        rays = O.append_frame_ids(O.generate_rays(K, T, H, W), pairs, L)        # CPU rays, as the dataset builds them
+        labels, bbox, near_far = torch.zeros(N), torch.zeros(N, 8, 3), torch.tensor([[-1.0, -1.0]]).repeat(N, 1)
+        model.shift, model.scale, model.alpha = [[0.0, 0.0, 0.0], [0.1, 0.0, 0.05], None], [1.0, 1.1, 0.9], 0.7
+        checks = {}
+
+        def reference_render_pose():
+            """render/layered_neural_renderer.py:364-391 with the HIP model in the model's seat"""
+            with torch.no_grad():
+                stage2, stage1, stage2_layer, stage1_layer, masks = layered_batchify_ray(
+                    model, rays.cuda(), labels.cuda(), bbox.cuda(), near_far=near_far.cuda(), density_threshold=0.05,
+                    bkgd_density_threshold=0.02)
+                color = stage2[0].reshape(H, W, 3)
+                depth = stage2[1].reshape(H, W, 1)
+                depth[depth < 0] = 0
+                depth = depth / far
+                color_layer = [i[0].reshape(H, W, 3) for i in stage2_layer]
+                depth_layer = []
+                for temp in stage2_layer:
+                    d1 = temp[1].reshape(H, W, 1)
+                    d1[depth < 0] = 0
+                    depth_layer.append(d1 / far)
+            return [color, depth] + color_layer + depth_layer + list(stage1) + [t for trip in stage1_layer for t in trip] + list(masks)
+
+        cfg = types.SimpleNamespace(DATASETS=types.SimpleNamespace(LAYER_NUM=L, FRAME_NUM=3, FRAME_OFFSET=0),
+                                    INPUT=types.SimpleNamespace(SIZE_TEST=[W, H]), OUTPUT_DIR="")
+        renderer = LayeredNeuralRenderer(cfg, model=model, gt_poses=torch.stack([T, T]), gt_Ks=[K, K])
+        model.shift, model.scale = [[0.0, 0.0, 0.0], [0.1, 0.0, 0.05], None], [1.0, 1.1, 0.9]
+
+        def ours():
+            a = render_pose(model, T, K, H, W, pairs, far, 0.05, 0.02)
+            b = renderer.render_pose(T, K, pairs, 0.05, 0.02)
+            return [a[0], a[1]] + a[2] + a[3] + [b[0], b[1]] + b[2] + b[3]
+
+        for name, fn in (("reference call sequence", reference_render_pose), ("render_pose", ours)):
+            for fresh in (False, True):
+                model.fresh_draws_per_call = fresh
+                model.shard_views, model.seed = False, 3
+                whole = [t.clone() for t in fn()]
+                seed_after = model.seed
+                model.shard_views, model.seed = True, 3
+                split = fn()
+                same = all(x.shape == y.shape and x.dtype == y.dtype and torch.equal(x, y) for x, y in zip(whole, split))
+                checks[f"{name}, fresh draws {fresh}"] = bool(same and len(whole) == len(split) and model.seed == seed_after
+                                                              and float(whole[0].std()) > 0.01)
+        q.put((rank, checks))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision, world", [("bf16x3", 2), ("fp32", 3)])
+def test_call_surface_shards_itself_under_a_process_group(precision, world):
+    """The reference's render_pose call sequence, stnerf_amd.render.render_pose and LayeredNeuralRenderer.render_pose on
+    `world` ranks sharing cuda:0: colour, depth, every layer's colour and depth, the coarse outputs and the masks are the
+    single-rank tensors bit for bit on every rank, and the draw counter advances the same way."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_surface_worker, args=(r, world, port, precision, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in results) == list(range(world))
+    for r, checks in results:
+        assert len(checks) == 4 and all(checks.values()), (r, checks)

@@ -549,7 +549,7 @@ def test_resample_random_layers_edits_and_device_rng(ops):
 
 
 @pytest.mark.parametrize("n1, n2", [(3, 2), (5, 4), (8, 4), (9, 5), (10, 64), (12, 6), (16, 8), (18, 7), (64, 64),
-                                    (90, 30), (128, 64), (200, 40), (300, 20)])
+                                    (90, 30), (128, 64), (200, 40), (300, 20), (512, 512), (640, 128)])   # (the last two: > 64 KB of LDS)
 def test_resample_bit_exact_vs_oracle_on_random_inputs(ops, n1, n2):
     """utils/sample_pdf.py on the CPU = torch.sum (ATen's fp32 reduction order) + torch.cumsum (fp64 accumulator);
     the kernel reproduces both orders, so cdf, inds and z are bit-equal for every row shape: rows shorter than one

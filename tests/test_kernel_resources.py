@@ -130,3 +130,36 @@ def test_compositor_and_resampler_production_kernels_resources(tmp_path):
                 loop = body[body.index("This Loop Header: Depth=1"):]
                 parked = len(re.findall(r"v_(?:read|write)lane_b32", loop))
                 assert parked <= 80, (part, parked)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="no hipcc")
+def test_no_valu_exec_write_within_five_wait_states_of_a_dpp_instruction(tmp_path):
+    """csrc/render.hip carries hand-written DPP blocks (the in-place wave scans, the bitonic stages).  LLVM's hazard
+    recognizer does not look inside inline asm: a VALU write of EXEC (v_cmpx*) needs 5 wait states before a DPP
+    instruction reads under it, and a block placed directly behind predicated code would get none from the compiler.  The
+    scans pad themselves (s_nop 4 in front of their first step); everything else is checked here on the generated ISA:
+    walking back from every *_dpp instruction, fewer than 5 wait states (an instruction = 1, s_nop N = N + 1) may not
+    separate it from a v_cmpx.  Branch targets end the walk (another path's padding is that path's business -- and LLVM's
+    own hazard pass covers code it generated)."""
+    text = open(_compile("render.hip", tmp_path, extra=("-ffp-contract=off",))).read()
+    lines = [ln.split(";")[0].strip() for ln in text.split("\n")]
+    lines = [ln for ln in lines if ln and not ln.startswith(".")]
+    n_dpp, offenders = 0, []
+    for i, ln in enumerate(lines):
+        op = ln.split()[0]
+        if not (op.endswith("_dpp") or " row_shr:" in ln or " quad_perm:" in ln or " row_bcast:" in ln or " row_ror:" in ln or " row_shl:" in ln):
+            continue
+        n_dpp += 1
+        waits, j = 0, i - 1
+        while j >= 0 and waits < 5:
+            prev = lines[j]
+            if prev.endswith(":"):                      # a label: stop at the basic-block boundary
+                break
+            pop = prev.split()[0]
+            if pop.startswith("v_cmpx"):
+                offenders.append((i, prev, ln, waits))
+                break
+            waits += (int(prev.split()[1], 0) + 1) if pop == "s_nop" else 1
+            j -= 1
+    assert n_dpp > 100, n_dpp                            # the scans and sorts are really there
+    assert not offenders, offenders[:5]

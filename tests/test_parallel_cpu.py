@@ -138,3 +138,181 @@ def test_gloo_render_and_gather(world, n_rays):
 def test_single_process_path_needs_no_process_group():
     assert torch.equal(render_view_sharded(_fake_render, 33), _fake_render(0, 33))
     assert torch.equal(render_view_striped(_fake_render, 33, 8), _fake_render(0, 33))
+
+
+# ---- the sharded CALL SURFACE: layered_batchify_ray / render_view / render_pose under a process group ------------------
+def _surface_model(L=2, n1=8, n2=4):
+    """The real LayeredRFRender host logic (boxes from row 0 of every reference chunk, launch pieces, ray windows); the
+    ONE native call, _render_launch, is answered by a deterministic function of the rays, their index IN THE VIEW (from
+    the ray window), the boxes and the thresholds -- what a bitwise sharded-vs-whole comparison needs to be sensitive to."""
+    import types
+    from stnerf_amd import synthetic as syn
+    from stnerf_amd.modeling.layered_rfrender import LayeredRFRender
+    m = types.SimpleNamespace(BOARDER_WEIGHT=1e10, SAMPLE_METHOD="BBOX", SAME_SPACENET=False, TKERNEL_INC_RAW=True,
+                              POSE_REFINEMENT=False, USE_DIR=True, USE_DEFORM_VIEW=False, USE_DEFORM_TIME=True,
+                              USE_SPACE_TIME=True, BKGD_USE_DEFORM_TIME=False, BKGD_USE_SPACE_TIME=False, DEEP_RGB=False,
+                              COARSE_RAY_SAMPLING=n1, FINE_RAY_SAMPLING=n2)
+    cfg = types.SimpleNamespace(MODEL=m, DATASETS=types.SimpleNamespace(LAYER_NUM=L))
+
+    class HostLogic(LayeredRFRender):
+        launches = 0
+
+        def _render_launch(self, rays, boxes, pivot, retiming, only_coarse, thr, bthr, window, replay, force_fp32=False):
+            type(self).launches += 1
+            n, l = rays.shape[0], self.layer_num + 1
+            first, stripe, period = window
+            g = _global_index(first, n, stripe, period).float()
+            bx = boxes if boxes.dim() == 4 else boxes.unsqueeze(0).expand(n, l, 8, 3)
+            key = bx[:, :, 0, 0] + rays[:, 6:6 + l] * 0.25                        # (n, l): boxes + frame ids
+            if replay is not None:
+                key = key + replay["jitter"].sum(-1).transpose(0, 1) + 2 * replay["u"].sum(-1).transpose(0, 1)
+            mix_f = torch.stack([g, torch.sin(g), rays[:, 0], rays[:, 4], key.sum(1) + thr + float(self.seed)], 1)
+            mix_c = mix_f * 0.5 + bthr
+            lo_f = torch.stack([key, key * g[:, None], key + 1, key + 2, key + 3], 2)        # (n, l, 5)
+            lo_c = lo_f - 7.0
+            mask = ((g[:, None] + torch.arange(l)) % 3 == 0).to(torch.uint8)
+            return mix_f, mix_c, lo_f, lo_c, mask
+
+        def render_rays_raw(self, rays, *a, **k):
+            return super().render_rays_raw(_AsIfOnGpu(rays), *a, **k)
+
+    model = HostLogic(cfg, camera_num=1).eval()
+    bk, per = syn.scene_boxes(L)
+    model.set_bkgd_bbox(bk)
+    model.set_bboxes(per)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    return model
+
+
+class _AsIfOnGpu(torch.Tensor):
+    """A CPU tensor that answers ``is_cuda`` with True (the host logic refuses CPU rays: there is no CPU fallback)."""
+    @staticmethod
+    def __new__(cls, t):
+        return torch.Tensor._make_subclass(cls, t)
+
+    @property
+    def is_cuda(self):
+        return True
+
+
+def _flatten5(out):
+    flat = list(out[0]) + list(out[1])
+    for trip in list(out[2]) + list(out[3]):
+        flat += list(trip)
+    return flat + list(out[4])
+
+
+def _surface_rays(n, l, chunk, varying_frames):
+    g = torch.Generator().manual_seed(n)
+    rays = torch.rand(n, 6 + l, generator=g)
+    rays[:, 6:] = 1.0
+    if varying_frames:                       # a new frame id in every reference chunk: boxes differ from chunk to chunk
+        rays[:, 7] = 1.0 + (torch.arange(n) // chunk % 3).float() * 0.5
+    return rays
+
+
+def _surface_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), str(rank)
+    from stnerf_amd import ops, parallel
+    from stnerf_amd.utils import layered_batchify_ray
+    assert parallel.init_from_env(backend="gloo") == (rank, world)
+    try:
+        ok, chunk, l = True, 64, 3
+        model = _surface_model()
+        for n, varying in [(64 * 5 + 10, False), (64 * 6, True), (64 * 2 + 1, True), (64, False), (64 * 7 + 63, True)]:
+            rays = _surface_rays(n, l, chunk, varying)
+            for fresh, replay in [(False, False), (True, False), (False, True)]:
+                model.fresh_draws_per_call, model.seed = fresh, 11
+                model.replay = None
+                if replay:
+                    g = torch.Generator().manual_seed(5)
+                    model.replay = {"jitter": torch.rand(l, n, 8, generator=g), "u": torch.rand(l, n, 4, generator=g)}
+                model.shard_views = False
+                whole = layered_batchify_ray(model, rays, None, None, chuncks=chunk, density_threshold=0.3, bkgd_density_threshold=0.1)
+                seed_whole, model.seed = model.seed, 11
+                model.shard_views = True
+                type(model).launches = 0
+                split = layered_batchify_ray(model, rays, None, None, chuncks=chunk, density_threshold=0.3, bkgd_density_threshold=0.1)
+                ok = ok and model.seed == seed_whole and model.ray_window == (0, 0, 0)
+                ok = ok and all(torch.equal(a, b) and a.dtype == b.dtype and a.shape == b.shape
+                                for a, b in zip(_flatten5(whole), _flatten5(split)))
+                owns = len(parallel.stripe_spans(n, chunk, rank, world)) > 0
+                ok = ok and (type(model).launches > 0) == owns
+        # fewer rays than one chunk: no sharding, the model is called like the reference calls it (defaults for the thresholds)
+        model.replay, model.fresh_draws_per_call = None, False
+        small = _AsIfOnGpu(_surface_rays(40, l, chunk, False))
+        type(model).launches = 0
+        layered_batchify_ray(model, small, None, None, chuncks=chunk, density_threshold=0.3)
+        ok = ok and type(model).launches == 1
+        # render_view / render_pose: device ray generation of the rank's row stripes only (here: a stand-in generator)
+        seen = []
+
+        def fake_generate_rays(K, T, h, w, frame_ids=None, first_ray=0, n=None, device="cpu", stripe=0, period=0):
+            n = ops.window_size(h * w, first_ray, stripe, period) if n is None else n
+            seen.append(n)
+            g = _global_index(first_ray, n, stripe, period).float()
+            cols = [g, g * 0.5, torch.cos(g), torch.sin(g), g % 7, g % 5] + [torch.full_like(g, f) for f in frame_ids]
+            return _AsIfOnGpu(torch.stack(cols, 1))
+        ops.generate_rays = fake_generate_rays
+        from stnerf_amd.render.render_pose import render_pose
+        K, T = torch.eye(3), torch.eye(4)
+        for h, w, rows in [(9, 16, 1), (8, 16, 2), (5, 16, 1), (2, 40, 1)]:
+            model.shard_views = False
+            whole = parallel.render_view(model, K, T, h, w, [1.0, 2.5, 1.0], 0.2, 0.05, chuncks=chunk, stripe_rows=rows, device="cpu")
+            pose_whole = render_pose(model, T, K, h, w, [(0, 1), (1, 2.5), (2, 1)], 20.0, 0.2, 0.05, device="cpu")
+            model.shard_views = True
+            seen.clear()
+            split = parallel.render_view(model, K, T, h, w, [1.0, 2.5, 1.0], 0.2, 0.05, chuncks=chunk, stripe_rows=rows, device="cpu")
+            ok = ok and all(torch.equal(a, b) for a, b in zip(_flatten5(whole), _flatten5(split)))
+            if h * w >= chunk:   # only this rank's stripes were generated
+                ok = ok and seen == [sum(e - s for s, e in parallel.stripe_spans(h * w, w * rows, rank, world))]
+            pose_split = render_pose(model, T, K, h, w, [(0, 1), (1, 2.5), (2, 1)], 20.0, 0.2, 0.05, device="cpu")
+            ok = ok and torch.equal(pose_whole[0], pose_split[0]) and torch.equal(pose_whole[1], pose_split[1])
+            ok = ok and all(torch.equal(a, b) for a, b in zip(pose_whole[2] + pose_whole[3], pose_split[2] + pose_split[3]))
+        # the switches
+        os.environ["STNERF_SHARD"] = "0"
+        ok = ok and parallel.active_group(model) is None
+        del os.environ["STNERF_SHARD"]
+        ok = ok and parallel.active_group(model) == (rank, world, None)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_call_surface_shards_and_gathers_the_whole_tuple(world):
+    """layered_batchify_ray / render_view / render_pose under gloo: every rank returns exactly what the single-process
+    call returns -- all 2 + 2 l triples and the l masks, same dtypes and shapes -- with ragged last chunks, frame ids
+    that change from chunk to chunk, replayed uniforms, fresh draws per call, and more ranks than stripes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_surface_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(r, True) for r in range(world)]
+
+
+def test_take_stripes_and_pack_round_trip():
+    from stnerf_amd.parallel import pack_outputs, packed_width, take_stripes, unpack_outputs
+    x = torch.arange(103 * 2).reshape(103, 2)
+    for stripe, world in [(8, 2), (8, 3), (5, 4), (200, 2), (103, 3)]:
+        for r in range(world):
+            want = [i for s, e in stripe_spans(103, stripe, r, world) for i in range(s, e)]
+            assert take_stripes(x, stripe, r, world)[:, 0].tolist() == [2 * i for i in want]
+    g = torch.Generator().manual_seed(0)
+    l, n = 3, 17
+    raw = (torch.rand(n, 5, generator=g), torch.rand(n, 5, generator=g), torch.rand(n, l, 5, generator=g),
+           torch.rand(n, l, 5, generator=g), (torch.rand(n, l, generator=g) > 0.5).to(torch.uint8))
+    packed = pack_outputs(raw)
+    assert packed.shape == (n, packed_width(l)) and packed.dtype == torch.float32
+    back = unpack_outputs(packed, l)
+    assert all(torch.equal(a, b) and a.dtype == b.dtype and b.is_contiguous() for a, b in zip(raw, back))
+    with pytest.raises(ValueError):
+        unpack_outputs(packed, l + 1)
