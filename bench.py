@@ -48,7 +48,7 @@ PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r03_pmc_hbm_traffic.json")   
 
 # Algorithmic work per network evaluation: 2 * MACs of every nn.Linear.
 FLOP_SPACE, FLOP_SPACE_TIME, FLOP_MOTION = 924_672, 930_048, 153_344
-PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (spec, no sparsity)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (spec, no sparsity)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
 
 WORKLOADS = {
@@ -289,20 +289,16 @@ PRECISION_NOTES = {
               "bf16's exponent range = fp32's), a*b = its six leading cross terms on v_mfma_f32_32x32x16_bf16, a0*b0 and the "
               "five small terms in separate f32 accumulators, heads in fp64: closer to an fp64 evaluation than the fp32 CPU "
               "chain on every layer (tests/test_gpu_stage.py)",
-    "fp16x3": "every product a*b as ah*bh + ah*bl + al*bh on the fp16 MFMA pipe (22-bit operands, |W| < 234, activations "
-              "< 65520 with an overflow guard), per-network launches; opt-in",
     "fp32": "exact f32 MFMA (v_mfma_f32_32x32x2_f32), model.set_precision('fp32')"}
 DTYPE_NOTES = {"fp32": "f32",
-               "bf16x3": "f32 (operands as 3 bf16 pieces each: 24-bit significand, f32 exponent range; 6 bf16 MFMA terms per product, f32 accumulate)",
-               "fp16x3": "f32-accurate products as 3 fp16 MFMA terms (22-bit split operands), f32 accumulate"}
-EXECUTED_TERMS = {"fp32": 1.0, "fp16x3": 3.0, "bf16x3": 6.0}     # MFMA products executed per algorithmic product
+               "bf16x3": "f32 (operands as 3 bf16 pieces each: 24-bit significand, f32 exponent range; 6 bf16 MFMA terms per product, f32 accumulate)"}
+EXECUTED_TERMS = {"fp32": 1.0, "bf16x3": 6.0}     # MFMA products executed per algorithmic product
 STAGE_KERNEL = {
     "bf16x3": "stnerf::mlp_bf16x3_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, a wave owns 32 "
               "samples and keeps their activations in registers as three bf16 planes, weights through an LDS-DMA ring, "
               "v_mfma_f32_32x32x16_bf16; achieved = EXECUTED MFMA rate = 6 x algorithmic)",
     "fp32": "stnerf::mlp_wave_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, a wave owns 32 "
-            "samples and keeps their activations in registers, v_mfma_f32_32x32x2_f32)",
-    "fp16x3": "stnerf::spacenet_f16x3_kernel (per-network launches, LDS-staged activations, v_mfma_f32_32x32x8_f16 x 3)"}
+            "samples and keeps their activations in registers, v_mfma_f32_32x32x2_f32)"}
 
 
 def main():
@@ -327,9 +323,9 @@ def main():
     ap.add_argument("--eager-gpu-baseline-rays", type=int, default=3584,
                     help=">0 (default: one reference chunk): also time the oracle restatement through eager PyTorch-ROCm on this GPU -- "
                          "the 'stock ATen on the same GPU' figure of BASELINE.md 3.5 (informative); 0 skips it")
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "fp16x3"],
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
                     help="arithmetic of the headline leg: split-bf16 (the library default: three bf16 pieces per fp32 operand, six MFMAs, "
-                         "two accumulators: fp32's significand and range), exact f32 MFMA, or split-fp16 (22-bit operands, range-limited)")
+                         "two accumulators: fp32's significand and range) or exact f32 MFMA")
     ap.add_argument("--mlp-schedule", default="stage", choices=["stage", "per_net"],
                     help="exact-f32 MLP scheduling: one persistent launch per stage (default) or one launch per network (round 1)")
     ap.add_argument("--no-second-precision", action="store_true",
@@ -486,7 +482,7 @@ def main():
             sp = stage_of(leg)
             alg = sp["flop"] / (sp["ms"] * 1e-3) / 1e12
             executed = EXECUTED_TERMS[prec] * alg
-            peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_F16_MFMA_TFLOPS
+            peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
             # HBM traffic cannot be counted inside this process: it comes from the committed rocprofv3 PMC passes
             # of the same command (profiles/), per launch, with the gfx950 FETCH_SIZE correction applied.
             pk = pmc.get({"bf16x3": "kernels_bf16x3", "fp32": "kernels"}.get(prec, "-"), {})

@@ -160,29 +160,6 @@ int stnerf_rgb_ray_bias(int kind, const void* packed, int64_t n_rays, const int3
                         const float* dirs, int64_t dirs_ray_stride, const float* times, int64_t times_ray_stride,
                         float* out, stnerf_stream_t stream);
 
-/* "fp16x3" variant of the SpaceNet kernel: fp32-accurate matrix products on the fp16 MFMA pipe.  Every
- * fp32 operand is split x = hi + lo into two fp16 numbers (22 significand bits) and a*b is evaluated as
- * ah*bh + ah*bl + al*bh with fp32 accumulation (exact fp16 products); encodings, bias, ReLU, heads and
- * outputs stay fp32.  Same work list, layouts and parity tolerances as stnerf_spacenet_fwd; needs its own
- * packed blob (stnerf_packed_bytes_f16x3 / stnerf_pack_net_f16x3; |W| must be < 234).  All three net kinds.
- * Range guard: an activation beyond the fp16 range (>= 65520) turns into inf in the split; the NaNs that follow are
- * flushed to 0 by the next layer's ReLU, i.e. the damage is SILENT (finite, wrong outputs).  The kernels therefore
- * track the largest activation they split: `overflow` (device uint32, may be NULL) is OR-ed with 1 when one left the
- * range (or an output is not finite), so that the caller can re-run the launch in exact f32 (the Python model does:
- * LayeredRFRender._render_launch). */
-int64_t stnerf_packed_bytes_f16x3(int kind);
-int stnerf_pack_net_f16x3(int kind, const float* const* weights_host, const float* const* biases_host,
-                          int n_tensors, void* dst_host, int64_t dst_bytes);
-int stnerf_spacenet_fwd_f16x3(int kind, const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
-                              const int32_t* ray_count, const float* xyz, int64_t xyz_ray_stride,
-                              const float* dirs, int64_t dirs_ray_stride, const float* times,
-                              int64_t times_ray_stride, float* raw, int64_t raw_ray_stride,
-                              uint32_t* overflow, stnerf_stream_t stream);
-int stnerf_motionnet_fwd_f16x3(const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
-                               const int32_t* ray_count, float* xyz, int64_t xyz_ray_stride,
-                               const float* times, int64_t times_ray_stride, float* flow,
-                               int64_t flow_ray_stride, int add_to_xyz, uint32_t* overflow, stnerf_stream_t stream);
-
 /* a7 + a8: fused positional encoding (with the fractional-time lerp) + MotionNet MLP.
  * modeling/motion_net.py:34-71.  Same work list as above.  flow (may be NULL) gets the 3-vector at
  * flow + j*flow_ray_stride + 3k.  `add_to_xyz` is a set of STNERF_MOTION_* bits: ADD_TO_XYZ updates the
@@ -201,7 +178,8 @@ int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32
  * weight (host side, here) and every activation (in the kernel) is split into three bf16 numbers, x = x0 + x1 + x2 --
  * 8 + 8 + 8 significand bits, i.e. exact for every finite fp32 value inside bf16's exponent range (|x| <= 3.39e38: above
  * bf16's largest finite value the leading piece rounds to inf; residual pieces below 2^-133 flush, an error < 2^-16 of
- * the smallest normal number), with fp32's exponent range: no |W| limit, no activation limit, no overflow flag -- and a product is evaluated with its six leading cross terms on the bf16 MFMA (dropped terms <= 2^-24 |a b|),
+ * the smallest normal number), with fp32's exponent range: no |W| limit, no activation limit, no overflow flag -- and a
+ * product is evaluated with its six leading cross terms on the bf16 MFMA (dropped terms <= 2^-24 |a b|),
  * fp32 accumulate.  Same tensors as stnerf_pack_net; the blob = [the exact-f32 blob of stnerf_pack_net | bias vectors and
  * head weights in the kernel's LDS order | the MFMA layers' weights as bf16 triples in consumption order].  All net
  * kinds.  The device copy must be 1 KB aligned. */
@@ -316,7 +294,7 @@ int stnerf_resample(const float* t, const float* weights, int64_t n, int l, int 
  * coarse sampler -> mask compaction -> [MotionNet] -> SpaceNets -> composite/merge -> resample -> [MotionNet] ->
  * fine SpaceNets -> composite/merge, all enqueued on `stream` into a caller-provided workspace.  Host-side
  * box interpolation / editing (l x 8 x 3 numbers, :190-242) stays with the caller, who passes the edited boxes
- * and the inverse point edits.  Packed-network pointers are device blobs of stnerf_pack_net[_f16x3]. */
+ * and the inverse point edits.  Packed-network pointers are device blobs of stnerf_pack_net[_bf16x3]. */
 typedef struct stnerf_nets {
     const void* bkgd;                           /* bkgd_spacenet            (STNERF_NET_SPACE)               */
     const void* bkgd_fine;                      /* bkgd_spacenet_fine                                        */
@@ -332,9 +310,10 @@ typedef struct stnerf_render_params {
     int32_t retiming;             /* 1: frame id of layer i in column 6+i; 0: per-ray frame id in column 6   */
     int32_t only_coarse;
     int32_t use_deform_time, use_space_time;
-    int32_t precision;            /* 0: exact f32 MFMA, one persistent stnerf_mlp_stage launch per stage; 1: fp16x3 (one launch
-                                     per network); 2: exact f32, one launch per network (round-1 scheduling, for A/B runs);
-                                     3: bf16x3 (split-bf16, stnerf_mlp_stage with STNERF_STAGE_BF16X3; nets packed by stnerf_pack_net_bf16x3) */
+    int32_t precision;            /* 3: bf16x3 (split-bf16, stnerf_mlp_stage with STNERF_STAGE_BF16X3; nets packed by
+                                     stnerf_pack_net_bf16x3) -- what the Python boundary selects by default; 0: exact f32 MFMA, one
+                                     persistent stnerf_mlp_stage launch per stage; 2: exact f32, one launch per network
+                                     (round-1 scheduling, for A/B runs).  (1 was the retired split-fp16 mode: rejected.) */
     int32_t has_edits;            /* edits_* / pivot are meaningful                                          */
     int32_t bkgd_use_deform_time; /* BKGD_USE_DEFORM_TIME: nets.motion[0] warps the background samples (:358-367) */
     int32_t bkgd_use_space_time;  /* BKGD_USE_SPACE_TIME: background SpaceNets take the frame id (needs use_space_time, :382-390) */
@@ -351,13 +330,12 @@ typedef struct stnerf_render_params {
 
 int64_t stnerf_render_workspace_bytes(int64_t n, int l, int n1, int n2, int only_coarse);
 /* Outputs: mixed_*[n][5], layer_*[n][l][5] = {colour(3), depth, acc}; mask[n][l].  jitter [l][n][n1] / u [l][n][n2]
- * replay uniform draws (NULL = device RNG).  With only_coarse the fine outputs may be NULL.  overflow: device uint32 or
- * NULL, OR-ed with 1 if an fp16x3 network produced a non-finite output (see stnerf_spacenet_fwd_f16x3). */
+ * replay uniform draws (NULL = device RNG).  With only_coarse the fine outputs may be NULL. */
 int stnerf_render_rays(const float* rays, int64_t n, const float* boxes, int64_t box_ray_stride,
                        const stnerf_nets* nets_host, const stnerf_render_params* params_host, const float* jitter,
                        const float* u, void* workspace, int64_t workspace_bytes, float* mixed_fine,
                        float* mixed_coarse, float* layer_fine, float* layer_coarse, uint8_t* mask,
-                       uint32_t* overflow, stnerf_stream_t stream);
+                       stnerf_stream_t stream);
 
 #ifdef __cplusplus
 }

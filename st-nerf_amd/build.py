@@ -28,7 +28,6 @@ SOURCES = [
     ("mlp_wave.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"] if os.environ.get("STNERF_WAVE_VGPR_FORM") else []),
     ("mlp_bf16x3.hip", []),
     ("stage_entry.hip", []),
-    ("mlp_f16x3.hip", []),
     ("pipeline.hip", []),
 ]
 EXTRA = os.environ.get("STNERF_EXTRA_FLAGS", "").split()   # e.g. -DSTNERF_PHASE_PROF (development only)

@@ -498,7 +498,7 @@ extern "C" int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays,
                                        times, times_ray_stride, ray_bias, as_stream(stream)))
         return rc;
     SpaceArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, dirs,
-                dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride, nullptr, ray_bias};
+                dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride, ray_bias};
     const TileCfg tc = tile_config(TILE_128X8);
     const int tm = tc == TILE_64 ? 64 : 128;
     const int lds = (64 + 16) * tm * 16;

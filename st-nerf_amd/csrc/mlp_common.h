@@ -1,4 +1,4 @@
-// Pieces shared by the fp32 (mlp.hip) and split-fp16 (mlp_f16x3.hip) fused MLP kernels.
+// Pieces shared by the fused MLP kernels (mlp.hip, the stage kernels).
 #pragma once
 #include "common.h"
 
@@ -155,7 +155,6 @@ struct SpaceArgs {
     int64_t times_ray_stride;
     float* raw;
     int64_t raw_ray_stride;
-    uint32_t* overflow;  // fp16x3 kernels: set to 1 if an output is not finite (an activation left the fp16 range); may be null
     const float* raybias;  // exact-f32 kernels: [n_rays][128] C operands of rgb_net.1 (mlp_raybias.hip)
 };
 
@@ -174,7 +173,6 @@ struct MotionArgs {
     float* flow;
     int64_t flow_ray_stride;
     int add_to_xyz;  // STNERF_MOTION_* flag bits
-    uint32_t* overflow;  // as SpaceArgs::overflow
 };
 
 // Positional-encoding feature f of a tile sample lives at col[(f >> 2) * TM * 4 + (f & 3)], col = encf + s * 4.

@@ -8,7 +8,7 @@
 // pairs per SAMPLE of the fused kernels go away.
 // This kernel defines the arithmetic for every exact-f32 MLP kernel (mlp.hip, mlp_wave.hip): c starts from
 // the bias and takes the encoded features in index order with one fmaf each; the layer then adds the 256 backbone
-// features in the kernels' usual k order.  (The fp16x3 kernels keep the columns inside their own K loop.)
+// features in the kernels' usual k order.
 #include "mlp_common.h"
 
 namespace stnerf {

@@ -26,6 +26,12 @@ struct Carve {
 // sizes of the workspace regions for n rays (shared by the size query and the carve)
 struct Plan {
     int64_t t_c, xyz_c, raw_c, w_c, t_f, xyz_f, raw_f, list, count, flags, raybias;
+    // Once the resampler has read t_c / w_c the whole coarse block [t_c | xyz_c | raw_c | w_c] is dead: the fine network outputs
+    // (raw_f, the largest fine buffer) are written over it.  shared = the larger of the two.  64 + 64 samples: 9 n1 = 576 floats
+    // of coarse block per (ray, layer) against 4 S = 512 of raw_f -- the workspace goes from 1728 to 1216 floats (- 30 %).
+    static int64_t pad(int64_t floats) { return (floats + 63) & ~int64_t(63); }   // 256-byte granules, as Carve::take
+    int64_t coarse_block() const { return pad(t_c) + pad(xyz_c) + pad(raw_c) + pad(w_c); }
+    int64_t shared() const { return coarse_block() > pad(raw_f) ? coarse_block() : pad(raw_f); }
 };
 Plan make_plan(int64_t n, int l, int n1, int n2, int only_coarse) {
     Plan p;
@@ -52,8 +58,7 @@ extern "C" int64_t stnerf_render_workspace_bytes(int64_t n, int l, int n1, int n
         return STNERF_EINVAL;
     }
     const Plan p = make_plan(n, l, n1, n2, only_coarse);
-    // xyz_c / raw_c are dead once the fine stage starts, but a single bump carve keeps the accounting obvious
-    const int64_t floats = p.t_c + p.xyz_c + p.raw_c + p.w_c + p.t_f + p.xyz_f + p.raw_f + p.raybias;
+    const int64_t floats = p.shared() + p.t_f + p.xyz_f + p.raybias;
     return floats * 4 + (p.list + p.count) * 4 + p.flags + 16 * 256;
 }
 
@@ -61,14 +66,14 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
                                   const stnerf_nets* nets, const stnerf_render_params* p, const float* jitter,
                                   const float* u, void* workspace, int64_t workspace_bytes, float* mixed_fine,
                                   float* mixed_coarse, float* layer_fine, float* layer_coarse, uint8_t* mask,
-                                  uint32_t* overflow, stnerf_stream_t stream) {
+                                  stnerf_stream_t stream) {
     STNERF_REQUIRE(rays && boxes && nets && p && workspace && mask, "render_rays: null pointer");
     STNERF_REQUIRE(mixed_coarse && layer_coarse, "render_rays: coarse outputs are required");
     STNERF_REQUIRE(p->only_coarse || (mixed_fine && layer_fine), "render_rays: fine outputs are required");
     const int l = p->l, n1 = p->n1, n2 = p->n2, S = n1 + n2, rs = p->ray_stride;
     STNERF_REQUIRE(n >= 0 && l >= 1 && l <= STNERF_MAX_LAYERS && n1 >= 3 && n2 >= 0, "render_rays: bad shape");
     STNERF_REQUIRE(rs >= (p->retiming ? 6 + l : 7), "render_rays: ray stride %d too small for the frame-id columns", rs);
-    STNERF_REQUIRE(p->precision >= 0 && p->precision <= 3, "render_rays: unknown precision %d", p->precision);
+    STNERF_REQUIRE(p->precision == 0 || p->precision == 2 || p->precision == 3, "render_rays: unknown precision %d", p->precision);
     STNERF_REQUIRE(nets->bkgd && (p->only_coarse || nets->bkgd_fine), "render_rays: background network missing");
     STNERF_REQUIRE(!p->bkgd_use_deform_time || nets->motion[0], "render_rays: bkgd_time_deform_net missing");
     STNERF_REQUIRE(!p->bkgd_use_space_time || p->use_space_time,
@@ -86,13 +91,15 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
 
     const Plan pl = make_plan(n, l, n1, n2, p->only_coarse);
     Carve ws{static_cast<char*>(workspace), 0, workspace_bytes};
-    float* t_c = ws.take<float>(pl.t_c);
-    float* xyz_c = ws.take<float>(pl.xyz_c);
-    float* raw_c = ws.take<float>(pl.raw_c);
-    float* w_c = ws.take<float>(pl.w_c);
+    float* shared = ws.take<float>(pl.shared());
+    Carve cb{reinterpret_cast<char*>(shared), 0, pl.shared() * 4};   // the coarse block inside the shared region
+    float* t_c = cb.take<float>(pl.t_c);
+    float* xyz_c = cb.take<float>(pl.xyz_c);
+    float* raw_c = cb.take<float>(pl.raw_c);
+    float* w_c = cb.take<float>(pl.w_c);
+    float* raw_f = shared;            // over the coarse block: first written by the fine stage, after the resampler read t_c / w_c
     float* t_f = ws.take<float>(pl.t_f);
     float* xyz_f = ws.take<float>(pl.xyz_f);
-    float* raw_f = ws.take<float>(pl.raw_f);
     int32_t* ray_list = ws.take<int32_t>(pl.list);
     int32_t* ray_count = ws.take<int32_t>(pl.count);
     uint8_t* ray_flags = ws.take<uint8_t>(pl.flags);
@@ -155,10 +162,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
             const int32_t* lst = i == 0 ? nullptr : ray_list + (int64_t)i * n;
             const int32_t* cnt = i == 0 ? nullptr : ray_count + i;
             const int flags = STNERF_MOTION_ADD_TO_XYZ | (i == 0 ? STNERF_MOTION_PLAIN_TIME : 0);
-            const int r2 = p->precision == 1
-                               ? stnerf_motionnet_fwd_f16x3(nets->motion[i], n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs,
-                                                            times, rs, nullptr, 0, flags, overflow, stream)
-                               : stnerf_motionnet_fwd(nets->motion[i], n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs, times,
+            const int r2 = stnerf_motionnet_fwd(nets->motion[i], n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs, times,
                                                       rs, nullptr, 0, flags, stream);
             if (r2) return r2;
         }
@@ -172,10 +176,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
             const float* times = timed ? rays + (p->retiming ? 6 + i : 6) : nullptr;
             const int32_t* lst = i == 0 ? nullptr : ray_list + (int64_t)i * n;
             const int32_t* cnt = i == 0 ? nullptr : ray_count + i;
-            const int r2 = p->precision == 1
-                               ? stnerf_spacenet_fwd_f16x3(kind, net, n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs, rays + 3,
-                                                           rs, times, rs, raw + (int64_t)i * ns * 4, ws_, overflow, stream)
-                               : stnerf_spacenet_fwd(kind, net, n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs, rays + 3, rs,
+            const int r2 = stnerf_spacenet_fwd(kind, net, n, ns, lst, cnt, xyz + (int64_t)i * ns * 3, xs, rays + 3, rs,
                                                      times, rs, raw + (int64_t)i * ns * 4, ws_, ray_bias + (int64_t)i * n * 128, stream);
             if (r2) return r2;
         }

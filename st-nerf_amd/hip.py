@@ -85,16 +85,9 @@ _PROTOS = {
                                       c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, C.c_void_p]),
     "stnerf_rgb_ray_bias": (C.c_int, [C.c_int, C.c_void_p, c_i64, C.c_void_p, C.c_void_p, c_f32p, c_i64, c_f32p, c_i64,
                                       c_f32p, C.c_void_p]),
-    "stnerf_packed_bytes_f16x3": (c_i64, [C.c_int]),
-    "stnerf_pack_net_f16x3": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
-                                        c_i64]),
     "stnerf_packed_bytes_bf16x3": (c_i64, [C.c_int]),
     "stnerf_pack_net_bf16x3": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
                                          c_i64]),
-    "stnerf_spacenet_fwd_f16x3": (C.c_int, [C.c_int, C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_i64,
-                                            c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, C.c_void_p, C.c_void_p]),
-    "stnerf_motionnet_fwd_f16x3": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_i64, c_f32p,
-                                             c_i64, c_f32p, c_i64, C.c_int, C.c_void_p, C.c_void_p]),
     "stnerf_motionnet_fwd": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_i64, c_f32p,
                                        c_i64, c_f32p, c_i64, C.c_int, C.c_void_p]),
     "stnerf_mlp_stage": (C.c_int, [C.POINTER(StageLayer), C.c_int, c_i64, C.c_int, c_f32p, c_i64, c_i64, c_i64, c_i64, C.c_int,
@@ -106,7 +99,7 @@ _PROTOS = {
     "stnerf_composite_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(c_i64)]),
     "stnerf_render_workspace_bytes": (c_i64, [c_i64, C.c_int, C.c_int, C.c_int, C.c_int]),
     "stnerf_render_rays": (C.c_int, [c_f32p, c_i64, c_f32p, c_i64, C.POINTER(Nets), C.POINTER(RenderParams), c_f32p, c_f32p,
-                                     C.c_void_p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                     C.c_void_p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
     "stnerf_resample": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_uint64, c_i64, c_i64, c_i64, c_f32p,
                                   C.c_int, C.POINTER(LayerEdit), C.POINTER(C.c_float), c_f32p, c_f32p, c_f32p,
                                   C.c_void_p, c_f32p, C.c_void_p]),

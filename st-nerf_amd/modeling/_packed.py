@@ -11,12 +11,13 @@ def _params_fingerprint(module: nn.Module):
 class _PackedMixin:
     """Lazily (re)packs a module's nn.Linear weights into the kernel layout."""
 
-    precision = "fp32"   # "fp32": exact f32 MFMA;  "fp16x3" / "bf16x3": split low-precision MFMA (ops.PRECISIONS)
+    precision = "bf16x3"   # the library default: split-bf16 MFMA (fp32 operands as three bf16 pieces: fp32's significand and
+                           # range, closer to an fp64 evaluation than an fp32 fma chain); "fp32": exact f32 MFMA (ops.PRECISIONS)
 
     def _packed(self, precision=None):
         """The kernel-layout blob for `precision` (default: the module's own).  One blob per precision is kept as long
-        as the parameters do not change, so that a launch which has to fall back to another arithmetic (the fp16x3 range
-        guard -> exact f32) does not repack on every call."""
+        as the parameters do not change (the op-level MotionNet call is exact f32 whatever the module's arithmetic, and A/B
+        runs switch back and forth: neither repacks on every call)."""
         precision = precision or self.precision
         fp = _params_fingerprint(self)
         cache = getattr(self, "_pack_cache", None)

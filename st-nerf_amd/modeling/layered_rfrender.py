@@ -94,20 +94,17 @@ class LayeredRFRender(nn.Module):
                                            # the whole 5-tuple (stnerf_amd.parallel); False: every rank renders what it is given
         self.shard_group = None            # the process group to shard over (None: the default group)
 
-    F16_LATCH_AFTER = 8    # fp16x3 range-guard fallbacks after which the model stays in exact f32
     FRESH_DRAWS_DEFAULT = False   # what a new model's fresh_draws_per_call starts as (dropin.patch_reference: True)
 
     def set_precision(self, precision: str):
-        """"fp32" (default: exact f32 MFMA), "bf16x3" (three bf16 pieces per operand, six MFMAs per product, two
-        accumulators: fp32's significand and range, closer to an fp64 evaluation than an fp32 fma chain) or "fp16x3" (two
-        fp16 pieces, three MFMAs: 22 significand bits, |W| < 234, activations < 65520 -- a launch that leaves the range is
-        re-run in exact f32)."""
+        """"bf16x3" (the default: three bf16 pieces per fp32 operand, six MFMAs per product, two accumulators: fp32's
+        significand and range, closer to an fp64 evaluation than an fp32 fma chain, 1.5 x the speed) or "fp32" (exact f32
+        MFMA, v_mfma_f32_32x32x2_f32)."""
         if precision not in ops.PRECISIONS:
             raise ValueError(f"precision must be one of {ops.PRECISIONS}")
         for m in self.modules():
             if isinstance(m, (SpaceNet, MotionNet)):
                 m.precision = precision
-        self.f16_fallbacks, self.f16_latched = 0, False
         return self
 
     # ---- reference API -----------------------------------------------------------------------
@@ -218,7 +215,7 @@ class LayeredRFRender(nn.Module):
             ops.spacenet_fwd(nets[i - 1]._packed("fp32"), xyz[:, i], rays[:, 3:6], tm, raw[:, i], ray_list=lst[i],
                              ray_count=cnt[i:i + 1])
 
-    def _render_launch(self, rays, boxes, pivot, retiming, only_coarse, thr, bthr, window, replay, force_fp32=False):
+    def _render_launch(self, rays, boxes, pivot, retiming, only_coarse, thr, bthr, window, replay):
         """One kernel sequence over `rays` (n <= max_rays_per_launch) = ONE call into the C ABI
         (stnerf_render_rays, csrc/pipeline.hip).  boxes: (l,8,3) shared or (n,l,8,3)."""
         from stnerf_amd import hip
@@ -229,11 +226,9 @@ class LayeredRFRender(nn.Module):
         p.use_deform_time, p.use_space_time = int(self.use_deform_time), int(self.use_space_time)
         p.bkgd_use_deform_time, p.bkgd_use_space_time = int(self.bkgd_use_deform_time), int(self.bkgd_use_space_time)
         p.deep_rgb = int(self.deep_rgb)
-        # 0: exact f32, one persistent launch per network stage; 1: fp16x3; 2: exact f32, one launch per network; 3: bf16x3
+        # 3: bf16x3 (the default); 0: exact f32, one persistent launch per network stage; 2: exact f32, one launch per network
         prec = self.bkgd_spacenet.precision
-        if force_fp32 or (prec == "fp16x3" and getattr(self, "f16_latched", False)):
-            prec = "fp32"   # the fp16x3 range guard fired: this launch (again) in exact f32 -- its blobs are cached per precision
-        p.precision = {"fp16x3": 1, "bf16x3": 3}.get(prec, 0 if self.mlp_schedule == "stage" else 2)
+        p.precision = 3 if prec == "bf16x3" else (0 if self.mlp_schedule == "stage" else 2)
         for i in range(l):
             p.shown[i] = int(self.is_shown_layer(i))
         p.border, p.near, p.alpha = float(self.boarder_weight), float(self.near), float(self.alpha)
@@ -265,25 +260,8 @@ class LayeredRFRender(nn.Module):
         ws = getattr(self, "_workspace", None)
         if ws is None or ws.numel() < need or ws.device != rays.device:
             self._workspace = ws = torch.empty(need, dtype=torch.uint8, device=rays.device)
-        guard = None
-        if p.precision == 1:   # fp16x3: a device flag says whether an activation left the fp16 range (non-finite output)
-            guard = getattr(self, "_f16_guard", None)
-            if guard is None or guard.device != rays.device:
-                self._f16_guard = guard = torch.zeros(1, dtype=torch.int32, device=rays.device)
-            guard.zero_()
-        out = ops.render_rays(rays, boxes, nets, p, ws, jitter=replay["jitter"] if replay else None,
-                              u=(replay.get("u") if replay else None), overflow=guard)
-        if guard is not None and int(guard.item()) != 0:   # (one 4-byte D2H per launch sequence, fp16x3 mode only)
-            self.f16_fallbacks = getattr(self, "f16_fallbacks", 0) + 1
-            if self.f16_fallbacks >= self.F16_LATCH_AFTER and not getattr(self, "f16_latched", False):
-                # a scene whose activations keep leaving the fp16 range pays the fp16x3 pass, a sync and the f32 pass per
-                # launch: stop trying
-                self.f16_latched = True
-                import warnings
-                warnings.warn(f"fp16x3: {self.f16_fallbacks} launches left the fp16 range and were re-run in exact f32; "
-                              "rendering in fp32 from now on (set_precision('bf16x3') has no range limit)")
-            return self._render_launch(rays, boxes, pivot, retiming, only_coarse, thr, bthr, window, replay, force_fp32=True)
-        return out
+        return ops.render_rays(rays, boxes, nets, p, ws, jitter=replay["jitter"] if replay else None,
+                               u=(replay.get("u") if replay else None))
 
     def render_rays(self, rays, only_coarse=False, density_threshold=0.0001, bkgd_density_threshold=0.0,
                     ref_chunk: Optional[int] = None):

@@ -136,7 +136,7 @@ SPACENET_KEYS = ["stage1.0", "stage1.2", "stage1.4", "stage1.6", "stage2.0", "st
 MOTIONNET_KEYS = [f"motion_net.{j}" for j in (0, 2, 4, 6, 8, 10)]
 
 
-PRECISIONS = ("fp32", "fp16x3", "bf16x3")
+PRECISIONS = ("bf16x3", "fp32")   # the library default first
 
 
 class PackedNet:
@@ -151,14 +151,14 @@ class PackedNet:
 
 
 def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cuda", precision: str = "fp32") -> PackedNet:
-    """Repack reference-layout nn.Linear tensors (host copy) and upload.  precision: "fp32" (exact f32 MFMA),
-    "fp16x3" (two fp16 pieces per operand, three MFMAs; |W| < 234, activations < 65520) or "bf16x3" (three bf16 pieces
-    per operand, six MFMAs, two accumulators: the full fp32 significand and exponent range; the stage kernel only)."""
+    """Repack reference-layout nn.Linear tensors (host copy) and upload.  precision: "fp32" (exact f32 MFMA) or "bf16x3"
+    (three bf16 pieces per operand, six MFMAs, two accumulators: the full fp32 significand and exponent range; the stage
+    kernel only)."""
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
     lib = hip.lib()
-    size_fn = {"fp32": lib.stnerf_packed_bytes, "fp16x3": lib.stnerf_packed_bytes_f16x3, "bf16x3": lib.stnerf_packed_bytes_bf16x3}[precision]
-    pack_fn = {"fp32": lib.stnerf_pack_net, "fp16x3": lib.stnerf_pack_net_f16x3, "bf16x3": lib.stnerf_pack_net_bf16x3}[precision]
+    size_fn = {"fp32": lib.stnerf_packed_bytes, "bf16x3": lib.stnerf_packed_bytes_bf16x3}[precision]
+    pack_fn = {"fp32": lib.stnerf_pack_net, "bf16x3": lib.stnerf_pack_net_bf16x3}[precision]
     nbytes = size_fn(kind)
     if nbytes < 0:
         hip.check(int(nbytes), "stnerf_packed_bytes")
@@ -255,8 +255,7 @@ def _worklist(ray_list, ray_count):
 
 
 def spacenet_fwd(net: PackedNet, xyz: Tensor, dirs: Tensor, times: Optional[Tensor], raw: Tensor,
-                 ray_list: Optional[Tensor] = None, ray_count: Optional[Tensor] = None,
-                 overflow: Optional[Tensor] = None) -> Tensor:
+                 ray_list: Optional[Tensor] = None, ray_count: Optional[Tensor] = None) -> Tensor:
     """xyz (n,ns,3), dirs (n,3), times (n,) | None, raw (n,ns,4) out; all may be strided views whose
     dim 0 is the ray.  Writes raw {r,g,b,sigma} for the listed rays.  modeling/spacenet.py:101-160."""
     n, ns = xyz.shape[0], xyz.shape[1]
@@ -274,15 +273,10 @@ def spacenet_fwd(net: PackedNet, xyz: Tensor, dirs: Tensor, times: Optional[Tens
     else:
         tp, ts = C.c_void_p(0), 0
     lp, cp = _worklist(ray_list, ray_count)
-    if net.precision == "fp16x3":   # overflow: int32 (1,) tensor OR-ed with 1 if an output is not finite (fp16 range left)
-        hip.check(hip.lib().stnerf_spacenet_fwd_f16x3(net.kind, hip.dptr(net.blob), n, ns, lp, cp, xp, xs, dp, ds, tp, ts, rp, rs,
-                                                      hip.dptr(overflow, torch.int32, "overflow"), hip.stream_ptr()),
-                  "stnerf_spacenet_fwd_f16x3")
-    else:
-        # workspace of the per-ray part of rgb_net.1 (stnerf_rgb_ray_bias): one row of 128 floats per ray
-        ray_bias = torch.empty(n, 128, dtype=torch.float32, device=raw.device)
-        hip.check(hip.lib().stnerf_spacenet_fwd(net.kind, hip.dptr(net.blob), n, ns, lp, cp, xp, xs, dp, ds, tp, ts, rp, rs,
-                                                hip.dptr(ray_bias), hip.stream_ptr()), "stnerf_spacenet_fwd")
+    # workspace of the per-ray part of rgb_net.1 (stnerf_rgb_ray_bias): one row of 128 floats per ray
+    ray_bias = torch.empty(n, 128, dtype=torch.float32, device=raw.device)
+    hip.check(hip.lib().stnerf_spacenet_fwd(net.kind, hip.dptr(net.blob), n, ns, lp, cp, xp, xs, dp, ds, tp, ts, rp, rs,
+                                            hip.dptr(ray_bias), hip.stream_ptr()), "stnerf_spacenet_fwd")
     return raw
 
 
@@ -307,7 +301,7 @@ def rgb_ray_bias(net: PackedNet, dirs: Tensor, times: Optional[Tensor], ray_list
 
 def motionnet_fwd(net: PackedNet, xyz: Tensor, times: Tensor, flow: Optional[Tensor] = None,
                   add_to_xyz: bool = True, ray_list: Optional[Tensor] = None, ray_count: Optional[Tensor] = None,
-                  plain_time: bool = False, overflow: Optional[Tensor] = None):
+                  plain_time: bool = False):
     """xyz (n,ns,3) (updated in place if add_to_xyz), times (n,), flow (n,ns,3) out | None.
     modeling/motion_net.py:34-71 + layered_rfrender.py:355-356.  plain_time = MotionNet(input_time=False):
     the time column is encoded as given instead of lerping the encodings of floor(t) and floor(t)+1."""
@@ -323,13 +317,8 @@ def motionnet_fwd(net: PackedNet, xyz: Tensor, times: Tensor, flow: Optional[Ten
         fp, fs = C.c_void_p(0), 0
     lp, cp = _worklist(ray_list, ray_count)
     flags = (hip.MOTION_ADD_TO_XYZ if add_to_xyz else 0) | (hip.MOTION_PLAIN_TIME if plain_time else 0)
-    if net.precision == "fp16x3":
-        hip.check(hip.lib().stnerf_motionnet_fwd_f16x3(hip.dptr(net.blob), n, ns, lp, cp, xp, xs, tp, ts, fp, fs, flags,
-                                                       hip.dptr(overflow, torch.int32, "overflow"), hip.stream_ptr()),
-                  "stnerf_motionnet_fwd_f16x3")
-    else:
-        hip.check(hip.lib().stnerf_motionnet_fwd(hip.dptr(net.blob), n, ns, lp, cp, xp, xs, tp, ts, fp, fs, flags,
-                                                 hip.stream_ptr()), "stnerf_motionnet_fwd")
+    hip.check(hip.lib().stnerf_motionnet_fwd(hip.dptr(net.blob), n, ns, lp, cp, xp, xs, tp, ts, fp, fs, flags,
+                                             hip.stream_ptr()), "stnerf_motionnet_fwd")
     return flow
 
 
@@ -471,7 +460,7 @@ def render_workspace_bytes(n: int, l: int, n1: int, n2: int, only_coarse: bool) 
 
 
 def render_rays(rays: Tensor, boxes: Tensor, nets: "hip.Nets", params: "hip.RenderParams", workspace: Tensor,
-                jitter: Optional[Tensor] = None, u: Optional[Tensor] = None, overflow: Optional[Tensor] = None):
+                jitter: Optional[Tensor] = None, u: Optional[Tensor] = None):
     """One call = the whole chunk pipeline (stnerf_render_rays).  Returns mixed_fine (n,5), mixed_coarse (n,5),
     layer_fine (n,l,5), layer_coarse (n,l,5), mask (n,l) uint8 (fine outputs alias the coarse ones if only_coarse)."""
     n, l = rays.shape[0], params.l
@@ -491,8 +480,7 @@ def render_rays(rays: Tensor, boxes: Tensor, nets: "hip.Nets", params: "hip.Rend
                                            hip.dptr(jitter, name="jitter"), hip.dptr(u, name="u"),
                                            hip.dptr(workspace, torch.uint8, "workspace"), workspace.numel(),
                                            hip.dptr(mix_f), hip.dptr(mix_c), hip.dptr(lo_f), hip.dptr(lo_c),
-                                           hip.dptr(mask, torch.uint8), hip.dptr(overflow, torch.int32, "overflow"),
-                                           hip.stream_ptr()), "stnerf_render_rays")
+                                           hip.dptr(mask, torch.uint8), hip.stream_ptr()), "stnerf_render_rays")
     if params.only_coarse:
         return mix_c, mix_c, lo_c, lo_c, mask
     return mix_f, mix_c, lo_f, lo_c, mask

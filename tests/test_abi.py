@@ -176,12 +176,16 @@ int main(void) {
 
 def test_render_workspace_query_and_argument_errors(lib):
     nb = lib.stnerf_render_workspace_bytes(1000, 3, 64, 64, 0)
-    floats = 1000 * 3 * (64 * (1 + 3 + 4 + 1) + 128 * (1 + 3 + 4) + 128)           # + 128 per (ray, layer): rgb_net.1's per-ray part
+    # per (ray, layer): the coarse block t + xyz + raw + weights = 9 n1 floats, which the fine network outputs (4 S) are written
+    # over once the resampler has read it; fine depths + points (1 + 3) S; rgb_net.1's per-ray part (128)
+    floats = 1000 * 3 * (max(64 * (1 + 3 + 4 + 1), 128 * 4) + 128 * (1 + 3) + 128)
     assert nb >= 4 * floats and nb < 4 * floats + 3 * 1000 * 4 + 1000 + 8192      # + ray lists, one flag byte per ray, counters, alignment
+    old = 1000 * 3 * (64 * (1 + 3 + 4 + 1) + 128 * (1 + 3 + 4) + 128)             # (round 3: every buffer on its own)
+    assert nb < 0.72 * 4 * old
     assert lib.stnerf_render_workspace_bytes(1000, 3, 64, 64, 1) < nb
     assert lib.stnerf_render_workspace_bytes(10, 99, 64, 64, 0) == hip.EINVAL
     null = C.c_void_p(0)
-    assert lib.stnerf_render_rays(null, 4, null, 0, None, None, null, null, null, 0, null, null, null, null, null, null, null) == hip.EINVAL
+    assert lib.stnerf_render_rays(null, 4, null, 0, None, None, null, null, null, 0, null, null, null, null, null, null) == hip.EINVAL
 
 
 def test_composite_launch_plan(lib):

@@ -182,7 +182,7 @@ def test_spacenet_vs_fp64_oracle(ops, use_time, deep):
     assert e_gpu <= 4 * e_cpu + 1e-6, (e_gpu, e_cpu)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("include_input, use_dir, use_time", [(False, True, True), (True, False, True), (False, False, False)])
 def test_spacenet_flavours_without_raw_input_or_direction(ops, precision, include_input, use_dir, use_time):
     """TKERNEL_INC_RAW=False / USE_DIR=False are packed as zero weight columns (ops._pe_columns): same kernels."""

@@ -148,9 +148,10 @@ def flatten(out):
     return d
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])     # the library default, and the exact f32 MFMA arithmetic
 @pytest.mark.parametrize("name", FWD_CASES)
-def test_forward_matches_reference(name):
-    run_forward_case(name, precision="fp32")
+def test_forward_matches_reference(name, precision):
+    run_forward_case(name, precision=precision)
 
 
 def run_forward_case(name, precision):

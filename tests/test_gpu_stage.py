@@ -5,7 +5,7 @@ modeling/layered_rfrender.py:340-418,495-576.  Needs an MI355X: `pytest -m gpu`.
 
 Bars:
   * both: |err| <= 2e-5 |ref| + 2e-5 scale against an fp64 evaluation (the tolerance of tests/test_gpu_ops.py);
-  * exact f32: no further from fp64 than 4 x the fp32 CPU chain (ATen addmm) is -- the round-2 bar;
+  * exact f32: no further from fp64 than 3 x the fp32 CPU chain (ATen addmm) is (measured <= 2.5 x);
   * bf16x3: no further from fp64 than the fp32 CPU chain is -- rms AND max, sigma and rgb, on plain and on deformed layers.
     Measured (MI355X, this file, `-s` prints every figure): where the networks' own arithmetic sets the error -- layers
     without deformation -- sigma 0.42 .. 0.58 x the fp32 chain's rms error (max 0.37 .. 0.45 x), rgb 0.63 x (deep_rgb) ..
@@ -24,6 +24,8 @@ pytestmark = pytest.mark.gpu
 
 NET_RTOL, NET_ATOL = 2e-5, 2e-5
 BX_MAX_RATIO, BX_RMS_RATIO = 1.15, 1.01   # bf16x3: error vs fp64 relative to the fp32 CPU chain's own (see above)
+F32_MAX_RATIO = 3.0                       # exact f32: measured 1.0 - 1.5 x (sigma), 1.9 - 2.5 x (rgb: 256-term dot products summed in
+                                          # the MFMA's k order against ATen's blocked order) -- a doubled head error does not pass
 
 
 @pytest.fixture(scope="module")
@@ -124,7 +126,7 @@ def test_mlp_stage_vs_fp64_oracle(ops, precision, deep, bkgd_deform, ns, n):
         if precision == "bf16x3":
             assert rm <= BX_MAX_RATIO and rr <= BX_RMS_RATIO, (i, name, rm, rr)
         else:
-            assert rm <= 4.0, (i, name, rm, rr)
+            assert rm <= F32_MAX_RATIO, (i, name, rm, rr)
     # the same launch again: same bits (the queue's dynamic scheduling does not touch the arithmetic)
     raw2 = torch.full((n, l, ns, 4), 7.0, device="cuda")
     for ly, i in zip(layers, list(range(1, l)) + [0]):
@@ -134,7 +136,7 @@ def test_mlp_stage_vs_fp64_oracle(ops, precision, deep, bkgd_deform, ns, n):
 
 
 def test_bf16x3_operands_have_no_range_limits(ops):
-    """fp16x3 needs |W| < 234 and activations < 65520; bf16x3 keeps fp32's exponent range: weights of magnitude 1e3 and
+    """(The retired split-fp16 mode needed |W| < 234 and activations < 65520.)  bf16x3 keeps fp32's exponent range: weights of magnitude 1e3 and
     activations of 1e6+ go through, to the accuracy of the fp32 chain (x 1.5: the scene is about range -- its last backbone
     layer divides 1e6-sized activations by 1.2e5, and both evaluations are at the mercy of that cancellation)."""
     torch.manual_seed(5)
@@ -144,7 +146,7 @@ def test_bf16x3_operands_have_no_range_limits(ops):
     sd["net.stage1.2.weight"] = sd["net.stage1.2.weight"] * 40.0       # ... 1e6 behind the second layer
     sd["net.stage2.4.weight"] = sd["net.stage2.4.weight"] / 120000.0   # and back, so that the heads stay O(1)
     with pytest.raises(ValueError):
-        ops.pack_spacenet(sd, "net", precision="fp16x3")
+        ops.pack_spacenet(sd, "net", precision="fp16x3")            # retired: not a precision any more
     n, ns = 300, 32
     xyz = (torch.rand(n, ns, 3) - 0.5) * 5.0
     dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
@@ -179,18 +181,9 @@ def test_mlp_stage_rejects_mixed_packings(ops):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# bf16x3 through the drop-in boundary: the reference's own outputs, same tolerances as the exact-f32 mode
+# bf16x3 through the drop-in boundary (every reference fixture in both arithmetics: tests/test_gpu_render.py::
+# test_forward_matches_reference, tests/test_gpu_round2.py::test_forward_matches_reference_round2_fixtures)
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["fwd_c1", "fwd_c3", "fwd_c3_64_64", "fwd_c3_90_30", "fwd_edit", "fwd_hide", "fwd_nonretime",
-                                  "fwd_only_coarse", "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet",
-                                  "fwd_deep_rgb", "fwd_no_raw_no_dir", "fwd_grazing", "fwd_c4", "fwd_c5"])
-def test_whole_path_bf16x3_matches_reference_fixtures(name):
-    """LayeredRFRender.forward / layered_batchify_ray in bf16x3 precision against the fixtures the reference itself wrote
-    (tests/golden/make_golden.py), with the tolerances and the measured fine-stage bar of the exact-f32 mode."""
-    import test_gpu_render as R
-    R.run_forward_case(name, precision="bf16x3")
-
-
 def test_c2_full_view_bf16x3_agrees_with_fp32():
     """C2 (512x512, 64+64) rendered in both arithmetics with the same device RNG stream."""
     import test_gpu_render as R
