@@ -290,6 +290,37 @@ int stnerf_resample(const float* t, const float* weights, int64_t n, int l, int 
                     float* t_fine, float* xyz_fine, float* z_new, int32_t* inds, float* cdf,
                     stnerf_stream_t stream);
 
+/* ---- backward pass of the two networks (csrc/train.hip) ------------------------------------------------------
+ * What engine/layered_trainer.py:192-217's loss.backward() does to modeling/spacenet.py:45-86 / modeling/motion_net.py:20-32
+ * through ATen (addmm_backward: two mm + a sum per nn.Linear), as f32 MFMA GEMMs (v_mfma_f32_32x32x2_f32, exact fp32
+ * products and accumulation) on matrices the caller owns.  stnerf_amd.modeling.autograd strings them into
+ * torch.autograd.Functions for SpaceNet / MotionNet: the forward is recomputed chunk by chunk with every layer's input kept
+ * (sample-major [rows][ld]), then walked backwards.  All row strides (ld*) in floats; operand rows that are read with 16-byte
+ * vectors need ld % 4 == 0, a 16-byte aligned base and allocations covering whole vectors (pad columns: weights zero).
+ *
+ * y[m][n] = act(sum_k x[m][k] w[n][k] + bias[n])   (w: the reference's nn.Linear layout, out x in; relu = 0 / 1) */
+int stnerf_train_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int64_t m, int n, int k,
+                            int relu, float* y, int64_t ldy, stnerf_stream_t stream);
+/* dx[m][k] (+)= (sum_n dy[m][n] w[n][k]) * (mask[m][k] > 0): `mask` = the stored post-ReLU tensor that fed this layer (the
+ * ReLU backward of the PRODUCING layer folded in; NULL: none); accumulate = 1 adds to dx (a tensor with two consumers). */
+int stnerf_train_linear_dx(const float* dy, int64_t lddy, const float* w, int64_t ldw, int64_t m, int n, int k, const float* mask,
+                           int64_t ldmask, int accumulate, float* dx, int64_t lddx, stnerf_stream_t stream);
+/* dw[n][k] (+)= sum_m dy[m][n] x[m][k];  db[n] (+)= sum_m dy[m][n] (db may be NULL).  The samples are cut into <= 64 slices
+ * reduced by separate workgroups into `workspace`, then summed in slice order: deterministic, no atomics. */
+int64_t stnerf_train_dw_workspace_bytes(int64_t m, int n, int k);
+int stnerf_train_linear_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t m, int n, int k, float* dw, int64_t lddw,
+                           float* db, int accumulate, void* workspace, int64_t workspace_bytes, stnerf_stream_t stream);
+/* Positional encoding (utils/dimension_kernel.py:54-73) of x[src][0..dim) into columns [col0, col0 + dim (include_input + 2
+ * n_freq)) of y[rows][ldy] (a column block of a layer's input matrix: the skip connection of modeling/spacenet.py:128 and
+ * rgb_net's input :141-151 are assembled in place).  rows_per_src = ns repeats a ray's encoding on its ns samples (:115,118);
+ * relu = 1 applies rgb_net's leading in-place ReLU to the encoded columns (:80); lerp_col >= 0 treats that input column as
+ * a frame id and blends the encodings of floor(t) and floor(t) + 1 (modeling/motion_net.py:52-60), -1: none. */
+int stnerf_train_encode(const float* x, int64_t ldx, int dim, int n_freq, int include_input, int64_t rows, int rows_per_src, int relu,
+                        int lerp_col, float* y, int64_t ldy, int col0, stnerf_stream_t stream);
+/* dx[row][j] (+)= sum_features dy[row][col0 + feature] d enc_feature / d x_j for the first dim_out input columns. */
+int stnerf_train_encode_bwd(const float* x, int64_t ldx, int dim, int n_freq, int include_input, int64_t rows, const float* dy,
+                            int64_t lddy, int col0, int dim_out, int accumulate, float* dx, int64_t lddx, stnerf_stream_t stream);
+
 /* The whole chunk pipeline of LayeredRFRender.forward (modeling/layered_rfrender.py:141-734) behind one call:
  * coarse sampler -> mask compaction -> [MotionNet] -> SpaceNets -> composite/merge -> resample -> [MotionNet] ->
  * fine SpaceNets -> composite/merge, all enqueued on `stream` into a caller-provided workspace.  Host-side

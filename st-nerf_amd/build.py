@@ -29,6 +29,7 @@ SOURCES = [
     ("mlp_bf16x3.hip", []),
     ("stage_entry.hip", []),
     ("pipeline.hip", []),
+    ("train.hip", []),
 ]
 EXTRA = os.environ.get("STNERF_EXTRA_FLAGS", "").split()   # e.g. -DSTNERF_PHASE_PROF (development only)
 COMMON = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -92,6 +92,16 @@ _PROTOS = {
                                        c_i64, c_f32p, c_i64, C.c_int, C.c_void_p]),
     "stnerf_mlp_stage": (C.c_int, [C.POINTER(StageLayer), C.c_int, c_i64, C.c_int, c_f32p, c_i64, c_i64, c_i64, c_i64, C.c_int,
                                    C.c_void_p, c_f32p, C.c_void_p]),
+    "stnerf_train_linear_fwd": (C.c_int, [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, c_i64, C.c_void_p]),
+    "stnerf_train_linear_dx": (C.c_int, [c_f32p, c_i64, c_f32p, c_i64, c_i64, C.c_int, C.c_int, c_f32p, c_i64, C.c_int, c_f32p, c_i64,
+                                         C.c_void_p]),
+    "stnerf_train_dw_workspace_bytes": (c_i64, [c_i64, C.c_int, C.c_int]),
+    "stnerf_train_linear_dw": (C.c_int, [c_f32p, c_i64, c_f32p, c_i64, c_i64, C.c_int, C.c_int, c_f32p, c_i64, c_f32p, C.c_int, C.c_void_p,
+                                         c_i64, C.c_void_p]),
+    "stnerf_train_encode": (C.c_int, [c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, c_i64, C.c_int,
+                                      C.c_void_p]),
+    "stnerf_train_encode_bwd": (C.c_int, [c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_i64, c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p,
+                                          c_i64, C.c_void_p]),
     "stnerf_encode": (C.c_int, [c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "stnerf_gen_weight": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "stnerf_composite": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_i64, C.c_int, C.c_int, C.POINTER(CompositeParams),

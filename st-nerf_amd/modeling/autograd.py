@@ -1,0 +1,216 @@
+"""torch.autograd.Functions for the two networks: what ``loss.backward()`` of
+engine/layered_trainer.py:192-217 needs from modeling/spacenet.py:101-160 and modeling/motion_net.py:34-71.
+
+Forward = the fused inference kernel (no activation is stored).  Backward recomputes the forward a chunk of samples at a time
+with every layer's input kept in a bounded workspace (``CHUNK_SAMPLES`` x ~11 KB), then walks the layers backwards; every
+matrix product -- the recomputed layers, dX = dY W, dW += dY^T X -- is the hand-written f32 MFMA GEMM of csrc/train.hip
+(``ops.train_linear_*``), the encodings and their chain rule are ``ops.train_encode*``.  PyTorch only owns the buffers.
+
+Gradients are returned for the sample points (``pos`` / MotionNet's xyz) and for every weight and bias; directions and
+frame ids are inputs of the renderer, not parameters (the reference's POSE_REFINEMENT / USE_DEFORM_VIEW are outside this
+path), and get none.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from stnerf_amd import ops
+
+CHUNK_SAMPLES = 1 << 16          # samples whose activations are kept at a time while recomputing
+
+
+def _pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+def _padded_weight(w: torch.Tensor) -> torch.Tensor:
+    """(n, k) nn.Linear weight -> a view (n, k) of zero-padded (n, round4(k)) storage: 16-byte aligned rows."""
+    n, k = w.shape
+    buf = torch.zeros(n, _pad4(k), dtype=torch.float32, device=w.device)
+    buf[:, :k] = w.detach()
+    return buf[:, :k]
+
+
+def _buf(m: int, cols: int, device) -> torch.Tensor:
+    return torch.empty(m, _pad4(cols), dtype=torch.float32, device=device)
+
+
+class SpaceNetFunction(torch.autograd.Function):
+    """(rgb, sigma) = SpaceNet(pos, dirs, times).  ``flavour`` = (include_input, use_dir, use_time, deep_rgb); ``params`` =
+    weight, bias of stage1.{0,2,4,6}, stage2.{0,2,4}, density_net.0, rgb_net.{1,3[,5,7]} in that order."""
+
+    @staticmethod
+    def forward(ctx, module, pos, dirs, times, *params):
+        n, ns = pos.shape[0], pos.shape[1]
+        raw = torch.empty(n, ns, 4, dtype=torch.float32, device=pos.device)
+        with torch.no_grad():
+            ops.spacenet_fwd(module._packed(), pos.detach().contiguous(), dirs.detach(), times, raw)
+        ctx.module, ctx.has_times = module, times is not None
+        ctx.save_for_backward(pos.detach(), dirs.detach(), times.detach() if times is not None else pos.new_empty(0),
+                              *[p.detach() for p in params])
+        ctx.set_materialize_grads(False)
+        return raw[..., :3], raw[..., 3:]
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_sigma):
+        pos, dirs, times, *params = ctx.saved_tensors
+        m_ = ctx.module
+        inc, use_dir, use_time, deep = m_.include_input, m_.use_dir, m_.use_time, m_.deep_rgb
+        n, ns = pos.shape[0], pos.shape[1]
+        dev = pos.device
+        W = [_padded_weight(params[2 * i]) for i in range(len(params) // 2)]
+        B = [params[2 * i + 1].detach().float().contiguous() for i in range(len(params) // 2)]
+        gW = [torch.zeros_like(params[2 * i], dtype=torch.float32) for i in range(len(params) // 2)]
+        gB = [torch.zeros_like(params[2 * i + 1], dtype=torch.float32) for i in range(len(params) // 2)]
+        d_pos = torch.zeros(n * ns, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        pe = 3 * (int(inc) + 20)
+        dir_w = 3 * (int(inc) + 8) if use_dir else 0
+        time_w = (int(inc) + 20) if use_time else 0
+        n_tail = len(W) - 8                                   # rgb_net: 2 linear layers, 4 with deep_rgb
+        flat_pos = pos.reshape(n * ns, 3)
+        rays_per_chunk = max(1, CHUNK_SAMPLES // ns)
+        for r0 in range(0, n, rays_per_chunk):
+            r1 = min(n, r0 + rays_per_chunk)
+            M = (r1 - r0) * ns
+            x = flat_pos[r0 * ns:r1 * ns]
+            # ---- recompute, keeping every layer's input (modeling/spacenet.py:101-160) -----------------------------------
+            Cc = _buf(M, 256 + pe, dev)                       # [h4 | PE(pos)]: stage2.0's input, the skip connection in place
+            P = Cc[:, 256:256 + pe]
+            ops.train_encode(x, P, 10, inc)
+            H = [_buf(M, 256, dev) for _ in range(3)]
+            ops.train_linear_fwd(P, W[0], B[0], H[0][:, :256], True)
+            ops.train_linear_fwd(H[0][:, :256], W[1], B[1], H[1][:, :256], True)
+            ops.train_linear_fwd(H[1][:, :256], W[2], B[2], H[2][:, :256], True)
+            ops.train_linear_fwd(H[2][:, :256], W[3], B[3], Cc[:, :256], True)
+            G = [_buf(M, 256, dev) for _ in range(2)]
+            R = _buf(M, 256 + dir_w + time_w, dev)            # [g3 | relu(PE(dir)) | relu(PE(t))]: rgb_net's input (:141-151, :80)
+            ops.train_linear_fwd(Cc[:, :256 + pe], W[4], B[4], G[0][:, :256], True)
+            ops.train_linear_fwd(G[0][:, :256], W[5], B[5], G[1][:, :256], True)
+            ops.train_linear_fwd(G[1][:, :256], W[6], B[6], R[:, :256], True)
+            if use_dir:
+                ops.train_encode(dirs[r0:r1], R[:, 256:256 + dir_w], 4, inc, rows_per_src=ns, relu=True)
+            if use_time:
+                ops.train_encode(times[r0:r1].reshape(-1, 1).float(), R[:, 256 + dir_w:256 + dir_w + time_w], 10, inc, rows_per_src=ns,
+                                 relu=True)
+            T = [_buf(M, 128, dev) for _ in range(n_tail - 1)]   # hidden activations of rgb_net
+            src = R[:, :256 + dir_w + time_w]
+            for j in range(n_tail - 1):
+                ops.train_linear_fwd(src, W[8 + j], B[8 + j], T[j][:, :128], True)
+                src = T[j][:, :128]
+            # ---- backwards --------------------------------------------------------------------------------------------------
+            first = r0 == 0
+            acc = not first
+            dA, dB_ = _buf(M, 256, dev), _buf(M, 256, dev)
+            g3 = R[:, :256]
+            have = False                                       # dA[:, :256] holds d(stage2.4 pre-activation) contributions
+            if d_rgb is not None:
+                dO = _buf(M, 3, dev)
+                dO[:, :3] = d_rgb[r0:r1].reshape(M, 3)
+                dy = dO[:, :3]
+                for j in range(n_tail - 1, -1, -1):            # rgb_net's linear layers, last first
+                    xin = T[j - 1][:, :128] if j > 0 else R[:, :256 + dir_w + time_w]
+                    ops.train_linear_dw(dy, xin, gW[8 + j], gB[8 + j], acc)
+                    if j > 0:
+                        dT = _buf(M, 128, dev)
+                        ops.train_linear_dx(dy, W[8 + j], dT[:, :128], mask=T[j - 1][:, :128])
+                        dy = dT[:, :128]
+                    else:                                      # into g3 only: the encodings are not differentiated
+                        ops.train_linear_dx(dy, W[8][:, :256], dA[:, :256], mask=g3)
+                        have = True
+            if d_sigma is not None:
+                dS = _buf(M, 1, dev)
+                dS[:, :1] = d_sigma[r0:r1].reshape(M, 1)
+                ops.train_linear_dw(dS[:, :1], g3, gW[7], gB[7], acc)
+                ops.train_linear_dx(dS[:, :1], W[7], dA[:, :256], mask=g3, accumulate=have)
+                have = True
+            if not have:
+                continue
+            # stage2 (dA = d pre-activation of stage2.4)
+            ops.train_linear_dw(dA[:, :256], G[1][:, :256], gW[6], gB[6], acc)
+            ops.train_linear_dx(dA[:, :256], W[6], dB_[:, :256], mask=G[1][:, :256])
+            ops.train_linear_dw(dB_[:, :256], G[0][:, :256], gW[5], gB[5], acc)
+            ops.train_linear_dx(dB_[:, :256], W[5], dA[:, :256], mask=G[0][:, :256])
+            ops.train_linear_dw(dA[:, :256], Cc[:, :256 + pe], gW[4], gB[4], acc)
+            dP = _buf(M, pe, dev)
+            ops.train_linear_dx(dA[:, :256], W[4][:, :256], dB_[:, :256], mask=Cc[:, :256])       # -> h4 (ReLU of stage1.6)
+            ops.train_linear_dx(dA[:, :256], W[4][:, 256:256 + pe], dP[:, :pe])                   # -> PE(pos), the skip connection
+            # stage1
+            ops.train_linear_dw(dB_[:, :256], H[2][:, :256], gW[3], gB[3], acc)
+            ops.train_linear_dx(dB_[:, :256], W[3], dA[:, :256], mask=H[2][:, :256])
+            ops.train_linear_dw(dA[:, :256], H[1][:, :256], gW[2], gB[2], acc)
+            ops.train_linear_dx(dA[:, :256], W[2], dB_[:, :256], mask=H[1][:, :256])
+            ops.train_linear_dw(dB_[:, :256], H[0][:, :256], gW[1], gB[1], acc)
+            ops.train_linear_dx(dB_[:, :256], W[1], dA[:, :256], mask=H[0][:, :256])
+            ops.train_linear_dw(dA[:, :256], P, gW[0], gB[0], acc)
+            if d_pos is not None:
+                ops.train_linear_dx(dA[:, :256], W[0], dP[:, :pe], accumulate=True)
+                ops.train_encode_bwd(x, dP[:, :pe], d_pos[r0 * ns:r1 * ns], 10, inc)
+        grads: List[Optional[torch.Tensor]] = []
+        for i in range(len(gW)):
+            grads += [gW[i] if ctx.needs_input_grad[4 + 2 * i] else None, gB[i] if ctx.needs_input_grad[5 + 2 * i] else None]
+        return (None, d_pos.reshape(n, ns, 3) if d_pos is not None else None, None, None, *grads)
+
+
+class MotionNetFunction(torch.autograd.Function):
+    """flow = MotionNet([xyz, t]) (modeling/motion_net.py:34-71).  ``params`` = weight, bias of motion_net.{0,2,4,6,8,10}."""
+
+    @staticmethod
+    def forward(ctx, module, xt, *params):
+        rows = xt.shape[0]
+        xyz = xt[:, :3].detach().reshape(rows, 1, 3).contiguous()
+        flow = torch.empty_like(xyz)
+        with torch.no_grad():
+            ops.motionnet_fwd(module._packed("fp32"), xyz, xt[:, 3].detach().contiguous(), flow=flow, add_to_xyz=False,
+                              plain_time=not module.input_time)
+        ctx.module = module
+        ctx.save_for_backward(xt.detach(), *[p.detach() for p in params])
+        return flow.reshape(rows, 3)
+
+    @staticmethod
+    def backward(ctx, d_flow):
+        xt, *params = ctx.saved_tensors
+        m_ = ctx.module
+        inc = m_.pos_dim == 84
+        dev = xt.device
+        rows = xt.shape[0]
+        L = len(params) // 2
+        W = [_padded_weight(params[2 * i]) for i in range(L)]
+        B = [params[2 * i + 1].detach().float().contiguous() for i in range(L)]
+        gW = [torch.zeros_like(params[2 * i], dtype=torch.float32) for i in range(L)]
+        gB = [torch.zeros_like(params[2 * i + 1], dtype=torch.float32) for i in range(L)]
+        d_xt = torch.zeros(rows, 4, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        pe = m_.pos_dim
+        x4 = xt.float().contiguous()
+        for r0 in range(0, rows, CHUNK_SAMPLES):
+            r1 = min(rows, r0 + CHUNK_SAMPLES)
+            M = r1 - r0
+            x = x4[r0:r1]
+            E = _buf(M, pe, dev)
+            ops.train_encode(x, E[:, :pe], 10, inc, lerp_col=3 if m_.input_time else -1)
+            A = [_buf(M, 128, dev) for _ in range(L - 1)]
+            src = E[:, :pe]
+            for j in range(L - 1):
+                ops.train_linear_fwd(src, W[j], B[j], A[j][:, :128], True)
+                src = A[j][:, :128]
+            acc = r0 > 0
+            dO = _buf(M, 3, dev)
+            dO[:, :3] = d_flow[r0:r1]
+            dy = dO[:, :3]
+            for j in range(L - 1, -1, -1):
+                xin = A[j - 1][:, :128] if j > 0 else E[:, :pe]
+                ops.train_linear_dw(dy, xin, gW[j], gB[j], acc)
+                if j > 0:
+                    d_prev = _buf(M, 128, dev)
+                    ops.train_linear_dx(dy, W[j], d_prev[:, :128], mask=A[j - 1][:, :128])
+                    dy = d_prev[:, :128]
+                elif d_xt is not None:
+                    dE = _buf(M, pe, dev)
+                    ops.train_linear_dx(dy, W[0], dE[:, :pe])
+                    # (the frame-id column gets no gradient: the lerp weights are data)
+                    ops.train_encode_bwd(x, dE[:, :pe], d_xt[r0:r1, :3], 10, inc)
+        grads: List[Optional[torch.Tensor]] = []
+        for i in range(L):
+            grads += [gW[i] if ctx.needs_input_grad[2 + 2 * i] else None, gB[i] if ctx.needs_input_grad[3 + 2 * i] else None]
+        return (None, d_xt, *grads)

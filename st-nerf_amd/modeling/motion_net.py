@@ -30,6 +30,13 @@ class MotionNet(nn.Module, _PackedMixin):
     def forward(self, input_0):
         """input_0 (N,L,4) or (N,4) = [x,y,z,t] -> flow (N,L,3) or (N,3).  The time may differ per sample."""
         bins = input_0.dim() > 2
+        if torch.is_grad_enabled() and (input_0.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # training (SURVEY 8(f)4): see stnerf_amd.modeling.autograd
+            from stnerf_amd.modeling.autograd import MotionNetFunction
+            named = dict(self.named_parameters())
+            params = [named[f"{k}.{what}"] for k in ops.MOTIONNET_KEYS for what in ("weight", "bias")]
+            flow = MotionNetFunction.apply(self, input_0.reshape(-1, 4).float(), *params)
+            return flow.reshape(*input_0.shape[:-1], 3)
         x = input_0.reshape(-1, 1, 4)
         xyz = x[..., :3].contiguous()
         flow = torch.empty_like(xyz)

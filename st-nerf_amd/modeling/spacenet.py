@@ -41,6 +41,12 @@ class SpaceNet(nn.Module, _PackedMixin):
             self.rgb_net = nn.Sequential(nn.ReLU(inplace=True), nn.Linear(bd + self.dir_dim + self.time_dim, hd),
                                          nn.ReLU(inplace=True), nn.Linear(hd, 3))
 
+    def training_parameters(self):
+        """weight, bias of every nn.Linear in evaluation order (ops.SPACENET_KEYS [+ rgb_net.5, rgb_net.7 with deep_rgb])."""
+        named = dict(self.named_parameters())
+        keys = ops.SPACENET_KEYS + (["rgb_net.5", "rgb_net.7"] if self.deep_rgb else [])
+        return [named[f"{k}.{what}"] for k in keys for what in ("weight", "bias")]
+
     def _pack(self, sd, dev):
         return ops.pack_spacenet({"net." + k: v for k, v in sd.items()}, "net", dev, self.precision)
 
@@ -54,6 +60,13 @@ class SpaceNet(nn.Module, _PackedMixin):
         x = x.contiguous()
         raw = torch.empty(n, s, 4, dtype=torch.float32, device=x.device)
         tm = times.reshape(n).contiguous() if (self.use_time and times is not None) else None
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # training: fused forward, recompute-and-walk-back backward on the f32 MFMA GEMMs of csrc/train.hip
+            from stnerf_amd.modeling.autograd import SpaceNetFunction
+            if self.use_time and tm is None:
+                raise ValueError("this SpaceNet takes time: pass times")
+            rgb, sig = SpaceNetFunction.apply(self, x, rays[:, 3:6], tm, *self.training_parameters())
+            return (rgb, sig) if bins else (rgb[:, 0], sig[:, 0])
         ops.spacenet_fwd(self._packed(), x, rays[:, 3:6], tm, raw)
         rgb, sig = raw[..., :3], raw[..., 3:]
         return (rgb, sig) if bins else (rgb[:, 0], sig[:, 0])

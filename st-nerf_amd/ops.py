@@ -484,3 +484,83 @@ def render_rays(rays: Tensor, boxes: Tensor, nets: "hip.Nets", params: "hip.Rend
     if params.only_coarse:
         return mix_c, mix_c, lo_c, lo_c, mask
     return mix_f, mix_c, lo_f, lo_c, mask
+
+
+# ---------------------------------------------------------------------------------------- 8(f)4: training GEMMs
+def _mat(t: Tensor, name: str, vec: bool = False):
+    """(pointer, row stride) of a 2-D fp32 device view whose columns are dense; `vec`: read with 16-byte vectors."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != torch.float32 or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"{name}: expected a 2-D float32 view with dense columns, got {t.dtype} {tuple(t.shape)} strides {t.stride()}")
+    if vec and (t.stride(0) % 4 or t.data_ptr() % 16):
+        raise ValueError(f"{name}: rows must be 16-byte aligned (row stride {t.stride(0)} floats, pointer % 16 = {t.data_ptr() % 16})")
+    return C.c_void_p(t.data_ptr()), t.stride(0)
+
+
+def train_linear_fwd(x: Tensor, w: Tensor, bias: Optional[Tensor], y: Tensor, relu: bool) -> Tensor:
+    """y (m,n) = act(x (m,k) @ w (n,k).T + bias): stnerf_train_linear_fwd (f32 MFMA).  x / w: views into padded storage."""
+    (m, k), n = x.shape, w.shape[0]
+    xp, ldx = _mat(x, "x", True)
+    wp, ldw = _mat(w, "w", True)
+    yp, ldy = _mat(y, "y")
+    if w.shape[1] != k or tuple(y.shape) != (m, n):
+        raise ValueError(f"train_linear_fwd: x {tuple(x.shape)}, w {tuple(w.shape)}, y {tuple(y.shape)}")
+    hip.check(hip.lib().stnerf_train_linear_fwd(xp, ldx, wp, ldw, hip.dptr(bias, name="bias"), m, n, k, int(relu), yp, ldy,
+                                                hip.stream_ptr()), "stnerf_train_linear_fwd")
+    return y
+
+
+def train_linear_dx(dy: Tensor, w: Tensor, dx: Tensor, mask: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """dx (m,k) (+)= (dy (m,n) @ w (n,k)) * (mask > 0): stnerf_train_linear_dx."""
+    (m, n), k = dy.shape, w.shape[1]
+    dp, lddy = _mat(dy, "dy", True)
+    wp, ldw = _mat(w, "w", True)
+    xp, lddx = _mat(dx, "dx")
+    mp, ldm = _mat(mask, "mask") if mask is not None else (C.c_void_p(0), 0)
+    if w.shape[0] != n or tuple(dx.shape) != (m, k) or (mask is not None and tuple(mask.shape) != (m, k)):
+        raise ValueError(f"train_linear_dx: dy {tuple(dy.shape)}, w {tuple(w.shape)}, dx {tuple(dx.shape)}")
+    hip.check(hip.lib().stnerf_train_linear_dx(dp, lddy, wp, ldw, m, n, k, mp, ldm, int(accumulate), xp, lddx, hip.stream_ptr()),
+              "stnerf_train_linear_dx")
+    return dx
+
+
+def train_linear_dw(dy: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], accumulate: bool) -> None:
+    """dw (n,k) (+)= dy (m,n).T @ x (m,k); db (n,) (+)= dy.sum(0): stnerf_train_linear_dw (deterministic split reduction)."""
+    (m, n), k = dy.shape, x.shape[1]
+    dp, lddy = _mat(dy, "dy", True)
+    xp, ldx = _mat(x, "x", True)
+    wp, lddw = _mat(dw, "dw")
+    if x.shape[0] != m or tuple(dw.shape) != (n, k) or (db is not None and tuple(db.shape) != (n,)):
+        raise ValueError(f"train_linear_dw: dy {tuple(dy.shape)}, x {tuple(x.shape)}, dw {tuple(dw.shape)}")
+    need = int(hip.lib().stnerf_train_dw_workspace_bytes(m, n, k))
+    ws = torch.empty(need, dtype=torch.uint8, device=dy.device)
+    hip.check(hip.lib().stnerf_train_linear_dw(dp, lddy, xp, ldx, m, n, k, wp, lddw, hip.dptr(db, name="db"), int(accumulate),
+                                               hip.dptr(ws, torch.uint8, "workspace"), need, hip.stream_ptr()), "stnerf_train_linear_dw")
+
+
+def train_encode(x: Tensor, y: Tensor, n_freq: int, include_input: bool = True, rows_per_src: int = 1, relu: bool = False,
+                 lerp_col: int = -1) -> Tensor:
+    """Positional encoding of x (src, dim) into the columns of the view y (rows, dim (include_input + 2 n_freq)):
+    stnerf_train_encode (rows = src * rows_per_src)."""
+    xp, ldx = _mat(x, "x")
+    yp, ldy = _mat(y, "y")
+    dim, rows = x.shape[1], y.shape[0]
+    if y.shape[1] != dim * (int(include_input) + 2 * n_freq) or rows != x.shape[0] * rows_per_src:
+        raise ValueError(f"train_encode: x {tuple(x.shape)} -> y {tuple(y.shape)}")
+    hip.check(hip.lib().stnerf_train_encode(xp, ldx, dim, n_freq, int(include_input), rows, rows_per_src, int(relu), lerp_col, yp, ldy, 0,
+                                            hip.stream_ptr()), "stnerf_train_encode")
+    return y
+
+
+def train_encode_bwd(x: Tensor, dy: Tensor, dx: Tensor, n_freq: int, include_input: bool = True, accumulate: bool = False) -> Tensor:
+    """dx (rows, dim_out) (+)= d enc / d x . dy for the first dim_out = dx.shape[1] input columns: stnerf_train_encode_bwd."""
+    xp, ldx = _mat(x, "x")
+    dp, lddy = _mat(dy, "dy")
+    op, lddx = _mat(dx, "dx")
+    dim, rows = x.shape[1], x.shape[0]
+    if dy.shape[1] != dim * (int(include_input) + 2 * n_freq) or dy.shape[0] != rows or dx.shape[0] != rows or dx.shape[1] > dim:
+        raise ValueError(f"train_encode_bwd: x {tuple(x.shape)}, dy {tuple(dy.shape)}, dx {tuple(dx.shape)}")
+    hip.check(hip.lib().stnerf_train_encode_bwd(xp, ldx, dim, n_freq, int(include_input), rows, dp, lddy, 0, dx.shape[1], int(accumulate),
+                                                op, lddx, hip.stream_ptr()), "stnerf_train_encode_bwd")
+    return dx

@@ -1,0 +1,263 @@
+"""the backward pass of SpaceNet / MotionNet (csrc/train.hip, stnerf_amd.modeling.autograd) --
+what engine/layered_trainer.py:192-217's loss.backward() asks of modeling/spacenet.py:101-160 and
+modeling/motion_net.py:34-71.  Needs an MI355X: `pytest -m gpu`.
+
+Reference = torch.autograd through the CPU oracle's restatement of the two networks in float64 (the same graph the
+reference's nn.Modules build).  Bars:
+  * every gradient tensor (all weights, all biases, the sample points) within 2e-5 of its fp64 value, relative to the
+    tensor's largest entry;
+  * no further from fp64 than 3 x the reference's own fp32 autograd is (the f32 MFMA GEMMs accumulate in another order);
+  * the GEMM building blocks against fp64 matmuls on ragged shapes, masks, accumulation, strided column blocks."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stnerf_oracle as O
+from stnerf_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+GRAD_RTOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from stnerf_amd import ops as _ops
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return _ops
+
+
+def _padded(t, extra=0):
+    """A (rows, cols) view of 16-byte aligned padded storage holding t."""
+    rows, cols = t.shape
+    buf = torch.full((rows, (cols + 3) // 4 * 4 + extra), float("nan"), device="cuda")
+    buf[:, :cols] = t.cuda()
+    return buf[:, :cols]
+
+
+def _rel(got, ref):
+    return float((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("m, n, k", [(1, 1, 4), (127, 3, 128), (129, 256, 63), (1000, 128, 319), (300, 256, 256), (2500, 1, 256), (64, 130, 84)])
+def test_linear_forward_dx_dw_match_fp64_matmuls(ops, m, n, k):
+    g = torch.Generator().manual_seed(m + n + k)
+    x, w, b = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g)
+    dy = torch.randn(m, n, generator=g)
+    xin = torch.relu(torch.randn(m, k, generator=g))                     # the stored post-ReLU tensor that fed the layer
+    xd, wd, dyd, maskd = _padded(x, 4), _padded(w), _padded(dy), _padded(xin)
+    x64, w64, dy64 = x.double(), w.double(), dy.double()
+    for relu in (False, True):
+        y = torch.full((m, n + 5), 7.0, device="cuda")                  # a column block of a wider matrix
+        ops.train_linear_fwd(xd, wd, b.cuda(), y[:, 2:2 + n], relu)
+        ref = x64 @ w64.T + b.double()
+        assert _rel(y[:, 2:2 + n], torch.relu(ref) if relu else ref) <= 2e-6
+        assert bool((y[:, :2] == 7.0).all()) and bool((y[:, 2 + n:] == 7.0).all())
+    dx = torch.full((m, k + 3), 7.0, device="cuda")
+    ops.train_linear_dx(dyd, wd, dx[:, 1:1 + k], mask=maskd)
+    ref = (dy64 @ w64) * (xin > 0)
+    assert _rel(dx[:, 1:1 + k], ref) <= 2e-6 and bool((dx[:, :1] == 7.0).all()) and bool((dx[:, 1 + k:] == 7.0).all())
+    ops.train_linear_dx(dyd, wd, dx[:, 1:1 + k], accumulate=True)        # second consumer, no mask
+    assert _rel(dx[:, 1:1 + k], ref + dy64 @ w64) <= 2e-6
+    dw, db = torch.full((n, k), 0.5, device="cuda"), torch.full((n,), -0.25, device="cuda")
+    ops.train_linear_dw(dyd, xd, dw, db, accumulate=True)
+    assert _rel(dw, 0.5 + dy64.T @ x64) <= 4e-6 and _rel(db, -0.25 + dy64.sum(0)) <= 4e-6
+    dw2 = torch.empty(n, k, device="cuda")
+    ops.train_linear_dw(dyd, xd, dw2, None, accumulate=False)
+    ops.train_linear_dw(dyd, xd, dw, db, accumulate=False)
+    assert torch.equal(dw, dw2)                                          # deterministic: same bits every time
+
+
+def test_dw_reduction_over_many_samples_is_deterministic_and_accurate(ops):
+    g = torch.Generator().manual_seed(3)
+    m, n, k = 150_000, 128, 256                                          # > 64 slices of 2048: the capped split
+    x, dy = torch.relu(torch.randn(m, k, generator=g)), torch.randn(m, n, generator=g)
+    xd, dyd = x.cuda(), dy.cuda()
+    a, b = torch.empty(n, k, device="cuda"), torch.empty(n, k, device="cuda")
+    da, db = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+    ops.train_linear_dw(dyd, xd, a, da, False)
+    ops.train_linear_dw(dyd, xd, b, db, False)
+    assert torch.equal(a, b) and torch.equal(da, db)
+    ref = dy.double().T @ x.double()
+    assert _rel(a, ref) <= 1e-5 and _rel(da, dy.double().sum(0)) <= 1e-5
+    fp32 = dy.T @ x
+    assert float((a.cpu().double() - ref).abs().max()) <= 3 * float((fp32.double() - ref).abs().max()) + 1e-6
+
+
+def test_encode_and_its_chain_rule(ops):
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(500, 3, generator=g) - 0.5) * 6.0
+    for inc in (True, False):
+        w = 3 * (int(inc) + 20)
+        y = torch.full((500, w + 9), 7.0, device="cuda")
+        ops.train_encode(x.cuda(), y[:, 4:4 + w], 10, inc)
+        ref = O.positional_encoding(x.double(), 10, inc)
+        assert float((y[:, 4:4 + w].cpu().double() - ref).abs().max()) <= 2e-6 and bool((y[:, :4] == 7.0).all())
+        dy = torch.randn(500, w, generator=g)
+        x64 = x.double().requires_grad_(True)
+        (O.positional_encoding(x64, 10, inc) * dy.double()).sum().backward()
+        dx = torch.zeros(500, 3, device="cuda")
+        ops.train_encode_bwd(x.cuda(), dy.cuda(), dx, 10, inc)
+        assert _rel(dx, x64.grad) <= 2e-6
+    # a ray's encoding repeated on its samples, rgb_net's leading ReLU applied
+    d = torch.nn.functional.normalize(torch.randn(20, 3, generator=g), dim=-1)
+    y = torch.empty(20 * 7, 27, device="cuda")
+    ops.train_encode(d.cuda(), y, 4, True, rows_per_src=7, relu=True)
+    ref = torch.relu(O.positional_encoding(d.double(), 4)).repeat_interleave(7, 0)
+    assert float((y.cpu().double() - ref).abs().max()) <= 2e-6
+    # MotionNet's fractional-time lerp on the frame-id column
+    xt = torch.cat([x[:64], torch.tensor([1.0, 2.25, 7.5, 30.0]).repeat(16).reshape(-1, 1)], -1)
+    y = torch.empty(64, 84, device="cuda")
+    ops.train_encode(xt.cuda(), y, 10, True, lerp_col=3)
+    lo = torch.floor(xt[:, 3:]).double()
+    wt = xt[:, 3:].double() - lo
+    ref = (1 - wt) * O.positional_encoding(torch.cat([xt[:, :3].double(), lo], -1), 10) + wt * O.positional_encoding(
+        torch.cat([xt[:, :3].double(), lo + 1], -1), 10)
+    assert float((y.cpu().double() - ref).abs().max()) <= 4e-6
+
+
+def _reference_grads(fn, params, inputs, cots, dtype):
+    ps = {k: v.to(dtype).clone().requires_grad_(True) for k, v in params.items()}
+    ins = [t.to(dtype).clone().requires_grad_(True) if t is not None and t.is_floating_point() and g else (t.to(dtype) if t is not None else None)
+           for t, g in inputs]
+    outs = fn(ps, *ins)
+    outs = outs if isinstance(outs, tuple) else (outs,)
+    sum((o * c.to(dtype)).sum() for o, c in zip(outs, cots)).backward()
+    return {k: v.grad for k, v in ps.items()}, [t.grad if (t is not None and t.requires_grad) else None for t in ins]
+
+
+def _check(name, got, ref64, ref32):
+    e = float((got.double().cpu() - ref64).abs().max())
+    scale = float(ref64.abs().max())
+    e32 = float((ref32.double() - ref64).abs().max())
+    assert e <= GRAD_RTOL * scale + 1e-12, f"{name}: |err| {e:.3e} = {e / max(scale, 1e-30):.2e} of the largest entry"
+    assert e <= 3 * e32 + 2e-7 * scale, f"{name}: {e:.3e} vs the fp32 autograd's {e32:.3e}"
+    return e / max(scale, 1e-30), e / max(e32, 1e-30)
+
+
+@pytest.mark.parametrize("use_time, deep, inc, use_dir, n, ns, chunk", [(True, False, True, True, 200, 64, None), (False, False, True, True, 97, 90, 3000),
+                                                                         (True, True, True, True, 150, 12, None), (True, False, False, False, 60, 33, 700),
+                                                                         (False, False, True, False, 40, 128, None)])
+def test_spacenet_backward_matches_fp64_autograd(use_time, deep, inc, use_dir, n, ns, chunk, monkeypatch):
+    from stnerf_amd.modeling import autograd as ag
+    from stnerf_amd.modeling.spacenet import SpaceNet
+    if chunk:
+        monkeypatch.setattr(ag, "CHUNK_SAMPLES", chunk)                   # several chunks: gradients accumulate across them
+    sd = syn.spacenet_state("net", np.random.RandomState(n + ns), use_time, deep_rgb=deep, include_input=inc, use_dir=use_dir)
+    net = SpaceNet(include_input=inc, use_dir=use_dir, use_time=use_time, deep_rgb=deep)
+    net.load_state_dict({k[4:]: v for k, v in sd.items()})
+    net = net.cuda()
+    g = torch.Generator().manual_seed(ns)
+    pos = (torch.rand(n, ns, 3, generator=g) - 0.5) * 4.0
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    times = torch.rand(n, 1, generator=g) * 20 + 1
+    c_rgb, c_sig = torch.randn(n, ns, 3, generator=g), torch.randn(n, ns, 1, generator=g) * 0.1
+    rays = torch.cat([torch.zeros(n, 3), dirs], -1).cuda()
+    pd = pos.cuda().requires_grad_(True)
+    rgb, sig = net(pd, rays, times.cuda() if use_time else None)
+    assert rgb.shape == (n, ns, 3) and sig.shape == (n, ns, 1)
+    ((rgb * c_rgb.cuda()).sum() + (sig * c_sig.cuda()).sum()).backward()
+    fn = lambda ps, p, d, t: O.space_net(ps, "net", p, d, t)
+    ins = [(pos, True), (dirs, False), (times if use_time else None, False)]
+    g64, i64 = _reference_grads(fn, sd, ins, (c_rgb, c_sig), torch.float64)
+    g32, i32 = _reference_grads(fn, sd, ins, (c_rgb, c_sig), torch.float32)
+    worst = {}
+    for k, p in net.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, k
+        worst[k] = _check(k, p.grad, g64["net." + k], g32["net." + k])
+    worst["pos"] = _check("pos", pd.grad, i64[0], i32[0])
+    print(f"SpaceNet time={use_time} deep={deep} inc={inc} dir={use_dir} {n}x{ns}: worst relative error "
+          f"{max(v[0] for v in worst.values()):.2e}, worst ratio to the fp32 autograd {max(v[1] for v in worst.values()):.2f}")
+    # sigma-only and rgb-only cotangents (the other output's gradient is None)
+    for which in (0, 1):
+        net.zero_grad()
+        out = net(pos.cuda(), rays, times.cuda() if use_time else None)
+        (out[which] * (c_rgb, c_sig)[which].cuda()).sum().backward()
+        cots = (c_rgb if which == 0 else torch.zeros_like(c_rgb), c_sig if which == 1 else torch.zeros_like(c_sig))
+        g64b, _ = _reference_grads(fn, sd, ins, cots, torch.float64)
+        for k, p in net.named_parameters():
+            ref = g64b["net." + k]
+            got = p.grad if p.grad is not None else torch.zeros_like(p)
+            assert float((got.double().cpu() - ref).abs().max()) <= GRAD_RTOL * float(ref.abs().max()) + 1e-9, (which, k)
+
+
+@pytest.mark.parametrize("input_time, inc, rows, chunk", [(True, True, 5000, None), (True, True, 3001, 1024), (False, True, 777, None), (True, False, 900, None)])
+def test_motionnet_backward_matches_fp64_autograd(input_time, inc, rows, chunk, monkeypatch):
+    from stnerf_amd.modeling import autograd as ag
+    from stnerf_amd.modeling.motion_net import MotionNet
+    if chunk:
+        monkeypatch.setattr(ag, "CHUNK_SAMPLES", chunk)
+    sd = syn.motionnet_state("net", np.random.RandomState(rows), include_input=inc)
+    net = MotionNet(c_input=4, include_input=inc, input_time=input_time)
+    net.load_state_dict({k[4:]: v for k, v in sd.items()})
+    net = net.cuda()
+    g = torch.Generator().manual_seed(rows)
+    xyz = (torch.rand(rows, 3, generator=g) - 0.5) * 4.0
+    t = torch.where(torch.rand(rows, 1, generator=g) < 0.5, torch.floor(torch.rand(rows, 1, generator=g) * 30), torch.rand(rows, 1, generator=g) * 30) + 1
+    xt = torch.cat([xyz, t], -1)
+    cot = torch.randn(rows, 3, generator=g)
+    xd = xt.cuda().requires_grad_(True)
+    flow = net(xd)
+    (flow * cot.cuda()).sum().backward()
+    fn = lambda ps, x: O.motion_net(ps, "net", x, input_time=input_time)
+    g64, i64 = _reference_grads(fn, sd, [(xt, True)], (cot,), torch.float64)
+    g32, i32 = _reference_grads(fn, sd, [(xt, True)], (cot,), torch.float32)
+    worst = {k: _check(k, p.grad, g64["net." + k], g32["net." + k]) for k, p in net.named_parameters()}
+    worst["xyz"] = _check("xyz", xd.grad[:, :3], i64[0][:, :3], i32[0][:, :3])
+    assert float(xd.grad[:, 3].abs().max()) == 0.0                       # the frame id is data
+    print(f"MotionNet input_time={input_time} inc={inc} rows={rows}: worst relative error {max(v[0] for v in worst.values()):.2e}, "
+          f"worst ratio to the fp32 autograd {max(v[1] for v in worst.values()):.2f}")
+
+
+def test_deformed_spacenet_chain_trains_both_networks():
+    """modeling/layered_rfrender.py:340-356 + :382-410: pos = xyz + MotionNet([xyz, t]), then SpaceNet(pos): the SpaceNet's
+    point gradient is the MotionNet's output gradient; one optimiser step lowers the loss."""
+    from stnerf_amd.modeling.motion_net import MotionNet
+    from stnerf_amd.modeling.spacenet import SpaceNet
+    rs = np.random.RandomState(8)
+    sd_s, sd_m = syn.spacenet_state("net", rs, True), syn.motionnet_state("net", rs)
+    space, motion = SpaceNet(use_time=True), MotionNet(c_input=4, input_time=True)
+    space.load_state_dict({k[4:]: v for k, v in sd_s.items()})
+    motion.load_state_dict({k[4:]: v for k, v in sd_m.items()})
+    space, motion = space.cuda(), motion.cuda()
+    g = torch.Generator().manual_seed(2)
+    n, ns = 128, 32
+    xyz = (torch.rand(n, ns, 3, generator=g) - 0.5) * 3.0
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    times = torch.full((n, 1), 2.5)
+    target = torch.rand(n, ns, 3, generator=g)
+    rays = torch.cat([torch.zeros(n, 3), dirs], -1).cuda()
+
+    def loss_of(space_fn, motion_fn, dev):
+        x = xyz.to(dev)
+        flow = motion_fn(torch.cat([x, times.to(dev).view(n, 1, 1).repeat(1, ns, 1)], -1))
+        rgb, sig = space_fn(x + flow)
+        return ((torch.sigmoid(rgb) - target.to(dev)) ** 2).mean() + 1e-3 * (sig ** 2).mean()
+    loss = loss_of(lambda p: space(p, rays, times.cuda()), motion, "cuda")
+    loss.backward()
+    ps = {"s." + k: v.double().requires_grad_(True) for k, v in sd_s.items()}
+    pm = {"m." + k: v.double().requires_grad_(True) for k, v in sd_m.items()}
+    ref = loss_of(lambda p: O.space_net({k[2:]: v for k, v in ps.items()}, "net", p, dirs.double(), times.double()),
+                  lambda x: O.motion_net({k[2:]: v for k, v in pm.items()}, "net", x.double()), "cpu")
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref)) + 1e-7
+    for k, p in motion.named_parameters():
+        r = pm["m.net." + k].grad
+        assert float((p.grad.double().cpu() - r).abs().max()) <= 5e-5 * float(r.abs().max()) + 1e-12, k
+    for k, p in space.named_parameters():
+        r = ps["s.net." + k].grad
+        assert float((p.grad.double().cpu() - r).abs().max()) <= 5e-5 * float(r.abs().max()) + 1e-12, k
+    opt = torch.optim.SGD(list(space.parameters()) + list(motion.parameters()), lr=1e-2)
+    opt.step()
+    with torch.no_grad():
+        after = loss_of(lambda p: space(p, rays, times.cuda()), motion, "cuda")
+    assert float(after) < float(loss)
+
+
+def test_whole_renderer_stays_inference_only_under_autograd():
+    """Only the two networks train on this path: LayeredRFRender.forward still refuses autograd."""
+    import test_gpu_render as R
+    model = R.build_model(dict(L=1, n1=8, n2=4, space_time=True, deform_time=True, weight_seed=1, edit={}))
+    rays = torch.rand(16, 8, device="cuda")
+    with pytest.raises(RuntimeError, match="inference-only"):
+        model(rays, None, None)

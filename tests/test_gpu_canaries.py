@@ -33,16 +33,12 @@ class Canaries:
         return buf[GUARD_BYTES:GUARD_BYTES + n].view(dtype).reshape(shape)
 
     def _wrap(self, orig, fill):
-        def alloc(*size, dtype=None, device=None, **kw):
+        def alloc(*args, dtype=None, device=None, **kw):
+            if device is None or torch.device(device).type != "cuda" or kw:
+                return orig(*args, dtype=dtype, device=device, **kw)          # host tensors / exotic calls: untouched
+            size, extra = (args[:-1], args[-1:]) if fill == "full" else (args, ())
             if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
                 size = tuple(size[0])
-            extra = ()
-            if fill == "full":
-                size, extra = size[:-1], size[-1:]
-                if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
-                    size = tuple(size[0])
-            if device is None or torch.device(device).type != "cuda" or kw:
-                return orig(*size, *extra, dtype=dtype, device=device, **kw)
             t = self._guarded(tuple(int(x) for x in size), dtype or torch.float32, device)
             if fill == "zeros":
                 t.zero_()
