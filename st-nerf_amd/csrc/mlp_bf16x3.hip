@@ -15,7 +15,9 @@
 // activations never leave the register file: a layer boundary is { big + small, ReLU, split into three bf16 planes }.
 // What differs:
 //   * 256-wide layers run as two PASSES of 128 output features (4 blocks x {big, small} = 128 accumulator registers);
-//     the first pass's outputs are parked in AGPRs until the second pass has consumed the layer's input.
+//     a pass's outputs are parked in AGPRs (ReLU'd fp32) and split into the bf16 planes under the MFMAs of the NEXT pass:
+//     the first pass's under the second half of the second pass, the second pass's under the first half of the next
+//     layer's first pass (UnparkHook).
 //   * Weights: 6 B per value and 2.7 x the f32 kernel's MFMA rate -- four waves streaming the blob through the vector L1
 //     would need ~60 B/clk/CU (measured ceiling 53).  They are fetched ONCE per CU by LDS-DMA (global_load_lds_dwordx4,
 //     no registers involved) into a ring of four 24 KB slots in consumption order and read by every wave with
@@ -376,8 +378,10 @@ __device__ __forceinline__ void finish_park(f32x16 (&big)[4], const f32x16 (&sma
             for (int j = 0; j < 8; ++j) park_put(pk.v[16 * fb + 8 * t + j], out_relu(big[fb], small[fb], 8 * t + j));
             BX_SB();  // (group by group: keeps the live values of this straight-line code bounded)
         }
-        load_c_block(big[fb], next_c, fb, lane);
-        BX_SB();
+        if (next_c) {  // (uniform; nullptr where the next pass starts from 0: rgb_net.1)
+            load_c_block(big[fb], next_c, fb, lane);
+            BX_SB();
+        }
     }
 }
 // the pass's outputs -> K steps KS0 .. KS0 + 7 of the activation planes
@@ -437,9 +441,14 @@ __device__ __forceinline__ void unpark_act(const Park& pk, bf16x8 (&act)[3][16])
 }
 
 // The same conversion as unpark_act's, for ONE block, spread over the MFMA shadows of one ring slot (a pair of values per
-// unit, in three steps).  Runs inside the second pass of a 256-wide layer, in slots 4 .. 7: K steps 0 .. 7 of the input planes
-// are dead by then and take the first pass's outputs directly -- 416 of a layer's 1344 boundary instructions under MFMAs.
-template <int FB>
+// unit, in three steps).  BOTH passes of a 256-wide layer carry one:
+//   * KS_OUT = 0, inside the SECOND pass, slots 4 .. 7: K steps 0 .. 7 of the input planes are dead by then and take the first
+//     pass's outputs (round 3);
+//   * KS_OUT = 8, inside the FIRST pass of the NEXT layer, slots 0 .. 3 (round 4): the previous layer's second pass parks its
+//     outputs as well (finish_park, 320 cycles) instead of converting them in the open (finish_act, 1350), and the conversion
+//     into K steps 8 .. 15 -- which the pass reads from slot 4 on -- rides under the MFMAs of K steps 0 .. 7.
+// 832 of a layer's 1344 boundary instructions under MFMAs; what stays in the open are the two parks (ReLU + v_accvgpr_write).
+template <int FB, int KS_OUT>
 struct UnparkHook {
     const Park& pk;
     bf16x8 (&act)[3][16];
@@ -447,7 +456,7 @@ struct UnparkHook {
     unsigned w0, w1;
     template <int U, int I>
     __device__ __forceinline__ void at() {
-        constexpr int T = 2 * FB + (U >> 2), W = U & 3;
+        constexpr int T = KS_OUT + 2 * FB + (U >> 2), W = U & 3;
         if (I == 0) {
             x0 = park_get(pk.v[16 * FB + 2 * U]);
             x1 = park_get(pk.v[16 * FB + 2 * U + 1]);
@@ -464,19 +473,30 @@ struct UnparkHook {
         }
     }
 };
-template <int FB>
+// one slot of a pass (K steps 2 FB, 2 FB + 1 of the half the pass is reading: the upper one for KS_OUT = 0, the lower one for
+// KS_OUT = 8) with block FB of the park converted into the OTHER half of the planes on the way
+template <int FB, int KS_OUT, bool FIRST = false, bool BIG0 = false>
 __device__ __forceinline__ void slot_unpark(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], bf16x8 (&act)[3][16], const Park& pk) {
-    constexpr int k = 8 + 2 * FB;
-    UnparkHook<FB> hook{pk, act, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
-    slot<false, false, UnparkHook<FB>>(cx, big, small, act[0][k], act[1][k], act[2][k], act[0][k + 1], act[1][k + 1], act[2][k + 1], &hook);
+    constexpr int k = (8 - KS_OUT) + 2 * FB;
+    UnparkHook<FB, KS_OUT> hook{pk, act, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
+    slot<FIRST, BIG0, UnparkHook<FB, KS_OUT>>(cx, big, small, act[0][k], act[1][k], act[2][k], act[0][k + 1], act[1][k + 1], act[2][k + 1], &hook);
 }
 // second pass of a 256-wide layer: 16 K steps, the parked first pass converted on the way
 __device__ __forceinline__ void pass_b_unpark(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], bf16x8 (&act)[3][16], const Park& pk) {
     pass_act<0, 4, true>(cx, big, small, act);
-    slot_unpark<0>(cx, big, small, act, pk);
-    slot_unpark<1>(cx, big, small, act, pk);
-    slot_unpark<2>(cx, big, small, act, pk);
-    slot_unpark<3>(cx, big, small, act, pk);
+    slot_unpark<0, 0>(cx, big, small, act, pk);
+    slot_unpark<1, 0>(cx, big, small, act, pk);
+    slot_unpark<2, 0>(cx, big, small, act, pk);
+    slot_unpark<3, 0>(cx, big, small, act, pk);
+}
+// K steps 0 .. 7 of a pass whose input's upper half (features 128 .. 255 = the previous layer's second pass) still waits in
+// the park: converted into K steps 8 .. 15 on the way.  The caller continues with pass_act<8, ..., false>.
+template <bool BIG0 = false>
+__device__ __forceinline__ void pass_a_unpark(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], bf16x8 (&act)[3][16], const Park& pk) {
+    slot_unpark<0, 8, true, BIG0>(cx, big, small, act, pk);
+    slot_unpark<1, 8>(cx, big, small, act, pk);
+    slot_unpark<2, 8>(cx, big, small, act, pk);
+    slot_unpark<3, 8>(cx, big, small, act, pk);
 }
 
 // 128 -> 3 head (rgb_net's last layer, MotionNet's flow) on relu(big + small): w = [3][128] in LDS; fp64 accumulation, two
@@ -591,9 +611,10 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     BXP(BXP_PARK);
     pass_act<0, 2, true>(cx, big, small, act);
     BXP(BXP_PASS);
-    finish_act<8>(big, small, act, cs + BXC_B + 256, lane);
-    unpark_act(pk, act);
-    BXP(BXP_ACT);
+    unpark_act(pk, act);                                     // first pass -> K steps 0 .. 7 (in the open: the only layer whose
+    BXP(BXP_ACT);                                            // successor's first pass cannot start before it)
+    finish_park(big, small, pk, cs + BXC_B + 256, lane);     // second pass -> park: converted under stage1.2's first K steps
+    BXP(BXP_PARK);
     // ---- stage1.2 .. stage2.4: six 256-wide layers, two passes each; stage2.0 (li == 4) takes PE(pos) again behind its 256
     // features (modeling/spacenet.py:45-57,136-138): four more K steps per pass, their B operands split on the spot from the
     // staged encoding (the activation planes are full)
@@ -621,7 +642,8 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     // (stage2.0 is peeled out of the layer loop: inside it, as a conditional block, its extra K steps redefine the
     // accumulators on one of two paths and the register allocator answers with ~200 spills)
     auto layer = [&](int li, auto with_pe) {
-        pass_act<0, 8, true>(cx, big, small, act);
+        pass_a_unpark(cx, big, small, act, pk);              // K steps 0 .. 7, the previous layer's second pass -> K steps 8 .. 15
+        pass_act<8, 4, false>(cx, big, small, act);
         if constexpr (decltype(with_pe)::value) pe_slots();
         BXP(BXP_PASS);
         finish_park(big, small, pk, cs + BXC_B + 256 * li + 128, lane);
@@ -631,8 +653,8 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
         BXP(BXP_PASS);
     };
     auto layer_end = [&](int li) {   // (+ the next layer's first C operand; behind stage2.4 comes rgb_net.1, which starts from 0)
-        finish_act<8>(big, small, act, li < 6 ? cs + BXC_B + 256 * (li + 1) : nullptr, lane);
-        BXP(BXP_ACT);
+        finish_park(big, small, pk, li < 6 ? cs + BXC_B + 256 * (li + 1) : nullptr, lane);
+        BXP(BXP_PARK);
     };
 #pragma unroll 1
     for (int li = 1; li <= 3; ++li) {
@@ -658,7 +680,8 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     // part, and as the C operand it would put every rounding of the a0 b0 chain at its scale (measured: the colour output at
     // 1.3 x the fp32 CPU chain's error instead of 0.5 x).  Its 16 loads go out in front of the pass's last slot (14 of the 16
     // K steps' activation registers are dead by then).
-    pass_act<0, 7, true, true>(cx, big, small, act);
+    pass_a_unpark<true>(cx, big, small, act, pk);            // (stage2.4's second pass is converted under its first K steps)
+    pass_act<8, 3, false>(cx, big, small, act);
     BXP(BXP_PASS);
     {
         float4 crow[4][4];

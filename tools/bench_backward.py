@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Throughput of the training kernels (csrc/train.hip) on the GPU box: the three GEMM flavours at the networks' shapes, and a
+whole SpaceNet / MotionNet backward (recompute + dX + dW) in TF/s of f32 MFMA work against the 157.3 TF/s peak."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from stnerf_amd import ops, synthetic as syn
+from stnerf_amd.modeling.spacenet import SpaceNet
+from stnerf_amd.modeling.motion_net import MotionNet
+PEAK = 157.3
+
+def timed(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+m = int(os.environ.get("SAMPLES", 1 << 18))
+print(f"{m} samples")
+for n, k in [(256, 256), (256, 64), (256, 320), (128, 304), (128, 128)]:
+    x, w, dy = torch.randn(m, k, device="cuda"), torch.randn(n, k, device="cuda"), torch.randn(m, n, device="cuda")
+    y, dx, dw, db = torch.empty(m, n, device="cuda"), torch.empty(m, k, device="cuda"), torch.empty(n, k, device="cuda"), torch.empty(n, device="cuda")
+    fl = 2.0 * m * n * k / 1e12
+    t1 = timed(lambda: ops.train_linear_fwd(x, w, db, y, True))
+    t2 = timed(lambda: ops.train_linear_dx(dy, w, dx, mask=x))
+    t3 = timed(lambda: ops.train_linear_dw(dy, x, dw, db, False))
+    tb = timed(lambda: torch.mm(x, w.t()))
+    print(f"  {n:3d} x {k:3d}: forward {fl / t1:6.1f} TF/s ({fl / t1 / PEAK:.2f})  dX {fl / t2:6.1f} ({fl / t2 / PEAK:.2f})  dW {fl / t3:6.1f} ({fl / t3 / PEAK:.2f})"
+          f"   [rocBLAS sgemm forward via torch.mm: {fl / tb:6.1f}]")
+rs = np.random.RandomState(0)
+n, ns = m // 64, 64
+for name, net, flop in [("SpaceNet (time)", SpaceNet(use_time=True), 930_048), ("MotionNet", MotionNet(c_input=4, input_time=True), 153_344)]:
+    sd = syn.spacenet_state("net", rs, True) if "Space" in name else syn.motionnet_state("net", rs)
+    net.load_state_dict({k[4:]: v for k, v in sd.items()})
+    net = net.cuda()
+    if "Space" in name:
+        pos = ((torch.rand(n, ns, 3, device="cuda") - 0.5) * 4).requires_grad_(True)
+        rays = torch.cat([torch.zeros(n, 3, device="cuda"), torch.nn.functional.normalize(torch.randn(n, 3, device="cuda"), dim=-1)], -1)
+        tm = torch.rand(n, 1, device="cuda") * 20 + 1
+        def step():
+            net.zero_grad(set_to_none=True)
+            rgb, sig = net(pos, rays, tm)
+            (rgb.sum() + sig.sum()).backward()
+    else:
+        xt = torch.cat([(torch.rand(m, 3, device="cuda") - 0.5) * 4, torch.rand(m, 1, device="cuda") * 20 + 1], -1).requires_grad_(True)
+        def step():
+            net.zero_grad(set_to_none=True)
+            net(xt).sum().backward()
+    t = timed(step, 3)
+    # forward (fused inference kernel) + recompute + dX + dW = 4 x the network's FLOPs, 3 of them in csrc/train.hip
+    print(f"{name}: forward + backward of {m} samples {1e3 * t:.1f} ms = {m / t / 1e6:.2f} M samples/s, {4 * flop * m / t / 1e12:.1f} TF/s of network work "
+          f"({4 * flop * m / t / 1e12 / PEAK:.2f} of the f32 MFMA peak)")
