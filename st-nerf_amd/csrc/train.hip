@@ -16,10 +16,10 @@
 //
 // v_mfma_f32_32x32x2_f32 (exact fp32 products and accumulation: gradients at the accuracy of an fp32 torch.autograd).
 // A workgroup of 4 waves owns a 128 x 128 tile of the output, a wave 64 x 64 of it (2 x 2 MFMA tiles = 64 accumulator
-// registers); operands are staged through LDS in 16-deep K slices ([row][k] with a 17-word row stride: the MFMA operand
-// fetch -- 32 consecutive rows at one k per half wave -- is conflict-free), the next slice's global loads are in flight
-// while the current one is multiplied.  One f32 MFMA is 64 cycles of matrix pipe for 4 LDS reads: the kernel is MFMA-bound
-// by construction, there is nothing to hide.
+// registers) -- 128 x 256 / 64 x 128 where the output is wider than 128 columns, so that the sample-major operand is read
+// from HBM once; operands are staged through LDS in 32-deep K slices as 16-byte quads of consecutive k (swizzled [row][36]
+// tiles, see lds_quad): one ds_read_b128 per operand block feeds four MFMAs, the operands of the next 8 k are fetched in
+// front of the current MFMAs, the next slice's global loads are in flight while the current one is multiplied.
 //
 // Positional encodings (utils/dimension_kernel.py:54-73): forward into a strided destination (a column block of a layer's
 // input matrix: the skip connection and rgb_net's input are built in place, no torch.cat), per-ray encodings broadcast to
@@ -31,7 +31,7 @@
 namespace stnerf {
 namespace {
 
-constexpr int GBM = 128, GBN = 128, GBK = 16, GLD = GBK + 1;
+constexpr int GBM = 128, GBK = 32, GLD = GBK + 4;   // (the N extent of a tile is a template parameter: 128 or 256)
 
 struct GemmArgs {
     const float* A;   // forward: X [M][lda];   dX: dY [M][lda];   dW: dY [Ksamples][lda] (read transposed)
@@ -46,116 +46,228 @@ struct GemmArgs {
     int k_per_split;  // dW: reduction range of one blockIdx.z
 };
 
-// One operand tile [128 rows][16 k] from global memory into registers (2 float4 per thread), zero beyond the edges.
-//   K_CONTIG: element (r, k) = src[(r0 + r) * ld + k0 + k]   (k contiguous: float4 along k)
-//  !K_CONTIG: element (r, k) = src[(k0 + k) * ld + r0 + r]   (r contiguous: float4 along r)
-// ld is a multiple of 4 and the allocation covers whole float4s (the Python side pads): only whole-vector guards.
-template <bool K_CONTIG>
-__device__ __forceinline__ void load_tile(float4 (&v)[2], const float* __restrict__ src, int64_t ld, int r0, int R, int k0, int k_end, int t) {
+// LDS tile of one operand: [row][36 floats] = 8 quads of 4 consecutive k + one pad quad (rows stay 16-byte aligned), quad q
+// of row r stored at quad position q ^ ((r >> 2) & 7).  Everything moves as 16-byte vectors:
+//   * the MFMA operand fetch: lane (h, c) reads quad 2 s + h of row c -- ONE ds_read_b128 feeds the four K = 2 steps of
+//     k = 8 s + 4 h + {0..3} (the order of k inside the reduction is free as long as both operands use the same one);
+//     16 consecutive rows at one quad fall on all 32 banks twice: the minimum for 64 dwords;
+//   * a k-contiguous source row (forward / dX: activations, nn.Linear weights) arrives as one global float4 = one quad;
+//   * a row-contiguous source (dW's operands, dX's weights) arrives as float4s along the rows for four consecutive k: a
+//     4 x 4 register transpose turns them into four quads.  Those go to rows 4 apart x 16 lanes -- a stride of 144 dwords,
+//     i.e. two bank groups without the swizzle, all eight with it.
+__device__ __forceinline__ int lds_quad(int row, int q) { return row * GLD + 4 * (q ^ ((row >> 2) & 7)); }
+
+// One operand tile [ROWS][32 k]: global -> registers with BUFFER loads: a resource descriptor over the whole matrix, a
+// per-lane byte offset that never changes and the slice's wave-uniform offset in a scalar register -- no vector
+// instruction per load (on gfx950 every VALU instruction takes its cycles out of the f32 MFMA stream, whichever wave issues
+// it: profiles/r01_dual_issue_microbench.md; with per-load 64-bit address arithmetic and edge selects this kernel ran at
+// 0.45 of the MFMA peak), and the hardware's range check returns 0 beyond the end of the matrix: rows past R and -- for the
+// row-contiguous flavour, whose k is the row index -- the tail of the reduction need no guard at all.
+//   K_CONTIG: element (r, k) = src[(r0 + r) * ld + k0 + k];  thread -> (row t >> 3 (+ 32 i), quad t & 7)
+//  !K_CONTIG: element (r, k) = src[(k0 + k) * ld + r0 + r];  thread -> unit f = t (+ 256 u): quad f / (ROWS / 4), rows 4 (f % (ROWS / 4)) ..+3
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+struct Operand {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t step;                  // bytes per 32-k slice (wave-uniform)
+};
+__device__ __forceinline__ Operand make_operand(const float* src, int64_t ld, int rows_total, int cols_total, bool k_contig) {
+    // bytes up to the end of the last row's round4(cols) floats (what the caller guarantees to be allocated)
+    const int64_t bytes = ((int64_t)(rows_total - 1) * ld + ((cols_total + 3) & ~3)) * 4;
+    Operand o;
+    o.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)bytes, 0x00020000);
+    o.step = k_contig ? GBK * 4u : (uint32_t)(GBK * ld * 4);
+    return o;
+}
+template <bool K_CONTIG, int ROWS>
+__device__ __forceinline__ void lane_offsets(uint32_t (&off)[ROWS / 32], int64_t ld, int r0, int t) {
+    if (K_CONTIG) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (K_CONTIG) {
-            const int r = r0 + (t >> 2) + 64 * i, k = k0 + 4 * (t & 3);
-            if (r < R && k < k_end) {
-                v[i] = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + k);
-                if (k + 1 >= k_end) v[i].y = 0.f;      // (a reduction range may end inside a vector: split-K slices, K % 4)
-                if (k + 2 >= k_end) v[i].z = 0.f;
-                if (k + 3 >= k_end) v[i].w = 0.f;
-            }
-        } else {
-            const int k = k0 + (t >> 5) + 8 * i, r = r0 + 4 * (t & 31);
-            if (k < k_end && r < R) v[i] = *reinterpret_cast<const float4*>(src + (int64_t)k * ld + r);   // (rows beyond R: unused outputs)
+        for (int i = 0; i < ROWS / 32; ++i) off[i] = (uint32_t)(((int64_t)(r0 + (t >> 3) + 32 * i) * ld + 4 * (t & 7)) * 4);
+    } else {
+        constexpr int RQ = ROWS / 4;
+#pragma unroll
+        for (int u = 0; u < ROWS / 128; ++u) {
+            const int f = t + 256 * u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) off[4 * u + j] = (uint32_t)(((int64_t)(4 * (f / RQ) + j) * ld + r0 + 4 * (f % RQ)) * 4);
         }
     }
 }
-template <bool K_CONTIG>
-__device__ __forceinline__ void store_tile(float* lds, const float4 (&v)[2], int t) {
+template <int NV>
+__device__ __forceinline__ void load_tile(float4 (&v)[NV], const Operand& op, const uint32_t (&off)[NV], uint32_t slice_bytes) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if (K_CONTIG) {
-            float* p = lds + ((t >> 2) + 64 * i) * GLD + 4 * (t & 3);
-            p[0] = v[i].x; p[1] = v[i].y; p[2] = v[i].z; p[3] = v[i].w;
-        } else {
-            float* p = lds + (4 * (t & 31)) * GLD + (t >> 5) + 8 * i;
-            p[0] = v[i].x; p[GLD] = v[i].y; p[2 * GLD] = v[i].z; p[3 * GLD] = v[i].w;
+    for (int i = 0; i < NV; ++i) {
+        const i32x4 r = __builtin_amdgcn_raw_buffer_load_b128(op.rsrc, off[i], slice_bytes, 0);
+        v[i] = make_float4(__int_as_float(r.x), __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w));
+    }
+}
+// ... and into LDS.  k_left = elements of the reduction range left from this slice's first k: only the k-contiguous flavour
+// can see a range end inside its rows (K % 32 != 0: the last slice), and only then (TAIL) are the elements selected.
+template <bool K_CONTIG, int ROWS, bool TAIL>
+__device__ __forceinline__ void store_tile(float* lds, const float4 (&v)[ROWS / 32], int k_left, int t) {
+    if (K_CONTIG) {
+#pragma unroll
+        for (int i = 0; i < ROWS / 32; ++i) {
+            float4 o = v[i];
+            if (TAIL) {
+                const int k = 4 * (t & 7);
+                o.x = k < k_left ? o.x : 0.f;
+                o.y = k + 1 < k_left ? o.y : 0.f;
+                o.z = k + 2 < k_left ? o.z : 0.f;
+                o.w = k + 3 < k_left ? o.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(lds + lds_quad((t >> 3) + 32 * i, t & 7)) = o;
+        }
+    } else {
+        constexpr int RQ = ROWS / 4;
+#pragma unroll
+        for (int u = 0; u < ROWS / 128; ++u) {
+            const int f = t + 256 * u, q = f / RQ, row = 4 * (f % RQ);
+            const float4 x0 = v[4 * u], x1 = v[4 * u + 1], x2 = v[4 * u + 2], x3 = v[4 * u + 3];
+            *reinterpret_cast<float4*>(lds + lds_quad(row, q)) = make_float4(x0.x, x1.x, x2.x, x3.x);
+            *reinterpret_cast<float4*>(lds + lds_quad(row + 1, q)) = make_float4(x0.y, x1.y, x2.y, x3.y);
+            *reinterpret_cast<float4*>(lds + lds_quad(row + 2, q)) = make_float4(x0.z, x1.z, x2.z, x3.z);
+            *reinterpret_cast<float4*>(lds + lds_quad(row + 3, q)) = make_float4(x0.w, x1.w, x2.w, x3.w);
         }
     }
 }
 
 // C = A' B' with A'[m][k], B'[k][n] read as the template flags say; MODE 0: forward epilogue (bias, ReLU), 1: dX epilogue
-// (mask, accumulate), 2: dW partial tile.
-template <bool A_KC, bool B_KC, int MODE>
-__global__ __launch_bounds__(256) void train_gemm_kernel(GemmArgs a) {
-    __shared__ float As[GBM * GLD], Bs[GBN * GLD];
+// (mask, accumulate), 2: dW partial tile.  BN = 256 where the output is wider than 128: the A' operand (the large,
+// sample-major matrix in every flavour but dW's) is then read once instead of twice.
+// (two workgroups per CU at least -- <= 256 registers: while one stores its tile, the other multiplies)
+template <bool A_KC, bool B_KC, int MODE, int BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void train_gemm_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_gemm[];
+    float* As = smem_gemm;
+    float* Bs = smem_gemm + GBM * GLD;
+    constexpr int NJ = BN / 64;                // 32-column MFMA tiles per wave
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, c = lane & 31;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * BN;
     int k_begin = 0, k_end = a.K;
-    if (MODE == 2) {
+    if (MODE == 2) {                           // (k_per_split is a multiple of 32: a slice never straddles two splits)
         k_begin = blockIdx.z * a.k_per_split;
         k_end = min(a.K, k_begin + a.k_per_split);
     }
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    f32x16 acc[2][2];
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float4 ra[2], rb[2];
-    load_tile<A_KC>(ra, a.A, a.lda, m0, a.M, k_begin, k_end, t);
-    load_tile<B_KC>(rb, a.B, a.ldb, n0, a.N, k_begin, k_end, t);
-    for (int k0 = k_begin; k0 < k_end; k0 += GBK) {
-        __syncthreads();                       // the previous slice has been consumed
-        store_tile<A_KC>(As, ra, t);
-        store_tile<B_KC>(Bs, rb, t);
-        __syncthreads();
-        if (k0 + GBK < k_end) {                // the next slice's loads fly under this slice's MFMAs
-            load_tile<A_KC>(ra, a.A, a.lda, m0, a.M, k0 + GBK, k_end, t);
-            load_tile<B_KC>(rb, a.B, a.ldb, n0, a.N, k0 + GBK, k_end, t);
-        }
+    // A' = [M rows][K] (k-contiguous) or [K rows][M] (row-contiguous); B' likewise with N
+    const Operand opa = make_operand(a.A, a.lda, A_KC ? a.M : a.K, A_KC ? a.K : a.M, A_KC);
+    const Operand opb = make_operand(a.B, a.ldb, B_KC ? a.N : a.K, B_KC ? a.K : a.N, B_KC);
+    uint32_t offa[GBM / 32], offb[BN / 32];
+    lane_offsets<A_KC, GBM>(offa, a.lda, m0, t);
+    lane_offsets<B_KC, BN>(offb, a.ldb, n0, t);
+    uint32_t sa = (uint32_t)(k_begin / GBK) * opa.step, sb = (uint32_t)(k_begin / GBK) * opb.step;   // this slice's scalar offsets
+    float4 ra[GBM / 32], rb[BN / 32];
+    load_tile(ra, opa, offa, sa);
+    load_tile(rb, opb, offb, sb);
+    // this lane's operand rows (the swizzle term (row >> 2) & 7 = (c >> 2) & 7 is the same for every 32-row block)
+    const float* arow = As + (wm + c) * GLD;
+    const float* brow = Bs + (wn + c) * GLD;
+    const int sw = (c >> 2) & 7;
+    auto fetch = [&](int s_, float4 (&av)[2], float4 (&bv)[NJ]) {
+        const int qo = 4 * ((2 * s_ + h) ^ sw);
 #pragma unroll
-        for (int kk = 0; kk < GBK / 2; ++kk) {
-            float av[2], bv[2];
+        for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const float4*>(arow + 32 * i * GLD + qo);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = As[(wm + 32 * i + c) * GLD + 2 * kk + h];
+        for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const float4*>(brow + 32 * j * GLD + qo);
+    };
+    auto mma = [&](const float4 (&av)[2], const float4 (&bv)[NJ]) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bv[j] = Bs[(wn + 32 * j + c) * GLD + 2 * kk + h];
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) {
+                    const float x = e == 0 ? av[i].x : e == 1 ? av[i].y : e == 2 ? av[i].z : av[i].w;
+                    const float y = e == 0 ? bv[j].x : e == 1 ? bv[j].y : e == 2 ? bv[j].z : bv[j].w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[i][j], 0, 0, 0);
+                }
+    };
+    auto multiply = [&]() {   // 4 steps of 8 k on the slice in LDS: the operands of step s + 1 are fetched in front of the MFMAs of step s
+        float4 av0[2], bv0[NJ], av1[2], bv1[NJ];
+        fetch(0, av0, bv0);
+        fetch(1, av1, bv1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(av0, bv0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(2, av0, bv0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(av1, bv1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(3, av1, bv1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(av0, bv0);
+        mma(av1, bv1);
+    };
+    for (int k0 = k_begin; k0 < k_end; k0 += GBK) {
+        const bool tail = (A_KC || B_KC) && k0 + GBK > k_end;     // (uniform) the reduction range ends inside this slice
+        __syncthreads();                       // the previous slice has been consumed
+        if (tail) {
+            store_tile<A_KC, GBM, true>(As, ra, k_end - k0, t);
+            store_tile<B_KC, BN, true>(Bs, rb, k_end - k0, t);
+        } else {
+            store_tile<A_KC, GBM, false>(As, ra, 0, t);
+            store_tile<B_KC, BN, false>(Bs, rb, 0, t);
         }
+        __syncthreads();
+        if (k0 + GBK < k_end) {                // the next slice's loads fly under this slice's MFMAs
+            sa += opa.step;
+            sb += opb.step;
+            load_tile(ra, opa, offa, sa);
+            load_tile(rb, opb, offb, sb);
+        }
+        multiply();
     }
     // accumulator register 4 q + r of lane (h, c): row 8 q + 4 h + r, column c of the 32 x 32 tile
     float* out = MODE == 2 ? a.C + (int64_t)blockIdx.z * a.M * a.N : a.C;
     const int64_t ldc = MODE == 2 ? a.N : a.ldc;
+    const bool inside = m0 + GBM <= a.M && n0 + BN <= a.N;       // (uniform) no edge of the matrix in this tile
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int n = n0 + wn + 32 * j + c;
-            if (n >= a.N) continue;
+            if (!inside && n >= a.N) continue;
             float bias = 0.f;
             if (MODE == 0 && a.bias) bias = a.bias[n];
+            float* o = out + (int64_t)(m0 + wm + 32 * i + 4 * h) * ldc + n;
+            const float* mk = MODE == 1 && a.mask ? a.mask + (int64_t)(m0 + wm + 32 * i + 4 * h) * a.ldmask + n : nullptr;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm + 32 * i + 8 * q + 4 * h + r;
-                    if (m >= a.M) continue;
+                    const int dm = 8 * q + r;
+                    if (!inside && m0 + wm + 32 * i + 4 * h + dm >= a.M) continue;
                     float v = acc[i][j][4 * q + r];
                     if (MODE == 0) {
                         v += bias;
                         if (a.relu) v = fmaxf(v, 0.f);
                     } else if (MODE == 1) {
-                        if (a.mask && !(a.mask[(int64_t)m * a.ldmask + n] > 0.f)) v = 0.f;
-                        if (a.accumulate) v += out[(int64_t)m * ldc + n];
+                        if (mk && !(mk[dm * a.ldmask] > 0.f)) v = 0.f;
+                        if (a.accumulate) v += o[dm * ldc];
                     }
-                    out[(int64_t)m * ldc + n] = v;
+                    o[dm * ldc] = v;
                 }
         }
+}
+template <bool A_KC, bool B_KC, int MODE>
+int launch_gemm(const GemmArgs& a, int grid_y, int grid_z, hipStream_t st, const char* what) {
+    if (a.N > 128) {
+        const dim3 grid((a.N + 255) / 256, grid_y, grid_z);
+        hipLaunchKernelGGL((train_gemm_kernel<A_KC, B_KC, MODE, 256>), grid, dim3(256), (GBM + 256) * GLD * 4, st, a);
+    } else {
+        const dim3 grid(1, grid_y, grid_z);
+        hipLaunchKernelGGL((train_gemm_kernel<A_KC, B_KC, MODE, 128>), grid, dim3(256), (GBM + 128) * GLD * 4, st, a);
+    }
+    STNERF_CHECK_LAUNCH(what);
+    return STNERF_OK;
 }
 
 // dst[i] (+)= sum_z partial[z][i] in z order (the second half of the dW / db reductions).
@@ -169,18 +281,49 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int sp
     *d = accumulate ? *d + s : s;
 }
 
-// Column sums of a row slice: partial[blockIdx.y][n] = sum over the block's rows of Y[m][n] (db = sum_samples dy).
+// Column sums of a row slice: partial[blockIdx.y][n] = sum over the block's rows of Y[m][n] (db = sum_samples dy).  A thread
+// owns four consecutive columns (one 16-byte load per row: rows are 16-byte aligned and readable up to round4(N), values
+// beyond N land in outputs nobody stores) and every 256 / CG-th row of the block's slice, four rows in flight; the row lanes
+// are folded through LDS.  HBM-bound: the matrix is read once.
+template <int CG>   // column groups (of 4) per block: 64 (N >= 256), 32, 16, ... -- 256 / CG row lanes
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y, int64_t ld, int M, int N, int rows_per_block,
                                                      float* __restrict__ partial) {
-    __shared__ float red[4][64];
-    const int n = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    constexpr int RL = 256 / CG;
+    __shared__ float4 red[RL][CG];
+    const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+    const int col = 4 * (blockIdx.x * CG + cg);
     const int m_begin = blockIdx.y * rows_per_block, m_end = min(M, m_begin + rows_per_block);
-    float s = 0.f;
-    if (n < N)
-        for (int m = m_begin + w; m < m_end; m += 4) s += y[(int64_t)m * ld + n];
-    red[w][threadIdx.x & 63] = s;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    if (col < N) {
+        const float* p = y + col;
+        int m = m_begin + rl;
+        for (; m + 3 * RL < m_end; m += 4 * RL) {
+            const float4 a0 = *reinterpret_cast<const float4*>(p + (int64_t)m * ld), a1 = *reinterpret_cast<const float4*>(p + (int64_t)(m + RL) * ld);
+            const float4 a2 = *reinterpret_cast<const float4*>(p + (int64_t)(m + 2 * RL) * ld), a3 = *reinterpret_cast<const float4*>(p + (int64_t)(m + 3 * RL) * ld);
+            s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+            s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+            s2.x += a2.x; s2.y += a2.y; s2.z += a2.z; s2.w += a2.w;
+            s3.x += a3.x; s3.y += a3.y; s3.z += a3.z; s3.w += a3.w;
+        }
+        for (; m < m_end; m += RL) {
+            const float4 a0 = *reinterpret_cast<const float4*>(p + (int64_t)m * ld);
+            s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+        }
+    }
+    red[rl][cg] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
     __syncthreads();
-    if (w == 0 && n < N) partial[(int64_t)blockIdx.y * N + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (rl == 0 && col < N) {
+        float4 t = red[0][cg];
+        for (int r = 1; r < RL; ++r) {
+            const float4 u = red[r][cg];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        float* o = partial + (int64_t)blockIdx.y * N + col;
+        o[0] = t.x;
+        if (col + 1 < N) o[1] = t.y;
+        if (col + 2 < N) o[2] = t.z;
+        if (col + 3 < N) o[3] = t.w;
+    }
 }
 
 // ---- positional encodings ------------------------------------------------------------------------------------------------
@@ -278,12 +421,10 @@ extern "C" int stnerf_train_linear_fwd(const float* x, int64_t ldx, const float*
     STNERF_REQUIRE(m >= 0 && m < (1ll << 31) && n >= 1 && k >= 1, "train_linear_fwd: bad shape m=%lld n=%d k=%d", (long long)m, n, k);
     STNERF_REQUIRE((ldx & 3) == 0 && (ldw & 3) == 0 && ldx >= k && ldw >= k && ldy >= n && aligned16(x) && aligned16(w),
                    "train_linear_fwd: x / w need 16-byte aligned rows (ld %% 4 == 0) of at least k floats");
+    STNERF_REQUIRE(m * ldx < (1ll << 29) && (int64_t)n * ldw < (1ll << 29), "train_linear_fwd: operands of 2 GiB and more: split the batch");
     if (m == 0) return STNERF_OK;
     GemmArgs a{x, w, y, ldx, ldw, ldy, (int)m, n, k, bias, nullptr, 0, relu, 0, 0};
-    const dim3 grid((n + GBN - 1) / GBN, (unsigned)((m + GBM - 1) / GBM), 1);
-    hipLaunchKernelGGL((train_gemm_kernel<true, true, 0>), grid, dim3(256), 0, as_stream(stream), a);
-    STNERF_CHECK_LAUNCH("train_linear_fwd");
-    return STNERF_OK;
+    return launch_gemm<true, true, 0>(a, (int)((m + GBM - 1) / GBM), 1, as_stream(stream), "train_linear_fwd");
 }
 
 extern "C" int stnerf_train_linear_dx(const float* dy, int64_t lddy, const float* w, int64_t ldw, int64_t m, int n, int k,
@@ -293,19 +434,17 @@ extern "C" int stnerf_train_linear_dx(const float* dy, int64_t lddy, const float
     STNERF_REQUIRE((lddy & 3) == 0 && (ldw & 3) == 0 && lddy >= n && ldw >= ((k + 3) & ~3) && lddx >= k && aligned16(dy) && aligned16(w),
                    "train_linear_dx: dy / w need 16-byte aligned rows (ld %% 4 == 0); w rows of at least round4(k) floats");
     STNERF_REQUIRE(!mask || ldmask >= k, "train_linear_dx: mask rows shorter than k");
+    STNERF_REQUIRE(m * lddy < (1ll << 29) && (int64_t)n * ldw < (1ll << 29), "train_linear_dx: operands of 2 GiB and more: split the batch");
     if (m == 0) return STNERF_OK;
     // dX[m][k] = sum_n dY[m][n] W[n][k]: output m x k, reduction over the layer's n outputs
     GemmArgs a{dy, w, dx, lddy, ldw, lddx, (int)m, k, n, nullptr, mask, ldmask, 0, accumulate, 0};
-    const dim3 grid((k + GBN - 1) / GBN, (unsigned)((m + GBM - 1) / GBM), 1);
-    hipLaunchKernelGGL((train_gemm_kernel<true, false, 1>), grid, dim3(256), 0, as_stream(stream), a);
-    STNERF_CHECK_LAUNCH("train_linear_dx");
-    return STNERF_OK;
+    return launch_gemm<true, false, 1>(a, (int)((m + GBM - 1) / GBM), 1, as_stream(stream), "train_linear_dx");
 }
 
 extern "C" int64_t stnerf_train_dw_workspace_bytes(int64_t m, int n, int k) {
     if (m < 0 || n < 1 || k < 1) return STNERF_EINVAL;
-    const int64_t splits = m <= 0 ? 1 : (m + 2047) / 2048 > 64 ? 64 : (m + 2047) / 2048;   // <= 64 slices of >= 2048 samples
-    const int64_t row_blocks = m <= 0 ? 1 : (m + 4095) / 4096 > 256 ? 256 : (m + 4095) / 4096;
+    const int64_t splits = m <= 0 ? 1 : (m + 1023) / 1024 > 128 ? 128 : (m + 1023) / 1024;   // <= 128 slices of >= 1024 samples
+    const int64_t row_blocks = m <= 0 ? 1 : (m + 1023) / 1024 > 512 ? 512 : (m + 1023) / 1024;
     return 4 * (splits * (int64_t)n * k + row_blocks * (int64_t)n) + 512;
 }
 
@@ -317,25 +456,30 @@ extern "C" int stnerf_train_linear_dw(const float* dy, int64_t lddy, const float
     STNERF_REQUIRE((lddy & 3) == 0 && (ldx & 3) == 0 && lddy >= ((n + 3) & ~3) && ldx >= ((k + 3) & ~3) && lddw >= k && aligned16(dy) && aligned16(x),
                    "train_linear_dw: dy / x need 16-byte aligned rows (ld %% 4 == 0) of at least round4(n) / round4(k) floats");
     STNERF_REQUIRE(workspace_bytes >= stnerf_train_dw_workspace_bytes(m, n, k) && aligned16(workspace), "train_linear_dw: workspace too small");
+    STNERF_REQUIRE(m * lddy < (1ll << 29) && m * ldx < (1ll << 29), "train_linear_dw: operands of 2 GiB and more: split the batch");
     if (m == 0) return STNERF_OK;
     hipStream_t st = as_stream(stream);
-    const int splits = (int)((m + 2047) / 2048 > 64 ? 64 : (m + 2047) / 2048);
+    const int splits = (int)((m + 1023) / 1024 > 128 ? 128 : (m + 1023) / 1024);
     int kps = (int)((m + splits - 1) / splits);
     kps = (kps + GBK - 1) / GBK * GBK;
     float* partial = static_cast<float*>(workspace);
     // dW[n][k] = sum_s dY[s][n] X[s][k]: output n x k, reduction over the m samples
     GemmArgs a{dy, x, partial, lddy, ldx, 0, n, k, (int)m, nullptr, nullptr, 0, 0, 0, kps};
-    const dim3 grid((k + GBN - 1) / GBN, (n + GBM - 1) / GBM, splits);
-    hipLaunchKernelGGL((train_gemm_kernel<false, false, 2>), grid, dim3(256), 0, st, a);
-    STNERF_CHECK_LAUNCH("train_linear_dw");
+    if (const int rc = launch_gemm<false, false, 2>(a, (n + GBM - 1) / GBM, splits, st, "train_linear_dw")) return rc;
     const int64_t count = (int64_t)n * k;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, partial, splits, count, k, dw, lddw, accumulate);
     STNERF_CHECK_LAUNCH("train_linear_dw (reduce)");
     if (db) {
         float* bpart = partial + (int64_t)splits * count;
-        const int row_blocks = (int)((m + 4095) / 4096 > 256 ? 256 : (m + 4095) / 4096);
+        const int row_blocks = (int)((m + 1023) / 1024 > 512 ? 512 : (m + 1023) / 1024);
         const int rpb = (int)((m + row_blocks - 1) / row_blocks);
-        hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, row_blocks), dim3(256), 0, st, dy, lddy, (int)m, n, rpb, bpart);
+        const int groups = (n + 3) / 4;
+        if (groups > 32)
+            hipLaunchKernelGGL(colsum_kernel<64>, dim3((groups + 63) / 64, row_blocks), dim3(256), 0, st, dy, lddy, (int)m, n, rpb, bpart);
+        else if (groups > 8)
+            hipLaunchKernelGGL(colsum_kernel<32>, dim3(1, row_blocks), dim3(256), 0, st, dy, lddy, (int)m, n, rpb, bpart);
+        else
+            hipLaunchKernelGGL(colsum_kernel<8>, dim3(1, row_blocks), dim3(256), 0, st, dy, lddy, (int)m, n, rpb, bpart);
         STNERF_CHECK_LAUNCH("train_linear_dw (bias partials)");
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bpart, row_blocks, (int64_t)n, n, db, (int64_t)n, accumulate);
         STNERF_CHECK_LAUNCH("train_linear_dw (bias reduce)");
