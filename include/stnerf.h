@@ -101,7 +101,11 @@ int stnerf_intersect(const float* rays, int64_t n, int ray_stride, const float* 
  * jitter: [l][n][n1] uniform draws to REPLAY (the reference's torch.rand tensors), or NULL to draw
  * on the device: Philox4x32-10 keyed by (seed, global ray index, layer, sample) -- independent
  * of chunking (global index: see the ray-window note above).  edits: host array of l entries or NULL; pivot: host, 3 floats.
- * Outputs: t[n][l][n1], xyz[n][l][n1][3] (may be NULL), mask[n][l] (|bin width| > 1e-5). */
+ * Outputs: t[n][l][n1], xyz[n][l][n1][3] (may be NULL), mask[n][l]: bit 0 = the reference's ray_mask (|bin width| > 1e-5,
+ * :105); bit 1 = a HINT for stnerf_composite: the ray misses the layer's box altogether (both slab hits -1000, :53-62), so
+ * every depth of the (ray, layer) pair is exactly -1000 and the compositor need not read them to find that out (40 % of a
+ * nine-layer ray's depth bytes).  Consumers of the mask as the reference's boolean take `mask & 1`; stnerf_compact_rays and
+ * stnerf_composite do.  A mask without hints (bit 1 clear everywhere) is always valid. */
 int stnerf_sample_coarse(const float* rays, int64_t n, int ray_stride, const float* boxes,
                          int64_t box_ray_stride, int l, int n1, const float* jitter, uint64_t seed,
                          int64_t ray_index_base, int64_t ray_index_stripe, int64_t ray_index_period,

@@ -387,7 +387,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) 
     CP_DECL
     for (int64_t ray0 = (int64_t)blockIdx.x * a.waves_per_block; ray0 < a.n; ray0 += rays_per_iter) {
         const int64_t ray = ray0 + wave;
-        const unsigned long long fb = __ballot(flags_next != 0);
+        const unsigned long long fb = __ballot((flags_next & 1) != 0 || (lane == 63u && flags_next != 0));
+        const unsigned miss_bits = (unsigned)__ballot((flags_next & 2) != 0) & 0xffffu;   // (hint of the sampler: every depth is -1000)
         flags_next = ray_flags(ray + rays_per_iter);
         const unsigned mask_bits = (unsigned)fb;
         const bool active = ray < a.n && !(fb >> 63 & 1ull);
@@ -416,7 +417,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(STNERF_WAVES_COMPOSITE, 8))) 
                 const int ev = a.p.evaluated[layer];
                 const bool have = ev == 2 || (ev != 0 && (!a.mask || (mask_bits >> layer & 1u)));
                 bool lv = have;
-                if (!have) {  // without output a layer still takes part if it has real depths (hidden, or a grazing hit)
+                if (!have && !(miss_bits >> layer & 1u)) {  // without output a layer still takes part if it has real depths (hidden, or a grazing hit)
                     bool missed = true;
                     for (int k = lane; k < a.S; k += 64) missed = missed && tsrc[layer * a.S + k] == -1000.f;
                     lv = !__all(missed);
@@ -729,10 +730,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXB >
     using Buf = SingleBuf<MAXB, MAXCHK>;
     auto mask_lane = [&](int64_t ray) -> int { return (a.mask && ray < a.n && lane < a.l) ? (int)a.mask[ray * a.l + lane] : 0; };
     auto have_of = [&](int mv) -> unsigned {
-        const unsigned mb = (unsigned)__ballot(mv != 0);
+        const unsigned mb = (unsigned)__ballot((mv & 1) != 0);
         return ev2 | (ev1 & (a.mask ? mb : ~0u));
     };
-    auto issue = [&](Buf& b, int64_t ray, unsigned have) {
+    auto miss_of = [&](int mv) -> unsigned { return (unsigned)__ballot((mv & 2) != 0); };   // (the sampler's hint: every depth -1000)
+    const unsigned all_layers = a.l >= 32 ? ~0u : (1u << a.l) - 1u;
+    auto issue = [&](Buf& b, int64_t ray, unsigned have, unsigned miss) {
         b.eligible = ray < a.n && __popc(have) == 1;
         b.layer = b.eligible ? __ffs(have) - 1 : 0;
 #pragma unroll
@@ -755,12 +758,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXB >
                     b.rw[i] = rl[k];
                 }
             }
+            const unsigned others = all_layers & ~(1u << b.layer);
+            if ((miss & others) != others) {   // (uniform) not every other layer carries the sampler's "missed" hint: look
 #pragma unroll
-            for (int c = 0; c < MAXCHK; ++c) {  // depths of the other layers: "missed" means every one of them is -1000
-                const int oi = c / B, blk = c - oi * B;
-                const int x = oi < b.layer ? oi : oi + 1;
-                const int k = blk * 64 + lane;
-                if (oi < a.l - 1 && k < a.S) b.chk[c] = tsrc[x * a.S + k];
+                for (int c = 0; c < MAXCHK; ++c) {  // depths of the other layers: "missed" means every one of them is -1000
+                    const int oi = c / B, blk = c - oi * B;
+                    const int x = oi < b.layer ? oi : oi + 1;
+                    const int k = blk * 64 + lane;
+                    if (oi < a.l - 1 && k < a.S) b.chk[c] = tsrc[x * a.S + k];
+                }
             }
         }
     };
@@ -770,12 +776,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXB >
     {
         const int m0 = mask_lane(r0);
         m1 = mask_lane(r1);
-        issue(cur, r0, have_of(m0));
+        issue(cur, r0, have_of(m0), miss_of(m0));
     }
     for (; r0 < a.n; r0 = r1, r1 = r2, r2 += stride) {
-        const unsigned have1 = have_of(m1);
+        const unsigned have1 = have_of(m1), miss1 = miss_of(m1);
         const int m2 = mask_lane(r2);
-        issue(nxt, r1, have1);
+        issue(nxt, r1, have1, miss1);
         __builtin_amdgcn_sched_barrier(0);  // keep the loads of the next ray ahead of this ray's arithmetic
         // ---- ray r0 from `cur`
         bool ok = cur.eligible;
@@ -962,7 +968,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(merge_
             if (a.mask) {
 #pragma unroll
                 for (int i = 0; i < STNERF_MAX_LAYERS; ++i)
-                    if (i < a.l) mk |= a.mask[ray * a.l + i] ? 1u << i : 0u;
+                    if (i < a.l) {   // bit i: hit (the reference's ray_mask); bit 16 + i: the sampler's "missed" hint
+                        const unsigned mv = a.mask[ray * a.l + i];
+                        mk |= (mv & 1u) << i | (mv >> 1 & 1u) << (16 + i);
+                    }
             }
         }
         return hnd;
@@ -980,7 +989,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(merge_
         const int jr = __ffs(todo_rays) - 1;
         todo_rays &= todo_rays - 1u;
         const int64_t ray = wave_id + (k0 + jr) * nwaves;
-        const unsigned mask_bits = (unsigned)__builtin_amdgcn_readlane((int)mk, jr);
+        const unsigned mask_word = (unsigned)__builtin_amdgcn_readlane((int)mk, jr);
+        const unsigned mask_bits = mask_word & 0xffffu, miss_bits = mask_word >> 16;
         const unsigned have_m = (ev2 | (ev1 & (a.mask ? mask_bits : ~0u))) & lmask;
         const float* __restrict__ tsrc = a.t + ray * LS;
         const float4* __restrict__ rsrc = a.raw + ray * LS;
@@ -1002,7 +1012,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(merge_
         // a grazing hit: they shape their neighbours' deltas; see composite_kernel).  Eight layers' depths per round trip.
         unsigned live = have_m;
         constexpr int CB = 8;
-        for (unsigned cand = ~have_m & lmask; cand;) {
+        for (unsigned cand = ~have_m & ~miss_bits & lmask; cand;) {   // (layers the sampler flagged as missed are not even looked at)
             int ly[CB];
             float v[CB][MAXB];
 #pragma unroll

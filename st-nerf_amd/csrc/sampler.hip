@@ -128,7 +128,9 @@ __global__ void sample_coarse_kernel(const float* __restrict__ rays, int64_t n, 
         xyz_out[e * 3 + 1] = y;
         xyz_out[e * 3 + 2] = z;
     }
-    if (k == 0) mask_out[ray * l + layer] = fabsf(width) > 1e-5f ? 1 : 0;  // :105
+    // bit 0: the reference's ray_mask (:105).  Bit 1 (a hint for the compositor, see include/stnerf.h): the ray misses the box
+    // altogether -- start = end = -1000 (:53-62), bin width 0, every depth of the layer is exactly -1000
+    if (k == 0) mask_out[ray * l + layer] = (fabsf(width) > 1e-5f ? 1 : 0) | ((width == 0.f && start == -1000.0f) ? 2 : 0);
 }
 
 // Same arithmetic, G = 4 or 2 consecutive samples of one (ray, layer) per thread: one slab test per group, vector
@@ -188,7 +190,7 @@ __global__ void sample_coarse_kernel_xg(const float* __restrict__ rays, int64_t 
     if (valid) {
         if (G == 4) *reinterpret_cast<float4*>(t_out + e) = make_float4(tv[0], tv[1], tv[G - 2], tv[G - 1]);
         else *reinterpret_cast<float2*>(t_out + e) = make_float2(tv[0], tv[1]);
-        if (k0 == 0) mask_out[ray * l + layer] = fabsf(width) > 1e-5f ? 1 : 0;
+        if (k0 == 0) mask_out[ray * l + layer] = (fabsf(width) > 1e-5f ? 1 : 0) | ((width == 0.f && start == -1000.0f) ? 2 : 0);   // (bit 1: see sample_coarse_kernel)
     }
     if (xyz_out) {
         // A wave's 64 groups are consecutive, so its points are 768 G bytes of contiguous output.  Written straight from
@@ -221,7 +223,7 @@ __global__ void compact_rays_kernel(const uint8_t* __restrict__ mask, int64_t n,
     __shared__ int block_base;
     const int layer = blockIdx.y;
     const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool hit = ray < n && mask[ray * l + layer] != 0;
+    const bool hit = ray < n && (mask[ray * l + layer] & 1) != 0;
     const unsigned long long ball = __ballot(hit);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int before = __popcll(ball & ((1ull << lane) - 1ull));

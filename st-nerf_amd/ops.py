@@ -101,8 +101,10 @@ def intersect(rays: Tensor, boxes: Tensor) -> Tensor:
 
 def sample_coarse(rays: Tensor, boxes: Tensor, n1: int, jitter: Optional[Tensor] = None, seed: int = 0,
                   ray_index_base: int = 0, edits=None, pivot=None, want_xyz: bool = True, ray_index_stripe: int = 0,
-                  ray_index_period: int = 0):
-    """-> t (n,l,n1), xyz (n,l,n1,3) | None, mask (n,l) uint8.  layers/RaySamplePoint.py:70-107."""
+                  ray_index_period: int = 0, raw_mask: bool = False):
+    """-> t (n,l,n1), xyz (n,l,n1,3) | None, mask (n,l) uint8 (0 / 1 = the reference's ray_mask; with ``raw_mask`` the
+    library's byte: bit 1 = the sampler's "every depth of this pair is -1000" hint, which ``composite`` accepts).
+    layers/RaySamplePoint.py:70-107."""
     n = rays.shape[0]
     bp, bstride, l = _boxes_arg(boxes, n)
     if jitter is not None and tuple(jitter.shape) != (l, n, n1):
@@ -116,7 +118,7 @@ def sample_coarse(rays: Tensor, boxes: Tensor, n1: int, jitter: Optional[Tensor]
                                              ray_index_period, ed, pv,
                                              hip.dptr(t), hip.dptr(xyz), hip.dptr(mask, torch.uint8),
                                              hip.stream_ptr()), "stnerf_sample_coarse")
-    return t, xyz, mask
+    return t, xyz, (mask if raw_mask else mask.bitwise_and_(1))
 
 
 def compact_rays(mask: Tensor):
@@ -481,6 +483,7 @@ def render_rays(rays: Tensor, boxes: Tensor, nets: "hip.Nets", params: "hip.Rend
                                            hip.dptr(workspace, torch.uint8, "workspace"), workspace.numel(),
                                            hip.dptr(mix_f), hip.dptr(mix_c), hip.dptr(lo_f), hip.dptr(lo_c),
                                            hip.dptr(mask, torch.uint8), hip.stream_ptr()), "stnerf_render_rays")
+    mask.bitwise_and_(1)     # (bit 1 was the sampler's hint to the compositor inside the call: include/stnerf.h)
     if params.only_coarse:
         return mix_c, mix_c, lo_c, lo_c, mask
     return mix_f, mix_c, lo_f, lo_c, mask

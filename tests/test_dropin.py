@@ -354,3 +354,116 @@ def test_launcher_runs_a_reference_script_unmodified(reference_env, tmp_path, mo
     dropin.main([str(script), "-c", "configs/config_taekwondo.yml"])
     out = capsys.readouterr().out
     assert "MODEL stnerf_amd.modeling BATCHIFY stnerf_amd.utils.batchify_rays ['-c', 'configs/config_taekwondo.yml']" in out
+
+
+# ---- N ranks: `torchrun ... -m stnerf_amd.dropin demo/...` -- the launcher joins the process group and the reference's own
+# render_pose, unmodified, renders 1 / N of the frame per rank -------------------------------------------------------------
+def _dropin_rank(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      STNERF_DIST_BACKEND="gloo")
+    sys.dont_write_bytecode = True
+    sys.meta_path.append(_StubFinder())
+    sys.path.insert(0, REFERENCE)
+    torch.Tensor.cuda = lambda self, *a, **k: self               # no GPU here (SURVEY 8c shim 2)
+    import torch.distributed as dist
+    import stnerf_amd.dropin as dropin
+    from oracle import stnerf_oracle as O
+    from stnerf_amd import parallel, synthetic as syn
+    dropin.patch_reference(REFERENCE)
+    assert dropin.join_process_group() == (rank, world)          # what `python -m stnerf_amd.dropin` does before the script runs
+    try:
+        assert dist.is_initialized() and dist.get_world_size() == world
+        lnr = importlib.import_module("render.layered_neural_renderer")
+        ray_dataset = importlib.import_module("data.datasets.ray_dataset")
+        import modeling
+        from stnerf_amd.modeling.layered_rfrender import LayeredRFRender
+        L, n1, n2, H, W = 2, 8, 4, 48, 80                        # 3840 rays = one full 3584-ray chunk + a ragged second one
+        l, N = L + 1, H * W
+        sd, bk, per = _scene(L)
+        K, T = syn.camera(H, W, 12.0)
+        pairs = [(0, 1), (1, 2.5), (2, 1)]
+        g = torch.Generator().manual_seed(7)
+        jitter, u = torch.rand(l, N, n1, generator=g), torch.rand(l, N, n2, generator=g)
+        launches = []
+
+        class HostLogicOnCpu(LayeredRFRender):
+            def render_rays_raw(self, rays, *a, **k):
+                torch.Tensor.is_cuda = property(lambda t: True)
+                try:
+                    return super().render_rays_raw(rays, *a, **k)
+                finally:
+                    torch.Tensor.is_cuda = property(lambda t: False)
+
+            def _render_launch(self, rays, boxes, pivot, retiming, only_coarse, thr_, bthr_, window, replay):
+                n = rays.shape[0]
+                launches.append((n, tuple(window)))
+                om = O.OracleModel(layer_num=L, n_coarse=n1, n_fine=n2, params=self.state_dict(), bkgd_bbox=bk, bboxes=per, near=self.near,
+                                   alpha=self.alpha, scale=self.scale, shift=self.shift)
+                bx = boxes.unsqueeze(0).expand(n, l, 8, 3) if boxes.dim() == 3 else boxes
+                saved = O.layer_boxes
+                O.layer_boxes = lambda m, r: (bx.clone(), pivot, retiming, r[:, 6:] if retiming else r[:, -1])
+                try:
+                    draws = iter(list(replay["jitter"]) + list(replay["u"]))
+                    out = O.render_chunk(om, rays, only_coarse, thr_, bthr_, rand=lambda shape: next(draws))
+                finally:
+                    O.layer_boxes = saved
+                cat = lambda trip: torch.cat(list(trip), -1)
+                return (cat(out[0]), cat(out[1]), torch.stack([cat(t) for t in out[2]], 1), torch.stack([cat(t) for t in out[3]], 1),
+                        torch.stack(out[4], 1).to(torch.uint8))
+
+        model = modeling.build_layered_model(_cfg(n1, n2, L), camera_num=1).eval()    # the reference's name, this framework's class
+        assert type(model) is LayeredRFRender
+        model.__class__ = HostLogicOnCpu
+        model.load_state_dict(sd)
+        model.set_bkgd_bbox(bk)
+        model.set_bboxes(per)
+        model.replay = {"jitter": jitter, "u": u}
+        ds = object.__new__(ray_dataset.Ray_Dataset_Render)
+        ds.height, ds.width, ds.layer_num = H, W, L
+        ds.use_deform_time = ds.use_space_time = True
+        ds.near_far = torch.tensor([[-1.0, -1.0]])
+        r = object.__new__(lnr.LayeredNeuralRenderer)
+        r.dataset, r.model, r.far = ds, model, 20.0
+        render_pose = lnr.LayeredNeuralRenderer.render_pose                       # the reference's own function object
+        model.shard_views = False
+        whole = render_pose(r, T.numpy(), K, pairs, density_threshold=0.05, bkgd_density_threshold=0.02)
+        n_whole = sum(n for n, _ in launches)
+        launches.clear()
+        model.shard_views = True
+        split = render_pose(r, T.numpy(), K, pairs, density_threshold=0.05, bkgd_density_threshold=0.02)
+        mine = sum(e - s for s, e in parallel.stripe_spans(N, 3584, rank, world))
+        flat = lambda o: [o[0], o[1]] + list(o[2]) + list(o[3])
+        same = all(a.shape == b.shape and torch.allclose(a, b, rtol=0, atol=2e-6) for a, b in zip(flat(whole), flat(split)))
+        q.put((rank, dict(same=bool(same), whole_rays=n_whole, my_rays=sum(n for n, _ in launches), my_share=mine,
+                          windows=[w for _, w in launches], picture=float(whole[0].std()) > 0.01)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_reference_render_pose_is_sharded_across_ranks_with_no_edit(world):
+    """What ``python -m torch.distributed.run --nproc-per-node N -m stnerf_amd.dropin demo/taekwondo_demo.py`` sets up, on
+    gloo: the reference's own render_pose (render/layered_neural_renderer.py:364-391), unmodified, on every rank; each rank's
+    model is handed only its chunks (ray window of stripes of one reference chunk), and every rank returns the full colour,
+    depth and per-layer images of the single-process render."""
+    import torch.multiprocessing as mp
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dropin_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    N = 48 * 80
+    assert sorted(results) == list(range(world))
+    for rank, res in results.items():
+        assert res["same"] and res["picture"], (rank, res)
+        assert res["whole_rays"] == N and res["my_rays"] == res["my_share"] < N, (rank, res)
+        assert all(w == (rank * 3584, 3584, world * 3584) for w in res["windows"]), (rank, res)
+    assert sum(res["my_rays"] for res in results.values()) == N

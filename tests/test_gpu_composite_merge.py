@@ -148,3 +148,32 @@ def test_merge_kernel_unsorted_layer_takes_the_general_rank(ops):
     mix = O.composite(t_mix, rgb_mix, sig_mix)
     torch.testing.assert_close(mo[:, :3].cpu(), mix[0], rtol=1e-5, atol=3e-6)
     torch.testing.assert_close(mo[:, 4:5].cpu(), mix[2], rtol=1e-5, atol=3e-6)
+
+
+@pytest.mark.parametrize("L, n1", [(2, 64), (4, 64), (8, 128), (2, 90)])
+def test_sampler_missed_hint_is_bitwise_neutral_for_the_compositor(L, n1):
+    """The sampler's "missed" hint (mask bit 1: both slab hits -1000, every depth of the pair exactly -1000) lets the
+    compositor skip reading those depths; the composites must be the SAME BITS as with a plain 0 / 1 mask, in all three
+    kernels (single-layer, merge, staged), and the hint must be set exactly on the pairs whose depths are all -1000."""
+    import numpy as np
+    from stnerf_amd import ops, synthetic as syn
+    h, w = 40, 64
+    K, T = syn.camera(h, w, 17.0)
+    rays = ops.generate_rays(K, T, h, w, frame_ids=[1.0] + [2.5] * L)
+    bk, per = syn.scene_boxes(L)
+    boxes = torch.cat([bk, per[1]], 0).cuda()
+    t, _, raw_mask = ops.sample_coarse(rays, boxes, n1, seed=3, raw_mask=True)
+    mask = raw_mask & 1
+    hinted = (raw_mask & 2) != 0
+    all_missed = (t == -1000.0).all(-1)
+    assert torch.equal(hinted, all_missed) and int(hinted.sum()) > 0.2 * hinted.numel() / (L + 1)
+    assert not bool((hinted & (mask != 0)).any()) and not bool(hinted[:, 0].any())
+    torch.manual_seed(L)
+    raw = torch.randn(t.shape + (4,), device="cuda")
+    kw = dict(near=0.1, fine=False, cut_negative_t=True, thresholds=[None] + [0.2] * L, evaluated=[2] + [1] * L, want_weights=True)
+    bits = lambda x: x.contiguous().view(torch.int32)
+    for two_pass, want_order in ((True, False), (False, False), (False, True)):
+        a = ops.composite(t, raw, mask, two_pass=two_pass, want_order=want_order, **kw)
+        b = ops.composite(t, raw, raw_mask, two_pass=two_pass, want_order=want_order, **kw)
+        for x, y in zip(a[:3], b[:3]):
+            assert torch.equal(bits(x), bits(y)), (two_pass, want_order)
