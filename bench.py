@@ -43,13 +43,18 @@ from stnerf_amd import parallel                         # noqa: E402
 from stnerf_amd.parallel import gather_tiles, render_view  # noqa: E402
 
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
-MEASURED_HBM_JSON = os.path.join(REPO, "profiles", "r03_hbm_copy_microbench.json")   # tools/micro/hbm_copy on the GPU box
-PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r03_pmc_hbm_traffic.json")         # tools/r03_summarise.py (pose 0 of the sweep)
+MEASURED_HBM_JSON = os.path.join(REPO, "profiles", "r04_hbm_copy_microbench.json")   # tools/micro/hbm_copy on the GPU box
+PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r04_pmc_hbm_traffic.json")         # tools/r04_summarise.py (pose 0 of the sweep)
 
 # Algorithmic work per network evaluation: 2 * MACs of every nn.Linear.
 FLOP_SPACE, FLOP_SPACE_TIME, FLOP_MOTION = 924_672, 930_048, 153_344
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (spec, no sparsity)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
+# What a register-only MFMA loop on all 256 CUs sustains over seconds on this part (tools/micro/mfma_rate.hip,
+# profiles/r01_mfma_rate_microbench.md): the 16-bit MFMA pipe is POWER-bound as soon as the operands carry real (random) data --
+# 1.67 PF/s at ~1.6 - 1.7 GHz and 1.3 kW, not the 2.5 PF/s of the 2.4 GHz spec (measured with f16 operands; the bf16 instruction
+# runs on the same datapath at the same rate); the f32 MFMA pipe is issue-bound at 154 TF/s whatever the data.
+SUSTAINED_16BIT_MFMA_TFLOPS, SUSTAINED_F32_MFMA_TFLOPS = 1670.0, 154.0
 
 WORKLOADS = {
     # name: (H, W, L, N1, N2, space_time, deform_time)
@@ -491,6 +496,10 @@ def main():
             return {"kernel": STAGE_KERNEL[prec] if dom == "mlp_stage" else "stnerf::spacenet_kernel (fused PE + 9-layer MLP)",
                     "bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s", "frac": executed / peak,
                     "executed_mfma_tflops": executed, "algorithmic_tflops": alg,
+                    "measured_sustained_peak": SUSTAINED_F32_MFMA_TFLOPS if prec == "fp32" else SUSTAINED_16BIT_MFMA_TFLOPS,
+                    "frac_of_measured_sustained_peak": executed / (SUSTAINED_F32_MFMA_TFLOPS if prec == "fp32" else SUSTAINED_16BIT_MFMA_TFLOPS),
+                    "measured_sustained_peak_source": "profiles/r01_mfma_rate_microbench.md: register-only MFMA loop, all 256 CUs, ~3 s, random operands "
+                                                      "(16-bit MFMA: power-bound at 1.3 kW; f32 MFMA: issue-bound)",
                     "traffic": traffic,
                     "traffic_source": ("profiles/" + os.path.basename(PMC_TRAFFIC_JSON) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over ONE "
                                        "step of this workload at pose 0 of the sweep (the timed steps sweep the orbit: +- 10 % evaluations)") if traffic else None,

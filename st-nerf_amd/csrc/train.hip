@@ -229,6 +229,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
     float* out = MODE == 2 ? a.C + (int64_t)blockIdx.z * a.M * a.N : a.C;
     const int64_t ldc = MODE == 2 ? a.N : a.ldc;
     const bool inside = m0 + GBM <= a.M && n0 + BN <= a.N;       // (uniform) no edge of the matrix in this tile
+    // ---- the usual case -- a tile inside the matrix, 16-byte aligned rows: the wave turns its 64 x BN/2 accumulators around
+    // through LDS, 16 rows at a time (the operand tiles are dead: every wave has its own 8.5 KB there), and bias / ReLU / mask
+    // / accumulate / store work on float4s along the row: a lane stores 16 bytes, 32 lanes one contiguous 512-byte piece of a
+    // row (straight from the accumulators a store instruction writes 2 x 128 bytes as single dwords).
+    const bool vec = inside && (ldc & 3) == 0 && ((uintptr_t)out & 15) == 0 &&
+                     (MODE != 1 || !a.mask || ((a.ldmask & 3) == 0 && ((uintptr_t)a.mask & 15) == 0)) &&
+                     (MODE != 0 || !a.bias || ((uintptr_t)a.bias & 15) == 0);
+    if (vec) {
+        constexpr int WN = BN / 2, SLD = WN + 4;                  // the wave's columns; staging row stride (floats)
+        static_assert(16 * SLD * 4 * 4 <= (GBM + BN) * GLD * 4, "epilogue staging must fit the operand tiles");
+        __syncthreads();                                          // every wave is done reading the operand tiles
+        float* stage = smem_gemm + wave * 16 * SLD;
+        const int64_t row0 = m0 + wm, col0 = n0 + wn;
+#pragma unroll
+        for (int R = 0; R < 4; ++R) {                             // rows 16 R .. 16 R + 15 of the wave's 64
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int i = R >> 1, qb = 2 * (R & 1);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stage[(8 * qq + 4 * h + r) * SLD + 32 * j + c] = acc[i][j][4 * (qb + qq) + r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int u = 0; u < 16 * WN / 4 / 64; ++u) {          // 16 rows x WN / 4 float4s over 64 lanes
+                const int idx = lane + 64 * u, rr = idx / (WN / 4), c4 = 4 * (idx % (WN / 4));
+                float4 v = *reinterpret_cast<const float4*>(stage + rr * SLD + c4);
+                const int64_t m = row0 + 16 * R + rr, n = col0 + c4;
+                if (MODE == 0) {
+                    if (a.bias) {
+                        const float4 bb = *reinterpret_cast<const float4*>(a.bias + n);
+                        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                    }
+                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                } else if (MODE == 1) {
+                    if (a.mask) {
+                        const float4 mk = *reinterpret_cast<const float4*>(a.mask + m * a.ldmask + n);
+                        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                    }
+                    if (a.accumulate) {
+                        const float4 o = *reinterpret_cast<const float4*>(out + m * ldc + n);
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                }
+                *reinterpret_cast<float4*>(out + m * ldc + n) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

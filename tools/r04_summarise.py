@@ -17,13 +17,55 @@ import sys
 src = sys.argv[1]
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
+
+
+def power_report(src, dst):
+    """socket power / clock over the whole 20-step bench run (rocm-smi samples, tools/power_trace.sh)"""
+    pw = ["# r04: socket power and shader clock over `python bench.py --steps 20 --warmup 5` (rocm-smi, ~7 Hz; `tools/power_trace.sh`)\n",
+          "The run renders 25 poses in bf16x3 (headline leg), then 25 in exact f32 (second leg), then the short config legs, the PSNR check and the CPU baseline: "
+          "the first plateau of the trace is the split-bf16 stage kernel, the second the exact-f32 one.\n"]
+    pcsv = os.path.join(src, "power_bench.csv")
+    if os.path.exists(pcsv):
+        rows_p = []
+        for line in open(pcsv):
+            # card0,(fclk),level,(mclk),level,(sclk),level,(socclk),level,power  -- levels may be digits or "S"
+            f = line.strip().split(",")
+            try:
+                rows_p.append((float(f[5].strip("()Mhz")), float(f[-1])))
+            except (ValueError, IndexError):
+                pass
+        n = len(rows_p)
+        pw.append(f"{n} samples.  Per sample: shader clock (sclk, MHz) and socket power (W).\n")
+        if n:
+            peak = max(p_ for _, p_ in rows_p)
+            med = lambda c: sorted(c)[len(c) // 2]
+            # the bf16x3 plateau draws > 93 % of the peak power, the f32 plateau 70 - 93 %
+            hi = [r for r in rows_p if r[1] > 0.93 * peak]
+            mid = [r for r in rows_p if 0.70 * peak < r[1] <= 0.93 * peak]
+            for name, sel in (("above 93 % of the peak power (the split-bf16 legs)", hi), ("70 - 93 % of the peak power (the exact-f32 legs)", mid)):
+                if sel:
+                    pw.append(f"* samples {name}: {len(sel)} of {n}; sclk min / median / max {min(r[0] for r in sel):.0f} / {med([r[0] for r in sel]):.0f} / "
+                              f"{max(r[0] for r in sel):.0f} MHz, power {min(r[1] for r in sel):.0f} / {med([r[1] for r in sel]):.0f} / {max(r[1] for r in sel):.0f} W")
+            step = max(1, n // 60)
+            pw.append(f"\n| sample | median sclk MHz | median power W |   (medians over {step} consecutive samples)\n|---|---|---|")
+            for i in range(0, n, step):
+                seg = rows_p[i:i + step]
+                pw.append(f"| {i} | {med([r[0] for r in seg]):.0f} | {med([r[1] for r in seg]):.0f} |")
+        open(os.path.join(dst, "r04_power_bench.csv"), "w").write(open(pcsv).read())
+    open(os.path.join(dst, "r04_power_clock_trace.md"), "w").write("\n".join(pw) + "\n")
+
+
+if "--power-only" in sys.argv:
+    power_report(src, dst)
+    print(open(os.path.join(dst, "r04_power_clock_trace.md")).read())
+    sys.exit(0)
 KERN = {"mlp_stage (f32 wave)": "%mlp_wave_stage_kernel%", "mlp_stage (bf16x3)": "%mlp_bf16x3_stage_kernel%", "ray_bias": "%ray_bias_kernel%",
         "composite_single": "%composite_single_kernel%", "composite": "%composite_kernel%", "resample": "%resample_kernel%",
         "sample_coarse": "%sample_coarse_kernel%", "compact_rays": "%compact_rays_kernel%", "generate_rays": "%generate_rays_kernel%"}
 
 
 def short(name):
-    name = name.replace("void ", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     return name.split("(")[0] if "stnerf::" in name else (name[:60] + "...") if len(name) > 60 else name
 
 
@@ -169,42 +211,7 @@ for cfg, tag in (("C3 taekwondo-1080p-64+64 (bf16x3)", "bf16x3"), ("C4 walking-1
 md.append("")
 traffic["hbm_kernels_on_counter_bytes"] = hbm_table
 json.dump(traffic, open(os.path.join(dst, "r04_pmc_hbm_traffic.json"), "w"), indent=1)
-# ---- socket power / clock over the whole 20-step bench run (rocm-smi samples, tools/power_trace.sh)
-pw = ["# r04: socket power and shader clock over `python bench.py --steps 20 --warmup 5` (rocm-smi, 20 Hz; `tools/power_trace.sh`)\n",
-      "The run renders 25 poses in bf16x3 (headline leg), then 25 in exact f32 (second leg), then the short config legs, the PSNR check and the CPU baseline: "
-      "the first plateau of the trace is the split-bf16 stage kernel, the second the exact-f32 one.\n"]
-pcsv = os.path.join(src, "power_bench.csv")
-if os.path.exists(pcsv):
-    rows_p = []
-    for line in open(pcsv):
-        nums = []
-        for tok in line.replace("(", ",").replace(")", ",").replace("Mhz", "").split(","):
-            try:
-                nums.append(float(tok))
-            except ValueError:
-                pass
-        if nums:
-            rows_p.append(nums)
-    width = max(len(r) for r in rows_p) if rows_p else 0
-    good = [r for r in rows_p if len(r) == width]
-    pw.append(f"{len(good)} samples (~{len(good) / 20:.0f} s).  rocm-smi csv columns: fclk, mclk, sclk, socclk (MHz, each with its level), socket power (W).\n")
-    if good and width > 4:
-        peak = max(r[-1] for r in good)
-        med = lambda c: sorted(c)[len(c) // 2]
-        # the bf16x3 plateau draws > 93 % of the peak power, the f32 plateau 70 - 93 %
-        hi = [r for r in good if r[-1] > 0.93 * peak]
-        mid = [r for r in good if 0.70 * peak < r[-1] <= 0.93 * peak]
-        for name, sel in (("above 93 % of the peak power (the split-bf16 leg)", hi), ("70 - 93 % of the peak power (the exact-f32 leg)", mid)):
-            if sel:
-                pw.append(f"* samples {name}: {len(sel)} (~{len(sel) / 20:.0f} s); sclk min / median / max {min(r[4] for r in sel):.0f} / {med([r[4] for r in sel]):.0f} / "
-                          f"{max(r[4] for r in sel):.0f} MHz, power {min(r[-1] for r in sel):.0f} / {med([r[-1] for r in sel]):.0f} / {max(r[-1] for r in sel):.0f} W")
-        # one line per 5 s: median clock and power
-        pw.append("\n| t (s) | median sclk MHz | median power W |\n|---|---|---|")
-        for i in range(0, len(good), 100):
-            seg = good[i:i + 100]
-            pw.append(f"| {i / 20:.0f} | {med([r[4] for r in seg]):.0f} | {med([r[-1] for r in seg]):.0f} |")
-    open(os.path.join(dst, "r04_power_bench.csv"), "w").write(open(pcsv).read())
-open(os.path.join(dst, "r04_power_clock_trace.md"), "w").write("\n".join(pw) + "\n")
+power_report(src, dst)
 open(os.path.join(dst, "r04_final.md"), "w").write("\n".join(md) + "\n")
 
 wl = ["# r04: every BASELINE configuration on the round's build (1 x MI355X, `tools/r04_evidence.sh`)\n",
