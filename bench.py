@@ -144,12 +144,12 @@ class KernelTimer:
                     weights = dense - (20 * l * r["ns"] + l + 20 * (l + 1))       # 4*l*S if weights were written
                     d["bytes"] += 20 * r["ns"] * hits + (l + 20 * (l + 1) + weights) * r["n_rays"]
                 elif name == "resample":
-                    # 8 B per coarse sample read and 16 B per fine sample written for hit layers; a missed
-                    # (ray, layer) pair only gets its constant fill written (16 B per fine sample), no weights read
+                    # 8 B per coarse sample read and 16 B per fine sample written for hit layers; a missed (ray, layer)
+                    # pair is skipped since round 4 (the sampler's hint: nobody reads its constant fill)
                     l = len(counts[call])
                     hits = r["n_rays"] + sum(int(c) for c in counts[call][1:])
                     n1 = self.n1
-                    d["bytes"] += 8 * n1 * hits + 16 * r["ns"] * l * r["n_rays"] + 24 * r["n_rays"]
+                    d["bytes"] += (8 * n1 + 16 * r["ns"]) * hits + (24 + l) * r["n_rays"]
                 else:
                     d["bytes"] += r["bytes_per_ray"] * r["n_rays"]
             d["launches"] += 1

@@ -286,11 +286,16 @@ int stnerf_composite_plan(int l, int S, int with_scratch, int with_order, int64_
  * (searchsorted index), cdf[n][l][n1-1].
  * Exactness: pdf = (w + 1e-5) / torch.sum(w + 1e-5) with the sum in ATen's CPU reduction order (8-float vectors x 4
  * interleaved accumulators), cdf = torch.cumsum accumulated in fp64 and rounded per prefix as ATen's CPU kernel does:
- * cdf, inds and z_new are bit-equal to the reference's CPU evaluation of utils/sample_pdf.py on the same (t, w, u). */
+ * cdf, inds and z_new are bit-equal to the reference's CPU evaluation of utils/sample_pdf.py on the same (t, w, u).
+ * mask (may be NULL): stnerf_sample_coarse's byte per (ray, layer).  A pair whose "missed" hint (bit 1) is set is SKIPPED:
+ * every one of its depths is -1000, so are its resampled depths, and nobody reads them -- stnerf_composite with the same mask
+ * never looks at a flagged layer's depths, the networks list hit rays only: its t_fine / xyz_fine rows are left unwritten
+ * (16 B x S per pair: at nine layers most of this kernel's bytes were such constant fills).  Without hints (NULL, or bit 1 clear)
+ * a pair whose depths are all -1000 gets t_fine = -1000 and the matching points, as before. */
 int stnerf_resample(const float* t, const float* weights, int64_t n, int l, int n1, int n2,
                     const float* u, uint64_t seed, int64_t ray_index_base, int64_t ray_index_stripe,
                     int64_t ray_index_period, const float* rays,
-                    int ray_stride, const stnerf_layer_edit* edits_host, const float* pivot_host,
+                    int ray_stride, const stnerf_layer_edit* edits_host, const float* pivot_host, const uint8_t* mask,
                     float* t_fine, float* xyz_fine, float* z_new, int32_t* inds, float* cdf,
                     stnerf_stream_t stream);
 

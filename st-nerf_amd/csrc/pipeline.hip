@@ -207,7 +207,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
     // ---- resample + fine points (:459-475), fine networks, fine composite (:538-606)
     rc = stnerf_resample(t_c, w_c, n, l, n1, n2, u, p->seed, p->ray_index_base, p->ray_index_stripe, p->ray_index_period,
                          rays, rs,
-                         p->has_edits ? p->edits_fine : nullptr, p->pivot, t_f, xyz_f, nullptr, nullptr, nullptr, stream);
+                         p->has_edits ? p->edits_fine : nullptr, p->pivot, mask, t_f, xyz_f, nullptr, nullptr, nullptr, stream);
     if (rc) return rc;
     rc = stage(xyz_f, raw_f, S, true);
     if (rc) return rc;

@@ -1395,6 +1395,7 @@ struct ResampleArgs {
     const float* rays;
     int ray_stride;
     EditArgs ed;
+    const uint8_t* mask;   // [n][l] or null: bit 1 = the sampler's "every depth of this pair is -1000" hint -> the pair is skipped
     float* t_fine;
     float* xyz_fine;
     float* z_new;
@@ -1443,8 +1444,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB1 >=
     constexpr int NBR = NB1 > 0 ? NB1 : 1;
     struct Pre {
         float t[NBR], w[NBR], r;   // r: lane i < 6 holds component i of the ray (origin, direction)
+        int m;                     // the pair's mask byte (every lane), fetched with the rest: no round trip of its own
     };
     auto issue = [&](Pre& q, int64_t pr, int64_t ray_of_pr) {
+        q.m = (a.mask && pr < pairs) ? (int)a.mask[pr] : 0;
         if (NB1 > 0 && pr < pairs) {
             const float* tsrc = a.t + pr * n1;
             const float* wsrc = a.weights + pr * n1;
@@ -1461,6 +1464,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB1 >=
 #pragma unroll
     for (int b = 0; b < NBR; ++b) nxt_in.t[b] = nxt_in.w[b] = 0.f;
     nxt_in.r = 0.f;
+    nxt_in.m = 0;
     // (ray, layer) of the wave's pair are carried along instead of divided out of the pair index every iteration: a 64-bit
     // division is ~ 80 scalar + vector instructions, and there were two per pair
     const int64_t dray = per_iter / a.l;
@@ -1484,6 +1488,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB1 >=
         issue(nxt_in, pr + per_iter, ray_n);
         __builtin_amdgcn_sched_barrier(0);  // the next pair's loads go out ahead of this pair's arithmetic
         const bool active = pr < pairs;
+        // the sampler flagged the pair as missed (include/stnerf.h): nothing of it is read downstream -- nothing is written
+        if (active && !z_out && !inds_out && !cdf_dbg && (__builtin_amdgcn_readfirstlane(in.m) & 2)) continue;
         bool sorted_z = false;
         float o0 = 0.f, o1 = 0.f, o2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
         if (active) {
@@ -1850,7 +1856,7 @@ extern "C" int stnerf_composite(const float* t, const float* raw, const uint8_t*
 extern "C" int stnerf_resample(const float* t, const float* weights, int64_t n, int l, int n1, int n2, const float* u,
                                uint64_t seed, int64_t ray_index_base, int64_t ray_index_stripe, int64_t ray_index_period,
                                const float* rays, int ray_stride,
-                               const stnerf_layer_edit* edits_host, const float* pivot_host, float* t_fine,
+                               const stnerf_layer_edit* edits_host, const float* pivot_host, const uint8_t* mask, float* t_fine,
                                float* xyz_fine, float* z_new, int32_t* inds, float* cdf, stnerf_stream_t stream) {
     STNERF_REQUIRE(t && weights && rays && t_fine, "resample: null pointer");
     STNERF_REQUIRE(n >= 0 && l >= 1 && l <= STNERF_MAX_LAYERS && n1 >= 3 && n2 >= 0 && ray_stride >= 6,
@@ -1861,6 +1867,7 @@ extern "C" int stnerf_resample(const float* t, const float* weights, int64_t n, 
     a.t = t; a.weights = weights; a.n = n; a.l = l; a.n1 = n1; a.n2 = n2; a.u = u; a.seed = seed;
     a.win = RayWindow{ray_index_base, ray_index_stripe, ray_index_period}; a.rays = rays; a.ray_stride = ray_stride;
     fill_edit_args(a.ed, edits_host, pivot_host, l);
+    a.mask = mask;
     a.t_fine = t_fine; a.xyz_fine = xyz_fine; a.z_new = z_new; a.inds = inds; a.cdf_out = cdf;
     const int lds = 4 * resample_lds_floats(n1, n2) * (int)sizeof(float);
     // (the +inf padding of the branch-free searches rounds three of the arrays up to powers of two: 512+512 samples need

@@ -111,7 +111,7 @@ _PROTOS = {
     "stnerf_render_rays": (C.c_int, [c_f32p, c_i64, c_f32p, c_i64, C.POINTER(Nets), C.POINTER(RenderParams), c_f32p, c_f32p,
                                      C.c_void_p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
     "stnerf_resample": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_uint64, c_i64, c_i64, c_i64, c_f32p,
-                                  C.c_int, C.POINTER(LayerEdit), C.POINTER(C.c_float), c_f32p, c_f32p, c_f32p,
+                                  C.c_int, C.POINTER(LayerEdit), C.POINTER(C.c_float), C.c_void_p, c_f32p, c_f32p, c_f32p,
                                   C.c_void_p, c_f32p, C.c_void_p]),
 }
 

@@ -415,10 +415,11 @@ def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e
 
 def resample(t: Tensor, weights: Tensor, n2: int, rays: Tensor, u: Optional[Tensor] = None, seed: int = 0,
              ray_index_base: int = 0, edits=None, pivot=None, want_xyz: bool = True, debug: bool = False,
-             ray_index_stripe: int = 0, ray_index_period: int = 0):
+             ray_index_stripe: int = 0, ray_index_period: int = 0, mask: Optional[Tensor] = None):
     """t (n,l,n1), weights (n,l,n1) -> t_fine (n,l,n1+n2) ascending, xyz_fine (n,l,n1+n2,3) | None
     [, z_new (n,l,n2), inds (n,l,n2) int32, cdf (n,l,n1-1) if debug].
-    utils/sample_pdf.py:18-63 + modeling/layered_rfrender.py:459-475."""
+    utils/sample_pdf.py:18-63 + modeling/layered_rfrender.py:459-475.  ``mask`` (n,l) uint8 with the sampler's hints
+    (``sample_coarse(raw_mask=True)``): pairs flagged "missed" are skipped, their output rows stay unwritten."""
     n, l, n1 = t.shape
     if u is not None and tuple(u.shape) != (l, n, n2):
         raise ValueError(f"u must be (l,n,n2) = {(l, n, n2)}, got {tuple(u.shape)}")
@@ -432,7 +433,7 @@ def resample(t: Tensor, weights: Tensor, n2: int, rays: Tensor, u: Optional[Tens
     hip.check(hip.lib().stnerf_resample(hip.dptr(t, name="t"), hip.dptr(weights, name="weights"), n, l, n1, n2,
                                         hip.dptr(u, name="u"), seed, ray_index_base, ray_index_stripe, ray_index_period,
                                         hip.dptr(rays, name="rays"),
-                                        rays.shape[1], ed, pv, hip.dptr(t_fine), hip.dptr(xyz), hip.dptr(z_new),
+                                        rays.shape[1], ed, pv, hip.dptr(mask, torch.uint8, "mask"), hip.dptr(t_fine), hip.dptr(xyz), hip.dptr(z_new),
                                         hip.dptr(inds, torch.int32), hip.dptr(cdf), hip.stream_ptr()),
               "stnerf_resample")
     if debug:

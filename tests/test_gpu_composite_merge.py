@@ -177,3 +177,32 @@ def test_sampler_missed_hint_is_bitwise_neutral_for_the_compositor(L, n1):
         b = ops.composite(t, raw, raw_mask, two_pass=two_pass, want_order=want_order, **kw)
         for x, y in zip(a[:3], b[:3]):
             assert torch.equal(bits(x), bits(y)), (two_pass, want_order)
+
+
+@pytest.mark.parametrize("L, n1, n2", [(2, 64, 64), (4, 64, 64), (8, 128, 64), (2, 90, 30), (3, 200, 40)])
+def test_resampler_skips_exactly_the_pairs_the_sampler_flagged(L, n1, n2):
+    """stnerf_resample with the sampler's mask: a pair flagged "missed" is left UNWRITTEN (sentinel intact), every other pair is
+    the bits of the call without a mask -- and on the flagged pairs that call wrote nothing but -1000 depths."""
+    from stnerf_amd import ops, synthetic as syn
+    import stnerf_amd.ops as O_
+    h, w = 24, 48
+    K, T = syn.camera(h, w, 17.0)
+    rays = ops.generate_rays(K, T, h, w, frame_ids=[1.0] + [2.5] * L)
+    bk, per = syn.scene_boxes(L)
+    boxes = torch.cat([bk, per[1]], 0).cuda()
+    t, _, raw_mask = ops.sample_coarse(rays, boxes, n1, seed=3, raw_mask=True)
+    torch.manual_seed(n1)
+    wts = torch.rand(t.shape, device="cuda") ** 6
+    plain_t, plain_xyz = ops.resample(t, wts, n2, rays, seed=9)
+    # a sentinel-filled output: call the entry point with pre-filled buffers through the wrapper's allocator
+    orig = torch.empty
+    torch.empty = lambda *a, **k: orig(*a, **k).fill_(7.0) if k.get("dtype", torch.float32) == torch.float32 else orig(*a, **k)
+    try:
+        hint_t, hint_xyz = ops.resample(t, wts, n2, rays, seed=9, mask=raw_mask)
+    finally:
+        torch.empty = orig
+    flagged = (raw_mask & 2) != 0
+    assert int(flagged.sum()) > 0 and int((~flagged).sum()) > 0
+    assert bool((hint_t[flagged] == 7.0).all()) and bool((hint_xyz[flagged] == 7.0).all())
+    assert bool((plain_t[flagged] == -1000.0).all())
+    assert torch.equal(hint_t[~flagged], plain_t[~flagged]) and torch.equal(hint_xyz[~flagged], plain_xyz[~flagged])
