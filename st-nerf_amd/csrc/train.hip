@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
     float* Bs = smem_gemm + GBM * GLD;
     constexpr int NJ = BN / 64;                // 32-column MFMA tiles per wave
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, c = lane & 31;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * BN;   // (row tiles on x: a grid's y extent ends at 65535 blocks)
     int k_begin = 0, k_end = a.K;
     if (MODE == 2) {                           // (k_per_split is a multiple of 32: a slice never straddles two splits)
         k_begin = blockIdx.z * a.k_per_split;
@@ -314,12 +314,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
         }
 }
 template <bool A_KC, bool B_KC, int MODE>
-int launch_gemm(const GemmArgs& a, int grid_y, int grid_z, hipStream_t st, const char* what) {
+int launch_gemm(const GemmArgs& a, int row_tiles, int grid_z, hipStream_t st, const char* what) {
     if (a.N > 128) {
-        const dim3 grid((a.N + 255) / 256, grid_y, grid_z);
+        const dim3 grid(row_tiles, (a.N + 255) / 256, grid_z);
         hipLaunchKernelGGL((train_gemm_kernel<A_KC, B_KC, MODE, 256>), grid, dim3(256), (GBM + 256) * GLD * 4, st, a);
     } else {
-        const dim3 grid(1, grid_y, grid_z);
+        const dim3 grid(row_tiles, 1, grid_z);
         hipLaunchKernelGGL((train_gemm_kernel<A_KC, B_KC, MODE, 128>), grid, dim3(256), (GBM + 128) * GLD * 4, st, a);
     }
     STNERF_CHECK_LAUNCH(what);

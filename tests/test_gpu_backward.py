@@ -45,7 +45,8 @@ def _rel(got, ref):
     return float((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("m, n, k", [(1, 1, 4), (127, 3, 128), (129, 256, 63), (1000, 128, 319), (300, 256, 256), (2500, 1, 256), (64, 130, 84)])
+@pytest.mark.parametrize("m, n, k", [(1, 1, 4), (127, 3, 128), (129, 256, 63), (1000, 128, 319), (300, 256, 256), (2500, 1, 256), (64, 130, 84),
+                                     (128 * 70001 + 5, 3, 4)])     # (the last one: more than 65535 row tiles)
 def test_linear_forward_dx_dw_match_fp64_matmuls(ops, m, n, k):
     g = torch.Generator().manual_seed(m + n + k)
     x, w, b = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g)
@@ -67,7 +68,7 @@ def test_linear_forward_dx_dw_match_fp64_matmuls(ops, m, n, k):
     assert _rel(dx[:, 1:1 + k], ref + dy64 @ w64) <= 2e-6
     dw, db = torch.full((n, k), 0.5, device="cuda"), torch.full((n,), -0.25, device="cuda")
     ops.train_linear_dw(dyd, xd, dw, db, accumulate=True)
-    assert _rel(dw, 0.5 + dy64.T @ x64) <= 4e-6 and _rel(db, -0.25 + dy64.sum(0)) <= 4e-6
+    assert _rel(dw, 0.5 + dy64.T @ x64) <= (4e-6 if m < 1_000_000 else 4e-5) and _rel(db, -0.25 + dy64.sum(0)) <= (4e-6 if m < 1_000_000 else 2e-4)
     dw2 = torch.empty(n, k, device="cuda")
     ops.train_linear_dw(dyd, xd, dw2, None, accumulate=False)
     ops.train_linear_dw(dyd, xd, dw, db, accumulate=False)
