@@ -1163,18 +1163,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(merge_
                             if (ok_lane(b)) ckey[rev ? S - 1u - k : k] = cur.tk[b];
                         }
                         wave_sync();
-                        // #{list entries <= v} for the MAXB samples of a lane in lockstep (independent LDS chains)
-                        unsigned pos[MAXB];
+                        // #{list entries <= v} for the MAXB samples of a lane in lockstep (independent LDS chains): a lower
+                        // bound whose interval LENGTH is the same for every lane (a scalar), so that a probe is an add, a
+                        // ds_read, a compare and a select -- no clamp against the list's end, no per-lane bound test.
+                        // `at[b]` points at the entry in front of the interval (never read before it has moved).
+                        const float* at[MAXB];
 #pragma unroll
-                        for (int b = 0; b < MAXB; ++b) pos[b] = 0u;
-                        for (unsigned step = (unsigned)__builtin_amdgcn_readfirstlane((int)(1u << (31 - __clz((int)m)))); step > 0u; step >>= 1) {
+                        for (int b = 0; b < MAXB; ++b) at[b] = mkey - 1;
+                        for (unsigned len = (unsigned)__builtin_amdgcn_readfirstlane((int)m); len > 1u;) {
+                            const unsigned half = (unsigned)__builtin_amdgcn_readfirstlane((int)(len >> 1));
 #pragma unroll
                             for (int b = 0; b < MAXB; ++b) {
-                                const unsigned np = pos[b] + step;
-                                const float x = mkey[(np < m ? np : m) - 1u];
-                                pos[b] = ((np <= m) & (x <= cur.tk[b])) ? np : pos[b];
+                                const float* probe = at[b] + half;
+                                at[b] = (*probe <= cur.tk[b]) ? probe : at[b];
                             }
+                            len = (unsigned)__builtin_amdgcn_readfirstlane((int)(len - half));
                         }
+                        unsigned pos[MAXB];
+#pragma unroll
+                        for (int b = 0; b < MAXB; ++b)   // (32-bit LDS addresses: `at` is one entry in front of the interval)
+                            pos[b] = (((unsigned)(uintptr_t)at[b] - (unsigned)(uintptr_t)mkey + 4u) >> 2) + ((at[b][1] <= cur.tk[b]) ? 1u : 0u);
 #pragma unroll
                         for (int b = 0; b < MAXB; ++b) {
                             const unsigned k = (unsigned)b * 64u + lane;

@@ -154,3 +154,66 @@ def test_call_surface_shards_itself_under_a_process_group(precision, world):
     assert sorted(r for r, _ in results) == list(range(world))
     for r, checks in results:
         assert len(checks) == 4 and all(checks.values()), (r, checks)
+
+
+def _rccl_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    from stnerf_amd import parallel, synthetic as syn
+    from stnerf_amd.utils import layered_batchify_ray
+    from oracle import stnerf_oracle as O
+    import test_gpu_render as R
+    try:                                    # the call init_from_env makes on a node, with the one rank this box can hold
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+        probe = torch.arange(12, device="cuda", dtype=torch.float32).reshape(4, 3)
+        echoed = parallel._all_gather_rows(probe, 4, 1)
+        torch.cuda.synchronize()
+    except Exception as e:                  # no RCCL transport on this box: nothing of ours has run yet
+        q.put(("unavailable", repr(e)))
+        return
+    try:
+        checks = {"backend": dist.get_backend() == "nccl", "echo": bool(torch.equal(echoed, probe))}
+        L, H, W = 2, 48, 80                                             # 3840 rays: one full chunk + a ragged tail
+        model = R.build_model(dict(L=L, n1=16, n2=8, space_time=True, deform_time=True, weight_seed=71, edit={}))
+        K, T = syn.camera(H, W, 12.0)
+        rays = O.append_frame_ids(O.generate_rays(K, T, H, W), [(0, 1), (1, 2.5), (2, 1)], L).cuda()
+
+        def flat(out):
+            stage2, stage1, stage2_layer, stage1_layer, masks = out
+            return list(stage2) + list(stage1) + [t for trip in list(stage2_layer) + list(stage1_layer) for t in trip] + list(masks)
+
+        for fresh in (False, True):
+            model.fresh_draws_per_call, model.seed = fresh, 5
+            with torch.no_grad():
+                whole = [t.clone() for t in flat(layered_batchify_ray(model, rays, None, None, density_threshold=0.05,
+                                                                      bkgd_density_threshold=0.02))]
+                model.seed = 5
+                split = flat(parallel.render_rays_sharded(model, rays, 512 * 7, 0.05, 0.02, act=(0, 1, None)))
+            checks[f"5-tuple through RCCL, fresh draws {fresh}"] = bool(
+                len(whole) == len(split) == 6 + 6 * (L + 1) + (L + 1) and float(whole[0].std()) > 0.01
+                and all(x.shape == y.shape and x.dtype == y.dtype and x.is_cuda and torch.equal(x, y) for x, y in zip(whole, split)))
+        q.put(("ran", checks))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_packed_tuple_goes_through_rccl_itself():
+    """What the gloo runs above cannot show: the one collective of the path on the backend a node uses.  A 1-rank "nccl"
+    group (RCCL refuses a second rank on the same device) initialised the way ``parallel.init_from_env`` does it; the
+    packed 5-tuple of this rank's stripes goes through ``all_gather_into_tensor`` on DEVICE tensors and comes back as the
+    unsharded render, bit for bit.  A box whose RCCL cannot initialise at all skips (nothing of ours has run by then)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    status, payload = q.get(timeout=600)
+    p.join(timeout=120)
+    if status == "unavailable":
+        pytest.skip(f"RCCL did not initialise on this box: {payload}")
+    assert p.exitcode == 0
+    assert len(payload) == 4 and all(payload.values()), payload

@@ -41,7 +41,10 @@ def make(n, l, S, pattern, seed=0):
     t[~hit] = -1000.0
     raw = torch.randn(n, l, S, 4, device="cuda", generator=g)
     raw[..., :3] = torch.sigmoid(raw[..., :3])
-    return t, raw, hit.to(torch.uint8)
+    mask = hit.to(torch.uint8)
+    if os.environ.get("HINT", "1") == "1":      # bit 1 = the sampler's "this layer's depths are all -1000" hint (include/stnerf.h)
+        mask = mask | ((~hit).to(torch.uint8) << 1)
+    return t, raw, mask
 
 
 def main():
