@@ -363,24 +363,10 @@ static int grid_for(int64_t n_rays, int ns, int tm) {
     return (int)(tiles < 8192 ? tiles : 8192);
 }
 
-// Tile configuration (STNERF_TILE overrides the default for A/B measurements):
-//   "128"   128 samples, 4 waves, 160 KiB LDS, 1 workgroup per CU (one wave per SIMD)
-//   "128x8" 128 samples, 8 waves (two per SIMD: the VALU phases of one hide in the issue gaps of the other)
-//   "64"    64 samples, 4 waves, 80 KiB LDS, 2 workgroups per CU
-// Measured on MI355X (tools/bench_mlp.py, 8.4 M rows): SpaceNet 138 / 141 / 137 TF/s, MotionNet 120 / 121 / 127 TF/s
-// for "128" / "128x8" / "64" -> defaults: SpaceNet 128x8, MotionNet 64.
-enum TileCfg { TILE_128 = 0, TILE_128X8 = 1, TILE_64 = 2 };
-static TileCfg tile_config(TileCfg dflt) {
-    static int cfg = -2;
-    if (cfg == -2) {
-        const char* e = getenv("STNERF_TILE");
-        cfg = -1;
-        if (e && !strcmp(e, "128")) cfg = TILE_128;
-        if (e && !strcmp(e, "128x8")) cfg = TILE_128X8;
-        if (e && !strcmp(e, "64")) cfg = TILE_64;
-    }
-    return cfg < 0 ? dflt : (TileCfg)cfg;
-}
+// One tile configuration per network is compiled -- the fastest of the three measured in round 1 (128 samples x 4 waves,
+// 128 x 8, 64 x 4: SpaceNet 138 / 141 / 137 TF/s, MotionNet 120 / 121 / 127 TF/s): SpaceNet 128 samples x 8 waves (two waves
+// per SIMD: the VALU phases of one hide in the issue gaps of the other, 160 KiB LDS), MotionNet 64 samples x 4 waves (80 KiB
+// LDS, two workgroups per CU).  The pipeline's stages do not come here (stage_entry.hip); these are the op-level entry points.
 
 // LDS opt-in (per device, see reserve_dynamic_lds) + launch.
 template <class Args>
@@ -499,29 +485,15 @@ extern "C" int stnerf_spacenet_fwd(int kind, const void* packed, int64_t n_rays,
         return rc;
     SpaceArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, dirs,
                 dirs_ray_stride, times, times_ray_stride, raw, raw_ray_stride, ray_bias};
-    const TileCfg tc = tile_config(TILE_128X8);
-    const int tm = tc == TILE_64 ? 64 : 128;
-    const int lds = (64 + 16) * tm * 16;
-    const int grid = grid_for(n_rays, ns, tm);
+    constexpr int TM = 128, NW = 8, LDS = (64 + 16) * TM * 16;
+    const int grid = grid_for(n_rays, ns, TM);
     const bool ut = STNERF_NET_USES_TIME(kind);
     const char* what = "spacenet_fwd";
-    const int PROF_KERNEL_ID = PROF_SPACENET, PROF_KIND_ID = kind;
-    if (STNERF_NET_IS_DEEP(kind)) {  // deep_rgb: the default tile configuration only
-        const int grid128 = grid_for(n_rays, ns, 128);
-        return ut ? launch_mlp(spacenet_kernel<128, 8, true, true>, (64 + 16) * 128 * 16, grid128, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
-                  : launch_mlp(spacenet_kernel<128, 8, false, true>, (64 + 16) * 128 * 16, grid128, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
-    }
-    switch (tc) {
-        case TILE_128:
-            return ut ? launch_mlp(spacenet_kernel<128, 4, true>, lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
-                      : launch_mlp(spacenet_kernel<128, 4, false>, lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
-        case TILE_128X8:
-            return ut ? launch_mlp(spacenet_kernel<128, 8, true>, lds, grid, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
-                      : launch_mlp(spacenet_kernel<128, 8, false>, lds, grid, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
-        default:
-            return ut ? launch_mlp(spacenet_kernel<64, 4, true>, lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID)
-                      : launch_mlp(spacenet_kernel<64, 4, false>, lds, grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
-    }
+    if (STNERF_NET_IS_DEEP(kind))
+        return ut ? launch_mlp(spacenet_kernel<TM, NW, true, true>, LDS, grid, NW * 64, stream, a, what, PROF_SPACENET, kind)
+                  : launch_mlp(spacenet_kernel<TM, NW, false, true>, LDS, grid, NW * 64, stream, a, what, PROF_SPACENET, kind);
+    return ut ? launch_mlp(spacenet_kernel<TM, NW, true>, LDS, grid, NW * 64, stream, a, what, PROF_SPACENET, kind)
+              : launch_mlp(spacenet_kernel<TM, NW, false>, LDS, grid, NW * 64, stream, a, what, PROF_SPACENET, kind);
 }
 
 extern "C" int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32_t* ray_list,
@@ -535,16 +507,7 @@ extern "C" int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, 
     if (n_rays == 0) return STNERF_OK;
     MotionArgs a{static_cast<const float*>(packed), {n_rays, ns, ray_list, ray_count}, xyz, xyz_ray_stride, times,
                  times_ray_stride, flow, flow_ray_stride, add_to_xyz};
-    const TileCfg tc = tile_config(TILE_64);
-    const int grid = grid_for(n_rays, ns, tc == TILE_64 ? 64 : 128);
-    const char* what = "motionnet_fwd";
-    const int PROF_KERNEL_ID = PROF_MOTIONNET, PROF_KIND_ID = STNERF_NET_MOTION;
-    switch (tc) {
-        case TILE_128:
-            return launch_mlp(motionnet_kernel<128, 4>, motion_lds_bytes<128, 4>(), grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
-        case TILE_128X8:
-            return launch_mlp(motionnet_kernel<128, 8>, motion_lds_bytes<128, 8>(), grid, 512, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
-        default:
-            return launch_mlp(motionnet_kernel<64, 4>, motion_lds_bytes<64, 4>(), grid, 256, stream, a, what, PROF_KERNEL_ID, PROF_KIND_ID);
-    }
+    constexpr int TM = 64, NW = 4;
+    return launch_mlp(motionnet_kernel<TM, NW>, motion_lds_bytes<TM, NW>(), grid_for(n_rays, ns, TM), NW * 64, stream, a,
+                      "motionnet_fwd", PROF_MOTIONNET, STNERF_NET_MOTION);
 }

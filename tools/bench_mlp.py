@@ -1,4 +1,4 @@
-"""Microbenchmark of the fused MLP kernels (one process per STNERF_TILE setting)."""
+"""Microbenchmark of the fused per-network MLP kernels (mlp.hip: the op-level entry points)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -35,4 +35,4 @@ for _ in range(iters):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 res["motion"] = (ms, n * ns * 153344 / ms / 1e9)
-print(prec, "TILE", os.environ.get("STNERF_TILE", "default"), os.environ.get("STNERF_TILE_H", ""), " ".join(f"{k}: {v[0]:.2f} ms {v[1]:.1f} TF/s" for k, v in res.items()), "rows", n * ns)
+print(prec, " ".join(f"{k}: {v[0]:.2f} ms {v[1]:.1f} TF/s" for k, v in res.items()), "rows", n * ns)

@@ -18,8 +18,8 @@ reader(buf, 1)
 ops.spacenet_fwd(net, xyz, dirs, None, raw); torch.cuda.synchronize()
 reader(buf, 1)
 names = ["PE", "MMA", "BAR1(pre-epilogue)", "EPI", "BAR2(post-epilogue)", "ENC2", "HEAD", "MISC"]
-wgs = buf[8]; tiles = n * ns // (64 if os.environ.get("STNERF_TILE") == "64" else 128)
+wgs = buf[8]; tiles = n * ns // 128
 tot = sum(buf[i] for i in range(8))
-print(os.environ.get("PRECISION", "fp32"), "TILE", os.environ.get("STNERF_TILE"), os.environ.get("STNERF_TILE_H"), "workgroups", wgs, "tiles", tiles, "cycles/tile", tot / tiles)
+print(os.environ.get("PRECISION", "fp32"), "workgroups", wgs, "tiles", tiles, "cycles/tile", tot / tiles)
 for i, nm in enumerate(names):
     print(f"  {nm:22s} {buf[i] / tiles:10.0f} cycles/tile  {100.0 * buf[i] / tot:5.1f} %")
