@@ -124,6 +124,15 @@ def test_compositor_and_resampler_production_kernels_resources(tmp_path):
         if "composite" in part:
             assert body.count("v_mul_f32_dpp") >= 6 and body.count("v_add_f32_dpp") >= 30, part      # in-place scans
             assert "ds_or_b32" in body and "v_mbcnt_hi_u32_b32" in body, part                         # slot mask + prefix count
+            # the insertion's search: a loop the SCALAR unit controls (interval length in an SGPR), whose body is, per sample
+            # block, an add, a ds_read_b32, a compare and a select -- nothing else on the vector unit
+            blocks = int(re.search(r"ILi(\d)E", part).group(1))
+            loops = [m.group(1) for m in re.finditer(r"Inner Loop Header: Depth=\d+\n((?:.*\n)*?)\s+s_cbranch_scc[01] ", body)]
+            search = [b for b in loops if b.count("ds_read_b32") == blocks and "s_lshr_b32" in b]
+            assert len(search) == 1, (part, [b.count("ds_read_b32") for b in loops])
+            vector = [l.split()[0] for l in search[0].splitlines() if l.strip().startswith("v_")]
+            assert len(vector) == 3 * blocks and sum(v.startswith("v_cmp") for v in vector) == blocks \
+                and sum(v.startswith("v_cndmask") for v in vector) == blocks, (part, vector)
         else:
             assert body.count("v_min_f32_dpp") >= 14 and body.count("ds_bpermute_b32") <= 2, part    # DPP bitonic stages
             if part.endswith("ELb1ELb1"):   # sizes known at compile time: (almost) no scalar registers parked in vector lanes
