@@ -175,6 +175,7 @@ def _rccl_worker(port, q):
     except Exception as e:                  # no RCCL transport on this box: nothing of ours has run yet
         q.put(("unavailable", repr(e)))
         return
+    q.put(("initialised", None))            # from here on a failure is ours
     try:
         checks = {"backend": dist.get_backend() == "nccl", "echo": bool(torch.equal(echoed, probe))}
         L, H, W = 2, 48, 80                                             # 3840 rays: one full chunk + a ragged tail
@@ -211,9 +212,25 @@ def test_packed_tuple_goes_through_rccl_itself():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
     p.start()
-    status, payload = q.get(timeout=600)
+
+    def next_message(seconds):
+        import queue
+        for _ in range(seconds):
+            try:
+                return q.get(timeout=1)
+            except queue.Empty:
+                if not p.is_alive() and q.empty():
+                    return None
+        return None
+
+    first = next_message(600)
+    if first is None or first[0] == "unavailable":      # (an RCCL that aborts the process instead of raising lands here too)
+        p.join(timeout=30)
+        pytest.skip(f"RCCL did not initialise on this box: {first[1] if first else f'worker exit code {p.exitcode}'}")
+    assert first[0] == "initialised"
+    result = next_message(600)
     p.join(timeout=120)
-    if status == "unavailable":
-        pytest.skip(f"RCCL did not initialise on this box: {payload}")
+    assert result is not None and result[0] == "ran", (result, p.exitcode)
     assert p.exitcode == 0
+    payload = result[1]
     assert len(payload) == 4 and all(payload.values()), payload
