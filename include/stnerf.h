@@ -314,8 +314,9 @@ int stnerf_train_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t
  * ReLU backward of the PRODUCING layer folded in; NULL: none); accumulate = 1 adds to dx (a tensor with two consumers). */
 int stnerf_train_linear_dx(const float* dy, int64_t lddy, const float* w, int64_t ldw, int64_t m, int n, int k, const float* mask,
                            int64_t ldmask, int accumulate, float* dx, int64_t lddx, stnerf_stream_t stream);
-/* dw[n][k] (+)= sum_m dy[m][n] x[m][k];  db[n] (+)= sum_m dy[m][n] (db may be NULL).  The samples are cut into <= 128 slices
- * reduced by separate workgroups into `workspace`, then summed in slice order: deterministic, no atomics. */
+/* dw[n][k] (+)= sum_m dy[m][n] x[m][k];  db[n] (+)= sum_m dy[m][n] (db may be NULL).  The samples are cut into <= 256 slices
+ * of >= 256 samples (as many as give the launch two workgroups per CU), reduced by separate workgroups into `workspace`, then
+ * summed in slice order: deterministic, no atomics. */
 int64_t stnerf_train_dw_workspace_bytes(int64_t m, int n, int k);
 int stnerf_train_linear_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t m, int n, int k, float* dw, int64_t lddw,
                            float* db, int accumulate, void* workspace, int64_t workspace_bytes, stnerf_stream_t stream);

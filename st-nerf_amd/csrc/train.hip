@@ -332,6 +332,7 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int sp
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     float s = 0.f;
+#pragma unroll 8
     for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * count + i];
     float* d = dst + (i / cols) * ld_dst + (i % cols);
     *d = accumulate ? *d + s : s;
@@ -497,11 +498,23 @@ extern "C" int stnerf_train_linear_dx(const float* dy, int64_t lddy, const float
     return launch_gemm<true, false, 1>(a, (int)((m + GBM - 1) / GBM), 1, as_stream(stream), "train_linear_dx");
 }
 
+// dW's contraction runs over the SAMPLES: the launch is tiles x slices workgroups (one slice of the samples per blockIdx.z, its
+// partial tile summed with the others afterwards, in slice order).  The networks' weight matrices are 1 - 3 tiles, so the slices
+// are what fills the chip: about two workgroups per CU (512), slices of at least 256 samples, at most 256 of them (a 256 x 256
+// layer: 2 tiles x 256 slices; the partial tiles are 64 MB written and read once -- 26 us of HBM against a 150 us GEMM).
+static int dw_slices(int64_t m, int n, int k) {
+    const int64_t tiles = (int64_t)((n + GBM - 1) / GBM) * (k > 128 ? (k + 255) / 256 : 1);
+    int64_t want = (512 + tiles - 1) / tiles;
+    const int64_t most = (m + 255) / 256;
+    if (want > most) want = most;
+    if (want > 256) want = 256;
+    return (int)(want < 1 ? 1 : want);
+}
+
 extern "C" int64_t stnerf_train_dw_workspace_bytes(int64_t m, int n, int k) {
     if (m < 0 || n < 1 || k < 1) return STNERF_EINVAL;
-    const int64_t splits = m <= 0 ? 1 : (m + 1023) / 1024 > 128 ? 128 : (m + 1023) / 1024;   // <= 128 slices of >= 1024 samples
     const int64_t row_blocks = m <= 0 ? 1 : (m + 1023) / 1024 > 512 ? 512 : (m + 1023) / 1024;
-    return 4 * (splits * (int64_t)n * k + row_blocks * (int64_t)n) + 512;
+    return 4 * ((int64_t)dw_slices(m, n, k) * n * k + row_blocks * (int64_t)n) + 512;
 }
 
 extern "C" int stnerf_train_linear_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t m, int n, int k, float* dw,
@@ -515,7 +528,7 @@ extern "C" int stnerf_train_linear_dw(const float* dy, int64_t lddy, const float
     STNERF_REQUIRE(m * lddy < (1ll << 29) && m * ldx < (1ll << 29), "train_linear_dw: operands of 2 GiB and more: split the batch");
     if (m == 0) return STNERF_OK;
     hipStream_t st = as_stream(stream);
-    const int splits = (int)((m + 1023) / 1024 > 128 ? 128 : (m + 1023) / 1024);
+    const int splits = dw_slices(m, n, k);
     int kps = (int)((m + splits - 1) / splits);
     kps = (kps + GBK - 1) / GBK * GBK;
     float* partial = static_cast<float*>(workspace);

@@ -12,13 +12,17 @@ path), and get none.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
 
 from stnerf_amd import ops
 
-CHUNK_SAMPLES = 1 << 16          # samples whose activations are kept at a time while recomputing
+# Samples whose activations are kept at a time while recomputing (~11 KB each for a SpaceNet: 2.9 GB of a 288 GB part).  Large
+# enough that the dW contraction's 256 slices are 1024 samples each with the chip full (csrc/train.hip: dw_slices); measured on
+# 524,288 samples: 0.54 / 0.60 / 0.63 / 0.64 of the f32 MFMA peak at 2^16 / 2^17 / 2^18 / 2^19.  STNERF_TRAIN_CHUNK_SAMPLES overrides.
+CHUNK_SAMPLES = int(os.environ.get("STNERF_TRAIN_CHUNK_SAMPLES", 1 << 18))
 
 
 def _pad4(n: int) -> int:
