@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Benchmark of the layered ray-march render path on MI355X (driver contract: one JSON line on rank 0).
+"""Benchmark of the layered ray-march render path on MI355X.  Driver contract: the LAST stdout line of rank 0 is the record,
+< 3 KB (tests/test_bench_record.py); the line before it is a digest of the detail, whose full form goes to bench_detail.json.
 
     python bench.py --gpus N --steps K --warmup W          # N > 1: launches its own N ranks (torch.distributed.run, 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -7,7 +8,7 @@
 
 A "step" = one pass of the hot path over ONE synthetic 1080p view: device ray generation (a1/a2) -> coarse sampler ->
 mask compaction -> MotionNet/SpaceNet (split-bf16 MFMA, the library default; the exact f32 MFMA arithmetic is timed as a
-second, co-equal leg) -> composite + merge -> inverse-CDF resample -> fine MotionNet/SpaceNet -> composite + merge,
+short cross-check leg of <= 5 steps) -> composite + merge -> inverse-CDF resample -> fine MotionNet/SpaceNet -> composite + merge,
 through the call surface a user of the reference calls: ``stnerf_amd.parallel.render_view`` = what ``render_pose`` runs
 (device ray generation + ``layered_batchify_ray``).
 
@@ -15,7 +16,8 @@ The SAME function is the step at every N.  N = 1: the whole view on the one GPU.
 configs[3]/[4] describe): the view is cut into interleaved single-row stripes over the N ranks (the performers cover only
 part of the picture; contiguous tiles would differ ~2x in cost), every rank generates and renders its 1/N of the rows
 as one launch sequence (striped ray window), one RCCL all-gather rebuilds the WHOLE 5-tuple (mixed + per-layer colour /
-depth / acc, fine and coarse, hit masks: 10 + 11 l floats per ray) on every rank.  `scaling` = "strong" at every N:
+depth / acc, fine and coarse, hit masks as one bit column: 11 + 10 l floats per ray; --gather fine / final move less) on
+every rank.  `scaling` = "strong" at every N:
 value = rays of the view x steps / max-over-ranks time.  `--partition views` (one whole view per rank per step, weak
 scaling) stays available as an explicit alternative.
 
@@ -206,6 +208,8 @@ def cpu_baseline(workload, budget_rays, threads=0):
     except Exception:
         pass
     return dict(value=rate, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample_short=f"{n_chunks} reference chunks of {chunk} rays spread over the {W}x{H} view, oracle/stnerf_oracle.py, "
+                             f"torch {torch.__version__} CPU fp32",
                 sample=f"{n_chunks} reference chunks of {chunk} rays spread evenly over the rows of the {W}x{H} view "
                        f"(the performer boxes span the image height: every chunk crosses them, see chunks[].performer_hit_fraction), "
                        f"oracle/stnerf_oracle.py on torch "
@@ -275,6 +279,42 @@ def eager_gpu_baseline(workload, n_rays, device):
                 sample=f"{n} rays ({n // chunk} reference chunks of {chunk}) from the centre rows, {dt_s:.2f} s")
 
 
+def emulate_share(model, dims, rank_counts, stripe_rows, device, steps):
+    """An EMULATION on this one GPU of what one rank of an N-GPU job computes -- not a scaling measurement: rank 0's
+    interleaved row stripes of the view (parallel.render_view_share = the code render_view runs before its all-gather, with
+    a made-up rank (0, N), no process group) timed for each N over the poses of the first timed steps.  t_share(N) against
+    t(1) / N exposes what does not shrink with the share: the persistent stage kernel's tail at 1/N of the items, per-view
+    host work, stripe imbalance.  predicted_compute_efficiency = t(1) / (N x max-over-emulated-ranks t_share(N)); the
+    all-gather (payload reported) is not in it."""
+    H, W, L, n1, n2, st, dt = dims
+    frame_ids = [1.0] + [2.5] * L
+    out = []
+    for N in [1] + [n for n in rank_counts if n > 1]:
+        per_rank_ms = []
+        for r in sorted({0, N // 2, N - 1}):                  # first, middle, last rank: stripe imbalance
+            for i in (-1,) + tuple(range(steps)):
+                if i == 0:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                K, T = syn.camera(H, W, orbit_deg=10.0 + 1.5 * i)
+                model.seed = i
+                packed = parallel.render_view_share(model, K, T, H, W, frame_ids, r, N, stripe_rows=stripe_rows, device=device)
+            torch.cuda.synchronize()
+            per_rank_ms.append((r, 1e3 * (time.perf_counter() - t0) / steps))
+        worst = max(ms for _, ms in per_rank_ms)
+        if N == 1:
+            t1_ms = worst                                     # the same function, the same poses, the whole view
+            continue
+        out.append({"ranks": N, "t_share_ms": {str(r): ms for r, ms in per_rank_ms}, "t_share_max_ms": worst,
+                    "n_times_t_share_over_t1": N * worst / t1_ms, "predicted_compute_efficiency": t1_ms / (N * worst),
+                    "rays_per_rank": packed.shape[0],
+                    "gather_payload_bytes_per_rank": {mode: packed.shape[0] * 4 * parallel.packed_width(L + 1, mode)
+                                                      for mode in parallel.GATHER_MODES}})
+    return {"note": "EMULATION on one GPU, not a scaling measurement: rank r's stripes of the view rendered alone (no process group, "
+                    "no collective); t1_ms = the same function with (rank, N) = (0, 1) over the same poses",
+            "t1_ms": t1_ms, "steps": steps, "stripe_rows": stripe_rows, "shares": out}
+
+
 def _self_launch(args):
     """`python bench.py --gpus N` (N > 1) without torch.distributed.run's environment: become the launcher of N ranks of
     this very command (one process per GPU, rendezvous on 127.0.0.1, a free port)."""
@@ -306,6 +346,207 @@ STAGE_KERNEL = {
             "samples and keeps their activations in registers, v_mfma_f32_32x32x2_f32)"}
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# The record.  The driver keeps the last 8 KB of stdout and parses the LAST line: that line is the compact contract record
+# (`final`, < 3 KB, tests/test_bench_record.py); everything else -- both arithmetics' full roofline blocks, the HBM-side
+# kernels, the other configs' legs, the CPU leg's per-chunk list, notes -- is `detail`: written to bench_detail.json beside
+# this script (and to gpurun_out/ when that exists, so that a gpurun call brings it home) and printed, trimmed, on the line
+# BEFORE the final one.
+FINAL_LINE_LIMIT = 3072
+DETAIL_LINE_LIMIT = 4096
+DETAIL_PATH = os.path.join(REPO, "bench_detail.json")
+DTYPE_SHORT = {"fp32": "f32", "bf16x3": "f32 (operands split into 3 bf16 pieces, 6 bf16 MFMA terms per product, f32 accumulate)"}
+KERNEL_SHORT = {"fp32": "stnerf::mlp_wave_stage_kernel", "bf16x3": "stnerf::mlp_bf16x3_stage_kernel"}
+
+
+def _stage_of(leg):
+    return leg["ksum"]["mlp_stage"] if "mlp_stage" in leg["ksum"] else leg["ksum"]["spacenet"]
+
+
+def roofline_of(leg, workload, ctx):
+    """MFMA roofline of the stage kernel of one leg: EXECUTED MFMA rate (what the matrix pipe does) over the dense peak
+    of the instruction it issues, and the algorithmic rate (network FLOPs of the reference's arithmetic) beside it."""
+    prec = leg["precision"]
+    pmc, world = ctx["pmc"], ctx["world"]
+    sp = _stage_of(leg)
+    alg = sp["flop"] / (sp["ms"] * 1e-3) / 1e12
+    executed = EXECUTED_TERMS[prec] * alg
+    peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    sustained = SUSTAINED_F32_MFMA_TFLOPS if prec == "fp32" else SUSTAINED_16BIT_MFMA_TFLOPS
+    # HBM traffic cannot be counted inside this process: it comes from the committed rocprofv3 PMC passes
+    # of the same command (profiles/), per launch, with the gfx950 FETCH_SIZE correction applied.
+    pk = pmc.get({"bf16x3": "kernels_bf16x3", "fp32": "kernels"}.get(prec, "-"), {})
+    dom = "mlp_stage" if "mlp_stage" in leg["ksum"] else "spacenet"
+    traffic = pk[dom]["hbm_bytes_per_launch"] if (pmc.get("workload") == workload and world == 1 and dom in pk) else None
+    return {"kernel": STAGE_KERNEL[prec] if dom == "mlp_stage" else "stnerf::spacenet_kernel (fused PE + 9-layer MLP)",
+            "bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s", "frac": executed / peak,
+            "executed_mfma_tflops": executed, "algorithmic_tflops": alg, "mfma_terms_per_product": EXECUTED_TERMS[prec],
+            "measured_sustained_peak": sustained, "frac_of_measured_sustained_peak": executed / sustained,
+            "measured_sustained_peak_source": "profiles/r01_mfma_rate_microbench.md: register-only MFMA loop, all 256 CUs, ~3 s, random operands "
+                                              "(16-bit MFMA: power-bound at 1.3 kW; f32 MFMA: issue-bound)",
+            "traffic": traffic,
+            "traffic_source": ("profiles/" + os.path.basename(PMC_TRAFFIC_JSON) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over ONE "
+                               "step of this workload at pose 0 of the sweep (the timed steps sweep the orbit: +- 10 % evaluations)") if traffic else None,
+            "algorithmic_bytes_per_launch": 28 * sp["evals"] / sp["launches"],   # 12 B point in + 16 B raw out per SpaceNet evaluation
+            "launches": sp["launches"], "avg_launch_ms": sp["ms"] / sp["launches"],
+            "algorithmic_flop_per_launch": sp["flop"] / sp["launches"],
+            "note": "algorithmic FLOPs = network evaluations x 924,672 (930,048 with time; + 153,344 per MotionNet evaluation in the fused "
+                    "stage kernel); executed = algorithmic x MFMA terms per product (1 for f32, 6 for bf16x3); HIP events recorded by the "
+                    "library on the launch stream around every launch of the timed steps (rank 0)"}
+
+
+def hbm_entry(leg, k, d, ctx):
+    pmc, measured = ctx["pmc"], ctx["hbm_microbench"]
+    hbm_meas = {"composite": measured.get("read_GBps"), "resample": measured.get("copy_GBps"),
+                "sample_coarse": measured.get("write_GBps")}
+    sec = d["ms"] * 1e-3
+    e = {"launches": d["launches"], "ms_per_step": d["ms"] / leg["steps"],
+         "algorithmic_GBps": d["bytes"] / sec / 1e9, "peak_GBps": PEAK_HBM_GBPS, "frac": d["bytes"] / sec / (PEAK_HBM_GBPS * 1e9),
+         "algorithmic_bytes_per_step": d["bytes"] / leg["steps"],
+         "dense_bytes_per_step": d["bytes_dense"] / leg["steps"]}
+    if hbm_meas.get(k):
+        e["measured_peak_GBps"] = hbm_meas[k]
+        e["frac_of_measured_peak"] = d["bytes"] / sec / (hbm_meas[k] * 1e9)
+    pk = pmc.get("kernels_bf16x3" if leg["precision"] == "bf16x3" else "kernels", {})
+    if (pmc.get("workload") == ctx["workload"] and ctx["world"] == 1 and k in pk
+            and leg.get("workload", ctx["workload"]) == ctx["workload"]):
+        cb = pk[k]["hbm_bytes_per_step"]
+        e["counter_bytes_per_step"] = cb
+        e["counter_GBps"] = cb / (d["ms"] / leg["steps"] * 1e-3) / 1e9
+        e["counter_over_algorithmic"] = cb / (d["bytes"] / leg["steps"])
+        e["counter_source"] = "profiles/" + os.path.basename(PMC_TRAFFIC_JSON)
+    return e
+
+
+def leg_record(leg, workload, ctx):
+    per_rank = leg["per_rank_compute_s"]
+    return {"precision": leg["precision"], "dtype": DTYPE_NOTES[leg["precision"]], "note": PRECISION_NOTES[leg["precision"]],
+            "workload": workload, "value": leg["rays"] / leg["elapsed"], "unit": "rays/s", "steps": leg["steps"], "warmup": leg["warmup"],
+            "ms_per_step": 1e3 * leg["elapsed"] / leg["steps"],
+            "ray_samples_per_s": leg["evals_all"] / leg["elapsed"],
+            "ray_samples_per_step_rank0": leg["evals"] / leg["steps"],
+            "mask_fraction": leg["mask_fraction"],
+            "per_rank_compute_s": {"min": min(per_rank), "mean": sum(per_rank) / len(per_rank), "max": max(per_rank), "all": per_rank,
+                                   "note": "render time of each rank's share over the timed steps, before the all-gather"},
+            "roofline": roofline_of(leg, workload, ctx),
+            "kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / leg["steps"],
+                            "algorithmic_tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12} for k, d in leg["ksum"].items() if "flop" in d},
+            "hbm_kernels": {k: hbm_entry(leg, k, d, ctx) for k, d in leg["ksum"].items() if "bytes" in d}}
+
+
+def _sig(x, n=6):
+    """Numbers of the final line keep n significant digits (a 17-digit double is noise at 1 % run-to-run)."""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def build_records(head, second, config_legs, ctx):
+    """(detail, final): `final` is the driver's contract line (< FINAL_LINE_LIMIT bytes as JSON), `detail` everything else.
+    head / second / config_legs[] are measure() results; ctx carries the run's arguments and the side legs."""
+    H, W, L, n1, n2, st, dt = ctx["dims"]
+    world, partition, precision, workload = ctx["world"], ctx["partition"], ctx["precision"], ctx["workload"]
+    hr = leg_record(head, workload, ctx)
+    roof = hr["roofline"]
+    cpu = ctx.get("cpu")
+    final = {
+        "metric": "rendered rays/s (and ray-samples/s) per GPU, 1080p x 128-sample layered render",
+        "value": hr["value"], "unit": "rays/s", "n_gpus": world, "steps": ctx["steps"], "warmup": ctx["warmup"],
+        "ms_per_step": hr["ms_per_step"], "higher_is_better": True,
+        "scaling": "strong" if partition == "stripes" else "weak", "vs_baseline": None,
+        "dtype": DTYPE_SHORT[precision], "data": "synthetic",
+        "config": {"workload": workload, "precision": precision, "height": H, "width": W, "performer_layers": L,
+                   "coarse_samples": n1, "fine_samples": n2,
+                   "parallelism": ("1 GPU, whole view" if world == 1 else
+                                   (f"{world} GPUs: interleaved {ctx['stripe_rows']}-row stripes of one view, one RCCL all-gather per view"
+                                    if partition == "stripes" else f"{world} GPUs: one whole view each, final tiles all-gathered"))},
+        "ray_samples_per_s": hr["ray_samples_per_s"],
+        "roofline": {"kernel": KERNEL_SHORT[head["precision"]] if "mlp_stage" in head["ksum"] else "stnerf::spacenet_kernel",
+                     "bound": "mfma", "achieved": roof["achieved"], "peak": roof["peak"], "unit": "TFLOP/s", "frac": roof["frac"],
+                     "algorithmic_tflops": roof["algorithmic_tflops"], "mfma_terms_per_product": roof["mfma_terms_per_product"],
+                     "traffic": roof["traffic"], "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"],
+                     "avg_launch_ms": roof["avg_launch_ms"], "launches": roof["launches"]},
+        "cpu_baseline": None if cpu is None else {
+            "value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
+            "sample": cpu.get("sample_short", cpu["sample"])[:200], "seconds": cpu["seconds"], "cpu": cpu["host"]["cpu"][:64]},
+    }
+    if second is not None:
+        sr = leg_record(second, workload, ctx)
+        final["other_precision"] = {"precision": second["precision"], "value": sr["value"], "ms_per_step": sr["ms_per_step"],
+                                    "steps": second["steps"], "warmup": second["warmup"], "frac": sr["roofline"]["frac"],
+                                    "algorithmic_tflops": sr["roofline"]["algorithmic_tflops"]}
+    if ctx.get("psnr"):
+        p = ctx["psnr"]
+        final["psnr_vs_reference_dB"] = {"reference_seed_b_vs_a": p.get("reference_seed_b_vs_seed_a_dB"),
+                                         "hip": p.get(f"hip_device_rng_{precision}_vs_reference_seed_a_dB")}
+    if ctx.get("share"):
+        final["share_emulation"] = {str(e["ranks"]): e["predicted_compute_efficiency"] for e in ctx["share"]["shares"]}
+    final["detail"] = os.path.basename(DETAIL_PATH)
+    final = _sig(final)
+
+    detail = {
+        "record": "detail", "workload": workload, "n_gpus": world,
+        "config": {"use_space_time": st, "use_deform_time": dt, "rays_per_view": H * W, "rays_per_launch": ctx["rays_per_launch"],
+                   "weights": "random, density head scaled (synthetic.make_state_dict seed 0)", "packed_floats_per_ray": parallel.packed_width(L + 1)},
+        "precision_legs": {"note": "the same workload and poses in both arithmetics, one after the other in this process; the second leg is "
+                                   "a short cross-check (<= 5 steps)", precision: hr},
+        "hbm_bytes_note": "algorithmic = bytes the kernel has to move (t, raw and weights only of the layers a ray hits); "
+                          "dense = every layer charged (round-1 accounting)",
+        "hbm_microbench": ctx["hbm_microbench"] or None, "psnr_vs_reference": ctx.get("psnr"), "device": ctx["device"],
+        "eager_gpu_baseline": ctx.get("eager"), "cpu_baseline": cpu, "share_emulation": ctx.get("share"),
+    }
+    if second is not None:
+        detail["precision_legs"][second["precision"]] = sr
+    if config_legs:
+        detail["config_legs"] = {leg["workload"]: {k: v for k, v in leg_record(leg, leg["workload"], ctx).items()
+                                                   if k not in ("note", "dtype", "per_rank_compute_s")} for leg in config_legs}
+    return detail, final
+
+
+def detail_line(detail):
+    """The one-line digest of `detail` printed before the final line (<= DETAIL_LINE_LIMIT bytes): the per-leg headline numbers."""
+    def leg(r):
+        return _sig({"value": r["value"], "ms_per_step": r["ms_per_step"], "ray_samples_per_s": r["ray_samples_per_s"],
+                     "frac": r["roofline"]["frac"], "algorithmic_tflops": r["roofline"]["algorithmic_tflops"],
+                     "hbm": {k: [round(e["ms_per_step"], 3), round(e["frac"], 3)] for k, e in r["hbm_kernels"].items()}}, 5)
+    d = {"record": "detail", "file": os.path.basename(DETAIL_PATH),
+         "precision_legs": {k: leg(v) for k, v in detail["precision_legs"].items() if k != "note"},
+         "config_legs": {k: leg(v) for k, v in detail.get("config_legs", {}).items()},
+         "eager_gpu_baseline": _sig({k: v for k, v in (detail.get("eager_gpu_baseline") or {}).items() if k in ("value", "unit")}),
+         "hbm_columns": "[ms_per_step, frac of 8 TB/s on algorithmic bytes]"}
+    if detail.get("share_emulation"):
+        d["share_emulation"] = _sig(detail["share_emulation"]["shares"], 5)
+    line = json.dumps(d)
+    if len(line) > DETAIL_LINE_LIMIT:
+        line = json.dumps({"record": "detail", "file": d["file"], "precision_legs": d["precision_legs"]})
+    return line
+
+
+def emit(detail, final):
+    line = json.dumps(final)
+    if len(line) >= FINAL_LINE_LIMIT:                       # never let verbosity cost the driver its record again
+        for k in ("share_emulation", "psnr_vs_reference_dB", "other_precision"):
+            final.pop(k, None)
+            line = json.dumps(final)
+            if len(line) < FINAL_LINE_LIMIT:
+                break
+    for path in (DETAIL_PATH, os.path.join(REPO, "gpurun_out", os.path.basename(DETAIL_PATH))):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    json.dump({"final": final, "detail": detail}, f, indent=1)
+        except OSError:
+            pass
+    print(detail_line(detail))
+    print(line)
+    sys.stdout.flush()
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,6 +563,9 @@ def main():
                          "(strong scaling, the split BASELINE configs[3]/[4] describe); 'views' = one whole view per GPU "
                          "per step (weak scaling)")
     ap.add_argument("--stripe-rows", type=int, default=1, help="image rows per stripe of the striped partition")
+    ap.add_argument("--gather", default="all", choices=list(parallel.GATHER_MODES),
+                    help="N > 1: what the one all-gather per view carries (stnerf_amd.parallel): the whole 5-tuple (default, the "
+                         "worst case), the fine images render_pose returns, or the two mixed images")
     ap.add_argument("--debug-single-device", action="store_true",
                     help="N>1 with every rank on cuda:0 over gloo: exercises the multi-rank code path on a 1-GPU box (not a measurement)")
     ap.add_argument("--no-psnr-check", action="store_true",
@@ -335,9 +579,13 @@ def main():
     ap.add_argument("--mlp-schedule", default="stage", choices=["stage", "per_net"],
                     help="exact-f32 MLP scheduling: one persistent launch per stage (default) or one launch per network (round 1)")
     ap.add_argument("--no-second-precision", action="store_true",
-                    help="skip the second, co-equal leg (same steps and warm-up) in the other arithmetic (fp32 <-> bf16x3)")
+                    help="skip the short cross-check leg (<= 5 steps) in the other arithmetic (fp32 <-> bf16x3)")
     ap.add_argument("--no-config-legs", action="store_true",
                     help="skip the short legs over the other BASELINE configs (C4 walking-1080p-L4, C2 single-512), N = 1 only")
+    ap.add_argument("--emulate-share", default="",
+                    help="comma list of rank counts, e.g. 2,4,8 (N = 1 only): time rank 0's interleaved-stripe share of the view for "
+                         "each count on this one GPU -- an EMULATION of a rank's compute, not a scaling measurement "
+                         "(profiles/r05_share_emulation.md)")
     ap.add_argument("--dump-outputs", default=None,
                     help="rank 0 writes the LAST timed step's whole 5-tuple (every rank holds it after the all-gather) to this "
                          "torch file: tests compare an N-rank run with the 1-rank run bit for bit")
@@ -369,7 +617,8 @@ def main():
         model, dims = build_scene(workload, device)
         model.max_rays_per_launch = args.rays_per_launch
         model.mlp_schedule = args.mlp_schedule
-        model.shard_views = partition == "stripes"
+        model.shard_views = partition == "stripes"      # sharding is opt-in (a collective call): the bench opts in
+        model.gather = args.gather
         return model, dims
 
     def fence():
@@ -392,7 +641,8 @@ def main():
             torch.cuda.synchronize()
             clock["compute"] += time.perf_counter() - clock["t0"]
             return out
-        model.render_rays_raw = timed_raw
+        if world > 1:                                     # (N = 1: no extra synchronise inside the step; compute = elapsed)
+            model.render_rays_raw = timed_raw
 
         def step(i):
             """Novel-view sweep, a new pose every step; every rank uses the same camera for step i."""
@@ -418,8 +668,8 @@ def main():
             elapsed = time.perf_counter() - t0
             timer.stop()
         finally:
-            del model.render_rays_raw
-        per_rank = [clock["compute"]]
+            model.__dict__.pop("render_rays_raw", None)
+        per_rank = [clock["compute"] if world > 1 else elapsed]
         if world > 1:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -430,13 +680,16 @@ def main():
             per_rank = allc.tolist()
         ksum = timer.summarise()  # this rank's launches over the timed steps
         evals = sum(d["evals"] for name, d in ksum.items() if name in ("spacenet", "mlp_stage"))
-        hit = torch.stack(out[4]).float().mean(1).double()       # the gathered masks of the last view (every rank holds them)
+        if out[4] is not None:
+            hit = torch.stack(out[4]).float().mean(1).double()   # the gathered masks of the last view (every rank holds them)
+        else:                                                    # --gather final: this rank's rays of the last view
+            hit = timer.masks[-1].ne(0).float().mean(0).double()
         evals_all = float(evals)
         if world > 1:
             ev = torch.tensor([evals], dtype=torch.float64, device=device)
             dist.all_reduce(ev)
             evals_all = float(ev.item())
-        flat = torch.cat(list(out[0]) + list(out[1]), 1)
+        flat = torch.cat(list(out[0]) + (list(out[1]) if out[1] is not None else []), 1)
         assert bool(torch.isfinite(flat).all()), "non-finite pixels in the rendered view"
         return dict(elapsed=elapsed, ksum=ksum, evals=evals, evals_all=evals_all, out=out, mask_fraction=hit.tolist(),
                     per_rank_compute_s=per_rank, steps=steps, warmup=warmup, precision=precision, dims=dims,
@@ -448,8 +701,8 @@ def main():
     head = measure(model, dims, args.precision, args.steps, args.warmup)
     second = None
     if not args.no_second_precision:
-        # the other arithmetic as a CO-EQUAL leg: same steps, same warm-up, same poses, full roofline block
-        second = measure(model, dims, "fp32" if args.precision != "fp32" else "bf16x3", args.steps, args.warmup)
+        # the other arithmetic as a short cross-check leg (<= 5 steps after <= 2 warm-up steps, the same first poses)
+        second = measure(model, dims, "fp32" if args.precision != "fp32" else "bf16x3", min(args.steps, 5), min(args.warmup, 2))
     model.set_precision(args.precision)
     config_legs = []
     if world == 1 and not args.no_config_legs and partition == "stripes":
@@ -464,6 +717,10 @@ def main():
             del m2
             torch.cuda.empty_cache()
     psnr_check = psnr_vs_reference(args.precision, device) if (rank == 0 and not args.no_psnr_check) else None
+    share = None
+    if world == 1 and args.emulate_share:
+        share = emulate_share(model, dims, [int(x) for x in args.emulate_share.split(",")], args.stripe_rows, device,
+                              steps=min(args.steps, 3))
 
     if args.dump_outputs and rank == 0:
         o = head["out"]
@@ -473,120 +730,18 @@ def main():
                     "world": world, "partition": partition, "precision": args.precision}, args.dump_outputs)
 
     if rank == 0:
-        pmc = json.load(open(PMC_TRAFFIC_JSON)) if os.path.exists(PMC_TRAFFIC_JSON) else {}
-        measured = json.load(open(MEASURED_HBM_JSON)) if os.path.exists(MEASURED_HBM_JSON) else {}
-        hbm_meas = {"composite": measured.get("read_GBps"), "resample": measured.get("copy_GBps"),
-                    "sample_coarse": measured.get("write_GBps")}
-
-        def stage_of(leg):
-            return leg["ksum"]["mlp_stage"] if "mlp_stage" in leg["ksum"] else leg["ksum"]["spacenet"]
-
-        def roofline_of(leg, workload):
-            """MFMA roofline of the stage kernel of one leg: EXECUTED MFMA rate (what the matrix pipe does) over the dense peak
-            of the instruction it issues, and the algorithmic rate (network FLOPs of the reference's arithmetic) beside it."""
-            prec = leg["precision"]
-            sp = stage_of(leg)
-            alg = sp["flop"] / (sp["ms"] * 1e-3) / 1e12
-            executed = EXECUTED_TERMS[prec] * alg
-            peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
-            # HBM traffic cannot be counted inside this process: it comes from the committed rocprofv3 PMC passes
-            # of the same command (profiles/), per launch, with the gfx950 FETCH_SIZE correction applied.
-            pk = pmc.get({"bf16x3": "kernels_bf16x3", "fp32": "kernels"}.get(prec, "-"), {})
-            dom = "mlp_stage" if "mlp_stage" in leg["ksum"] else "spacenet"
-            traffic = pk[dom]["hbm_bytes_per_launch"] if (pmc.get("workload") == workload and world == 1 and dom in pk) else None
-            return {"kernel": STAGE_KERNEL[prec] if dom == "mlp_stage" else "stnerf::spacenet_kernel (fused PE + 9-layer MLP)",
-                    "bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s", "frac": executed / peak,
-                    "executed_mfma_tflops": executed, "algorithmic_tflops": alg,
-                    "measured_sustained_peak": SUSTAINED_F32_MFMA_TFLOPS if prec == "fp32" else SUSTAINED_16BIT_MFMA_TFLOPS,
-                    "frac_of_measured_sustained_peak": executed / (SUSTAINED_F32_MFMA_TFLOPS if prec == "fp32" else SUSTAINED_16BIT_MFMA_TFLOPS),
-                    "measured_sustained_peak_source": "profiles/r01_mfma_rate_microbench.md: register-only MFMA loop, all 256 CUs, ~3 s, random operands "
-                                                      "(16-bit MFMA: power-bound at 1.3 kW; f32 MFMA: issue-bound)",
-                    "traffic": traffic,
-                    "traffic_source": ("profiles/" + os.path.basename(PMC_TRAFFIC_JSON) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over ONE "
-                                       "step of this workload at pose 0 of the sweep (the timed steps sweep the orbit: +- 10 % evaluations)") if traffic else None,
-                    "algorithmic_bytes_per_launch": 28 * sp["evals"] / sp["launches"],   # 12 B point in + 16 B raw out per SpaceNet evaluation
-                    "launches": sp["launches"], "avg_launch_ms": sp["ms"] / sp["launches"],
-                    "algorithmic_flop_per_launch": sp["flop"] / sp["launches"],
-                    "note": "algorithmic FLOPs = network evaluations x 924,672 (930,048 with time; + 153,344 per MotionNet evaluation in the fused "
-                            "stage kernel); executed = algorithmic x MFMA terms per product (1 for f32, 6 for bf16x3); HIP events recorded by the "
-                            "library on the launch stream around every launch of the timed steps (rank 0)"}
-
-        def hbm_entry(leg, k, d):
-            sec = d["ms"] * 1e-3
-            e = {"launches": d["launches"], "ms_per_step": d["ms"] / leg["steps"],
-                 "algorithmic_GBps": d["bytes"] / sec / 1e9, "peak_GBps": PEAK_HBM_GBPS, "frac": d["bytes"] / sec / (PEAK_HBM_GBPS * 1e9),
-                 "algorithmic_bytes_per_step": d["bytes"] / leg["steps"],
-                 "dense_bytes_per_step": d["bytes_dense"] / leg["steps"]}
-            if hbm_meas.get(k):
-                e["measured_peak_GBps"] = hbm_meas[k]
-                e["frac_of_measured_peak"] = d["bytes"] / sec / (hbm_meas[k] * 1e9)
-            pk = pmc.get("kernels_bf16x3" if leg["precision"] == "bf16x3" else "kernels", {})
-            if pmc.get("workload") == args.workload and world == 1 and k in pk and leg.get("workload", args.workload) == args.workload:
-                cb = pk[k]["hbm_bytes_per_step"]
-                e["counter_bytes_per_step"] = cb
-                e["counter_GBps"] = cb / (d["ms"] / leg["steps"] * 1e-3) / 1e9
-                e["counter_over_algorithmic"] = cb / (d["bytes"] / leg["steps"])
-                e["counter_source"] = "profiles/" + os.path.basename(PMC_TRAFFIC_JSON)
-            return e
-
-        def leg_record(leg, workload):
-            per_rank = leg["per_rank_compute_s"]
-            return {"precision": leg["precision"], "dtype": DTYPE_NOTES[leg["precision"]], "note": PRECISION_NOTES[leg["precision"]],
-                    "workload": workload, "value": leg["rays"] / leg["elapsed"], "unit": "rays/s", "steps": leg["steps"], "warmup": leg["warmup"],
-                    "ms_per_step": 1e3 * leg["elapsed"] / leg["steps"],
-                    "ray_samples_per_s": leg["evals_all"] / leg["elapsed"],
-                    "ray_samples_per_step_rank0": leg["evals"] / leg["steps"],
-                    "mask_fraction": leg["mask_fraction"],
-                    "per_rank_compute_s": {"min": min(per_rank), "mean": sum(per_rank) / len(per_rank), "max": max(per_rank), "all": per_rank,
-                                           "note": "render time of each rank's share over the timed steps, before the all-gather"},
-                    "roofline": roofline_of(leg, workload),
-                    "kernels": {k: {"launches": d["launches"], "ms_per_step": d["ms"] / leg["steps"],
-                                    "algorithmic_tflops": d["flop"] / (d["ms"] * 1e-3) / 1e12} for k, d in leg["ksum"].items() if "flop" in d},
-                    "hbm_kernels": {k: hbm_entry(leg, k, d) for k, d in leg["ksum"].items() if "bytes" in d}}
-
-        hr = leg_record(head, args.workload)
-        rec = {
-            "metric": "rendered rays/s (and ray-samples/s) per GPU, 1080p x 128-sample layered render",
-            "value": hr["value"], "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": hr["ms_per_step"],
-            "higher_is_better": True, "scaling": "strong" if partition == "stripes" else "weak", "vs_baseline": None,
-            "dtype": DTYPE_NOTES[args.precision], "data": "synthetic",
-            "config": {"workload": args.workload, "precision": args.precision, "height": H, "width": W, "performer_layers": L,
-                       "coarse_samples": n1, "fine_samples": n2, "use_space_time": st, "use_deform_time": dt,
-                       "rays_per_view": n_rays, "rays_per_launch": args.rays_per_launch,
-                       "weights": "random, density head scaled (synthetic.make_state_dict seed 0)",
-                       "parallelism": (f"ONE view per step through stnerf_amd.parallel.render_view (what render_pose calls) at every N; "
-                                       f"{world} GPU(s): interleaved {args.stripe_rows}-row stripes, each rank generates and renders its "
-                                       f"rows as one launch sequence, one RCCL all-gather of the whole 5-tuple "
-                                       f"({parallel.packed_width(L + 1)} floats per ray) per step"
-                                       if partition == "stripes" else
-                                       f"one whole view per GPU per step x {world} GPUs (same camera, own RNG stream), "
-                                       "one RCCL all-gather of the final tiles per step")},
-            "ray_samples_per_s": hr["ray_samples_per_s"], "ray_samples_per_step_rank0": hr["ray_samples_per_step_rank0"],
-            "mask_fraction": hr["mask_fraction"], "per_rank_compute_s": hr["per_rank_compute_s"],
-            "roofline": hr["roofline"], "kernels": hr["kernels"], "hbm_kernels": hr["hbm_kernels"],
-            "hbm_bytes_note": "algorithmic = bytes the kernel has to move (t, raw and weights only of the layers a ray hits); "
-                              "dense = every layer charged (round-1 accounting)",
-            "precision_legs": {"note": "the same workload, poses, steps and warm-up in both arithmetics, one after the other in this process; "
-                                       "`value` / `roofline` at the top level are those of config.precision",
-                               args.precision: hr},
-            "hbm_microbench": measured or None,
-            "psnr_vs_reference": psnr_check,
-            "device": info,
-        }
-        if second is not None:
-            rec["precision_legs"][second["precision"]] = leg_record(second, args.workload)
-        if config_legs:
-            rec["config_legs"] = {leg["workload"]: {k: v for k, v in leg_record(leg, leg["workload"]).items()
-                                                    if k not in ("note", "dtype", "per_rank_compute_s")} for leg in config_legs}
-        if world == 1 and args.eager_gpu_baseline_rays > 0:
-            rec["eager_gpu_baseline"] = eager_gpu_baseline(args.workload, args.eager_gpu_baseline_rays, device)
-        if world == 1 and args.cpu_baseline_rays > 0:
-            rec["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_baseline_rays, args.cpu_threads)
-        else:
-            rec["cpu_baseline"] = None
-        print(json.dumps(rec))
-        sys.stdout.flush()
+        ctx = dict(workload=args.workload, precision=args.precision, steps=args.steps, warmup=args.warmup, world=world,
+                   partition=partition, stripe_rows=args.stripe_rows, rays_per_launch=args.rays_per_launch, dims=dims,
+                   device=info, psnr=psnr_check,
+                   pmc=json.load(open(PMC_TRAFFIC_JSON)) if os.path.exists(PMC_TRAFFIC_JSON) else {},
+                   hbm_microbench=json.load(open(MEASURED_HBM_JSON)) if os.path.exists(MEASURED_HBM_JSON) else {},
+                   eager=(eager_gpu_baseline(args.workload, args.eager_gpu_baseline_rays, device)
+                          if world == 1 and args.eager_gpu_baseline_rays > 0 else None),
+                   cpu=(cpu_baseline(args.workload, args.cpu_baseline_rays, args.cpu_threads)
+                        if world == 1 and args.cpu_baseline_rays > 0 else None),
+                   share=share)
+        detail, final = build_records(head, second, config_legs, ctx)
+        emit(detail, final)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

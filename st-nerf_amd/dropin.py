@@ -32,7 +32,11 @@ launcher picks cuda:LOCAL_RANK and initialises the process group (RCCL) before t
 render/layered_neural_renderer.py:378 -- deals its chunks out to the ranks in turn and all-gathers the whole 5-tuple
 (stnerf_amd.parallel.render_rays_sharded), so every rank holds every image and the frame takes 1 / N of the time.  Ranks
 other than 0 have ``imageio``'s writers silenced (if imageio is installed) so that each file is written once.
-``STNERF_SHARD=0`` or ``model.shard_views = False`` turns the sharding off.
+Sharding is opt-in -- this launcher opts in (``LayeredRFRender.SHARD_VIEWS_DEFAULT = True``: it runs the same script on every
+rank, the contract of a collective call); a process group set up any other way (a DDP trainer whose ranks evaluate different
+views, or rank 0 alone) leaves the call surface local unless ``model.shard_views = True`` / ``STNERF_SHARD=1`` says otherwise.
+``STNERF_SHARD=0`` or ``model.shard_views = False`` turns the sharding off.  Every sharded call checks a fingerprint of its
+rays across the ranks first and raises if they differ.
 
 Exercised against the real reference tree by tests/test_dropin.py.
 """
@@ -227,6 +231,11 @@ def join_process_group() -> Tuple[int, int]:
     no-ops, if imageio is installed.  -> (rank, world); (0, 1) and nothing done for a plain ``python`` launch."""
     from stnerf_amd import parallel
     rank, world = parallel.init_from_env(single_device=os.environ.get("STNERF_SINGLE_DEVICE", "0") == "1")
+    if world > 1:
+        # sharding is opt-in (a collective every rank must join with the same rays): this launcher runs the SAME render script
+        # on every rank, which is exactly that contract, so models built from here on shard their views
+        from stnerf_amd.modeling.layered_rfrender import LayeredRFRender
+        LayeredRFRender.SHARD_VIEWS_DEFAULT = True
     if world > 1 and rank != 0:
         try:
             imageio = importlib.import_module("imageio")

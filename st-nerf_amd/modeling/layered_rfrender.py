@@ -89,12 +89,19 @@ class LayeredRFRender(nn.Module):
                                            # one launch per (layer, network) as in round 1 (A/B measurements)
         self.ray_window = (0, 0, 0)        # (first, stripe, period): which rays of the view `rays` are (include/stnerf.h);
                                            # keeps the RNG stream of a view under multi-GPU sharding
-        self.shard_views = True            # with an initialised torch.distributed group of > 1 ranks, layered_batchify_ray /
-                                           # render_pose cut the view into interleaved stripes over the ranks and all-gather
-                                           # the whole 5-tuple (stnerf_amd.parallel); False: every rank renders what it is given
+        self.shard_views = type(self).SHARD_VIEWS_DEFAULT
+                                           # OPT-IN (default False): with an initialised torch.distributed group of > 1 ranks,
+                                           # layered_batchify_ray / render_pose cut the view into interleaved stripes over the ranks
+                                           # and all-gather the outputs -- a COLLECTIVE call every rank must make with the same
+                                           # rays (stnerf_amd.parallel).  The `python -m stnerf_amd.dropin` launcher under
+                                           # torch.distributed.run and bench.py switch it on
+        self.gather = "all"                # what a sharded call all-gathers: "all" (the whole 5-tuple), "fine" (what render_pose
+                                           # consumes: mixed + per-layer fine images, masks), "final" (the two mixed images);
+                                           # entries that are not gathered come back as None
         self.shard_group = None            # the process group to shard over (None: the default group)
 
     FRESH_DRAWS_DEFAULT = False   # what a new model's fresh_draws_per_call starts as (dropin.patch_reference: True)
+    SHARD_VIEWS_DEFAULT = False   # what a new model's shard_views starts as (the dropin launcher under torch.distributed.run: True)
 
     def set_precision(self, precision: str):
         """"bf16x3" (the default: three bf16 pieces per fp32 operand, six MFMAs per product, two accumulators: fp32's
@@ -275,10 +282,10 @@ class LayeredRFRender(nn.Module):
         reference's 5-tuple of (color (n,3), depth (n,1), acc (n,1)) triples and bool masks (layered_rfrender.py:725-734)."""
         mix_f, mix_c, lo_f, lo_c, mask = raw
         l = self.layer_num + 1
-        trip = lambda x: (x[:, 0:3], x[:, 3:4], x[:, 4:5])
-        fine_layer = [trip(lo_f[:, i]) for i in range(l)]
-        coarse_layer = [trip(lo_c[:, i]) for i in range(l)]
-        ray_mask = [mask[:, i].bool() for i in range(l)]
+        trip = lambda x: None if x is None else (x[:, 0:3], x[:, 3:4], x[:, 4:5])
+        fine_layer = None if lo_f is None else [trip(lo_f[:, i]) for i in range(l)]
+        coarse_layer = None if lo_c is None else [trip(lo_c[:, i]) for i in range(l)]
+        ray_mask = None if mask is None else [mask[:, i].bool() for i in range(l)]
         return trip(mix_f), trip(mix_c), fine_layer, coarse_layer, ray_mask
 
     def advance_seed(self):

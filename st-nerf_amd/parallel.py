@@ -13,13 +13,18 @@ contiguous tiles of ONE view differ in cost by ~2x between its centre and its bo
 The helpers are device-agnostic (they run under gloo on CPU tensors in tests/test_parallel_cpu.py);
 only the ``render_rows`` callable passed in touches the GPU.
 
-The call surface shards by itself: as soon as a torch.distributed group of more than one rank
-is initialised, ``utils.layered_batchify_ray`` (-> ``render_rays_sharded``: the caller holds the whole ray tensor, as
-the reference's ``render_pose`` does, render/layered_neural_renderer.py:364-391) and ``render.render_pose`` (->
-``render_view``: rays generated on the device for the rank's stripes only) render interleaved stripes of the view and
-rebuild the WHOLE 5-tuple -- mixed fine / coarse, every layer's fine / coarse colour, depth, acc and the hit masks --
-on every rank with ONE all-gather (``pack_outputs``: 10 + 11 l floats per ray).  ``model.shard_views = False`` or
-``STNERF_SHARD=0`` switches that off (ranks that render different views).
+The call surface shards on request: with ``model.shard_views = True`` (the ``python -m
+stnerf_amd.dropin`` launcher under torch.distributed.run and bench.py set it; ``STNERF_SHARD=1`` sets it for every model,
+``STNERF_SHARD=0`` forbids it) and a torch.distributed group of more than one rank, ``utils.layered_batchify_ray`` (->
+``render_rays_sharded``: the caller holds the whole ray tensor, as the reference's ``render_pose`` does,
+render/layered_neural_renderer.py:364-391) and ``render.render_pose`` (-> ``render_view``: rays generated on the device for
+the rank's stripes only) render interleaved stripes of the view and rebuild the 5-tuple on every rank with ONE all-gather.
+The call is then COLLECTIVE: every rank must make it with the same rays.  It is therefore opt-in (the default is off: a
+trainer's rank-0-only evaluation, or ranks rendering different views, must not meet a collective), and each sharded call first
+all-reduces a fingerprint of its inputs and raises on every rank when they differ.  ``model.gather`` picks the payload
+(``GATHER_MODES``): "all" = mixed + per-layer, fine + coarse, masks (11 + 10 l floats per ray), "fine" = what ``render_pose``
+consumes (mixed fine + per-layer fine + masks: 6 + 5 l), "final" = the two mixed images (10); what is not gathered comes back
+as None.
 """
 from __future__ import annotations
 
@@ -169,13 +174,16 @@ def make_row_renderer(model, K, T, h: int, w: int, frame_ids, density_threshold:
 # The sharded call surface: layered_batchify_ray / render_pose under an initialised process group
 # ---------------------------------------------------------------------------------------------------------------
 def active_group(model=None) -> Optional[Tuple[int, int, object]]:
-    """(rank, world, group) when a view handed to the call surface is to be split over the ranks, else None:
-    an initialised process group of more than one rank, not switched off by ``STNERF_SHARD=0`` or
-    ``model.shard_views = False``, and no ray window already set on the model (a caller that windows its own rays --
+    """(rank, world, group) when a view handed to the call surface is to be split over the ranks, else None.  Sharding is
+    OPT-IN: ``model.shard_views`` is True (or ``STNERF_SHARD=1``), ``STNERF_SHARD`` is not "0", a process group of more than
+    one rank is initialised, and no ray window is already set on the model (a caller that windows its own rays --
     ``make_row_renderer`` -- is doing the partition itself)."""
-    if os.environ.get("STNERF_SHARD", "1") == "0":
+    env = os.environ.get("STNERF_SHARD", "")
+    if env == "0":
         return None
-    if model is not None and (not getattr(model, "shard_views", True) or tuple(getattr(model, "ray_window", (0, 0, 0))) != (0, 0, 0)):
+    if model is not None and tuple(getattr(model, "ray_window", (0, 0, 0))) != (0, 0, 0):
+        return None
+    if not (env == "1" or (model is not None and getattr(model, "shard_views", False))):
         return None
     if not (dist.is_available() and dist.is_initialized()):
         return None
@@ -184,6 +192,35 @@ def active_group(model=None) -> Optional[Tuple[int, int, object]]:
     if world < 2:
         return None
     return dist.get_rank(group), world, group
+
+
+def check_collective(fingerprint, what: str, group=None, device=None) -> None:
+    """A sharded call is collective: every rank must make it with the same inputs.  ``fingerprint`` (a short list of
+    floats, exact in fp64) is all-reduced (MAX of [x, -x] = max and -min in one collective); a rank that sees max != min
+    raises -- and so does every other rank, the reduced values being the same everywhere -- instead of stitching stripes of
+    different views together.  (A rank that never makes the call cannot be detected from inside it: that hangs, like any
+    unmatched collective; sharding is opt-in for that reason.)"""
+    x = torch.tensor([float(v) for v in fingerprint], dtype=torch.float64)
+    both = torch.cat([x, -x])
+    if dist.get_backend(group) != "gloo" and device is not None:
+        both = both.to(device)
+    dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
+    both = both.cpu()
+    n = x.numel()
+    if not torch.equal(both[:n], -both[n:]):
+        raise RuntimeError(f"{what}: the ranks of this process group called with different inputs (fingerprint max "
+                           f"{both[:n].tolist()} vs min {(-both[n:]).tolist()}).  A sharded render is one view split over the "
+                           "ranks: give every rank the same rays, or set model.shard_views = False (STNERF_SHARD=0) when the "
+                           "ranks render different views")
+
+
+def rays_fingerprint(rays: torch.Tensor):
+    """N, the width, and three cheap checksums of a ray tensor (one tiny D2H)."""
+    n = rays.shape[0]
+    r = rays.detach()
+    sums = torch.stack([r[0].double().sum(), r[n // 2].double().sum(), r[-1].double().sum(),
+                        r[:: max(1, n // 4096)].double().sum()]).cpu().tolist()
+    return [n, rays.shape[1]] + sums
 
 
 def take_stripes(x: torch.Tensor, stripe: int, rank: int, world: int) -> torch.Tensor:
@@ -202,27 +239,55 @@ def take_stripes(x: torch.Tensor, stripe: int, rank: int, world: int) -> torch.T
     return parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, 0)
 
 
-def packed_width(l: int) -> int:
-    """Floats per ray of the packed 5-tuple: mixed fine + coarse (5 + 5), l layers fine + coarse (5 l + 5 l), l masks."""
-    return 10 + 11 * l
+GATHER_MODES = ("all", "fine", "final")
 
 
-def pack_outputs(raw) -> torch.Tensor:
-    """The five tensors of ``LayeredRFRender.render_rays_raw`` -> (n, 10 + 11 l) float32 (masks as 0.0 / 1.0): the payload
-    of the one all-gather."""
+def packed_width(l: int, mode: str = "all") -> int:
+    """Floats per ray of the packed outputs: "all" = mixed fine + coarse (5 + 5), l layers fine + coarse (5 l + 5 l), the l hit
+    masks as the bits of ONE float column (l <= 24: exact in fp32); "fine" = mixed fine, l layers fine, the mask column;
+    "final" = mixed fine + mixed coarse."""
+    if mode not in GATHER_MODES:
+        raise ValueError(f"gather mode must be one of {GATHER_MODES}")
+    if l > 24:
+        raise ValueError("the hit masks of more than 24 layers do not fit one fp32 column")
+    return {"all": 11 + 10 * l, "fine": 6 + 5 * l, "final": 10}[mode]
+
+
+def pack_outputs(raw, mode: str = "all") -> torch.Tensor:
+    """The five tensors of ``LayeredRFRender.render_rays_raw`` -> (n, packed_width(l, mode)) float32: the payload of the one
+    all-gather."""
     mix_f, mix_c, lo_f, lo_c, mask = raw
-    n = mix_f.shape[0]
-    return torch.cat([mix_f, mix_c, lo_f.reshape(n, -1), lo_c.reshape(n, -1), mask.to(torch.float32)], 1)
+    n, l = mix_f.shape[0], mask.shape[1]
+    packed_width(l, mode)
+    if mode == "final":
+        return torch.cat([mix_f, mix_c], 1)
+    bits = (mask != 0).to(torch.float32) @ (2.0 ** torch.arange(l, dtype=torch.float32, device=mask.device)).reshape(l, 1)
+    if mode == "fine":
+        return torch.cat([mix_f, lo_f.reshape(n, -1), bits], 1)
+    return torch.cat([mix_f, mix_c, lo_f.reshape(n, -1), lo_c.reshape(n, -1), bits], 1)
 
 
-def unpack_outputs(packed: torch.Tensor, l: int):
-    """Inverse of ``pack_outputs`` (dense tensors, the layout ``render_rays_raw`` returns)."""
+def unpack_outputs(packed: torch.Tensor, l: int, mode: str = "all"):
+    """Inverse of ``pack_outputs`` (dense tensors, the layout ``render_rays_raw`` returns; None for what the mode leaves out)."""
     n = packed.shape[0]
-    if packed.shape[1] != packed_width(l):
-        raise ValueError(f"packed outputs of {l} layers are {packed_width(l)} floats wide, got {packed.shape[1]}")
+    if packed.shape[1] != packed_width(l, mode):
+        raise ValueError(f"packed outputs ({mode}) of {l} layers are {packed_width(l, mode)} floats wide, got {packed.shape[1]}")
+    if mode == "final":
+        return packed[:, 0:5].contiguous(), packed[:, 5:10].contiguous(), None, None, None
+    bits = packed[:, -1].to(torch.int32)
+    mask = ((bits.unsqueeze(1) >> torch.arange(l, dtype=torch.int32, device=packed.device)) & 1).to(torch.uint8)
+    if mode == "fine":
+        return packed[:, 0:5].contiguous(), None, packed[:, 5:5 + 5 * l].reshape(n, l, 5).contiguous(), None, mask
     a, b, c = 10, 10 + 5 * l, 10 + 10 * l
     return (packed[:, 0:5].contiguous(), packed[:, 5:10].contiguous(), packed[:, a:b].reshape(n, l, 5).contiguous(),
-            packed[:, b:c].reshape(n, l, 5).contiguous(), packed[:, c:].to(torch.uint8))
+            packed[:, b:c].reshape(n, l, 5).contiguous(), mask)
+
+
+def gather_mode(model) -> str:
+    mode = getattr(model, "gather", "all")
+    if mode not in GATHER_MODES:
+        raise ValueError(f"model.gather must be one of {GATHER_MODES}, got {mode!r}")
+    return mode
 
 
 def _all_gather_rows(local: torch.Tensor, per_rank: int, world: int, group=None) -> torch.Tensor:
@@ -255,6 +320,7 @@ def gather_stripes(local: torch.Tensor, n_total: int, stripe: int, rank: int, wo
 def _render_local(model, local_rays, window, n_total, stripe, rank, world, group, only_coarse, thr, bthr, chuncks, replay_full):
     """This rank's stripes through the model (ray window set: the RNG stream is the view's), packed, gathered, unpacked."""
     l = model.layer_num + 1
+    mode = gather_mode(model)
     saved_window, saved_replay = model.ray_window, model.replay
     try:
         model.ray_window = window
@@ -262,14 +328,14 @@ def _render_local(model, local_rays, window, n_total, stripe, rank, world, group
             model.replay = {k: take_stripes(v.transpose(0, 1), stripe, rank, world).transpose(0, 1).contiguous()
                             for k, v in replay_full.items()}
         if local_rays.shape[0]:
-            packed = pack_outputs(model.render_rays_raw(local_rays, only_coarse, thr, bthr, ref_chunk=chuncks))
+            packed = pack_outputs(model.render_rays_raw(local_rays, only_coarse, thr, bthr, ref_chunk=chuncks), mode)
         else:                            # more ranks than stripes: only the collective (and the seed) on this rank
-            packed = local_rays.new_zeros((0, packed_width(l)))
+            packed = local_rays.new_zeros((0, packed_width(l, mode)))
             model.advance_seed()
     finally:
         model.ray_window, model.replay = saved_window, saved_replay
     whole = gather_stripes(packed, n_total, stripe, rank, world, group)
-    return model.as_reference_tuple(unpack_outputs(whole, l))
+    return model.as_reference_tuple(unpack_outputs(whole, l, mode))
 
 
 def render_rays_sharded(model, rays, chuncks: int, density_threshold=0.0, bkgd_density_threshold=0.0, only_coarse=False,
@@ -280,17 +346,20 @@ def render_rays_sharded(model, rays, chuncks: int, density_threshold=0.0, bkgd_d
     launch sequence and the whole 5-tuple is rebuilt on every rank by one all-gather.  Bitwise equal to the unsharded
     render: the device RNG is keyed by the ray's index in the view."""
     rank, world, group = act or active_group(model)
+    check_collective(rays_fingerprint(rays) + [chuncks, float(density_threshold), float(bkgd_density_threshold), int(model.seed) % (1 << 52)],
+                     "layered_batchify_ray (sharded)", group, rays.device)
     local = take_stripes(rays, chuncks, rank, world)
     return _render_local(model, local, (rank * chuncks, chuncks, world * chuncks), rays.shape[0], chuncks, rank, world, group,
                          only_coarse, density_threshold, bkgd_density_threshold, chuncks, model.replay)
 
 
 def render_view(model, K, T, h: int, w: int, frame_ids, density_threshold=0.0, bkgd_density_threshold=0.0,
-                chuncks: int = 512 * 7, stripe_rows: int = 1, device="cuda"):
+                chuncks: int = 512 * 7, stripe_rows: int = 1, device="cuda", gather: Optional[str] = None):
     """One view from its camera: rays generated on the device (no CPU ray tensor), ``layered_batchify_ray`` semantics, the
     reference's 5-tuple on every rank.  Without a process group: the whole view on this GPU.  With one: interleaved
     stripes of ``stripe_rows`` image rows over the ranks (rank r generates and renders rows r, r + G, ... only), one
-    all-gather.  The SAME function is bench.py's step at every N and what ``render.render_pose`` calls."""
+    all-gather of ``gather`` (default: ``model.gather``).  The SAME function is bench.py's step at every N and what
+    ``render.render_pose`` calls (with gather="fine": the images it returns)."""
     from stnerf_amd import ops
     from stnerf_amd.utils.batchify_rays import layered_batchify_ray
     act = active_group(model)
@@ -302,13 +371,41 @@ def render_view(model, K, T, h: int, w: int, frame_ids, density_threshold=0.0, b
                                         bkgd_density_threshold=bkgd_density_threshold)
     rank, world, group = act
     stripe = w * max(1, int(stripe_rows))
+    mode = gather_mode(model) if gather is None else gather
+    check_collective([h, w, stripe_rows, chuncks, float(density_threshold), float(bkgd_density_threshold), int(model.seed) % (1 << 52)]
+                     + torch.as_tensor(K, dtype=torch.float64).flatten().tolist() + torch.as_tensor(T, dtype=torch.float64).flatten().tolist()
+                     + [float(f) for f in frame_ids], "render_view (sharded)", group, device)
+    packed = render_view_share(model, K, T, h, w, frame_ids, rank, world, density_threshold, bkgd_density_threshold, chuncks,
+                               stripe_rows, device, mode)
+    whole = gather_stripes(packed, n_total, stripe, rank, world, group)
+    return model.as_reference_tuple(unpack_outputs(whole, model.layer_num + 1, mode))
+
+
+def render_view_share(model, K, T, h: int, w: int, frame_ids, rank: int, world: int, density_threshold=0.0,
+                      bkgd_density_threshold=0.0, chuncks: int = 512 * 7, stripe_rows: int = 1, device="cuda",
+                      mode: str = "all") -> torch.Tensor:
+    """What rank ``rank`` of ``world`` computes for one view BEFORE the all-gather: its interleaved row stripes' rays generated
+    on the device and rendered as one launch sequence, packed (``pack_outputs``).  No process group is touched:
+    ``render_view`` calls this with the group's rank, ``bench.py --emulate-share`` with a made-up (0, N) to time a rank's
+    share on one GPU."""
+    from stnerf_amd import ops
+    n_total = h * w
+    stripe = w * max(1, int(stripe_rows))
     window = (rank * stripe, stripe, world * stripe)
     n_local = ops.window_size(n_total, *window)
+    l = model.layer_num + 1
+    if n_local == 0:                          # more ranks than stripes: only the collective (and the seed) on this rank
+        model.advance_seed()
+        return torch.zeros((0, packed_width(l, mode)), dtype=torch.float32, device=device)
     rays = ops.generate_rays(K, T, h, w, frame_ids=frame_ids, first_ray=window[0], n=n_local, device=device, stripe=stripe,
                              period=window[2])
-    with torch.no_grad():
-        return _render_local(model, rays, window, n_total, stripe, rank, world, group, False, density_threshold,
-                             bkgd_density_threshold, chuncks, None)
+    saved = model.ray_window
+    try:
+        model.ray_window = window
+        with torch.no_grad():
+            return pack_outputs(model.render_rays_raw(rays, False, density_threshold, bkgd_density_threshold, ref_chunk=chuncks), mode)
+    finally:
+        model.ray_window = saved
 
 
 def init_from_env(backend: Optional[str] = None, single_device: bool = False):

@@ -23,15 +23,16 @@ def render_pose(model, pose, K, height: int, width: int, layer_frame_pair: Seque
     clamped mixed depth and therefore never fires -- reproduced as a no-op.
 
     One process per GPU under an initialised torch.distributed group: every rank generates and renders its interleaved
-    row stripes of the view only, one all-gather rebuilds all the images on every rank (stnerf_amd.parallel.render_view);
-    the return value is the single-GPU one, bit for bit."""
+    row stripes of the view only (``model.shard_views = True``: opt-in), one all-gather rebuilds the images this function
+    returns on every rank -- gather mode "fine": 6 + 5 l floats per ray instead of the whole 5-tuple's 11 + 10 l
+    (stnerf_amd.parallel.render_view); the return value is the single-GPU one, bit for bit."""
     L = model.layer_num
     frame_ids = [0.0] * (L + 1)
     for layer_id, frame_id in layer_frame_pair:
         frame_ids[layer_id] = float(frame_id)
     stage2, _, stage2_layer, _, _ = render_view(model, torch.as_tensor(K, dtype=torch.float32),
                                                 torch.as_tensor(pose, dtype=torch.float32), height, width, frame_ids,
-                                                density_threshold, bkgd_density_threshold, device=device)
+                                                density_threshold, bkgd_density_threshold, device=device, gather="fine")
     color = stage2[0].reshape(height, width, 3)
     depth = stage2[1].reshape(height, width, 1).clamp_min(0) / far
     color_layer = [t[0].reshape(height, width, 3) for t in stage2_layer]

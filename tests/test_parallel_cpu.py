@@ -267,15 +267,56 @@ def _surface_worker(rank, world, port, q):
             split = parallel.render_view(model, K, T, h, w, [1.0, 2.5, 1.0], 0.2, 0.05, chuncks=chunk, stripe_rows=rows, device="cpu")
             ok = ok and all(torch.equal(a, b) for a, b in zip(_flatten5(whole), _flatten5(split)))
             if h * w >= chunk:   # only this rank's stripes were generated
-                ok = ok and seen == [sum(e - s for s, e in parallel.stripe_spans(h * w, w * rows, rank, world))]
+                mine = sum(e - s for s, e in parallel.stripe_spans(h * w, w * rows, rank, world))
+                ok = ok and seen == ([mine] if mine else [])      # (a rank without a stripe generates nothing)
             pose_split = render_pose(model, T, K, h, w, [(0, 1), (1, 2.5), (2, 1)], 20.0, 0.2, 0.05, device="cpu")
             ok = ok and torch.equal(pose_whole[0], pose_split[0]) and torch.equal(pose_whole[1], pose_split[1])
             ok = ok and all(torch.equal(a, b) for a, b in zip(pose_whole[2] + pose_whole[3], pose_split[2] + pose_split[3]))
-        # the switches
+        # what is gathered: "fine" (what render_pose consumes) and "final" return None for the rest, the same bits for what they carry
+        rays = _surface_rays(64 * 5 + 10, l, chunk, True)
+        model.shard_views, model.gather = False, "all"
+        whole = layered_batchify_ray(model, rays, None, None, chuncks=chunk, density_threshold=0.3, bkgd_density_threshold=0.1)
+        model.shard_views = True
+        for mode, present in (("fine", (0, 2, 4)), ("final", (0, 1))):
+            model.gather = mode
+            got = layered_batchify_ray(model, rays, None, None, chuncks=chunk, density_threshold=0.3, bkgd_density_threshold=0.1)
+            for j in range(5):
+                if j not in present:
+                    ok = ok and got[j] is None
+                else:
+                    flat = lambda x: [x] if torch.is_tensor(x) else [t for y in x for t in flat(y)]
+                    ok = ok and all(torch.equal(a, b) and a.dtype == b.dtype for a, b in zip(flat(whole[j]), flat(got[j])))
+        model.gather = "fine"            # render_pose reads only what "fine" carries
+        pose_fine = render_pose(model, T, K, 9, 16, [(0, 1), (1, 2.5), (2, 1)], 20.0, 0.2, 0.05, device="cpu")
+        model.gather, model.shard_views = "all", False
+        pose_whole = render_pose(model, T, K, 9, 16, [(0, 1), (1, 2.5), (2, 1)], 20.0, 0.2, 0.05, device="cpu")
+        ok = ok and all(torch.equal(a, b) for a, b in zip([pose_whole[0], pose_whole[1]] + pose_whole[2] + pose_whole[3],
+                                                          [pose_fine[0], pose_fine[1]] + pose_fine[2] + pose_fine[3]))
+        # a sharded call is collective: ranks that hand in DIFFERENT rays get an error on every rank, not a stitched picture
+        model.shard_views = True
+        bad = rays.clone()
+        bad[0, 0] += float(rank)
+        try:
+            layered_batchify_ray(model, bad, None, None, chuncks=chunk)
+            ok = False
+        except RuntimeError as e:
+            ok = ok and "different inputs" in str(e)
+        try:
+            parallel.render_view(model, K, T * (1.0 + rank), 9, 16, [1.0, 2.5, 1.0], chuncks=chunk, device="cpu")
+            ok = False
+        except RuntimeError as e:
+            ok = ok and "different inputs" in str(e)
+        ok = ok and model.ray_window == (0, 0, 0)
+        # the switches: opt-in per model or by STNERF_SHARD=1, forbidden by STNERF_SHARD=0; a NEW model does not shard
         os.environ["STNERF_SHARD"] = "0"
         ok = ok and parallel.active_group(model) is None
         del os.environ["STNERF_SHARD"]
         ok = ok and parallel.active_group(model) == (rank, world, None)
+        fresh = _surface_model()
+        ok = ok and fresh.shard_views is False and parallel.active_group(fresh) is None
+        os.environ["STNERF_SHARD"] = "1"
+        ok = ok and parallel.active_group(fresh) == (rank, world, None)
+        del os.environ["STNERF_SHARD"]
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -311,8 +352,23 @@ def test_take_stripes_and_pack_round_trip():
     raw = (torch.rand(n, 5, generator=g), torch.rand(n, 5, generator=g), torch.rand(n, l, 5, generator=g),
            torch.rand(n, l, 5, generator=g), (torch.rand(n, l, generator=g) > 0.5).to(torch.uint8))
     packed = pack_outputs(raw)
-    assert packed.shape == (n, packed_width(l)) and packed.dtype == torch.float32
+    assert packed.shape == (n, packed_width(l)) == (n, 11 + 10 * l) and packed.dtype == torch.float32
     back = unpack_outputs(packed, l)
     assert all(torch.equal(a, b) and a.dtype == b.dtype and b.is_contiguous() for a, b in zip(raw, back))
     with pytest.raises(ValueError):
         unpack_outputs(packed, l + 1)
+    # the hit hint of the C ABI (mask byte 2 = "missed, and the sampler knows") is not a hit; 24 layers still fit one column
+    hinted = (raw[0], raw[1], raw[2], raw[3], raw[4] * 3)
+    assert torch.equal(unpack_outputs(pack_outputs(hinted), l)[4], raw[4])
+    fine = unpack_outputs(pack_outputs(raw, "fine"), l, "fine")
+    assert fine[1] is None and fine[3] is None and torch.equal(fine[0], raw[0]) and torch.equal(fine[2], raw[2]) and torch.equal(fine[4], raw[4])
+    final = unpack_outputs(pack_outputs(raw, "final"), l, "final")
+    assert final[2:] == (None, None, None) and torch.equal(final[0], raw[0]) and torch.equal(final[1], raw[1])
+    assert (packed_width(9, "all"), packed_width(9, "fine"), packed_width(9, "final")) == (101, 51, 10)
+    big = (torch.rand(5, 24, generator=g) > 0.5).to(torch.uint8)
+    z5 = torch.zeros(5, 5)
+    assert torch.equal(unpack_outputs(pack_outputs((z5, z5, torch.zeros(5, 24, 5), torch.zeros(5, 24, 5), big)), 24)[4], big)
+    with pytest.raises(ValueError):
+        packed_width(25)
+    with pytest.raises(ValueError):
+        packed_width(3, "everything")
