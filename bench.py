@@ -526,7 +526,9 @@ def detail_line(detail):
     return line
 
 
-def emit(detail, final):
+def emit(detail, final, detail_path=None):
+    detail_path = detail_path or DETAIL_PATH
+    final["detail"] = os.path.basename(detail_path)
     line = json.dumps(final)
     if len(line) >= FINAL_LINE_LIMIT:                       # never let verbosity cost the driver its record again
         for k in ("share_emulation", "psnr_vs_reference_dB", "other_precision"):
@@ -534,7 +536,7 @@ def emit(detail, final):
             line = json.dumps(final)
             if len(line) < FINAL_LINE_LIMIT:
                 break
-    for path in (DETAIL_PATH, os.path.join(REPO, "gpurun_out", os.path.basename(DETAIL_PATH))):
+    for path in (detail_path, os.path.join(REPO, "gpurun_out", os.path.basename(detail_path))):
         try:
             if os.path.isdir(os.path.dirname(path)):
                 with open(path, "w") as f:
@@ -586,6 +588,7 @@ def main():
                     help="comma list of rank counts, e.g. 2,4,8 (N = 1 only): time rank 0's interleaved-stripe share of the view for "
                          "each count on this one GPU -- an EMULATION of a rank's compute, not a scaling measurement "
                          "(profiles/r05_share_emulation.md)")
+    ap.add_argument("--detail-out", default=DETAIL_PATH, help="where the full record goes (default: bench_detail.json beside this script)")
     ap.add_argument("--dump-outputs", default=None,
                     help="rank 0 writes the LAST timed step's whole 5-tuple (every rank holds it after the all-gather) to this "
                          "torch file: tests compare an N-rank run with the 1-rank run bit for bit")
@@ -741,7 +744,7 @@ def main():
                         if world == 1 and args.cpu_baseline_rays > 0 else None),
                    share=share)
         detail, final = build_records(head, second, config_legs, ctx)
-        emit(detail, final)
+        emit(detail, final, args.detail_out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -23,12 +23,17 @@ def _run_bench(extra, dump):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):     # a plain `python bench.py`, as the driver runs it
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + BENCH_COMMON + ["--dump-outputs", dump] + extra,
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + BENCH_COMMON + ["--dump-outputs", dump,
+                        "--detail-out", dump + ".detail.json"] + extra,
                        cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0]), torch.load(dump)
+    assert len(lines) == 2 and len(lines[-1]) < 3072, r.stdout[-2000:]      # the detail digest, then the contract record LAST
+    rec = json.loads(lines[-1])
+    side = json.load(open(dump + ".detail.json"))
+    assert side["final"] == rec
+    rec["_leg"] = side["detail"]["precision_legs"][rec["config"]["precision"]]   # the full leg record (per-rank times, counts)
+    return rec, torch.load(dump)
 
 
 def _flat(d):
@@ -55,8 +60,8 @@ def test_bench_launches_its_own_ranks_and_matches_one_rank(tmp_path, workload, p
     for x, y in zip(fa, fb):
         assert x.shape == y.shape and x.dtype == y.dtype and torch.equal(x, y)
     assert float(a["mixed_fine"][0].std()) > 0.01                                  # a picture, not zeros
-    assert len(many["per_rank_compute_s"]["all"]) == world
-    assert abs(many["ray_samples_per_step_rank0"] * world - one["ray_samples_per_step_rank0"]) <= 0.35 * one["ray_samples_per_step_rank0"]
+    assert len(many["_leg"]["per_rank_compute_s"]["all"]) == world
+    assert abs(many["_leg"]["ray_samples_per_step_rank0"] * world - one["_leg"]["ray_samples_per_step_rank0"]) <= 0.35 * one["_leg"]["ray_samples_per_step_rank0"]
     assert many["roofline"]["frac"] > 0 and many["cpu_baseline"] is None
 
 

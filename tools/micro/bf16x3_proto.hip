@@ -10,9 +10,14 @@
 //   2. the layer loop's rate with its parts switched off one at a time (conversion pass, barrier, ds_read, DMA)
 //   3. vector instructions in the shadow of bf16 MFMAs (same wave), dependent-accumulator distance
 //   4. weights straight through the vector L1 (four waves, same addresses) instead of the LDS ring
+//   5. (round 5, `--sustain SEC`) joules per item at the socket's power limit: every variant run for SEC seconds with the
+//      socket's energy counter read on both sides (rocm_smi), next to an UPPER BOUND for a wave that owns 64 samples
+//      (proto64_kernel: every weight operand read from the ring feeds two sample tiles' MFMAs, so the L2 -> LDS stream, the
+//      LDS -> AGPR reads and the barriers per MFMA all halve -- with accumulators that a real kernel has no registers for)
 //
-// hipcc --offload-arch=gfx950 -O3 -o bf16x3_proto bf16x3_proto.hip
+// hipcc --offload-arch=gfx950 -O3 -o bf16x3_proto bf16x3_proto.hip -L/opt/rocm/lib -lrocm_smi64
 #include <hip/hip_runtime.h>
+#include <rocm_smi/rocm_smi.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -407,6 +412,113 @@ __global__ __launch_bounds__(256, 1) void proto_kernel(const char* blob, const f
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// 5. A wave that owns 64 samples -- an UPPER BOUND, not a kernel: each weight operand pair read from the ring is used for
+// the MFMAs of TWO sample tiles (act0, act1: 2 x 192 registers).  That leaves 80 registers for everything else, so all eight
+// feature blocks of a tile accumulate into ONE accumulator (a real kernel needs 8 x 16 x {big, small} per tile
+// and pass: the organisation cannot exist in a 512-register wave).  What it has in common with a real one is what costs
+// energy: per slot 96 MFMAs on live random operands, 24 operand reads, 6 DMA instructions, one barrier.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mma_quad(f32x16& c, f32x16& d, const Apair& A, const bf16x8& b0,
+                                         const bf16x8& b1, const bf16x8& b2, const bf16x8& e0, const bf16x8& e1, const bf16x8& e2) {
+    // (back-to-back dependent 32x32x16 MFMAs issue at the full rate: shadow test, DIST = 1: 32.01 cycles)
+#define Q4(pa, pb, pe) \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[0][pa], pb, c, 0, 0, 0); \
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[0][pa], pe, d, 0, 0, 0); \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[1][pa], pb, c, 0, 0, 0); \
+    d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.a[1][pa], pe, d, 0, 0, 0);
+    Q4(2, b0, e0) Q4(0, b2, e2) Q4(1, b1, e1) Q4(1, b0, e0) Q4(0, b1, e1) Q4(0, b0, e0)
+#undef Q4
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(256, 1) void proto64_kernel(const char* blob, int nl, const float* x, float* out, int items,
+                                                         unsigned long long* cycles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    const unsigned nslots = nl * 16;
+    unsigned g = 0;
+    dma_slot<FLAGS>(blob, 0, nslots, ring, wave, lane);
+    dma_slot<FLAGS>(blob, 1, nslots, ring, wave, lane);
+    dma_slot<FLAGS>(blob, 2, nslots, ring, wave, lane);
+    if (FLAGS & F_DMA) VMCNT(12);
+    __builtin_amdgcn_s_barrier();
+    bf16x8 act0[3][16], act1[3][16];
+    // tile 0 = samples 32 wave + c, tile 1 = samples 128 + 32 wave + c of x[256][256]
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        float v[8], w[8];
+        const float* xs = x + (size_t)(32 * wave + c) * 256 + 32 * (t >> 1) + 16 * (t & 1) + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = xs[8 * (j >> 2) + (j & 3)];
+            w[j] = xs[(size_t)128 * 256 + 8 * (j >> 2) + (j & 3)];
+        }
+        split8(v, act0[0][t], act0[1][t], act0[2][t]);
+        split8(w, act1[0][t], act1[1][t], act1[2][t]);
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    Apair Ax, Ay;
+    read_pair<F_ALL>(Ax, ring, 0, lane);
+    wait_pair(Ax);
+    const unsigned long long t0 = clock64();
+    for (int it = 0; it < items; ++it) {
+#pragma unroll 1
+        for (int l = 0; l < nl; ++l) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const char* slot = ring + (s % RING) * SLOT;
+                const char* nslot = ring + ((s + 1) % RING) * SLOT;
+                __builtin_amdgcn_sched_barrier(0);
+                read_pair<FLAGS>(Ay, slot, 1, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_quad(acc[0], acc[1], Ax, act0[0][s], act0[1][s], act0[2][s], act1[0][s], act1[1][s], act1[2][s]);
+                __builtin_amdgcn_sched_barrier(0);
+                wait_pair(Ay);
+                read_pair<FLAGS>(Ax, slot, 2, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_quad(acc[0], acc[1], Ay, act0[0][s], act0[1][s], act0[2][s], act1[0][s], act1[1][s], act1[2][s]);
+                __builtin_amdgcn_sched_barrier(0);
+                wait_pair(Ax);
+                read_pair<FLAGS>(Ay, slot, 3, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_quad(acc[0], acc[1], Ax, act0[0][s], act0[1][s], act0[2][s], act1[0][s], act1[1][s], act1[2][s]);
+                __builtin_amdgcn_sched_barrier(0);
+                if ((FLAGS & F_DMA) && !(FLAGS & F_NOWAITV)) VMCNT(6);
+                if (FLAGS & F_BAR) __builtin_amdgcn_s_barrier();
+                dma_slot<FLAGS>(blob, g + 3, nslots, ring, wave, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                wait_pair(Ay);
+                read_pair<FLAGS>(Ax, nslot, 0, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_quad(acc[0], acc[1], Ay, act0[0][s], act0[1][s], act0[2][s], act1[0][s], act1[1][s], act1[2][s]);
+                g += 1;
+                __builtin_amdgcn_sched_barrier(0);
+                wait_pair(Ax);
+            }
+            // keep the running sums bounded (they are not a layer's outputs): halve them once per layer
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= 0.5f;
+        }
+    }
+    const unsigned long long t1 = clock64();
+    VMCNT(0);
+    float* o = out + ((size_t)blockIdx.x * 256 + tid) * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[16 * i + r] = acc[i][r];
+    if (tid == 0 && blockIdx.x == 0) *cycles = t1 - t0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 3. vector instructions in the shadow of bf16 MFMAs (one wave per SIMD): V instructions behind each MFMA; DIST = number
 // of independent accumulators the MFMAs rotate over (1 = every MFMA depends on the previous one)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -580,6 +692,92 @@ static void run_shadow(float* d_out, unsigned long long* d_cyc) {
     fflush(stdout);
 }
 
+// ---- 5. sustained, energy-metered runs -------------------------------------------------------------------------------
+struct Meter {
+    bool ok = false;
+    float res = 0.f;   // micro joules per count
+    Meter() { ok = rsmi_init(0) == RSMI_STATUS_SUCCESS; }
+    double joules() {
+        uint64_t e = 0, ts = 0;
+        if (!ok || rsmi_dev_energy_count_get(0, &e, &res, &ts) != RSMI_STATUS_SUCCESS) return -1.0;
+        return (double)e * res * 1e-6;
+    }
+    double watts() {
+        uint64_t p = 0;
+        if (!ok || rsmi_dev_current_socket_power_get(0, &p) != RSMI_STATUS_SUCCESS) return -1.0;
+        return p * 1e-6;
+    }
+    double sclk_mhz() {
+        rsmi_frequencies_t f;
+        if (!ok || rsmi_dev_gpu_clk_freq_get(0, RSMI_CLK_TYPE_SYS, &f) != RSMI_STATUS_SUCCESS) return -1.0;
+        return f.frequency[f.current] * 1e-6;
+    }
+};
+
+// `launch(items)` enqueues one kernel; tiles = sample tiles of 32 per wave (1 or 2): MFMAs per wave and launch = items * nl * 768 * tiles
+template <typename L>
+static void sustain(Meter& m, const char* name, double seconds, int items, int nl, int tiles, unsigned long long* d_cyc, int blocks, L launch) {
+    launch(4);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    // a second of load first: the clock settles at the power limit within ~0.3 s
+    for (double t = 0; t < 1.0;) {
+        CK(hipEventRecord(e0)); launch(items); CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); t += ms * 1e-3;
+    }
+    const double j0 = m.joules();
+    double busy = 0, cyc_sum = 0, w_sum = 0, f_sum = 0;
+    int launches = 0, samples = 0;
+    while (busy < seconds) {
+        CK(hipEventRecord(e0));
+        launch(items);
+        CK(hipEventRecord(e1));
+        // sample instantaneous power / sclk while the launch runs
+        while (hipEventQuery(e1) == hipErrorNotReady) {
+            const double w = m.watts(), f = m.sclk_mhz();
+            if (w > 0) { w_sum += w; f_sum += f; ++samples; }
+        }
+        CK(hipDeviceSynchronize());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned long long cyc;
+        CK(hipMemcpy(&cyc, d_cyc, 8, hipMemcpyDeviceToHost));
+        busy += ms * 1e-3;
+        cyc_sum += (double)cyc;
+        ++launches;
+    }
+    const double j1 = m.joules();
+    const double mfma_wave = (double)launches * items * nl * 768.0 * tiles;      // per wave
+    const double mfma_all = mfma_wave * blocks * 4;
+    const double exec_tf = mfma_all * 32768.0 / busy * 1e-12;
+    const double items32 = (double)launches * items * blocks * 4 * tiles;         // 32-sample x nl-layer units
+    // (the energy window includes the host gaps between launches: a few % idle at ~200 W; power from the samples is launch-only)
+    printf("%-44s %7.1f exec TF/s  %6.2f cyc/MFMA  %6.0f MHz(clock64)  %6.0f MHz(smi)  %6.0f W(smi, %d samples)  %7.1f W(energy ctr)  %8.3f mJ per 32-sample x %d-layer unit  %6.2f pJ/FLOP exec\n",
+           name, exec_tf, cyc_sum / mfma_wave, cyc_sum / (busy * 1e6), samples ? f_sum / samples : -1.0, samples ? w_sum / samples : -1.0, samples,
+           (j1 - j0) / busy, (j1 - j0) / items32 * 1e3, nl, (j1 - j0) / (mfma_all * 32768.0) * 1e12);
+    fflush(stdout);
+}
+
+template <int FLAGS>
+static void sustain32(Meter& m, const char* name, double seconds, const char* d_blob, const float* d_bias, int nl, const float* d_x, float* d_out,
+                      unsigned long long* d_cyc, int blocks) {
+    const int lds = RING * SLOT + NLMAX * 1024 + 64;
+    if (!g_spins) { CK(hipMalloc(&g_spins, 8)); }
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(proto_kernel<FLAGS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    sustain(m, name, seconds, 400, nl, 1, d_cyc, blocks,
+            [&](int items) { proto_kernel<FLAGS><<<blocks, 256, lds>>>(d_blob, d_bias, nl, d_x, d_out, items, d_cyc, g_spins); });
+}
+template <int FLAGS>
+static void sustain64(Meter& m, const char* name, double seconds, const char* d_blob, int nl, const float* d_x2, float* d_out,
+                      unsigned long long* d_cyc, int blocks) {
+    const int lds = RING * SLOT + 64;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(proto64_kernel<FLAGS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    sustain(m, name, seconds, 200, nl, 2, d_cyc, blocks,
+            [&](int items) { proto64_kernel<FLAGS><<<blocks, 256, lds>>>(d_blob, nl, d_x2, d_out, items, d_cyc); });
+}
+
 int main(int argc, char** argv) {
     const int nl = 7, blocks = 256;
     srand(1234);
@@ -616,6 +814,28 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(d_bias, B.data(), B.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_x, X.data(), X.size() * 4, hipMemcpyHostToDevice));
 
+    if (argc > 2 && !strcmp(argv[1], "--sustain")) {
+        const double sec = atof(argv[2]);
+        std::vector<float> X2(256 * 256);
+        for (auto& v : X2) v = (float)(frand() * 2.0);
+        float* d_x2;
+        CK(hipMalloc(&d_x2, X2.size() * 4));
+        CK(hipMemcpy(d_x2, X2.data(), X2.size() * 4, hipMemcpyHostToDevice));
+        Meter m;
+        printf("sustained runs, %.1f s each after 1 s of the same load, 256 workgroups of 4 waves (one per SIMD); energy counter %s\n", sec,
+               m.ok ? "rocm_smi rsmi_dev_energy_count_get" : "UNAVAILABLE");
+        for (int rep = 0; rep < 2; ++rep) {
+            sustain32<F_ALL>(m, "M=32 full (ring, reads, barrier, conversion)", sec, d_blob, d_bias, nl, d_x, d_out, d_cyc, blocks);
+            sustain32<F_ALL & ~F_CONV>(m, "M=32 no conversion", sec, d_blob, d_bias, nl, d_x, d_out, d_cyc, blocks);
+            sustain64<F_ALL & ~F_CONV>(m, "M=64 upper bound, no conversion", sec, d_blob, nl, d_x2, d_out, d_cyc, blocks);
+            sustain32<(F_ALL & ~F_CONV) | F_NOISSUE>(m, "M=32 no conv, NO L2->LDS stream (stale ring)", sec, d_blob, d_bias, nl, d_x, d_out, d_cyc, blocks);
+            sustain32<(F_ALL & ~F_CONV & ~F_LDS)>(m, "M=32 no conv, NO operand reads", sec, d_blob, d_bias, nl, d_x, d_out, d_cyc, blocks);
+            sustain64<(F_ALL & ~F_CONV) | F_NOISSUE>(m, "M=64 upper bound, NO L2->LDS stream", sec, d_blob, nl, d_x2, d_out, d_cyc, blocks);
+            sustain32<0>(m, "M=32 MFMAs only", sec, d_blob, d_bias, nl, d_x, d_out, d_cyc, blocks);
+            sustain64<0>(m, "M=64 MFMAs only", sec, d_blob, nl, d_x2, d_out, d_cyc, blocks);
+        }
+        return 0;
+    }
     // ---- 1. numerics: one item
     {
         const int lds = RING * SLOT + NLMAX * 1024;
