@@ -519,6 +519,81 @@ __global__ __launch_bounds__(256, 1) void proto64_kernel(const char* blob, int n
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// 6. (round 5, `--reuse SEC`) does the ORDER of a unit's MFMAs matter for energy?  MFMAs only, random operands in registers,
+// 12 MFMAs per group = two feature blocks x the six cross terms (A: 2 blocks x 3 weight pieces, B: 3 activation pieces,
+// accumulators small0, big0, small1, big1), in different orders.  Per-accumulator term order is the product's in patterns
+// 0 - 2 (bit-identical results); 3 - 5 are bounds.
+//   0 product (csrc/mlp_bf16x3.hip unit<>): block 0's five small terms back to back, its big term, then block 1
+//   1 the two blocks interleaved term by term (B reused by consecutive MFMAs, accumulators alternate)
+//   2 B-major: every MFMA that reads b0, then b1, then b2 (per-accumulator order NOT the product's)
+//   3 A-major: each weight piece with all its activation pieces back to back
+//   4 one A, one B for all twelve (floor)      5 A and B both change on every MFMA (ceiling)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int PATTERN>
+__global__ __launch_bounds__(256, 1) void reuse_kernel(float* out, int iters, unsigned long long* cycles) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.001f * ((threadIdx.x * 7 + i * 3 + r) & 63);
+    bf16x8 a[2][3], b[3];
+    {
+        unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+        for (int i = 0; i < 9; ++i) {
+            u32x4 w;
+            for (int j = 0; j < 4; ++j) {
+                h = h * 1664525u + 1013904223u;
+                // two bf16 in [0.5, 2) with random significands and signs
+                w[j] = ((h & 0x807f807fu) | 0x3f003f00u) ^ ((h >> 9) & 0x00800080u);
+            }
+            if (i < 6) a[i / 3][i % 3] = *reinterpret_cast<bf16x8*>(&w);
+            else b[i - 6] = *reinterpret_cast<bf16x8*>(&w);
+        }
+    }
+#define MM(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[ACC]) : "v"(A), "v"(B))
+    const unsigned long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        if (PATTERN == 0) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                MM(2 * f, a[f][2], b[0]); MM(2 * f, a[f][0], b[2]); MM(2 * f, a[f][1], b[1]); MM(2 * f, a[f][1], b[0]); MM(2 * f, a[f][0], b[1]);
+                MM(2 * f + 1, a[f][0], b[0]);
+            }
+        } else if (PATTERN == 1) {
+            MM(0, a[0][2], b[0]); MM(2, a[1][2], b[0]); MM(0, a[0][0], b[2]); MM(2, a[1][0], b[2]); MM(0, a[0][1], b[1]); MM(2, a[1][1], b[1]);
+            MM(0, a[0][1], b[0]); MM(2, a[1][1], b[0]); MM(0, a[0][0], b[1]); MM(2, a[1][0], b[1]); MM(1, a[0][0], b[0]); MM(3, a[1][0], b[0]);
+        } else if (PATTERN == 2) {
+            MM(0, a[0][2], b[0]); MM(0, a[0][1], b[0]); MM(1, a[0][0], b[0]); MM(2, a[1][2], b[0]); MM(2, a[1][1], b[0]); MM(3, a[1][0], b[0]);
+            MM(0, a[0][1], b[1]); MM(0, a[0][0], b[1]); MM(2, a[1][1], b[1]); MM(2, a[1][0], b[1]); MM(0, a[0][0], b[2]); MM(2, a[1][0], b[2]);
+        } else if (PATTERN == 3) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                MM(2 * f + 1, a[f][0], b[0]); MM(2 * f, a[f][0], b[1]); MM(2 * f, a[f][0], b[2]); MM(2 * f, a[f][1], b[0]); MM(2 * f, a[f][1], b[1]);
+                MM(2 * f, a[f][2], b[0]);
+            }
+        } else if (PATTERN == 4) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) MM(i & 3, a[0][0], b[0]);
+        } else {
+            MM(0, a[0][0], b[0]); MM(2, a[1][1], b[1]); MM(0, a[0][2], b[2]); MM(2, a[1][0], b[0]); MM(0, a[0][1], b[1]); MM(2, a[1][2], b[2]);
+            MM(0, a[0][0], b[1]); MM(2, a[1][1], b[2]); MM(1, a[0][2], b[0]); MM(3, a[1][0], b[1]); MM(0, a[0][1], b[2]); MM(2, a[1][2], b[0]);
+        }
+        if ((it & 63) == 63) {   // keep the running sums finite
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= 0.001f;
+        }
+    }
+#undef MM
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const unsigned long long t1 = clock64();
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cycles = t1 - t0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 3. vector instructions in the shadow of bf16 MFMAs (one wave per SIMD): V instructions behind each MFMA; DIST = number
 // of independent accumulators the MFMAs rotate over (1 = every MFMA depends on the previous one)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -814,6 +889,23 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(d_bias, B.data(), B.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_x, X.data(), X.size() * 4, hipMemcpyHostToDevice));
 
+    if (argc > 2 && !strcmp(argv[1], "--reuse")) {
+        const double sec = atof(argv[2]);
+        Meter m;
+        printf("MFMA order / operand reuse, %.1f s each after 1 s, 256 x 4 waves, 12 MFMAs per group; a 'unit' below = 768 MFMAs of one wave\n", sec);
+        const int items = 470;     // one "item" = 64 iterations x 12 MFMAs = 768 MFMAs per wave (sustain()'s unit): ~6 ms per launch
+        for (int rep = 0; rep < 2; ++rep) {
+#define RUN_REUSE(P, NAME) sustain(m, NAME, sec, items, 1, 1, d_cyc, blocks, [&](int it) { reuse_kernel<P><<<blocks, 256>>>(d_out, it * 64, d_cyc); })
+            RUN_REUSE(0, "order 0: product (5 small back to back, big)");
+            RUN_REUSE(1, "order 1: two blocks interleaved (B reuse x2)");
+            RUN_REUSE(2, "order 2: B-major (b0 x6, b1 x4, b2 x2)");
+            RUN_REUSE(3, "order 3: A-major (each piece's terms in a row)");
+            RUN_REUSE(4, "order 4: one A, one B (floor)");
+            RUN_REUSE(5, "order 5: A and B change every MFMA (ceiling)");
+#undef RUN_REUSE
+        }
+        return 0;
+    }
     if (argc > 2 && !strcmp(argv[1], "--sustain")) {
         const double sec = atof(argv[2]);
         std::vector<float> X2(256 * 256);
