@@ -270,6 +270,20 @@ int stnerf_composite(const float* t, const float* raw, const uint8_t* mask, int6
                      const stnerf_composite_params* params_host, float* layer_out, float* mixed_out,
                      float* weights, int32_t* order, uint8_t* scratch, stnerf_stream_t stream);
 
+/* backward of stnerf_composite -- what loss.backward() (engine/layered_trainer.py:277) does to
+ * VolumeRenderer.forward / gen_weight (layers/render_layer.py:8-58) and to the merge gather
+ * (modeling/layered_rfrender.py:425-429, :587-592) through ATen: given g_layer[n][l][5] and g_mixed[n][5] = dLoss /
+ * d{colour(3), depth, acc} of every layer's composite and of the merged one (either may be NULL), writes
+ * d_raw[n][l][S][4] = dLoss / d{rgb(3), sigma} of the raw network outputs (zeros where a layer was not evaluated on a ray).
+ * t, raw, mask, params: exactly what the forward call got; order[n][l*S]: the forward's `order` output (required with
+ * g_mixed).  The density edits act as in the reference's in-place writes: an overwritten sigma gets no gradient, layer 2's
+ * `*= alpha` scales it.  Depths get none (the sampler and sample_pdf are detached, :314-315, :460-461).
+ * torch.cumprod's backward is reproduced as ATen computes it without zeros in the input (reversed cumsum / input; the
+ * 1e-10 of gen_weight keeps every factor positive).  csrc/render_bwd.hip. */
+int stnerf_composite_bwd(const float* t, const float* raw, const uint8_t* mask, const int32_t* order, int64_t n, int l, int S,
+                         const stnerf_composite_params* params_host, const float* g_layer, const float* g_mixed,
+                         float* d_raw, stnerf_stream_t stream);
+
 /* The launch plan stnerf_composite follows for a shape (host arithmetic only, no GPU needed): plan[0] 1 = the LDS-staged
  * kernel alone; [1] single-layer pre-pass (0 none, 1 / 2 = its two instantiations); [2] launches of the merge kernel (1 or
  * 2); [3] layers the first launch's merged list holds; [4] 1 = scratch is cleared first; [5], [6] waves per workgroup and

@@ -385,7 +385,7 @@ def layer_boxes(m: OracleModel, rays: Tensor):
 
 def render_chunk(m: OracleModel, rays: Tensor, only_coarse: bool = False,
                  density_threshold: float = 0.0001, bkgd_density_threshold: float = 0.0,
-                 rand: RandFn = _default_rand, trace: Optional[dict] = None):
+                 rand: RandFn = _default_rand, trace: Optional[dict] = None, sample_dtype: Optional[torch.dtype] = None):
     """LayeredRFRender.forward for one chunk (BBOX sampling, no pose refinement / view deform /
     background deform, background net without time: the configuration of both shipped ymls).
 
@@ -393,6 +393,9 @@ def render_chunk(m: OracleModel, rays: Tensor, only_coarse: bool = False,
     entry a (color (n,3), depth (n,1), acc (n,1)) triple (:725-734).  ``rand(shape)`` supplies the
     uniform draws in the reference's order: l coarse-jitter tensors (RaySamplePoint.py:98) then l
     resampling tensors (sample_pdf.py:31).  ``trace`` (dict) receives every intermediate.
+    ``sample_dtype`` (error analysis only): evaluate the DETACHED parts -- the coarse sampler and the inverse-CDF resampler with
+    its sort and point generation (:314-315, :460-465) -- in that dtype and cast the depths / points back, so that an fp64
+    evaluation of the differentiable graph sits on the sample positions of the fp32 one.
     """
     n, L = rays.shape[0], m.layer_num
     l, N1, N2 = L + 1, m.n_coarse, m.n_fine
@@ -462,7 +465,12 @@ def render_chunk(m: OracleModel, rays: Tensor, only_coarse: bool = False,
 
     # ---- coarse
     jitter = [rand((n, N1)).to(rays.dtype) for _ in range(l)]
-    ts, xyz, masks = sample_coarse(rays, boxes, N1, jitter)
+    if sample_dtype is None:
+        ts, xyz, masks = sample_coarse(rays, boxes, N1, jitter)
+    else:
+        ts, xyz, masks = sample_coarse(rays.to(sample_dtype), boxes.to(sample_dtype), N1, [j.to(sample_dtype) for j in jitter])
+        ts, xyz = [t_.to(rays.dtype) for t_ in ts], [x_.to(rays.dtype) for x_ in xyz]
+    ts, xyz = [t_.detach() for t_ in ts], [x_.detach() for x_ in xyz]      # :314-315 (only matters under autograd)
     xyz = [unedit(xyz[i], i, False) for i in range(l)]
     deform(xyz, masks, N1)
     rgbs, sig = run_nets(xyz, masks, N1, False)
@@ -484,12 +492,15 @@ def render_chunk(m: OracleModel, rays: Tensor, only_coarse: bool = False,
     zf, xf, us, zs = [], [], [], []
     for i in range(l):                                                    # :459-475
         u = rand((n, N2)).to(rays.dtype)
-        z = sample_pdf(ts[i].squeeze(-1), coarse_layer[i][3].squeeze(-1)[..., 1:-1], u)
-        zi, _ = torch.sort(torch.cat([ts[i].squeeze(-1), z], -1), -1)
+        sd_ = rays.dtype if sample_dtype is None else sample_dtype
+        z = sample_pdf(ts[i].squeeze(-1).to(sd_), coarse_layer[i][3].squeeze(-1)[..., 1:-1].detach().to(sd_), u.to(sd_)).detach()   # :460-461
+        zi, _ = torch.sort(torch.cat([ts[i].squeeze(-1).to(sd_), z], -1), -1)
+        pts = zi.unsqueeze(-1) * d.to(sd_).unsqueeze(1) + o.to(sd_).unsqueeze(1)
+        z, zi, pts = z.to(rays.dtype), zi.to(rays.dtype), pts.to(rays.dtype)
         us.append(u)
         zs.append(z)
         zf.append(zi)
-        xf.append(unedit(zi.unsqueeze(-1) * d.unsqueeze(1) + o.unsqueeze(1), i, True))
+        xf.append(unedit(pts, i, True))
     deform(xf, masks, N1 + N2)
     rgbs, sig = run_nets(xf, masks, N1 + N2, True)
     z_mix, order = torch.sort(torch.cat(zf, -1), -1)                      # :587

@@ -9,13 +9,14 @@ demo/taekwondo_demo.py:21).  ``patch_reference`` therefore imports the reference
 render-path symbols to the HIP implementation, in those packages and in every already-imported reference module
 that holds one of the originals.
 
-**Patching makes the model inference-only.**  The replacements (LayeredRFRender, SpaceNet, MotionNet, RaySamplePoint,
-sample_pdf, Trigonometric_kernel, VolumeRenderer) run on the MI355X only -- CPU tensors are refused -- and have no
-backward pass: ``engine.layered_trainer`` would fail at ``loss.backward()``, so ``LayeredRFRender.forward`` raises a
-clear error as soon as it is called with autograd enabled on trainable parameters; NEAR_FAR sampling, USE_DEFORM_VIEW
-and POSE_REFINEMENT configurations are refused by the constructor.  Render / demo / evaluation scripts (which run under
-``torch.no_grad()``, render/layered_neural_renderer.py:377) are what this is for; train with the reference's own model
-(``patch.undo()`` restores it).  Models built after patching draw fresh jitter / resampling numbers on every forward
+**Rendering and training.**  The replacements (LayeredRFRender, SpaceNet, MotionNet, RaySamplePoint, sample_pdf,
+Trigonometric_kernel, VolumeRenderer) run on the MI355X only -- CPU tensors are refused.  Under ``torch.no_grad()``
+(render/layered_neural_renderer.py:377) or in ``eval()`` mode the fused inference pipeline runs; in ``train()`` mode under autograd
+-- what ``engine.layered_trainer.do_train`` sets up (:186-202) -- ``LayeredRFRender.forward`` runs the same stages with autograd
+history and ``loss.backward()`` reaches every network parameter through hand-written HIP backward kernels
+(stnerf_amd.modeling.training; tests/test_dropin.py runs the reference's own ``do_train`` on the patched model).  NEAR_FAR
+sampling, USE_DEFORM_VIEW and POSE_REFINEMENT configurations are refused by the constructor (``patch.undo()`` restores the
+reference's classes).  Models built after patching draw fresh jitter / resampling numbers on every forward
 call, as the reference's torch.rand does (``model.fresh_draws_per_call``; set ``model.seed`` and switch it off for
 reproducible frames).  Two lines at the top of a reference script::
 

@@ -106,6 +106,8 @@ _PROTOS = {
     "stnerf_gen_weight": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "stnerf_composite": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_i64, C.c_int, C.c_int, C.POINTER(CompositeParams),
                                    c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "stnerf_composite_bwd": (C.c_int, [c_f32p, c_f32p, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int, C.POINTER(CompositeParams),
+                                       c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "stnerf_composite_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(c_i64)]),
     "stnerf_render_workspace_bytes": (c_i64, [c_i64, C.c_int, C.c_int, C.c_int, C.c_int]),
     "stnerf_render_rays": (C.c_int, [c_f32p, c_i64, c_f32p, c_i64, C.POINTER(Nets), C.POINTER(RenderParams), c_f32p, c_f32p,

@@ -22,7 +22,9 @@ from stnerf_amd import ops
 # Samples whose activations are kept at a time while recomputing (~11 KB each for a SpaceNet: 2.9 GB of a 288 GB part).  Large
 # enough that the dW contraction's 256 slices are 1024 samples each with the chip full (csrc/train.hip: dw_slices); measured on
 # 524,288 samples: 0.54 / 0.60 / 0.63 / 0.64 of the f32 MFMA peak at 2^16 / 2^17 / 2^18 / 2^19.  STNERF_TRAIN_CHUNK_SAMPLES overrides.
-CHUNK_SAMPLES = int(os.environ.get("STNERF_TRAIN_CHUNK_SAMPLES", 1 << 18))
+# Clamped to [1024, 2^29 / 320]: the widest activation row is 320 floats and a GEMM operand may hold at most 2^29 of them
+# (csrc/train.hip), and a zero or negative value would make the chunk loops below step by nothing.
+CHUNK_SAMPLES = min(max(int(os.environ.get("STNERF_TRAIN_CHUNK_SAMPLES", 1 << 18)), 1024), (1 << 29) // 320)
 
 
 def _pad4(n: int) -> int:
@@ -50,7 +52,9 @@ class SpaceNetFunction(torch.autograd.Function):
         n, ns = pos.shape[0], pos.shape[1]
         raw = torch.empty(n, ns, 4, dtype=torch.float32, device=pos.device)
         with torch.no_grad():
-            ops.spacenet_fwd(module._packed(), pos.detach().contiguous(), dirs.detach(), times, raw)
+            # exact f32 whatever the module renders with: the backward recomputes the activations in fp32, and the ReLU masks it
+            # walks back through must be the ones of the forward that produced the loss
+            ops.spacenet_fwd(module._packed("fp32"), pos.detach().contiguous(), dirs.detach(), times, raw)
         ctx.module, ctx.has_times = module, times is not None
         ctx.save_for_backward(pos.detach(), dirs.detach(), times.detach() if times is not None else pos.new_empty(0),
                               *[p.detach() for p in params])

@@ -313,10 +313,10 @@ class LayeredRFRender(nn.Module):
             raise RuntimeError("set_bkgd_bbox / set_bboxes must be called before rendering")
         if N == 0:  # the reference dereferences row 0 (rays_frame_id[0, i+1], layered_rfrender.py:200)
             raise IndexError("empty ray batch: LayeredRFRender needs at least one ray")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError("LayeredRFRender (MI355X) is inference-only: the HIP render path has no backward pass.  Call it "
-                               "under torch.no_grad() (render/layered_neural_renderer.py:377 does) or freeze the parameters; "
-                               "training stays with the reference's own model")
+        # Training: model.train() + autograd enabled + trainable parameters = what engine/layered_trainer.py:186-194
+        # sets up -> the same stages launched op by op with autograd history (stnerf_amd.modeling.training).  In eval() mode the
+        # inference kernels run and the outputs carry no history, as under torch.no_grad() (render/layered_neural_renderer.py:377).
+        train = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
         step = N if ref_chunk is None else ref_chunk
         groups = []  # (start, end, boxes, pivot)
         if retiming:
@@ -349,8 +349,13 @@ class LayeredRFRender(nn.Module):
                 rp = None
                 if self.replay is not None:
                     rp = {k: v[:, s:e].contiguous() for k, v in self.replay.items()}
-                outs.append(self._render_launch(rays[s:e], bx, pivot, retiming, only_coarse, density_threshold,
-                                                bkgd_density_threshold, window_at(s), rp))
+                if train:
+                    from stnerf_amd.modeling.training import render_rays_train
+                    outs.append(render_rays_train(self, rays[s:e], bx, pivot, retiming, only_coarse, density_threshold,
+                                                  bkgd_density_threshold, window_at(s), rp))
+                else:
+                    outs.append(self._render_launch(rays[s:e], bx, pivot, retiming, only_coarse, density_threshold,
+                                                    bkgd_density_threshold, window_at(s), rp))
         cat = (lambda j: outs[0][j]) if len(outs) == 1 else (lambda j: torch.cat([o[j] for o in outs], 0))
         raw = tuple(cat(j) for j in range(5))
         self.advance_seed()

@@ -30,8 +30,8 @@ class MotionNet(nn.Module, _PackedMixin):
     def forward(self, input_0):
         """input_0 (N,L,4) or (N,4) = [x,y,z,t] -> flow (N,L,3) or (N,3).  The time may differ per sample."""
         bins = input_0.dim() > 2
-        if torch.is_grad_enabled() and (input_0.requires_grad or any(p.requires_grad for p in self.parameters())):
-            # training (SURVEY 8(f)4): see stnerf_amd.modeling.autograd
+        if torch.is_grad_enabled() and (input_0.requires_grad or (self.training and any(p.requires_grad for p in self.parameters()))):
+            # training (SURVEY 8(f)4; model.train(), or an input that asks for its gradient): see stnerf_amd.modeling.autograd
             from stnerf_amd.modeling.autograd import MotionNetFunction
             named = dict(self.named_parameters())
             params = [named[f"{k}.{what}"] for k in ops.MOTIONNET_KEYS for what in ("weight", "bias")]

@@ -60,8 +60,10 @@ class SpaceNet(nn.Module, _PackedMixin):
         x = x.contiguous()
         raw = torch.empty(n, s, 4, dtype=torch.float32, device=x.device)
         tm = times.reshape(n).contiguous() if (self.use_time and times is not None) else None
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            # training: fused forward, recompute-and-walk-back backward on the f32 MFMA GEMMs of csrc/train.hip
+        if torch.is_grad_enabled() and (x.requires_grad or (self.training and any(p.requires_grad for p in self.parameters()))):
+            # training (model.train(), or an input that asks for its gradient): fused exact-f32 forward,
+            # recompute-and-walk-back backward on the f32 MFMA GEMMs of csrc/train.hip.  A plain call in eval() mode stays on the
+            # inference path below even when autograd happens to be enabled: nothing is saved, the result carries no history
             from stnerf_amd.modeling.autograd import SpaceNetFunction
             if self.use_time and tm is None:
                 raise ValueError("this SpaceNet takes time: pass times")

@@ -287,6 +287,9 @@ def rgb_ray_bias(net: PackedNet, dirs: Tensor, times: Optional[Tensor], ray_list
     """The per-ray part of rgb_net.1 (stnerf_rgb_ray_bias): (n, 128) = bias + W[:, 256:] relu([PE_4(dir), PE_10(time)]) for
     the listed rays (other rows are zero here).  modeling/spacenet.py:80-86,141-151."""
     n = dirs.shape[0]
+    if net.precision != "fp32":
+        raise ValueError("stnerf_rgb_ray_bias reads the exact-f32 blob layout: pack the network 'fp32' for this call "
+                         f"(got a {net.precision!r} blob)")
     dp, ds = _strided_view_ptr(dirs, (3,), "dirs")
     if net.use_time:
         if times is None:
@@ -383,15 +386,10 @@ def gen_weight(sigma: Tensor, delta: Tensor) -> Tensor:
 
 
 # ---------------------------------------------------------------------------------------- a10-a13
-def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e10, near: float = 0.0,
-              fine: bool = False, cut_negative_t: bool = False, thresholds: Optional[Sequence[Optional[float]]] = None,
-              sigma_scale: Optional[Sequence[float]] = None, evaluated: Optional[Sequence[int]] = None,
-              want_weights: bool = False, want_order: bool = False, rgb_activated: bool = False, two_pass: bool = True):
-    """t (n,l,S), raw (n,l,S,4), mask (n,l) uint8 | None ->
-    layer_out (n,l,5), mixed_out (n,5), weights (n,l,S) | None, order (n,l*S) int32 | None.
-    layers/render_layer.py:8-58 + modeling/layered_rfrender.py:414-448 / :538-606.
-    evaluated[i]: 0 = hidden layer, 1 = evaluated where mask is set, 2 = evaluated on every ray (the background)."""
-    n, l, S = t.shape
+def composite_params(border: float = 1e10, near: float = 0.0, fine: bool = False, cut_negative_t: bool = False,
+                     thresholds: Optional[Sequence[Optional[float]]] = None, sigma_scale: Optional[Sequence[float]] = None,
+                     evaluated: Optional[Sequence[int]] = None, rgb_activated: bool = False) -> "hip.CompositeParams":
+    """The stnerf_composite_params of a stage (include/stnerf.h): shared by ``composite`` and ``composite_bwd``."""
     p = hip.CompositeParams()
     p.border, p.near, p.fine, p.cut_negative_t = border, near, int(fine), int(cut_negative_t)
     p.rgb_activated = int(rgb_activated)
@@ -401,6 +399,21 @@ def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e
         p.use_threshold[i] = 0 if th is None else 1
         p.sigma_scale[i] = float(sigma_scale[i]) if sigma_scale is not None and i < len(sigma_scale) else 1.0
         p.evaluated[i] = int(evaluated[i]) if evaluated is not None and i < len(evaluated) else 1
+    return p
+
+
+def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e10, near: float = 0.0,
+              fine: bool = False, cut_negative_t: bool = False, thresholds: Optional[Sequence[Optional[float]]] = None,
+              sigma_scale: Optional[Sequence[float]] = None, evaluated: Optional[Sequence[int]] = None,
+              want_weights: bool = False, want_order: bool = False, rgb_activated: bool = False, two_pass: bool = True,
+              params: Optional["hip.CompositeParams"] = None):
+    """t (n,l,S), raw (n,l,S,4), mask (n,l) uint8 | None ->
+    layer_out (n,l,5), mixed_out (n,5), weights (n,l,S) | None, order (n,l*S) int32 | None.
+    layers/render_layer.py:8-58 + modeling/layered_rfrender.py:414-448 / :538-606.
+    evaluated[i]: 0 = hidden layer, 1 = evaluated where mask is set, 2 = evaluated on every ray (the background)."""
+    n, l, S = t.shape
+    p = params if params is not None else composite_params(border, near, fine, cut_negative_t, thresholds, sigma_scale, evaluated,
+                                                           rgb_activated)
     layer_out = torch.empty(n, l, 5, dtype=torch.float32, device=t.device)
     mixed_out = torch.empty(n, 5, dtype=torch.float32, device=t.device)
     weights = torch.empty(n, l, S, dtype=torch.float32, device=t.device) if want_weights else None
@@ -411,6 +424,19 @@ def composite(t: Tensor, raw: Tensor, mask: Optional[Tensor], border: float = 1e
                                          hip.dptr(mixed_out), hip.dptr(weights), hip.dptr(order, torch.int32),
                                          hip.dptr(scratch, torch.uint8), hip.stream_ptr()), "stnerf_composite")
     return layer_out, mixed_out, weights, order
+
+
+def composite_bwd(t: Tensor, raw: Tensor, mask: Optional[Tensor], order: Optional[Tensor], params: "hip.CompositeParams",
+                  g_layer: Optional[Tensor], g_mixed: Optional[Tensor]) -> Tensor:
+    """dLoss/d raw (n,l,S,4) from dLoss/d layer_out (n,l,5) and dLoss/d mixed_out (n,5) (either may be None):
+    stnerf_composite_bwd, the backward of ``composite`` called with the same t / raw / mask / params (order: its output)."""
+    n, l, S = t.shape
+    d_raw = torch.empty(n, l, S, 4, dtype=torch.float32, device=t.device)
+    hip.check(hip.lib().stnerf_composite_bwd(hip.dptr(t, name="t"), hip.dptr(raw, name="raw"), hip.dptr(mask, torch.uint8, "mask"),
+                                             hip.dptr(order, torch.int32, "order"), n, l, S, C.byref(params),
+                                             hip.dptr(g_layer, name="g_layer"), hip.dptr(g_mixed, name="g_mixed"), hip.dptr(d_raw),
+                                             hip.stream_ptr()), "stnerf_composite_bwd")
+    return d_raw
 
 
 def resample(t: Tensor, weights: Tensor, n2: int, rays: Tensor, u: Optional[Tensor] = None, seed: int = 0,

@@ -139,3 +139,22 @@ def frame_id_columns(n: int, layer_num: int, frame: float = 2.5, bkgd_frame: flo
     cols = torch.full((n, layer_num + 1), float(frame), dtype=torch.float32)
     cols[:, 0] = float(bkgd_frame)
     return cols
+
+
+def digest_positions(name: str, numel: int, k: int) -> torch.Tensor:
+    """k distinct flat positions of a tensor of ``numel`` entries, a fixed function of (name, numel): the gradient fixtures of
+    tests/golden/make_golden.py keep a parameter's gradient at these positions (whole networks are too large to commit)."""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff)
+    return torch.from_numpy(np.sort(rs.choice(numel, size=min(k, numel), replace=False)).astype(np.int64))
+
+
+def tensor_digest(name: str, g: torch.Tensor, k: int = 512) -> torch.Tensor:
+    """One float32 vector standing for a (gradient / parameter) tensor in a fixture: the tensor itself when it has at most 4096
+    entries, else [absmax, L2 norm, row sums, column sums, k entries at ``digest_positions(name, ...)``] (sums in fp64)."""
+    g = g.detach().double().cpu()
+    if g.numel() <= 4096:
+        return g.reshape(-1).float()
+    g2 = g.reshape(g.shape[0], -1)
+    return torch.cat([g.abs().max().reshape(1), g.norm().reshape(1), g2.sum(1), g2.sum(0),
+                      g.reshape(-1)[digest_positions(name, g.numel(), k)]]).float()

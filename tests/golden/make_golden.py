@@ -550,6 +550,116 @@ def g_psnr_view():
     save("psnr_view", dict(L=L, n1=n1, n2=n2, h=H, w=W, orbit=10.0, weight_seed=0, frame=2.5, seeds=[1, 2]), **imgs)
 
 
+# ----------------------------------------------------------------------------- training step
+GRAD_SAMPLES = 512
+
+
+def grad_digest(name, g):
+    """What a fixture keeps of one parameter's gradient (whole SpaceNets are 463 k floats each), as ONE float vector:
+    stnerf_amd.synthetic.tensor_digest (the tensor itself when small, else absmax, L2 norm, row sums, column sums and
+    GRAD_SAMPLES entries at seeded positions); the test digests its own gradient with the same function."""
+    return {name: syn.tensor_digest(name.split("|", 1)[1], g.detach(), GRAD_SAMPLES)}
+
+
+def g_train_step(name, L, n1, n2, st, dt, seed, n_rays=96, only_coarse=False, remove_outliers=True, h=40, w=64):
+    """One iteration of do_train's inner loop (engine/layered_trainer.py:178-282) with the reference's OWN model, loss
+    (layers/loss.py:4) and optimiser (solver/build.py:10-27, Adam as configs/config_taekwondo.yml:3-5), on a batch of
+    training-style rays (7 columns: one integer frame id per ray, data/datasets/ray_dataset.py): the loss, every parameter's
+    gradient (digested) and the parameters after optimizer.step().  The trainer's surroundings (loaders, tensorboard, checkpoints,
+    val_vis) are not run: the lines between `optimizer.zero_grad()` (:187) and `optimizer.step()` (:279) are restated here with
+    the same expressions."""
+    from layers import make_loss
+    from solver import make_optimizer
+    model = build_ref_model(L, n1, n2, st, dt, seed)
+    cfg = types.SimpleNamespace(SOLVER=types.SimpleNamespace(OPTIMIZER_NAME="Adam", BASE_LR=0.0004, WEIGHT_DECAY=0.0))
+    loss_fn = make_loss(cfg)
+    optimizer = make_optimizer(cfg, model)
+    all_rays = view_rays(h, w, L, per_ray_frames=True)
+    g = torch.Generator().manual_seed(500 + seed)
+    pick = torch.randperm(all_rays.shape[0], generator=g)[:n_rays]
+    rays = all_rays[pick].contiguous()
+    rgbs = torch.rand(n_rays, 3, generator=g)
+    bbox_labels, bboxes, near_far = torch.zeros(n_rays), torch.zeros(n_rays, 8, 3), torch.zeros(n_rays, 2)
+    epoch, coarse_stage = (1, 10) if only_coarse else (1, 0)
+    torch.manual_seed(600 + seed)
+    model.train()                                                       # :186
+    optimizer.zero_grad()                                               # :187
+    with RandRecorder() as rr:
+        if epoch < coarse_stage:                                        # :199-202
+            stage2, stage1, stage2_layer, stage1_layer, ray_mask = model(rays, bbox_labels, bboxes, True, near_far=near_far)
+        else:
+            stage2, stage1, stage2_layer, stage1_layer, ray_mask = model(rays, bbox_labels, bboxes, False, near_far=near_far)
+    # labels (N,1): 0 = outlier, i = the ray belongs to layer i (the dataset's masks); here: the first performer the ray hits
+    labels = torch.zeros(n_rays, 1)
+    for i in range(L, 0, -1):
+        labels[ray_mask[i]] = float(i)
+    labels[torch.rand(n_rays, generator=g) < 0.25] = 0.0
+    predict_rgb_0, predict_rgb_1 = stage1[0], stage2[0]                 # :211-212
+    loss1 = loss_fn(predict_rgb_0, rgbs)                                # :224-225
+    loss2 = loss_fn(predict_rgb_1, rgbs)
+    if epoch < 3 and remove_outliers:                                   # :226-272
+        outliers_1, outliers_2, inliers_1, inliers_2 = [], [], [], []
+        for i in range(len(stage1_layer)):
+            if i != 0:
+                outliers_1.append(stage1_layer[i][2][labels == 0])
+                outliers_2.append(stage2_layer[i][2][labels == 0])
+            inliers_1.append(stage1_layer[i][2][labels == i])
+            inliers_2.append(stage2_layer[i][2][labels == i])
+        if outliers_1 != []:
+            outliers_1 = torch.cat(outliers_1, 0)
+            outliers_2 = torch.cat(outliers_2, 0)
+        inliers_1 = torch.cat(inliers_1, 0)
+        inliers_2 = torch.cat(inliers_2, 0)
+        scalar, penalty = 100000, 1
+        if outliers_1 != []:
+            loss_mask_0 = torch.sum(torch.abs(outliers_1)) * penalty + torch.sum(torch.abs(1 - inliers_1))
+            loss_mask_1 = torch.sum(torch.abs(outliers_2)) * penalty + torch.sum(torch.abs(1 - inliers_2))
+        else:
+            loss_mask_0 = torch.sum(torch.abs(1 - inliers_1))
+            loss_mask_1 = torch.sum(torch.abs(1 - inliers_2))
+        loss_mask_0 = loss_mask_0 / scalar if loss_mask_0 > rays.shape[0] * 0.0005 and remove_outliers else torch.Tensor([0])
+        loss_mask_1 = loss_mask_1 / scalar if loss_mask_1 > rays.shape[0] * 0.0005 and remove_outliers else torch.Tensor([0])
+    else:
+        loss_mask_0, loss_mask_1 = torch.Tensor([0]), torch.Tensor([0])
+    if epoch < coarse_stage:                                            # :274-277
+        loss = loss1 + loss_mask_0
+    else:
+        loss = loss1 + loss2 + loss_mask_0 + loss_mask_1
+    loss.backward()                                                     # :281
+    arrays = dict(rays=rays, rgbs=rgbs, labels=labels, loss=loss.detach().reshape(1), loss1=loss1.detach().reshape(1),
+                  loss2=loss2.detach().reshape(1), loss_mask_0=torch.as_tensor(loss_mask_0).detach().reshape(1),
+                  loss_mask_1=torch.as_tensor(loss_mask_1).detach().reshape(1))
+    arrays.update(flatten_out(tuple(tuple(x.detach() for x in t) if isinstance(t, tuple) else
+                                    [tuple(x.detach() for x in tr) if isinstance(tr, tuple) else tr for tr in t]
+                                    for t in (stage2, stage1, stage2_layer, stage1_layer, ray_mask))))
+    without_grad = []
+    for pname, prm in model.named_parameters():
+        if prm.grad is None:
+            without_grad.append(pname)
+            continue
+        arrays.update(grad_digest("grad|" + pname, prm.grad))
+    optimizer.step()                                                    # :283
+    for pname, prm in model.named_parameters():
+        if prm.grad is not None:
+            arrays.update(grad_digest("stepped|" + pname, prm.detach()))
+    for i, dr in enumerate(rr.draws):
+        arrays[f"draw{i}"] = dr
+    meta = dict(L=L, n1=n1, n2=n2, space_time=st, deform_time=dt, weight_seed=seed, n_rays=n_rays, only_coarse=only_coarse,
+                remove_outliers=remove_outliers, n_draws=len(rr.draws), without_grad=without_grad, lr=0.0004,
+                grad_samples=GRAD_SAMPLES, scalar=100000, penalty=1,
+                hit_fraction=[float(mk.float().mean()) for mk in ray_mask])
+    save(name, meta, **arrays)
+
+
+def g_train_cases():
+    # C3-shaped (two performers, space-time + deform), both stages, with the outlier / inlier mask losses on the layers' acc maps;
+    # S = 80 > 64 samples per layer, 240 in the merged list: the compositor backward's scans cross wave blocks
+    g_train_step("train_c3", 2, 40, 40, True, True, 41)
+    # the coarse-only epochs (:199-200, :274-275) of a deform-only single performer
+    g_train_step("train_coarse_only", 1, 24, 8, False, True, 42, n_rays=64, only_coarse=True)
+
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--psnr-view":
         g_psnr_view()
@@ -565,6 +675,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "--teacher":
         g_teacher_cases()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--grads":
+        g_train_cases()
         return
     g_generate_rays()
     g_sampler()
@@ -595,6 +708,7 @@ def main():
     g_round2()
     g_psnr_view()
     g_teacher_cases()
+    g_train_cases()
 
 
 if __name__ == "__main__":

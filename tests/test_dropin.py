@@ -467,3 +467,107 @@ def test_reference_render_pose_is_sharded_across_ranks_with_no_edit(world):
         assert res["whole_rays"] == N and res["my_rays"] == res["my_share"] < N, (rank, res)
         assert all(w == (rank * 3584, 3584, world * 3584) for w in res["windows"]), (rank, res)
     assert sum(res["my_rays"] for res in results.values()) == N
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's OWN training loop drives this framework's model
+# ---------------------------------------------------------------------------------------------------------------------
+def test_reference_do_train_runs_one_iteration_on_the_patched_model(reference_env, tmp_path, monkeypatch):
+    """``engine.layered_trainer.do_train`` -- the reference's function object, unmodified -- with the reference's ``make_loss``
+    (layers/loss.py:4) and ``make_optimizer`` (solver/build.py:10-27), one batch, one epoch, on the model
+    ``modeling.build_layered_model`` returns after ``patch_reference`` (= this framework's ``LayeredRFRender`` in train() mode under
+    autograd: stnerf_amd.modeling.training).  There is no GPU here, so the ONE native piece, ``render_rays_train`` (sampler ->
+    networks -> compositor, with autograd history), is answered by the CPU oracle evaluated on the model's own nn.Parameters with the
+    boxes / thresholds / draws this framework's host code hands it; everything around it -- the batch unpacking, model.train(),
+    the loss with its outlier / inlier terms, loss.backward(), optimizer.step(), scheduler.step(), the psnr monitor, the checkpoint
+    -- is the reference's code.  The parameters after the step are the ones the reference's own model ends up with
+    (tests/golden/train_c3.npz, recorded by make_golden.py --grads).  tests/test_gpu_training.py runs the same iteration on the
+    HIP kernels against the same fixture."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from train_step_common import compare_digest, load_fixture, replay_of
+    from oracle import stnerf_oracle as O
+    from stnerf_amd import synthetic as syn
+    dropin = reference_env
+    dropin.patch_reference(REFERENCE)
+    trainer = importlib.import_module("engine.layered_trainer")
+    modeling = importlib.import_module("modeling")
+    make_loss = importlib.import_module("layers").make_loss
+    make_optimizer = importlib.import_module("solver").make_optimizer
+    assert trainer.__file__.startswith(REFERENCE) and make_loss.__module__ == "layers.loss"
+    from stnerf_amd.modeling import training as ours_training
+    from stnerf_amd.modeling.layered_rfrender import LayeredRFRender
+
+    z, meta = load_fixture("train_c3")
+    L, n1, n2 = meta["L"], meta["n1"], meta["n2"]
+    cfg = _cfg(n1, n2, L)
+    cfg.SOLVER.MAX_EPOCHS, cfg.SOLVER.COARSE_STAGE, cfg.SOLVER.LOG_PERIOD, cfg.SOLVER.CHECKPOINT_PERIOD = 2, 0, 1, 10
+    cfg.SOLVER.BASE_LR, cfg.SOLVER.WEIGHT_DECAY, cfg.SOLVER.OPTIMIZER_NAME = meta["lr"], 0.0, "Adam"
+    cfg.MODEL.REMOVE_OUTLIERS = True
+    cfg.OUTPUT_DIR = str(tmp_path / "out")
+    model = modeling.build_layered_model(cfg, camera_num=1)
+    assert type(model) is LayeredRFRender
+    model.load_state_dict(syn.make_state_dict(L, True, True, seed=meta["weight_seed"]))
+    bk, per = syn.scene_boxes(L)
+    model.set_bkgd_bbox(bk)
+    model.set_bboxes(per)
+    _, model.replay = replay_of(z, meta)
+    model.fresh_draws_per_call = False
+    calls = []
+
+    def oracle_render_rays_train(self, rays, boxes, pivot, retiming, only_coarse, thr, bthr, window, replay):
+        n, l = rays.shape[0], self.layer_num + 1
+        calls.append((n, retiming, only_coarse, tuple(window), self.training, torch.is_grad_enabled()))
+        om = O.OracleModel(layer_num=L, n_coarse=n1, n_fine=n2, params=dict(self.named_parameters()), bkgd_bbox=bk, bboxes=per,
+                           near=self.near, alpha=self.alpha, scale=self.scale, shift=self.shift)
+        bx = boxes.unsqueeze(0).expand(n, l, 8, 3) if boxes.dim() == 3 else boxes
+        saved = O.layer_boxes
+        O.layer_boxes = lambda m_, r: (bx.clone(), pivot, retiming, r[:, 6:] if retiming else r[:, -1])
+        try:
+            draws = iter(list(replay["jitter"]) + list(replay.get("u", [])))
+            out = O.render_chunk(om, rays, only_coarse, thr, bthr, rand=lambda shape: next(draws))
+        finally:
+            O.layer_boxes = saved
+        cat = lambda trip: torch.cat(list(trip), -1)
+        return (cat(out[0]), cat(out[1]), torch.stack([cat(t) for t in out[2]], 1), torch.stack([cat(t) for t in out[3]], 1),
+                torch.stack(out[4], 1).to(torch.uint8))
+    monkeypatch.setattr(ours_training, "render_rays_train", oracle_render_rays_train)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda t: True))          # (the host logic refuses CPU rays)
+    # the trainer's surroundings that need a dataset / files: validation images and checkpoints
+    checkpoints = []
+    monkeypatch.setattr(trainer, "val_vis", lambda *a, **k: None)
+    monkeypatch.setattr(trainer, "ModelCheckpoint", lambda model_, opt_, sch_, out_dir, epoch, global_step=0: checkpoints.append((epoch, global_step)))
+
+    class Writer:
+        def __init__(self):
+            self.scalars = {}
+
+        def add_scalar(self, tag, value, step):
+            self.scalars[tag] = float(value)
+
+    class Scheduler:
+        steps = 0
+
+        def step(self):
+            type(self).steps += 1
+
+    n = meta["n_rays"]
+    batch = (torch.from_numpy(z["rays"]), torch.from_numpy(z["rgbs"]), torch.from_numpy(z["labels"]), torch.zeros(n), torch.zeros(n, 8, 3),
+             torch.zeros(n, 2))
+    writer = Writer()
+    anomaly = torch.is_anomaly_enabled()
+    try:
+        trainer.do_train(cfg, model, [batch], None, make_optimizer(cfg, model), Scheduler(), make_loss(cfg), writer)
+    finally:
+        torch.autograd.set_detect_anomaly(anomaly)                                  # (do_train switches it on, :160)
+    assert len(calls) == 1 and calls[0] == (n, False, False, (0, 0, 0), True, True), calls
+    assert Scheduler.steps == 1 and checkpoints, (Scheduler.steps, checkpoints)
+    assert writer.scalars["Loss/train_loss"] == pytest.approx(float(z["loss"][0]), rel=1e-6)
+    assert writer.scalars["Loss/mask_loss"] == pytest.approx(float(z["loss_mask_0"][0] + z["loss_mask_1"][0]), rel=1e-5)
+    named = dict(model.named_parameters())
+    for k in z.files:
+        if k.startswith("stepped|"):
+            p = k.split("|", 1)[1]
+            assert compare_digest(p, syn.tensor_digest(p, named[p], meta["grad_samples"]), z[k], rel=2e-6) <= 1.0, p
+        if k.startswith("grad|"):
+            p = k.split("|", 1)[1]
+            assert compare_digest(p, syn.tensor_digest(p, named[p].grad, meta["grad_samples"]), z[k], rel=2e-5) <= 1.0, p

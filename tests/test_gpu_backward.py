@@ -305,12 +305,3 @@ def test_deformed_spacenet_chain_trains_both_networks():
     with torch.no_grad():
         after = loss_of(lambda p: space(p, rays, times.cuda()), motion, "cuda", keep)
     assert float(after) < float(loss)
-
-
-def test_whole_renderer_stays_inference_only_under_autograd():
-    """Only the two networks train on this path: LayeredRFRender.forward still refuses autograd."""
-    import test_gpu_render as R
-    model = R.build_model(dict(L=1, n1=8, n2=4, space_time=True, deform_time=True, weight_seed=1, edit={}))
-    rays = torch.rand(16, 8, device="cuda")
-    with pytest.raises(RuntimeError, match="inference-only"):
-        model(rays, None, None)

@@ -1,0 +1,62 @@
+"""The oracle's training step against the reference's: loss, every parameter's gradient and the parameters
+after one Adam step, recorded by tests/golden/make_golden.py --grads from the reference's OWN nn.Modules, loss and optimiser.
+This pins the oracle's autograd (what the GPU tests compare the HIP backward with in fp64) to the reference's."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle import stnerf_oracle as O                    # noqa: E402
+from stnerf_amd import synthetic as syn                  # noqa: E402
+from train_step_common import compare_digest, load_fixture, oracle_step   # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["train_c3", "train_coarse_only"])
+def test_oracle_training_step_matches_the_reference(name):
+    z, meta = load_fixture(name)
+    sd, out, loss, parts = oracle_step(z, meta, torch.float32)
+    assert float(loss) == pytest.approx(float(z["loss"][0]), rel=1e-6)
+    for k, v in parts.items():
+        assert float(v) == pytest.approx(float(z[k][0]), rel=1e-5, abs=1e-9), k
+    assert torch.allclose(out[0][0], torch.from_numpy(z["fine_mixed_color"]), atol=1e-6)
+    recorded = [k.split("|", 1)[1] for k in z.files if k.startswith("grad|")]
+    assert len(recorded) >= 20 and not meta["without_grad"] or name == "train_coarse_only"
+    worst = 0.0
+    for pname in recorded:
+        g = sd[pname].grad
+        assert g is not None, pname
+        worst = max(worst, compare_digest(pname, syn.tensor_digest(pname, g, meta["grad_samples"]), z["grad|" + pname], rel=2e-5))
+    assert worst <= 1.0, worst
+    # parameters the reference left without a gradient (the fine networks of a coarse-only epoch) get none here either
+    for pname in meta["without_grad"]:
+        assert sd[pname].grad is None or float(sd[pname].grad.abs().max()) == 0.0, pname
+    # one Adam step (solver/build.py:18: betas (0.9, 0.999), no weight decay)
+    params = [sd[p] for p in recorded]
+    opt = torch.optim.Adam(params, lr=meta["lr"], betas=(0.9, 0.999), weight_decay=0.0)
+    opt.step()
+    for pname in recorded:
+        assert compare_digest(pname, syn.tensor_digest(pname, sd[pname], meta["grad_samples"]), z["stepped|" + pname], rel=2e-6) <= 1.0, pname
+
+
+def test_reference_fp32_gradients_against_an_fp64_evaluation_of_the_same_graph():
+    """What the reference's own fp32 autograd is worth as a yardstick.  The fp64 evaluation (on the fp32 run's sample positions)
+    agrees with it to fp32 rounding on train_coarse_only -- and on train_c3 for most tensors, but ONE hidden unit of
+    bkgd_spacenet.stage2.0 on ONE sample has a pre-activation of 4e-9 in fp64 and <= 0 in ATen's fp32 sgemm: ReLU'(0) passes the
+    cotangent in one evaluation and not in the other, which moves that network's gradients by up to 3.7 % of a tensor's largest
+    entry.  The GPU test therefore accepts either side of such an event (tests/test_gpu_training.py)."""
+    z, meta = load_fixture("train_coarse_only")
+    sd, _, loss, _ = oracle_step(z, meta, torch.float64, sample_dtype=torch.float32)
+    assert float(loss) == pytest.approx(float(z["loss"][0]), rel=1e-6)
+    errs = [compare_digest(k, syn.tensor_digest(k.split("|", 1)[1], sd[k.split("|", 1)[1]].grad, meta["grad_samples"]), z[k], rel=2e-5)
+            for k in z.files if k.startswith("grad|")]
+    assert max(errs) <= 1.0, max(errs)
+    z, meta = load_fixture("train_c3")
+    sd, _, loss, _ = oracle_step(z, meta, torch.float64, sample_dtype=torch.float32)
+    assert float(loss) == pytest.approx(float(z["loss"][0]), rel=1e-6)
+    errs = {k: compare_digest(k, syn.tensor_digest(k.split("|", 1)[1], sd[k.split("|", 1)[1]].grad, meta["grad_samples"]), z[k], rel=1.0)
+            for k in z.files if k.startswith("grad|")}
+    ranked = sorted(errs.values())
+    assert ranked[len(ranked) // 2] <= 2e-5 and ranked[-1] <= 0.05, (ranked[len(ranked) // 2], ranked[-1])
+    assert max(errs, key=errs.get).startswith("grad|bkgd_spacenet.")
