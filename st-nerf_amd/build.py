@@ -31,6 +31,7 @@ SOURCES = [
     ("pipeline.hip", []),
     ("train.hip", []),
     ("render_bwd.hip", []),
+    ("train_wave.hip", []),
 ]
 EXTRA = os.environ.get("STNERF_EXTRA_FLAGS", "").split()   # e.g. -DSTNERF_PHASE_PROF (development only)
 COMMON = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

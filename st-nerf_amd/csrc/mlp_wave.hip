@@ -33,8 +33,42 @@
 
 namespace stnerf {
 
-template <bool DEEP>
-__global__ __launch_bounds__(WV_THREADS, 1) void mlp_wave_stage_kernel(StageArgs a) {
+// Training: the same kernel with a tap that writes every layer's input -- the activations the backward pass
+// needs -- to row-major matrices the caller owns, as the item's rows pass through the registers: one launch instead of a
+// chain of per-layer GEMMs through HBM for the recomputation, and the SAME arithmetic as the forward that produced the loss.
+// Slot 0 of the queue only (the training entry point launches one network).  Row r of the launch <-> row r of every matrix.
+struct NoTapArgs {};
+struct StoreTapArgs {
+    float* buf[8];     // stage s: the input of stage1.2 .. stage2.4 (0 .. 5), of the heads / rgb_net.1 (6: 256 wide), of rgb_net.3 (7: 128)
+    int32_t ld[8];     // row strides in floats (multiples of 4; 16-byte aligned bases)
+    float* pe;         // PE(pos): 63 features + one zero
+    int32_t ld_pe;
+};
+struct StoreTap {
+    const StoreTapArgs* a;
+    uint32_t row;
+    bool valid;
+    template <int NBLK>
+    __device__ __forceinline__ void blocks(int stage, const f32x16 (&blk)[NBLK], int nblk, int lane) const {
+        if (!valid) return;
+        float* base = stage == TAP_PE ? a->pe : a->buf[stage];
+        const int ld = stage == TAP_PE ? a->ld_pe : a->ld[stage];
+        // register 4 q + r of block fb <-> feature 32 fb + 8 q + 4 h + r: 16 bytes per (fb, q), the two lanes of a sample side by side
+        float4* p = reinterpret_cast<float4*>(base + (size_t)row * (size_t)ld + 4 * (lane >> 5));
+#pragma unroll
+        for (int fb = 0; fb < NBLK; ++fb)
+            if (fb < nblk) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    p[fb * 8 + 2 * q] = make_float4(blk[fb][4 * q + 0], blk[fb][4 * q + 1], blk[fb][4 * q + 2], blk[fb][4 * q + 3]);
+            }
+    }
+};
+__device__ __forceinline__ NoTap make_tap(const NoTapArgs&, uint32_t, bool) { return NoTap(); }
+__device__ __forceinline__ StoreTap make_tap(const StoreTapArgs& t, uint32_t row, bool valid) { return StoreTap{&t, row, valid}; }
+
+template <bool DEEP, class TapArgs>
+__global__ __launch_bounds__(WV_THREADS, 1) void mlp_wave_stage_kernel(StageArgs a, TapArgs targs) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -153,8 +187,10 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_wave_stage_kernel(StageArgs
         int ln = lane;
         if constexpr (DEEP) asm volatile("" : "+v"(ln));
         if (ly.motion) motion_wave(ly.motion, encw, p, cur.tv, ly.motion_flags, ln, acc, in, wa, wb WV_DBG_ARG WP_ARG);
+        // (training: the row of this lane's sample in the launch; items of slot 0 are rows 128 item ..)
+        const auto tap = make_tap(targs, it0 * (uint32_t)WV_ITEM + (uint32_t)(wave * WV_ROWS + (lane & 31)), cur.valid);
         float4 o = space_wave<DEEP>(ly.space, ly.use_time != 0, encw, p, ly.raybias, cur.ray, ln, acc, in, wa, wb,
-                                    [&]() { fetch(it1, rr_next, nxt); } WV_DBG_ARG WP_ARG);
+                                    [&]() { fetch(it1, rr_next, nxt); } WV_DBG_ARG WP_ARG, tap);
         if (cur.valid && lane < 32) {
             if (a.sigmoid_rgb) {  // torch.sigmoid(rgb): 1-ulp v_exp_f32 / v_rcp_f32, the same expression the compositor uses
                 o.x = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(o.x * -1.44269504088896340736f));
@@ -194,14 +230,33 @@ int launch_wave_stage(const StageArgs& a_in, bool deep_rgb, int cus, hipStream_t
 #endif
     const int64_t max_items = ((a.n_rays * a.ns + WV_ITEM - 1) / WV_ITEM) * a.n_layers;
     const int grid = (int)(max_items < cus ? max_items : cus);  // one persistent workgroup per CU
-    const void* kfn = deep_rgb ? reinterpret_cast<const void*>(mlp_wave_stage_kernel<true>)
-                               : reinterpret_cast<const void*>(mlp_wave_stage_kernel<false>);
+    const void* kfn = deep_rgb ? reinterpret_cast<const void*>(mlp_wave_stage_kernel<true, NoTapArgs>)
+                               : reinterpret_cast<const void*>(mlp_wave_stage_kernel<false, NoTapArgs>);
     if (const int rc = reserve_dynamic_lds(kfn, WV_LDS, "mlp_stage (wave)")) return rc;
     if (deep_rgb)
-        hipLaunchKernelGGL(mlp_wave_stage_kernel<true>, dim3(grid), dim3(WV_THREADS), WV_LDS, stream, a);
+        hipLaunchKernelGGL((mlp_wave_stage_kernel<true, NoTapArgs>), dim3(grid), dim3(WV_THREADS), WV_LDS, stream, a, NoTapArgs());
     else
-        hipLaunchKernelGGL(mlp_wave_stage_kernel<false>, dim3(grid), dim3(WV_THREADS), WV_LDS, stream, a);
+        hipLaunchKernelGGL((mlp_wave_stage_kernel<false, NoTapArgs>), dim3(grid), dim3(WV_THREADS), WV_LDS, stream, a, NoTapArgs());
     STNERF_CHECK_LAUNCH("mlp_stage (wave)");
+    return STNERF_OK;
+}
+
+// One SpaceNet (queue slot 0 of `a`, no MotionNet, not deep_rgb) with every layer's input written out: see StoreTapArgs.
+int launch_wave_stage_store(const StageArgs& a, float* const (&buf)[8], const int32_t (&ld)[8], float* pe, int32_t ld_pe, int cus,
+                            hipStream_t stream) {
+    StoreTapArgs t;
+    for (int i = 0; i < 8; ++i) {
+        t.buf[i] = buf[i];
+        t.ld[i] = ld[i];
+    }
+    t.pe = pe;
+    t.ld_pe = ld_pe;
+    const int64_t max_items = (a.n_rays * a.ns + WV_ITEM - 1) / WV_ITEM;
+    const int grid = (int)(max_items < cus ? max_items : cus);
+    if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(mlp_wave_stage_kernel<false, StoreTapArgs>), WV_LDS, "train_space_fwd"))
+        return rc;
+    hipLaunchKernelGGL((mlp_wave_stage_kernel<false, StoreTapArgs>), dim3(grid), dim3(WV_THREADS), WV_LDS, stream, a, t);
+    STNERF_CHECK_LAUNCH("train_space_fwd");
     return STNERF_OK;
 }
 

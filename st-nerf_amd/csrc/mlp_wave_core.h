@@ -385,10 +385,19 @@ __device__ __forceinline__ void head3(const f32x16 (&in)[8], const float* wlds /
 // arithmetic without a memory wait, where the caller issues the HBM loads of the next work item (the counters are in
 // order: a load issued elsewhere stalls the next weight wait for its whole latency).
 // ---------------------------------------------------------------------------------------------
-template <bool DEEP, class Mid>
+// `tap` sees every layer's input as the layer reads it (training: csrc/mlp_wave.hip's StoreTap writes them out for the backward
+// pass; NoTap compiles to nothing): stage TAP_PE = PE(pos) (2 blocks), 0 .. 5 = the inputs of stage1.2 .. stage2.4 (8 blocks each;
+// 3 = h4, stage2.0's input next to PE), 6 = g3 (the heads' and rgb_net.1's input), 7 = rgb_net.3's input (4 blocks).
+constexpr int TAP_PE = 100;
+struct NoTap {
+    template <int NBLK>
+    __device__ __forceinline__ void blocks(int, const f32x16 (&)[NBLK], int, int) const {}
+};
+template <bool DEEP, class Mid, class Tap = NoTap>
 __device__ __forceinline__ float4 space_wave(const float* net, const bool use_time, float* encw, const float (&p)[3],
                                              const float* __restrict__ raybias, int32_t ray, int lane, f32x16 (&acc)[8],
-                                             f32x16 (&in)[8], float4 (&wa)[8], float4 (&wb)[8], Mid mid WV_DBG_PARAM WP_PARAM) {
+                                             f32x16 (&in)[8], float4 (&wa)[8], float4 (&wb)[8], Mid mid WV_DBG_PARAM WP_PARAM,
+                                             const Tap& tap = Tap()) {
     const SpaceLayout L = space_layout(use_time, DEEP);
     const __amdgpu_buffer_rsrc_t rsrc = weight_rsrc(net);
     const int h = lane >> 5, c = lane & 31;
@@ -429,6 +438,7 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
         stage_bias_issue<3>(hst, rsrc, lane, ho, 32);
     }
     WV_DBG(100, pe, 2);
+    tap.template blocks<2>(TAP_PE, pe, 2, lane);
     WP(WP_S_PE);
     segment_r<8, 2, 8, 0, 8>(acc, pe, wa, wb, rsrc, wl256, (uint32_t)L.w[0] * 4u, WSTEP256, nx256, (uint32_t)L.w[1] * 4u);
     stage_bias_store<3>(hst, biasw + WV_HEAD_SLOT * 256, lane);
@@ -446,6 +456,7 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
         // the previous layer's ReLU, this layer's bias (rotated: see relu_rebias)
         relu_rebias<8, 8>(acc, in, biasw + (li - 1) * 256, lane);
         WV_DBG(li - 1, in, 8);
+        tap.template blocks<8>(li - 1, in, 8, lane);
         WP(WP_L_EPI);
         // (one copy of the 32-step body: behind stage2.0's 256 features the skip segment simply continues in the blob)
         segment_r<8, 8, 32, 0, 8>(acc, in, wa, wb, rsrc, wl256, soff, WSTEP256, next_wl,  // (li == 4: next_wl == wl256)
@@ -456,6 +467,7 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
     }
     relu_rebias<8, 0>(acc, in, biasw, lane);
     WV_DBG(6, in, 8);
+    tap.template blocks<8>(6, in, 8, lane);
     WP(WP_L_EPI);
     // ---- rgb_net.1's C operands: this sample's row of the ray-bias table straight into the accumulators.  (Fetching them
     // inside the preceding ReLU pass, block by block, would cover their latency, but keeps the row pointer live through
@@ -497,6 +509,7 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
     WP(WP_S_RGB1);
     relu_rebias<4, 0>(acc, in, biasw, lane);
     WV_DBG(7, in, 4);
+    tap.template blocks<8>(7, in, 4, lane);
     float rgb[3];
     head3(in, biasw + (WV_HEAD_SLOT + 1) * 256, net + L.b_rgb2, lane, rgb);
     WP(WP_S_HEAD);

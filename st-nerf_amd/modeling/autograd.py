@@ -24,6 +24,15 @@ from stnerf_amd import ops
 # 524,288 samples: 0.54 / 0.60 / 0.63 / 0.64 of the f32 MFMA peak at 2^16 / 2^17 / 2^18 / 2^19.  STNERF_TRAIN_CHUNK_SAMPLES overrides.
 # Clamped to [1024, 2^29 / 320]: the widest activation row is 320 floats and a GEMM operand may hold at most 2^29 of them
 # (csrc/train.hip), and a zero or negative value would make the chunk loops below step by nothing.
+# STNERF_TRAIN_FUSED=0: the round-4 backward (one GEMM launch per layer and direction) instead of the fused launches of
+# csrc/train_wave.hip -- kept for A/B measurements and for the configurations the fused kernels do not cover (deep_rgb, no raw input
+# columns in the encodings, no view directions)
+FUSED_BACKWARD = os.environ.get("STNERF_TRAIN_FUSED", "1") != "0"
+# The training forward of a SpaceNet KEEPS every layer's input (8.1 KB per sample, written by the forward kernel itself) when the call's
+# samples fit this budget -- as the reference's autograd does, and what 288 GB of HBM are for: the backward then starts without any
+# recomputation.  Above the budget (or with STNERF_TRAIN_KEEP_GB=0) nothing is kept and the backward recomputes chunk by chunk.
+KEEP_BYTES = int(float(os.environ.get("STNERF_TRAIN_KEEP_GB", "32")) * (1 << 30))
+ACT_FLOATS_PER_SAMPLE = 320 + 5 * 256 + 304 + 128
 CHUNK_SAMPLES = min(max(int(os.environ.get("STNERF_TRAIN_CHUNK_SAMPLES", 1 << 18)), 1024), (1 << 29) // 320)
 
 
@@ -43,6 +52,46 @@ def _buf(m: int, cols: int, device) -> torch.Tensor:
     return torch.empty(m, _pad4(cols), dtype=torch.float32, device=device)
 
 
+def transposed_spacenet(module, params) -> tuple:
+    """(wt, offsets): the A operands of the fused backward chain (csrc/train_wave.hip), one section [out / 4][N][4] per product
+    d x = d y W -- wt[(o // 4), n, o % 4] = W[o][n], N = the layer's inputs padded to a multiple of 32 -- in the order
+    stnerf_train_spacenet_dx takes them: rgb_net.1's 256 backbone columns, stage1.0 .. stage2.4, then density_net.0's weights and
+    the colour head as they are.  Cached on the module until a parameter changes."""
+    key = tuple((p.data_ptr(), p._version) for p in params)
+    cache = getattr(module, "_wt_cache", None)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+
+    def section(w):
+        out, k = w.shape
+        n = (k + 31) // 32 * 32
+        wp = torch.zeros(out, n, dtype=torch.float32, device=w.device)
+        wp[:, :k] = w.detach().float()
+        return wp.reshape(out // 4, 4, n).permute(0, 2, 1).contiguous().reshape(-1)
+    W = [params[2 * i] for i in range(len(params) // 2)]
+    parts = [section(W[8][:, :256])] + [section(W[i]) for i in range(7)] + [W[7].detach().float().reshape(-1), W[9].detach().float().reshape(-1)]
+    offsets, off = [], 0
+    for part in parts:
+        offsets.append(off)
+        off += part.numel()
+    wt = torch.cat(parts + [torch.zeros(4096, dtype=torch.float32, device=parts[0].device)])   # (slack: operand prefetches run past a section's end)
+    module._wt_cache = (key, wt, offsets)
+    return wt, offsets
+
+
+def _activation_buffers(rows: int, tail: int, device) -> List[torch.Tensor]:
+    """Row-major storage of a SpaceNet's layer inputs for `rows` samples: [h4 | PE(pos) + pad] (320), the outputs of stage1.0, 1.2, 1.4
+    and stage2.0, 2.2 (256 each), [g3 | relu PE(dir) | relu PE(t)] (256 + tail, padded), rgb_net.1's output (128)."""
+    return [_buf(rows, 320, device)] + [_buf(rows, 256, device) for _ in range(5)] + [_buf(rows, 256 + tail, device), _buf(rows, 128, device)]
+
+
+def _act_views(bufs: List[torch.Tensor]) -> List[torch.Tensor]:
+    """The eight matrices stnerf_train_spacenet_fwd writes / stnerf_train_spacenet_dx masks with (the post-ReLU outputs of
+    stage1.0 .. stage2.4 and rgb_net.1), as views of ``_activation_buffers``."""
+    Cc, h0, h1, h2, g0, g1, R, t0 = bufs
+    return [h0[:, :256], h1[:, :256], h2[:, :256], Cc[:, :256], g0[:, :256], g1[:, :256], R[:, :256], t0[:, :128]]
+
+
 class SpaceNetFunction(torch.autograd.Function):
     """(rgb, sigma) = SpaceNet(pos, dirs, times).  ``flavour`` = (include_input, use_dir, use_time, deep_rgb); ``params`` =
     weight, bias of stage1.{0,2,4,6}, stage2.{0,2,4}, density_net.0, rgb_net.{1,3[,5,7]} in that order."""
@@ -50,36 +99,89 @@ class SpaceNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, pos, dirs, times, *params):
         n, ns = pos.shape[0], pos.shape[1]
-        raw = torch.empty(n, ns, 4, dtype=torch.float32, device=pos.device)
+        dev = pos.device
+        raw = torch.empty(n, ns, 4, dtype=torch.float32, device=dev)
+        fused = FUSED_BACKWARD and module.include_input and module.use_dir and not module.deep_rgb
+        kept = []
         with torch.no_grad():
-            # exact f32 whatever the module renders with: the backward recomputes the activations in fp32, and the ReLU masks it
-            # walks back through must be the ones of the forward that produced the loss
-            ops.spacenet_fwd(module._packed("fp32"), pos.detach().contiguous(), dirs.detach(), times, raw)
-        ctx.module, ctx.has_times = module, times is not None
+            # exact f32 whatever the module renders with: the backward walks back through the ReLU masks of THIS evaluation
+            packed = module._packed("fp32")
+            if fused and n * ns * ACT_FLOATS_PER_SAMPLE * 4 <= KEEP_BYTES:
+                kept = _activation_buffers(n * ns, 27 + (21 if module.use_time else 0), dev)
+                ops.train_spacenet_fwd(packed, pos.detach(), dirs.detach(), times, raw, _act_views(kept), kept[0][:, 256:320])
+            else:
+                ops.spacenet_fwd(packed, pos.detach().contiguous(), dirs.detach(), times, raw)
+        ctx.module, ctx.has_times, ctx.kept = module, times is not None, bool(kept)
         ctx.save_for_backward(pos.detach(), dirs.detach(), times.detach() if times is not None else pos.new_empty(0),
-                              *[p.detach() for p in params])
+                              *[p.detach() for p in params], *kept)
         ctx.set_materialize_grads(False)
         return raw[..., :3], raw[..., 3:]
 
     @staticmethod
     def backward(ctx, d_rgb, d_sigma):
         pos, dirs, times, *params = ctx.saved_tensors
+        kept = []
+        if ctx.kept:
+            params, kept = params[:-8], list(params[-8:])
         m_ = ctx.module
         inc, use_dir, use_time, deep = m_.include_input, m_.use_dir, m_.use_time, m_.deep_rgb
         n, ns = pos.shape[0], pos.shape[1]
         dev = pos.device
-        W = [_padded_weight(params[2 * i]) for i in range(len(params) // 2)]
-        B = [params[2 * i + 1].detach().float().contiguous() for i in range(len(params) // 2)]
+        fused = ctx.kept or (FUSED_BACKWARD and inc and use_dir and not deep)
+        W = [] if fused else [_padded_weight(params[2 * i]) for i in range(len(params) // 2)]
+        B = [] if fused else [params[2 * i + 1].detach().float().contiguous() for i in range(len(params) // 2)]
         gW = [torch.zeros_like(params[2 * i], dtype=torch.float32) for i in range(len(params) // 2)]
         gB = [torch.zeros_like(params[2 * i + 1], dtype=torch.float32) for i in range(len(params) // 2)]
         d_pos = torch.zeros(n * ns, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         pe = 3 * (int(inc) + 20)
         dir_w = 3 * (int(inc) + 8) if use_dir else 0
         time_w = (int(inc) + 20) if use_time else 0
-        n_tail = len(W) - 8                                   # rgb_net: 2 linear layers, 4 with deep_rgb
+        n_tail = len(params) // 2 - 8                         # rgb_net: 2 linear layers, 4 with deep_rgb
         flat_pos = pos.reshape(n * ns, 3)
         rays_per_chunk = max(1, CHUNK_SAMPLES // ns)
-        for r0 in range(0, n, rays_per_chunk):
+        if fused:
+            # ---- fused launches (csrc/train_wave.hip): the layers' inputs come from the forward itself (kept) or from one more run of
+            # its stage kernel per chunk (recomputation); then the whole d x chain with the gradient carried in registers; only the
+            # weight gradients and the encodings' chain rule stay per layer
+            wt, offsets = transposed_spacenet(m_, params)
+            packed = m_._packed("fp32")
+            for r0 in range(0, n, rays_per_chunk):
+                r1 = min(n, r0 + rays_per_chunk)
+                M = (r1 - r0) * ns
+                x = flat_pos[r0 * ns:r1 * ns]
+                if kept:
+                    bufs = [b[r0 * ns:r1 * ns] for b in kept]
+                else:
+                    bufs = _activation_buffers(M, dir_w + time_w, dev)
+                    raw_tmp = torch.empty(r1 - r0, ns, 4, dtype=torch.float32, device=dev)
+                    ops.train_spacenet_fwd(packed, pos[r0:r1], dirs[r0:r1], times[r0:r1] if use_time else None, raw_tmp, _act_views(bufs),
+                                           bufs[0][:, 256:320])
+                Cc, R = bufs[0], bufs[6]
+                acts = _act_views(bufs)
+                ops.train_encode(dirs[r0:r1], R[:, 256:256 + dir_w], 4, inc, rows_per_src=ns, relu=True)
+                if use_time:
+                    ops.train_encode(times[r0:r1].reshape(-1, 1).float(), R[:, 256 + dir_w:256 + dir_w + time_w], 10, inc, rows_per_src=ns,
+                                     relu=True)
+                d_raw = torch.zeros(M, 4, dtype=torch.float32, device=dev)
+                if d_rgb is not None:
+                    d_raw[:, :3] = d_rgb[r0:r1].reshape(M, 3)
+                if d_sigma is not None:
+                    d_raw[:, 3:] = d_sigma[r0:r1].reshape(M, 1)
+                dys = [_buf(M, 256, dev)[:, :256] for _ in range(7)] + [_buf(M, 128, dev)[:, :128]]
+                dpe = _buf(M, 64, dev)[:, :64] if d_pos is not None else None
+                ops.train_spacenet_dx(wt, offsets, d_raw, acts, dys, dpe)
+                acc = r0 > 0
+                xin = [Cc[:, 256:256 + pe], acts[0], acts[1], acts[2], Cc[:, :256 + pe], acts[4], acts[5]]
+                for i in range(7):
+                    ops.train_linear_dw(dys[i], xin[i], gW[i], gB[i], acc)
+                dS = _buf(M, 1, dev)
+                dS[:, :1] = d_raw[:, 3:]
+                ops.train_linear_dw(dS[:, :1], acts[6], gW[7], gB[7], acc)
+                ops.train_linear_dw(dys[7], R[:, :256 + dir_w + time_w], gW[8], gB[8], acc)
+                ops.train_linear_dw(d_raw[:, :3], acts[7], gW[9], gB[9], acc)
+                if d_pos is not None:
+                    ops.train_encode_bwd(x, dpe[:, :pe], d_pos[r0 * ns:r1 * ns], 10, inc)
+        for r0 in ([] if fused else range(0, n, rays_per_chunk)):
             r1 = min(n, r0 + rays_per_chunk)
             M = (r1 - r0) * ns
             x = flat_pos[r0 * ns:r1 * ns]

@@ -305,3 +305,94 @@ def test_deformed_spacenet_chain_trains_both_networks():
     with torch.no_grad():
         after = loss_of(lambda p: space(p, rays, times.cuda()), motion, "cuda", keep)
     assert float(after) < float(loss)
+
+
+# ---- round 5: the fused launches (csrc/train_wave.hip, csrc/mlp_wave.hip StoreTap) ------------------------------------------------
+def _space_case(use_time, n=37, ns=19, seed=0):
+    from stnerf_amd.modeling.spacenet import SpaceNet
+    rs = np.random.RandomState(seed)
+    net = SpaceNet(use_time=use_time)
+    sd = syn.spacenet_state("net", rs, use_time)
+    net.load_state_dict({k[4:]: v for k, v in sd.items()})
+    net = net.cuda()
+    g = torch.Generator().manual_seed(seed)
+    pos = ((torch.rand(n, ns, 3, generator=g) - 0.5) * 4).cuda()
+    rays = torch.cat([torch.zeros(n, 3), torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)], -1).cuda()
+    tm = (torch.rand(n, 1, generator=g) * 20 + 1).cuda() if use_time else None
+    net.oracle_state = sd
+    return net, pos, rays, tm
+
+
+@pytest.mark.parametrize("use_time", [False, True])
+def test_fused_forward_writes_the_activations_the_layerwise_recompute_builds(ops, use_time):
+    """stnerf_train_spacenet_fwd = the inference stage kernel + a tap: its outputs are stnerf_spacenet_fwd's bit for bit, and every
+    layer input it writes out is what the per-layer recomputation (train_encode + train_linear_fwd, round 4) produces."""
+    from stnerf_amd.modeling import autograd as A
+    net, pos, rays, tm = _space_case(use_time)
+    n, ns = pos.shape[0], pos.shape[1]
+    M = n * ns
+    packed = net._packed("fp32")
+    dir_w, time_w = 27, 21 if use_time else 0
+    Cc, R, T0 = A._buf(M, 320, "cuda"), A._buf(M, 256 + dir_w + time_w, "cuda"), A._buf(M, 128, "cuda")
+    Hs, Gs = [A._buf(M, 256, "cuda") for _ in range(3)], [A._buf(M, 256, "cuda") for _ in range(2)]
+    for b in [Cc, R, T0] + Hs + Gs:
+        b.fill_(float("nan"))
+    acts = [Hs[0], Hs[1], Hs[2], Cc[:, :256], Gs[0], Gs[1], R[:, :256], T0]
+    raw = torch.empty(n, ns, 4, device="cuda")
+    ops.train_spacenet_fwd(packed, pos, rays[:, 3:6], tm.reshape(n) if use_time else None, raw, acts, Cc[:, 256:320])
+    want = torch.empty(n, ns, 4, device="cuda")
+    ops.spacenet_fwd(packed, pos, rays[:, 3:6], tm.reshape(n) if use_time else None, want)
+    assert torch.equal(raw, want)
+    # the round-4 recomputation, layer by layer
+    params = [p.detach() for p in net.training_parameters()]
+    W = [A._padded_weight(params[2 * i]) for i in range(10)]
+    B = [params[2 * i + 1].float().contiguous() for i in range(10)]
+    x = pos.reshape(M, 3)
+    C2 = A._buf(M, 320, "cuda")
+    P = C2[:, 256:319]
+    ops.train_encode(x, P, 10, True)
+    assert torch.allclose(Cc[:, 256:319], P, rtol=0, atol=2e-7) and float(Cc[:, 319].abs().max()) == 0.0
+    h = [A._buf(M, 256, "cuda") for _ in range(3)]
+    ops.train_linear_fwd(P, W[0], B[0], h[0][:, :256], True)
+    ops.train_linear_fwd(h[0][:, :256], W[1], B[1], h[1][:, :256], True)
+    ops.train_linear_fwd(h[1][:, :256], W[2], B[2], h[2][:, :256], True)
+    ops.train_linear_fwd(h[2][:, :256], W[3], B[3], C2[:, :256], True)
+    g_ = [A._buf(M, 256, "cuda") for _ in range(3)]
+    ops.train_linear_fwd(C2[:, :319], W[4], B[4], g_[0][:, :256], True)
+    ops.train_linear_fwd(g_[0][:, :256], W[5], B[5], g_[1][:, :256], True)
+    ops.train_linear_fwd(g_[1][:, :256], W[6], B[6], g_[2][:, :256], True)
+    for got, ref in zip(acts[:7], [h[0], h[1], h[2], C2[:, :256], g_[0], g_[1], g_[2]]):
+        assert torch.allclose(got[:, :256], ref[:, :256], rtol=1e-5, atol=1e-6)
+        assert float(got[:, :256].min()) >= 0.0
+    assert bool(torch.isfinite(T0).all()) and float(T0.min()) >= 0.0 and float(T0.max()) > 0.0
+
+
+@pytest.mark.parametrize("use_time, want_dpos", [(True, True), (False, True), (True, False)])
+def test_fused_backward_matches_the_layerwise_backward(ops, monkeypatch, use_time, want_dpos):
+    """Same gradients from the two fused launches + per-layer dW as from the round-4 chain of per-layer GEMMs (every weight, bias and
+    the sample points), several chunks with a ragged last one."""
+    from stnerf_amd.modeling import autograd as A
+    net, pos, rays, tm = _space_case(use_time, n=301, ns=23, seed=3)
+    monkeypatch.setattr(A, "CHUNK_SAMPLES", 2048)
+    g = torch.Generator().manual_seed(9)
+    # (the two recomputations round differently: a hidden unit within fp32 rounding of zero passes its cotangent in one and not in the
+    # other -- such samples get a zero cotangent, as in the fp64 comparisons above)
+    sd64 = {k: v.double() for k, v in net.oracle_state.items()}
+    safe = _safe_samples(lambda: O.space_net(sd64, "net", pos.cpu().double(), rays[:, 3:6].cpu().double(),
+                                             tm.cpu().double() if use_time else None)).reshape(301, 23, 1).cuda()
+    c_rgb, c_sig = torch.randn(301, 23, 3, generator=g).cuda() * safe, torch.randn(301, 23, 1, generator=g).cuda() * safe
+    grads = {}
+    for fused in (True, False):
+        monkeypatch.setattr(A, "FUSED_BACKWARD", fused)
+        net.zero_grad(set_to_none=True)
+        p = pos.clone().requires_grad_(want_dpos)
+        rgb, sig = net(p, rays, tm)
+        ((rgb * c_rgb).sum() + (sig * c_sig).sum()).backward()
+        grads[fused] = {k: v.grad.clone() for k, v in net.named_parameters()}
+        grads[fused]["pos"] = p.grad.clone() if want_dpos else None
+    for k, a in grads[True].items():
+        b = grads[False][k]
+        if a is None:
+            assert b is None
+            continue
+        assert float((a - b).abs().max()) <= GRAD_RTOL * float(b.abs().max()), k

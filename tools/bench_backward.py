@@ -19,7 +19,7 @@ def timed(fn, reps=5):
 
 m = int(os.environ.get("SAMPLES", 1 << 18))
 print(f"{m} samples")
-for n, k in [(256, 256), (256, 64), (256, 320), (128, 304), (128, 128)]:
+for n, k in ([] if os.environ.get("ONLY_NETS") else [(256, 256), (256, 64), (256, 320), (128, 304), (128, 128)]):
     x, w, dy = torch.randn(m, k, device="cuda"), torch.randn(n, k, device="cuda"), torch.randn(m, n, device="cuda")
     y, dx, dw, db = torch.empty(m, n, device="cuda"), torch.empty(m, k, device="cuda"), torch.empty(n, k, device="cuda"), torch.empty(n, device="cuda")
     fl = 2.0 * m * n * k / 1e12
@@ -49,6 +49,12 @@ for name, net, flop in [("SpaceNet (time)", SpaceNet(use_time=True), 930_048), (
             net.zero_grad(set_to_none=True)
             net(xt).sum().backward()
     t = timed(step, 3)
+    if "Space" in name and not os.environ.get("ONLY_FUSED"):     # A/B: the round-4 per-layer backward
+        from stnerf_amd.modeling import autograd as A
+        A.FUSED_BACKWARD = False
+        t_old = timed(step, 3)
+        A.FUSED_BACKWARD = True
+        print(f"{name}: per-layer backward (STNERF_TRAIN_FUSED=0) {1e3 * t_old:.1f} ms; fused {1e3 * t:.1f} ms")
     # forward (fused inference kernel) + recompute + dX + dW = 4 x the network's FLOPs, 3 of them in csrc/train.hip
     print(f"{name}: forward + backward of {m} samples {1e3 * t:.1f} ms = {m / t / 1e6:.2f} M samples/s, {4 * flop * m / t / 1e12:.1f} TF/s of network work "
           f"({4 * flop * m / t / 1e12 / PEAK:.2f} of the f32 MFMA peak)")
