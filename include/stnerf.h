@@ -105,7 +105,8 @@ int stnerf_intersect(const float* rays, int64_t n, int ray_stride, const float* 
  * :105); bit 1 = a HINT for stnerf_composite: the ray misses the layer's box altogether (both slab hits -1000, :53-62), so
  * every depth of the (ray, layer) pair is exactly -1000 and the compositor need not read them to find that out (40 % of a
  * nine-layer ray's depth bytes).  Consumers of the mask as the reference's boolean take `mask & 1`; stnerf_compact_rays and
- * stnerf_composite do.  A mask without hints (bit 1 clear everywhere) is always valid. */
+ * stnerf_composite do.  A mask without hints (bit 1 clear everywhere) is always valid; a caller-made mask must be strictly 0 / 1
+ * (any other value is read as hit-bit + hint).  stnerf_render_rays clears the hints before it returns: its `mask` output is 0 / 1. */
 int stnerf_sample_coarse(const float* rays, int64_t n, int ray_stride, const float* boxes,
                          int64_t box_ray_stride, int l, int n1, const float* jitter, uint64_t seed,
                          int64_t ray_index_base, int64_t ray_index_stripe, int64_t ray_index_period,
@@ -186,7 +187,13 @@ int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32
  * product is evaluated with its six leading cross terms on the bf16 MFMA (dropped terms <= 2^-24 |a b|),
  * fp32 accumulate.  Same tensors as stnerf_pack_net; the blob = [the exact-f32 blob of stnerf_pack_net | bias vectors and
  * head weights in the kernel's LDS order | the MFMA layers' weights as bf16 triples in consumption order].  All net
- * kinds.  The device copy must be 1 KB aligned. */
+ * kinds.  The device copy must be 1 KB aligned.
+ * Edge semantics (tests/test_gpu_stage.py::test_bf16x3_edge_semantics, tests/test_bf16x3_pack_cpu.py):
+ *   weights / biases: STNERF_EINVAL for NaN, +-inf and |w| > 3.3895e38 (bf16's largest finite value; fp32's top 0.4 % cannot be split);
+ *   fp32-subnormal weights are accepted, pieces below 2^-133 flush (absolute error < 2^-133 per weight);
+ *   activations at run time: a sample whose point is NaN / inf, or whose activations leave bf16's range (|x| > 3.39e38, where the
+ *   fp32 chain would hold +-inf), gets NaN outputs -- ATen gives NaN or +-inf there; every other sample of the launch is unaffected;
+ *   subnormal activations and products behave as in the exact-f32 kernel up to the 2^-133 flush above. */
 int64_t stnerf_packed_bytes_bf16x3(int kind);
 int stnerf_pack_net_bf16x3(int kind, const float* const* weights_host, const float* const* biases_host,
                            int n_tensors, void* dst_host, int64_t dst_bytes);

@@ -1028,6 +1028,16 @@ extern "C" int stnerf_pack_net_bf16x3(int kind, const float* const* W, const flo
     memset(dst_host, 0, (size_t)X.total_bytes);
     // ---- the f32 section = the exact-f32 blob (also validates the tensor count)
     if (const int rc = stnerf_pack_net(kind, W, B, n_tensors, dst_host, X.f32_floats * 4)) return rc;
+    // The split x = x0 + x1 + x2 is exact for finite values up to bf16's largest finite number, 0x7f7f = 3.3895e38; above it (fp32's
+    // last 0.4 %) the leading piece rounds to inf and x0 + x1 is inf - inf; an inf or NaN weight would likewise turn every output
+    // it touches into NaN where ATen propagates the inf.  Refused here rather than silently different: the f32 section holds
+    // every weight and bias of the network.
+    {
+        const float* f = static_cast<const float*>(dst_host);
+        for (int64_t i = 0; i < X.f32_floats; ++i)
+            STNERF_REQUIRE(fabsf(f[i]) <= 3.3895313892515355e38f, "pack_net_bf16x3: a weight or bias is not finite or exceeds bf16's range "
+                           "(|w| <= 3.3895e38): %g -- use the exact-f32 packing (stnerf_pack_net) for such a network", (double)f[i]);
+    }
     char* base = static_cast<char*>(dst_host);
     float* cst = reinterpret_cast<float*>(base + X.consts_off);
     uint16_t* st = reinterpret_cast<uint16_t*>(base + X.stream_off);

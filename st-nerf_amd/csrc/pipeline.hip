@@ -62,6 +62,18 @@ extern "C" int64_t stnerf_render_workspace_bytes(int64_t n, int l, int n1, int n
     return floats * 4 + (p.list + p.count) * 4 + p.flags + 16 * 256;
 }
 
+// The mask the caller gets back is the reference's ray_mask (0 / 1): the sampler's "missed" hint (bit 1) served the compositor and
+// the resampler inside the call and is cleared on the way out (a C caller testing `mask != 0` must not see it).
+static __global__ void clear_mask_hints_kernel(uint8_t* mask, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) mask[i] &= 1;
+}
+static int clear_mask_hints(uint8_t* mask, int64_t count, hipStream_t stream) {
+    hipLaunchKernelGGL(clear_mask_hints_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, mask, count);
+    STNERF_CHECK_LAUNCH("render_rays (mask)");
+    return STNERF_OK;
+}
+
 extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* boxes, int64_t box_ray_stride,
                                   const stnerf_nets* nets, const stnerf_render_params* p, const float* jitter,
                                   const float* u, void* workspace, int64_t workspace_bytes, float* mixed_fine,
@@ -202,7 +214,8 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
     }
     rc = stnerf_composite(t_c, raw_c, mask, n, l, n1, &cp, layer_coarse, mixed_coarse, p->only_coarse ? nullptr : w_c,
                           nullptr, ray_flags, stream);
-    if (rc || p->only_coarse) return rc;
+    if (rc) return rc;
+    if (p->only_coarse) return clear_mask_hints(mask, n * l, as_stream(stream));
 
     // ---- resample + fine points (:459-475), fine networks, fine composite (:538-606)
     rc = stnerf_resample(t_c, w_c, n, l, n1, n2, u, p->seed, p->ray_index_base, p->ray_index_stripe, p->ray_index_period,
@@ -218,5 +231,7 @@ extern "C" int stnerf_render_rays(const float* rays, int64_t n, const float* box
         cp.threshold[i] = i == 0 ? p->bkgd_density_threshold : p->density_threshold;
     }
     if (l > 2) cp.sigma_scale[2] = p->alpha;                             // :575-576
-    return stnerf_composite(t_f, raw_f, mask, n, l, S, &cp, layer_fine, mixed_fine, nullptr, nullptr, ray_flags, stream);
+    rc = stnerf_composite(t_f, raw_f, mask, n, l, S, &cp, layer_fine, mixed_fine, nullptr, nullptr, ray_flags, stream);
+    if (rc) return rc;
+    return clear_mask_hints(mask, n * l, as_stream(stream));
 }

@@ -510,7 +510,6 @@ def render_rays(rays: Tensor, boxes: Tensor, nets: "hip.Nets", params: "hip.Rend
                                            hip.dptr(workspace, torch.uint8, "workspace"), workspace.numel(),
                                            hip.dptr(mix_f), hip.dptr(mix_c), hip.dptr(lo_f), hip.dptr(lo_c),
                                            hip.dptr(mask, torch.uint8), hip.stream_ptr()), "stnerf_render_rays")
-    mask.bitwise_and_(1)     # (bit 1 was the sampler's hint to the compositor inside the call: include/stnerf.h)
     if params.only_coarse:
         return mix_c, mix_c, lo_c, lo_c, mask
     return mix_f, mix_c, lo_f, lo_c, mask

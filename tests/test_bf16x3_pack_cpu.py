@@ -146,3 +146,31 @@ def test_bf16x3_packer_takes_any_fp32_weight():
             assert got[k] == w, (k, w, got[k])
         else:   # below 2^-126 * 2^16 the third piece leaves the normal range: exact to the bf16 denormal grid
             assert abs(got[k] - w) <= 2.0 ** -133, (k, w, got[k])
+
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), -float("inf"), 3.3999e38, -3.4028235e38])
+def test_bf16x3_packer_refuses_what_it_cannot_split(bad):
+    """include/stnerf.h: NaN, +-inf and |w| above bf16's largest finite value (3.3895e38) cannot be written as three bf16 pieces
+    that add up (the leading piece rounds to inf): STNERF_EINVAL instead of a network that silently returns NaN.  The exact-f32
+    packer takes the same tensors."""
+    rs = np.random.RandomState(4)
+    lib = hip.lib()
+    for kind, which in ((hip.NET_MOTION, "w"), (hip.NET_SPACE_TIME, "b"), (hip.NET_SPACE, "w")):
+        ws, bs = _tensors(kind, rs)
+        tgt = ws if which == "w" else bs
+        tgt[2] = tgt[2].copy()
+        tgt[2].reshape(-1)[5] = bad
+        nbytes = lib.stnerf_packed_bytes_bf16x3(kind)
+        dst = np.zeros(nbytes, dtype=np.uint8)
+        wp = (C.c_void_p * len(ws))(*(w.ctypes.data for w in ws))
+        bp = (C.c_void_p * len(bs))(*(b.ctypes.data for b in bs))
+        assert lib.stnerf_pack_net_bf16x3(kind, wp, bp, len(ws), C.c_void_p(dst.ctypes.data), nbytes) == hip.EINVAL
+        assert "bf16" in hip.last_error()
+        f32 = np.zeros(lib.stnerf_packed_bytes(kind), dtype=np.uint8)
+        assert lib.stnerf_pack_net(kind, wp, bp, len(ws), C.c_void_p(f32.ctypes.data), f32.size) == 0
+    # the largest value that CAN be split is accepted
+    ws, bs = _tensors(hip.NET_MOTION, rs)
+    ws[1] = ws[1].copy()
+    ws[1][0, 0] = 3.3895313892515355e38
+    _pack("stnerf_packed_bytes_bf16x3", "stnerf_pack_net_bf16x3", hip.NET_MOTION, ws, bs)

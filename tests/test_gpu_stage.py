@@ -226,3 +226,61 @@ def test_bf16x3_module_level_calls(ops):
     sdm = {"net." + k: v.detach().double().cpu() for k, v in model.time_deform_nets[0].state_dict().items()}
     f64 = O.motion_net(sdm, "net", torch.cat([pos, t.view(n, 1, 1).repeat(1, s, 1)], -1).double().cpu())
     _close(flow.cpu(), f64, 1.0, "flow")
+
+
+def test_bf16x3_edge_semantics(ops):
+    """What include/stnerf.h promises for values outside the comfortable range, next to what ATen (the fp32 oracle) does:
+      * a sample whose point is NaN / +-inf: NaN outputs for THAT sample (ATen: NaN -- sin(inf)), every other sample of the launch,
+        of the same wave included, bit-identical to a launch without the bad points;
+      * activations that leave fp32's / bf16's range (two layers scaled by 1e20): non-finite outputs where ATen's are non-finite
+        (ATen: +-inf or NaN; bf16x3: NaN), finite and accurate where ATen's are finite;
+      * a layer of fp32-SUBNORMAL weights (~1e-40): accepted, its contribution (<= 1e-37) arrives up to the 2^-133 flush --
+        indistinguishable from the fp32 chain at the outputs' scale;
+      * weights NaN / inf / above 3.3895e38 never reach the kernel: the packer refuses them (tests/test_bf16x3_pack_cpu.py)."""
+    rs = np.random.RandomState(33)
+    torch.manual_seed(33)
+    sd = syn.spacenet_state("net", rs, False)
+    n, ns = 64, 16
+    xyz = (torch.rand(n, ns, 3) - 0.5) * 4.0
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=-1)
+    net = ops.pack_spacenet(sd, "net", precision="bf16x3")
+
+    def run(packed, pts):
+        raw = torch.full((n, ns, 4), 7.0, device="cuda")
+        ops.spacenet_fwd(packed, dev(pts), dev(dirs), None, raw)
+        return raw.cpu()
+    clean = run(net, xyz)
+    assert bool(torch.isfinite(clean).all())
+    # ---- bad points
+    bad = xyz.clone()
+    bad[3, 5, 1], bad[7, 0, 0], bad[9, 2, 2], bad[9, 3, 0] = float("nan"), float("inf"), -float("inf"), float("nan")
+    got = run(net, bad)
+    is_bad = torch.zeros(n, ns, dtype=torch.bool)
+    is_bad[3, 5] = is_bad[7, 0] = is_bad[9, 2] = is_bad[9, 3] = True
+    assert bool(torch.isnan(got[is_bad]).all())
+    assert torch.equal(got[~is_bad], clean[~is_bad])
+    rgb32, sig32, _ = _oracle(sd, None, bad, dirs, torch.zeros(n), False, False, torch.float32)
+    assert bool(torch.isnan(rgb32[is_bad]).all()) and bool(torch.isnan(sig32[is_bad]).all())
+    got32 = run(ops.pack_spacenet(sd, "net", precision="fp32"), bad)                       # the exact-f32 kernel: the same contract
+    assert bool(torch.isnan(got32[is_bad]).all()) and bool(torch.isfinite(got32[~is_bad]).all())
+    # ---- activations out of range
+    big = {k: v.clone() for k, v in sd.items()}
+    big["net.stage1.0.weight"] *= 1e20
+    big["net.stage1.2.weight"] *= 1e20
+    got = run(ops.pack_spacenet(big, "net", precision="bf16x3"), xyz)
+    rgb32, sig32, _ = _oracle(big, None, xyz, dirs, torch.zeros(n), False, False, torch.float32)
+    aten_finite = torch.isfinite(sig32[..., 0]) & torch.isfinite(rgb32).all(-1)
+    assert float((~aten_finite).float().mean()) > 0.5                                     # the scene does overflow
+    assert not bool(torch.isfinite(got[~aten_finite][:, 3]).any())                        # sigma: non-finite wherever ATen's is
+    if bool(aten_finite.any()):
+        assert bool(torch.isfinite(got[aten_finite]).all())
+    # ---- a layer of subnormal weights
+    tiny = {k: v.clone() for k, v in sd.items()}
+    tiny["net.stage2.2.weight"] = tiny["net.stage2.2.weight"] * (1e-40 / float(tiny["net.stage2.2.weight"].abs().max()))
+    assert 0 < float(tiny["net.stage2.2.weight"].abs().max()) < 1.2e-38
+    got = run(ops.pack_spacenet(tiny, "net", precision="bf16x3"), xyz)
+    rgb64, sig64, _ = _oracle(tiny, None, xyz, dirs, torch.zeros(n), False, False, torch.float64)
+    rgb32, sig32, _ = _oracle(tiny, None, xyz, dirs, torch.zeros(n), False, False, torch.float32)
+    assert bool(torch.isfinite(got).all())
+    for g, r64, r32 in ((got[..., :3], rgb64, rgb32), (got[..., 3:], sig64, sig32)):
+        assert _err(g, r64)[0] <= max(1.5 * _err(r32, r64)[0], 1e-6)

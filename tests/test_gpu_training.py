@@ -158,7 +158,7 @@ def training_step(name, device="cuda"):
 
 GRAD_RTOL = 2e-5   # of each gradient tensor's largest entry (the bar of the network-level tests, tests/test_gpu_backward.py)
 FP32_NOISE_FACTOR = 3.0
-DEFORMED_RTOL = 1e-3   # networks behind a MotionNet: see the test's docstring (the conditioning of sin(2^9 (x + flow)), not of the kernels)
+CONDITIONED_RTOL = 1e-3   # networks behind a MotionNet or the resampler: see the test's docstring (the conditioning of sin(2^9 x), not of the kernels)
 
 
 @pytest.mark.parametrize("name", ["train_c3", "train_coarse_only"])
@@ -167,12 +167,14 @@ def test_training_step_matches_the_reference_fixture(ops, name):
     autograd departs from an fp64 evaluation of the same graph by more than that -- a ReLU'(0) event: train_c3 has ONE hidden unit
     of bkgd_spacenet.stage2.0 whose pre-activation is 4e-9 in fp64 and <= 0 in ATen's fp32 sgemm, which moves that network's
     gradients by up to 3.7 % (tests/test_train_step_cpu.py) -- either side of the event is right: the HIP gradient must then be no
-    further from the fp64 evaluation than FP32_NOISE_FACTOR x the reference's own distance from it.  The factor covers the second
-    kind of fp32 noise in this fixture: a performer's points are xyz + MotionNet(xyz, t) in front of a 2^9 positional-encoding
-    frequency, so the last bit of the flow (a 128-deep dot product summed in another order than ATen's sgemm) moves sin(512 x) by
-    5e-5: the reference's fp32 gradients of the deformed layers' networks are 2 - 4e-4 (of a tensor's largest entry) away from the
-    fp64 evaluation, and so are the HIP ones -- from it and from each other (measured 1.1e-4 .. 5.8e-4, moving with every change of a
-    kernel's summation order): for those tensors the bar is DEFORMED_RTOL of the largest entry."""
+    further from the fp64 evaluation than FP32_NOISE_FACTOR x the reference's own distance from it.  The second kind of fp32 noise in
+    this fixture: a performer's points are xyz + MotionNet(xyz, t), and every fine-stage point is o + z d with z resampled from the
+    coarse weights -- both in front of a 2^9 positional-encoding frequency, so the last bit of a flow or of a weight (dot products
+    summed in another order than ATen's sgemm) moves sin(512 x) by ~5e-5.  The reference's fp32 gradients of those networks are
+    2 - 4e-4 (of a tensor's largest entry) away from the fp64 evaluation, and so are the HIP ones -- from it and from each other
+    (measured 1e-4 .. 6e-4, moving with every change of a kernel's summation order): for every network but the coarse background one
+    (whose points are the sampler's, bit for bit) the bar is CONDITIONED_RTOL.  train_coarse_only has neither effect: there the 2e-5
+    bar holds for every tensor (measured 3e-7)."""
     model, out, loss, parts, z, meta = training_step(name)
     # forward: the reference's outputs on the same rays, weights and draws
     assert torch.allclose(out[1][0].detach().cpu(), torch.from_numpy(z["coarse_mixed_color"]), atol=2e-6)
@@ -200,8 +202,8 @@ def test_training_step_matches_the_reference_fixture(ops, name):
             d64 = digest(pname, sd64[pname].grad)
             ref_vs_64 = compare_digest(pname, torch.from_numpy(z["grad|" + pname]), d64, rel=GRAD_RTOL)
             hip_vs_64 = compare_digest(pname, digest(pname, named[pname].grad), d64, rel=GRAD_RTOL)
-            deformed = meta["deform_time"] and pname.startswith(("spacenets", "time_deform_nets"))
-            bar = max(1.0, FP32_NOISE_FACTOR * ref_vs_64, DEFORMED_RTOL / GRAD_RTOL if deformed else 0.0)
+            conditioned = not pname.startswith("bkgd_spacenet.")      # behind a MotionNet and / or the resampler
+            bar = max(1.0, FP32_NOISE_FACTOR * ref_vs_64, CONDITIONED_RTOL / GRAD_RTOL if conditioned else 0.0)
             assert ref_vs_64 > 1.0 and hip_vs_64 <= bar, (pname, vs_ref[pname], hip_vs_64, ref_vs_64)
         assert name == "train_c3", off
     for pname in meta["without_grad"]:       # the fine networks of a coarse-only epoch

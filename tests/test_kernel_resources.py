@@ -24,15 +24,16 @@ def test_wave_stage_kernel_uses_no_scratch_and_one_wave_per_simd(tmp_path):
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL, timeout=600)
     text = asm.read_text()
     kernels = re.findall(r"^(_ZN6stnerf21mlp_wave_stage_kernelILb[01]E\S*):", text, re.M)
-    assert len(kernels) == 2, kernels  # the plain and the deep_rgb variant
+    # the plain and the deep_rgb variant, and (round 5) the training instantiation of the plain one that writes every layer's input out
+    assert len(kernels) == 3 and sum("StoreTapArgs" in k for k in kernels) == 1, kernels
     scratch = [int(v) for v in re.findall(r"; ScratchSize: (\d+)", text)]
     vgprs = [int(v) for v in re.findall(r"; TotalNumVgprs: (\d+)", text)]
     occupancy = [int(v) for v in re.findall(r"; Occupancy: (\d+)", text)]
-    assert scratch == [0, 0], f"the wave stage kernel spills to scratch: {scratch} bytes"
-    assert all(v <= 512 for v in vgprs) and len(vgprs) == 2, vgprs
-    assert occupancy == [1, 1], occupancy
+    assert scratch == [0, 0, 0], f"the wave stage kernel spills to scratch: {scratch} bytes"
+    assert all(v <= 512 for v in vgprs) and len(vgprs) == 3, vgprs
+    assert occupancy == [1, 1, 1], occupancy
     # the hot loop is what it is supposed to be: f32 MFMAs fed from registers, accumulators loaded by LDS reads directly
-    assert text.count("v_mfma_f32_32x32x2_f32") >= 2 * 2400
+    assert text.count("v_mfma_f32_32x32x2_f32") >= 3 * 2400
     assert "scratch_load" not in text and "scratch_store" not in text
 
 
@@ -172,3 +173,22 @@ def test_no_valu_exec_write_within_five_wait_states_of_a_dpp_instruction(tmp_pat
             j -= 1
     assert n_dpp > 100, n_dpp                            # the scans and sorts are really there
     assert not offenders, offenders[:5]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="no hipcc")
+def test_fused_backward_kernel_resources(tmp_path):
+    """csrc/train_wave.hip (round 5): the dX chain keeps a wave's gradient in registers from the heads to stage1.2 -- one wave per
+    SIMD, no scratch, exactly the MFMAs of the chain (16 + 6 x 32 K steps of 32, + the two 2-block products of the PE columns when
+    the points need a gradient), every mask read and gradient write a 16-byte vector access."""
+    text = open(_compile("train_wave.hip", tmp_path)).read()
+    kernels = re.findall(r"^(_ZN6stnerf21train_space_dx_kernelILb[01]EEE\S*):", text, re.M)
+    assert len(kernels) == 2, kernels
+    assert [int(v) for v in re.findall(r"; ScratchSize: (\d+)", text)] == [0, 0]
+    assert [int(v) for v in re.findall(r"; Occupancy: (\d+)", text)] == [1, 1]
+    assert "scratch_" not in text
+    for k in kernels:
+        body = text[text.index(k + ":"):]
+        body = body[:body.index("s_endpgm")]
+        want = (16 + 6 * 32) * 32 + (2 * 32 * 8 if "Lb1" in k else 0)
+        assert body.count("v_mfma_f32_32x32x2_f32") == want, (k, body.count("v_mfma_f32_32x32x2_f32"), want)
+        assert body.count("global_load_dwordx4") >= 7 * 32 + 16 and body.count("global_store_dwordx4") >= 7 * 32 + 16

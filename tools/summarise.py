@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""Turn the outputs of tools/r04_evidence.sh (gpurun_out/<tag>/) into the small files committed under profiles/ (round 4: the
-bench line carries `precision_legs` / `config_legs`; bf16x3 is the headline arithmetic, fp32 the co-equal second leg):
-    r04_final.md            suite / smoke, the driver line's key figures, rocprofv3 kernel traces (f32 and bf16x3, pose 0),
+"""Turn the outputs of tools/evidence.sh (gpurun_out/<tag>/) into the small files committed under profiles/ (RND = the round's
+prefix, e.g. r05; the bench command's last line is the contract record, its detail -- `precision_legs` / `config_legs` -- sits in
+the --detail-out file beside it):
+    RND_final.md            suite / smoke, the driver line's key figures, rocprofv3 kernel traces (f32 and bf16x3, pose 0),
                             PMC passes (FETCH_SIZE, WRITE_SIZE, MfmaUtil, SQ_*) per kernel
-    r04_workloads.md        C2 / C3 64+64 / C3 90+30 / C4 / C5: bench line + per-kernel ms, both arithmetics
-    r04_pmc_hbm_traffic.json   what bench.py reads for roofline.traffic / hbm_kernels.*.counter_bytes_per_step
-    r04_bench*.json         the bench lines themselves
+    RND_workloads.md        C2 / C3 64+64 / C3 90+30 / C4 / C5: bench line + per-kernel ms
+    RND_pmc_hbm_traffic.json   what bench.py reads for roofline.traffic / hbm_kernels.*.counter_bytes_per_step
+    RND_bench*.json         the bench records themselves (final line + detail)
 Runs ON THE GPU BOX at the end of the evidence pass (the .db files are too large to travel) and writes into
-gpurun_out/<tag>/summary/.      python tools/r04_summarise.py gpurun_out/<tag>"""
+gpurun_out/<tag>/summary/.      python tools/summarise.py gpurun_out/<tag> [RND]"""
 import glob
 import json
 import os
@@ -15,14 +16,15 @@ import sqlite3
 import sys
 
 src = sys.argv[1]
+RND = next((a for a in sys.argv[2:] if not a.startswith("--")), os.path.basename(src.rstrip("/"))[:3])
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
 
 
 def power_report(src, dst):
     """socket power / clock over the whole 20-step bench run (rocm-smi samples, tools/power_trace.sh)"""
-    pw = ["# r04: socket power and shader clock over `python bench.py --steps 20 --warmup 5` (rocm-smi, ~7 Hz; `tools/power_trace.sh`)\n",
-          "The run renders 25 poses in bf16x3 (headline leg), then 25 in exact f32 (second leg), then the short config legs, the PSNR check and the CPU baseline: "
+    pw = ["# " + RND + ": socket power and shader clock over `python bench.py --steps 20 --warmup 5` (rocm-smi, ~7 Hz; `tools/power_trace.sh`)\n",
+          "The run renders 25 poses in bf16x3 (headline leg), then up to 5 in exact f32 (the short cross-check leg), then the short config legs, the PSNR check and the CPU baseline: "
           "the first plateau of the trace is the split-bf16 stage kernel, the second the exact-f32 one.\n"]
     pcsv = os.path.join(src, "power_bench.csv")
     if os.path.exists(pcsv):
@@ -51,13 +53,13 @@ def power_report(src, dst):
             for i in range(0, n, step):
                 seg = rows_p[i:i + step]
                 pw.append(f"| {i} | {med([r[0] for r in seg]):.0f} | {med([r[1] for r in seg]):.0f} |")
-        open(os.path.join(dst, "r04_power_bench.csv"), "w").write(open(pcsv).read())
-    open(os.path.join(dst, "r04_power_clock_trace.md"), "w").write("\n".join(pw) + "\n")
+        open(os.path.join(dst, RND + "_power_bench.csv"), "w").write(open(pcsv).read())
+    open(os.path.join(dst, RND + "_power_clock_trace.md"), "w").write("\n".join(pw) + "\n")
 
 
 if "--power-only" in sys.argv:
     power_report(src, dst)
-    print(open(os.path.join(dst, "r04_power_clock_trace.md")).read())
+    print(open(os.path.join(dst, RND + "_power_clock_trace.md")).read())
     sys.exit(0)
 KERN = {"mlp_stage (f32 wave)": "%mlp_wave_stage_kernel%", "mlp_stage (bf16x3)": "%mlp_bf16x3_stage_kernel%", "ray_bias": "%ray_bias_kernel%",
         "composite_single": "%composite_single_kernel%", "composite": "%composite_kernel%", "resample": "%resample_kernel%",
@@ -70,9 +72,21 @@ def short(name):
 
 
 def last_json(path):
+    """The contract record (last stdout line) of a bench run, with the legs of its detail file (<path minus .json>_detail.json)."""
     try:
         lines = [l for l in open(path).read().strip().splitlines() if l.startswith("{")]
-        return json.loads(lines[-1])
+        rec = json.loads(lines[-1])
+        dpath = path[:-5] + "_detail.json"
+        if os.path.exists(dpath):
+            det = json.load(open(dpath))["detail"]
+            for k in ("precision_legs", "config_legs", "cpu_baseline", "eager_gpu_baseline", "psnr_vs_reference", "share_emulation", "device", "config"):
+                if k in det and (k not in rec or k in ("cpu_baseline", "config")):
+                    rec[k if k != "config" else "config_detail"] = det[k]
+            head = det["precision_legs"].get(rec["config"]["precision"], {})
+            for k in ("kernels", "hbm_kernels", "mask_fraction", "per_rank_compute_s", "ray_samples_per_step_rank0"):
+                rec.setdefault(k, head.get(k))
+            rec["roofline"] = dict(head.get("roofline", {}), **rec["roofline"])
+        return rec
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
 
@@ -98,13 +112,13 @@ def pmc_rows(db, counters):
     return res
 
 
-md = ["# r04: evidence for HEAD (one build, one GPU box)\n", "```", open(os.path.join(src, "env.txt")).read().strip(), "```\n"]
+md = ["# " + RND + ": evidence for HEAD (one build, one GPU box)\n", "```", open(os.path.join(src, "env.txt")).read().strip(), "```\n"]
 md.append("## parity suite, smoke\n```")
 for f in ("pytest.log", "smoke.log"):
     md += open(os.path.join(src, f)).read().strip().splitlines()[-3:]
 md.append("```\n")
 b = last_json(os.path.join(src, "bench.json"))
-json.dump(b, open(os.path.join(dst, "r04_bench.json"), "w"), indent=1)
+json.dump(b, open(os.path.join(dst, RND + "_bench.json"), "w"), indent=1)
 
 
 def leg_line(tag, e):
@@ -210,17 +224,17 @@ for cfg, tag in (("C3 taekwondo-1080p-64+64 (bf16x3)", "bf16x3"), ("C4 walking-1
         hbm_table.setdefault(cfg, {})[fam] = {"dispatches": nd, "ms_per_step": ms, "counter_GB": gb, "TBps": rate, "frac_of_measured": frac_m, "measured": ref}
 md.append("")
 traffic["hbm_kernels_on_counter_bytes"] = hbm_table
-json.dump(traffic, open(os.path.join(dst, "r04_pmc_hbm_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(dst, RND + "_pmc_hbm_traffic.json"), "w"), indent=1)
 power_report(src, dst)
-open(os.path.join(dst, "r04_final.md"), "w").write("\n".join(md) + "\n")
+open(os.path.join(dst, RND + "_final.md"), "w").write("\n".join(md) + "\n")
 
-wl = ["# r04: every BASELINE configuration on the round's build (1 x MI355X, `tools/r04_evidence.sh`)\n",
+wl = ["# " + RND + ": every BASELINE configuration on the round's build (1 x MI355X, `tools/evidence.sh`)\n",
       "| config | workload | arithmetic | rays/s | ray-samples/s | s per frame | stage kernel TF/s (algorithmic) | frac of its MFMA peak (executed) | composite ms | resample ms | sample_coarse ms |",
       "|---|---|---|---|---|---|---|---|---|---|---|"]
 for cfg, fn in (("C2", "bench_c2.json"), ("C3", "bench.json"), ("C3 (yml 90+30)", "bench_c3_90_30.json"), ("C4", "bench_c4.json"), ("C5 (one GPU)", "bench_c5.json"),
                 ("C3-small, 2 ranks on ONE GPU (gloo; code path only)", "bench_2ranks_one_device.json")):
     bb = last_json(os.path.join(src, fn))
-    json.dump(bb, open(os.path.join(dst, "r04_" + fn), "w"), indent=1)
+    json.dump(bb, open(os.path.join(dst, RND + "_" + fn), "w"), indent=1)
     if "value" not in bb:
         wl.append(f"| {cfg} | {fn} | failed: {bb.get('error')} | | | | | | | | |")
         continue
@@ -236,9 +250,9 @@ for f in ("bench_stage.txt", "bxab/time.log", "bx_prof.txt", "bench_composite.tx
     p = os.path.join(src, f)
     if os.path.exists(p):
         wl += [f"## {f}\n", "```", open(p).read().strip(), "```\n"]
-open(os.path.join(dst, "r04_workloads.md"), "w").write("\n".join(wl) + "\n")
+open(os.path.join(dst, RND + "_workloads.md"), "w").write("\n".join(wl) + "\n")
 # ---- training kernels
-tk = ["# r04: the training kernels (csrc/train.hip, SURVEY 8(f)4) on the round's build\n", "## tools/bench_backward.py\n", "```"]
+tk = ["# " + RND + ": the training kernels (csrc/train.hip, SURVEY 8(f)4) on the round's build\n", "## tools/bench_backward.py\n", "```"]
 p = os.path.join(src, "bench_backward.txt")
 tk += [l for l in (open(p).read().strip().splitlines() if os.path.exists(p) else ["(missing)"]) if "amdgpu.ids" not in l] + ["```\n"]
 db = os.path.join(src, "trace_backward", "p_results.db")
@@ -247,12 +261,12 @@ if os.path.exists(db):
     trace_table(db, tk)
 else:
     tk.append("(missing)\n")
-open(os.path.join(dst, "r04_training_kernels.md"), "w").write("\n".join(tk) + "\n")
+open(os.path.join(dst, RND + "_training_kernels.md"), "w").write("\n".join(tk) + "\n")
 for f in ("hbm_copy.json",):
     p = os.path.join(src, f)
     if os.path.exists(p) and os.path.getsize(p):
-        open(os.path.join(dst, "r04_hbm_copy_microbench.json"), "w").write(open(p).read())
-print(open(os.path.join(dst, "r04_final.md")).read()[:6000])
-print(open(os.path.join(dst, "r04_workloads.md")).read()[:3000])
-print(open(os.path.join(dst, "r04_training_kernels.md")).read()[:2500])
-print(open(os.path.join(dst, "r04_power_clock_trace.md")).read()[:2000])
+        open(os.path.join(dst, RND + "_hbm_copy_microbench.json"), "w").write(open(p).read())
+print(open(os.path.join(dst, RND + "_final.md")).read()[:6000])
+print(open(os.path.join(dst, RND + "_workloads.md")).read()[:3000])
+print(open(os.path.join(dst, RND + "_training_kernels.md")).read()[:2500])
+print(open(os.path.join(dst, RND + "_power_clock_trace.md")).read()[:2000])
