@@ -191,9 +191,13 @@ int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32
  * Edge semantics (tests/test_gpu_stage.py::test_bf16x3_edge_semantics, tests/test_bf16x3_pack_cpu.py):
  *   weights / biases: STNERF_EINVAL for NaN, +-inf and |w| > 3.3895e38 (bf16's largest finite value; fp32's top 0.4 % cannot be split);
  *   fp32-subnormal weights are accepted, pieces below 2^-133 flush (absolute error < 2^-133 per weight);
- *   activations at run time: a sample whose point is NaN / inf, or whose activations leave bf16's range (|x| > 3.39e38, where the
- *   fp32 chain would hold +-inf), gets NaN outputs -- ATen gives NaN or +-inf there; every other sample of the launch is unaffected;
- *   subnormal activations and products behave as in the exact-f32 kernel up to the 2^-133 flush above. */
+ *   sample points must be FINITE (the sampler's and the resampler's are).  Neither stage kernel propagates NaN / inf the way ATen does:
+ *   their ReLU is an integer max on the bit pattern (one instruction; -inf and sign-bit NaNs become 0), and the bf16 split turns what is
+ *   left into zero pieces.  A sample with a NaN / inf coordinate therefore gets, in bf16x3, the FINITE outputs of zeroed hidden units
+ *   (sigma = the density head's bias ...) where ATen returns NaN; the exact-f32 kernel returns NaN for NaN / +inf coordinates and the
+ *   same finite values for -inf.  Likewise activations that overflow fp32 (|x| > 3.4e38: ATen carries +-inf / NaN on) give unspecified
+ *   values for that sample.  In every case ONLY that sample is affected: every other sample of the launch, of the same wave included,
+ *   is bit-identical to a launch without it.  Subnormal activations and products behave as in the exact-f32 kernel up to the flush. */
 int64_t stnerf_packed_bytes_bf16x3(int kind);
 int stnerf_pack_net_bf16x3(int kind, const float* const* weights_host, const float* const* biases_host,
                            int n_tensors, void* dst_host, int64_t dst_bytes);

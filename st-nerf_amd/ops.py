@@ -554,6 +554,9 @@ def train_linear_dx(dy: Tensor, w: Tensor, dx: Tensor, mask: Optional[Tensor] = 
     return dx
 
 
+_DW_WORKSPACE: dict = {}
+
+
 def train_linear_dw(dy: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], accumulate: bool) -> None:
     """dw (n,k) (+)= dy (m,n).T @ x (m,k); db (n,) (+)= dy.sum(0): stnerf_train_linear_dw (deterministic split reduction)."""
     (m, n), k = dy.shape, x.shape[1]
@@ -563,9 +566,14 @@ def train_linear_dw(dy: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], acc
     if x.shape[0] != m or tuple(dw.shape) != (n, k) or (db is not None and tuple(db.shape) != (n,)):
         raise ValueError(f"train_linear_dw: dy {tuple(dy.shape)}, x {tuple(x.shape)}, dw {tuple(dw.shape)}")
     need = int(hip.lib().stnerf_train_dw_workspace_bytes(m, n, k))
-    ws = torch.empty(need, dtype=torch.uint8, device=dy.device)
+    # one workspace per device and stream, grown on demand (a backward issues ~10 of these calls per chunk on one stream: they run
+    # in order, so the partial tiles of one may overwrite the previous call's; up to 64 MB each -- ADVICE r04)
+    key = (dy.device, torch.cuda.current_stream(dy.device).cuda_stream)
+    ws = _DW_WORKSPACE.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _DW_WORKSPACE[key] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=dy.device)
     hip.check(hip.lib().stnerf_train_linear_dw(dp, lddy, xp, ldx, m, n, k, wp, lddw, hip.dptr(db, name="db"), int(accumulate),
-                                               hip.dptr(ws, torch.uint8, "workspace"), need, hip.stream_ptr()), "stnerf_train_linear_dw")
+                                               hip.dptr(ws, torch.uint8, "workspace"), ws.numel(), hip.stream_ptr()), "stnerf_train_linear_dw")
 
 
 def train_encode(x: Tensor, y: Tensor, n_freq: int, include_input: bool = True, rows_per_src: int = 1, relu: bool = False,

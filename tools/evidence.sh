@@ -27,8 +27,8 @@ done
 W="--cpu-baseline-rays 0 --eager-gpu-baseline-rays 0 --no-psnr-check --no-config-legs"
 timeout 300 python bench.py --workload single-512-64+64 --steps 5 --warmup 1 $W --detail-out $out/bench_c2_detail.json > $out/bench_c2.json 2> $out/bench_c2.err
 timeout 300 python bench.py --workload taekwondo-1080p-90+30 --steps 3 --warmup 1 $W --detail-out $out/bench_c3_90_30_detail.json > $out/bench_c3_90_30.json 2> $out/bench_c3_90_30.err
-timeout 400 python bench.py --workload walking-1080p-L4-64+64 --steps 2 --warmup 1 $W --detail-out $out/bench_c4_detail.json > $out/bench_c4.json 2> $out/bench_c4.err
-timeout 900 python bench.py --workload synthetic-4k-L8-128+64 --steps 1 --warmup 1 --rays-per-launch 131072 $W --detail-out $out/bench_c5_detail.json > $out/bench_c5.json 2> $out/bench_c5.err
+timeout 500 python bench.py --workload walking-1080p-L4-64+64 --steps 2 --warmup 1 --emulate-share 2,4,8 $W --detail-out $out/bench_c4_detail.json > $out/bench_c4.json 2> $out/bench_c4.err
+timeout 900 python bench.py --workload synthetic-4k-L8-128+64 --steps 1 --warmup 1 --rays-per-launch 131072 --emulate-share 2,4,8 $W --detail-out $out/bench_c5_detail.json > $out/bench_c5.json 2> $out/bench_c5.err
 # ---- 4b. compositor / resampler at C4 and C5 on counter bytes: kernel trace + FETCH_SIZE + WRITE_SIZE of one step each
 CMDX="python bench.py --steps 1 --warmup 0 --cpu-baseline-rays 0 --eager-gpu-baseline-rays 0 --no-psnr-check --no-second-precision --no-config-legs --precision bf16x3 --detail-out /tmp/d.json"
 for cfg in "c4 walking-1080p-L4-64+64" "c5 synthetic-4k-L8-128+64 --rays-per-launch 131072"; do

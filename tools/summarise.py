@@ -80,7 +80,7 @@ def last_json(path):
         if os.path.exists(dpath):
             det = json.load(open(dpath))["detail"]
             for k in ("precision_legs", "config_legs", "cpu_baseline", "eager_gpu_baseline", "psnr_vs_reference", "share_emulation", "device", "config"):
-                if k in det and (k not in rec or k in ("cpu_baseline", "config")):
+                if k in det and (k not in rec or k in ("cpu_baseline", "config", "share_emulation")):
                     rec[k if k != "config" else "config_detail"] = det[k]
             head = det["precision_legs"].get(rec["config"]["precision"], {})
             for k in ("kernels", "hbm_kernels", "mask_fraction", "per_rank_compute_s", "ray_samples_per_step_rank0"):
@@ -251,6 +251,28 @@ for f in ("bench_stage.txt", "bxab/time.log", "bx_prof.txt", "bench_composite.tx
     if os.path.exists(p):
         wl += [f"## {f}\n", "```", open(p).read().strip(), "```\n"]
 open(os.path.join(dst, RND + "_workloads.md"), "w").write("\n".join(wl) + "\n")
+# ---- a rank's share, emulated on the one GPU (bench.py --emulate-share)
+se = ["# " + RND + ": what one rank of an N-GPU job computes, EMULATED on one GPU (`bench.py --emulate-share 2,4,8`)\n",
+      "Not a scaling measurement: no second GPU, no process group, no collective.  Rank r's interleaved single-row stripes of the view are rendered "
+      "alone through `stnerf_amd.parallel.render_view_share` -- the code `render_view` runs before its all-gather -- for the first, middle and last "
+      "rank of each N; t(1) is the same function with (rank, N) = (0, 1) over the same poses.  `N t_share / t(1)` exposes what does not shrink with the "
+      "share: the persistent stage kernel's tail at 1/N of the items, per-view host work, stripe imbalance.  Gather payload = bytes ONE rank "
+      "contributes to the frame's single all-gather for `model.gather` = all / fine / final.\n",
+      "| config | N | t_share ms (rank: ms) | worst | N t_share / t(1) | predicted compute efficiency | rays per rank | payload per rank MB (all / fine / final) |",
+      "|---|---|---|---|---|---|---|---|"]
+for cfg, fn in (("C3 taekwondo-1080p-64+64", "bench.json"), ("C4 walking-1080p-L4-64+64", "bench_c4.json"), ("C5 synthetic-4k-L8-128+64", "bench_c5.json")):
+    bb = last_json(os.path.join(src, fn))
+    sh = bb.get("share_emulation") if isinstance(bb.get("share_emulation"), dict) and "shares" in bb.get("share_emulation", {}) else None
+    if not sh:
+        se.append(f"| {cfg} | (no emulation in {fn}) | | | | | | |")
+        continue
+    se.append(f"| {cfg} | 1 | {sh['t1_ms']:.1f} | | | | | |")
+    for e in sh["shares"]:
+        pl = e["gather_payload_bytes_per_rank"]
+        se.append(f"| {cfg} | {e['ranks']} | " + ", ".join(f"{r}: {ms:.1f}" for r, ms in e["t_share_ms"].items()) + f" | {e['t_share_max_ms']:.1f} | "
+                  f"{e['n_times_t_share_over_t1']:.4f} | **{e['predicted_compute_efficiency']:.4f}** | {e['rays_per_rank']} | "
+                  f"{pl['all'] / 1e6:.1f} / {pl['fine'] / 1e6:.1f} / {pl['final'] / 1e6:.1f} |")
+open(os.path.join(dst, RND + "_share_emulation.md"), "w").write("\n".join(se) + "\n")
 # ---- training kernels
 tk = ["# " + RND + ": the training kernels (csrc/train.hip, SURVEY 8(f)4) on the round's build\n", "## tools/bench_backward.py\n", "```"]
 p = os.path.join(src, "bench_backward.txt")
@@ -270,3 +292,4 @@ print(open(os.path.join(dst, RND + "_final.md")).read()[:6000])
 print(open(os.path.join(dst, RND + "_workloads.md")).read()[:3000])
 print(open(os.path.join(dst, RND + "_training_kernels.md")).read()[:2500])
 print(open(os.path.join(dst, RND + "_power_clock_trace.md")).read()[:2000])
+print(open(os.path.join(dst, RND + "_share_emulation.md")).read())
