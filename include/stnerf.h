@@ -361,25 +361,28 @@ int stnerf_train_encode_bwd(const float* x, int64_t ldx, int dim, int n_freq, in
  * stnerf_train_spacenet_fwd = stnerf_mlp_stage on ONE SpaceNet (exact f32, the arithmetic of the training forward), every ray
  * evaluated, which ALSO writes each layer's input as it passes through the registers: act[s][row][ld_act[s]], row = ray * ns + k,
  * s = 0 .. 6 the post-ReLU outputs of stage1.0 .. stage2.4 (256 columns), s = 7 of rgb_net.1 (128 columns), and pe[row][ld_pe] =
- * PE_10(pos) (63 columns + one zero).  The matrices are the caller's (16-byte aligned, row strides multiples of 4 floats), e.g.
- * column blocks of wider ones (stage2.0's input [h4 | PE]).  One launch recomputes what the backward needs.
+ * PE_10(pos) (63 columns + one zero) -- the right operands of the weight gradients -- and relu_bits (uint32, may be NULL): stage s's
+ * plane starts at relu_bits + s * relu_bits_stride and holds 8 words per row: the ReLU masks [act_s > 0] as bits, 32 bytes per row and
+ * layer in the lane order of the wave kernels (csrc/mlp_wave.hip StoreTap) -- all stnerf_train_spacenet_dx reads of the activations
+ * (a row range of a larger launch's planes is addressed by offsetting the pointer and keeping the stride).  The matrices are the caller's (16-byte aligned, row
+ * strides multiples of 4 floats), e.g. column blocks of wider ones (stage2.0's input [h4 | PE]).
  * act_host / ld_act_host: host arrays of 8 device pointers / strides.  queue, ray_bias: as for stnerf_mlp_stage (one layer).
  *
  * stnerf_train_spacenet_dx: from d_raw[rows][4] = dLoss / d {r, g, b, sigma} walks the layers backwards, a wave carrying the
  * gradient of its 32 rows from layer to layer in registers: d act_{s-1} = (d act_s * [act_s > 0]) W_s (threshold_backward, then
- * addmm_backward's grad_input).  dy[s][row][ld_dy[s]] receives the masked gradient = dLoss / d (pre-activation of that layer),
- * the left operand of its weight gradient (stnerf_train_linear_dw); dpe (may be NULL) receives dLoss / d PE(pos) (64 columns),
- * for stnerf_train_encode_bwd.  wt: the transposed weights, sections [out / 4][N][4] (N = inputs padded to a multiple of 32) at
- * offsets_host[0] (rgb_net.1's 256 backbone columns: out 128), [1 .. 7] (stage1.0: N 64; stage1.2 .. 1.6: N 256; stage2.0: N 320 =
- * [h4 | PE]; stage2.2, 2.4: N 256), then density_net.0's 256 weights at [8] and the colour head's [3][128] at [9] (float offsets,
- * multiples of 4); stnerf_amd.modeling.autograd builds it. */
+ * addmm_backward's grad_input), the masks from relu_bits.  dy[s][row][ld_dy[s]] receives the masked gradient = dLoss / d
+ * (pre-activation of that layer), the left operand of its weight gradient (stnerf_train_linear_dw); dpe (may be NULL) receives
+ * dLoss / d PE(pos) (64 columns), for stnerf_train_encode_bwd.  wt: the transposed weights, sections [out / 4][N][4] (N = inputs
+ * padded to a multiple of 32) at offsets_host[0] (rgb_net.1's 256 backbone columns: out 128), [1 .. 7] (stage1.0: N 64; stage1.2 ..
+ * 1.6: N 256; stage2.0: N 320 = [h4 | PE]; stage2.2, 2.4: N 256), then density_net.0's 256 weights at [8] and the colour head's
+ * [3][128] at [9] (float offsets, multiples of 4); stnerf_amd.modeling.autograd builds it. */
 int stnerf_train_spacenet_fwd(int kind, const void* packed, int64_t n_rays, int ns, const float* xyz, int64_t xyz_ray_stride,
                               const float* dirs, int64_t dirs_ray_stride, const float* times, int64_t times_ray_stride, float* raw,
                               int64_t raw_ray_stride, float* const* act_host, const int32_t* ld_act_host, float* pe, int32_t ld_pe,
-                              uint32_t* queue, float* ray_bias, stnerf_stream_t stream);
-int stnerf_train_spacenet_dx(const float* wt, const uint32_t* offsets_host, const float* d_raw, int64_t rows,
-                             const float* const* act_host, const int32_t* ld_act_host, float* const* dy_host, const int32_t* ld_dy_host,
-                             float* dpe, int32_t ld_dpe, stnerf_stream_t stream);
+                              uint32_t* relu_bits, int64_t relu_bits_stride, uint32_t* queue, float* ray_bias, stnerf_stream_t stream);
+int stnerf_train_spacenet_dx(const float* wt, const uint32_t* offsets_host, const float* d_raw, int64_t rows, const uint32_t* relu_bits,
+                             int64_t relu_bits_stride, float* const* dy_host, const int32_t* ld_dy_host, float* dpe, int32_t ld_dpe,
+                             stnerf_stream_t stream);
 
 /* The whole chunk pipeline of LayeredRFRender.forward (modeling/layered_rfrender.py:141-734) behind one call:
  * coarse sampler -> mask compaction -> [MotionNet] -> SpaceNets -> composite/merge -> resample -> [MotionNet] ->

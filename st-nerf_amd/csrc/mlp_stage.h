@@ -67,7 +67,7 @@ __device__ __forceinline__ float lerp_enc(bool frac, float om, float wgt, float 
 
 // mlp_wave.hip
 int launch_wave_stage(const StageArgs& a, bool deep_rgb, int cus, hipStream_t stream);
-int launch_wave_stage_store(const StageArgs& a, float* const (&buf)[8], const int32_t (&ld)[8], float* pe, int32_t ld_pe, int cus,
-                            hipStream_t stream);
+int launch_wave_stage_store(const StageArgs& a, float* const (&buf)[8], const int32_t (&ld)[8], float* pe, int32_t ld_pe, uint32_t* bits,
+                            int64_t bits_stride, int cus, hipStream_t stream);
 
 }  // namespace stnerf

@@ -43,6 +43,8 @@ struct StoreTapArgs {
     int32_t ld[8];     // row strides in floats (multiples of 4; 16-byte aligned bases)
     float* pe;         // PE(pos): 63 features + one zero
     int32_t ld_pe;
+    uint32_t* bits;    // [8][.. bits_stride ..]: rows x 8 words per stage: the ReLU masks of stages 0 .. 7 as bit planes (see StoreTap), or null
+    int64_t bits_stride;   // uint32 words between two stages' planes
 };
 struct StoreTap {
     const StoreTapArgs* a;
@@ -62,6 +64,25 @@ struct StoreTap {
                 for (int q = 0; q < 4; ++q)
                     p[fb * 8 + 2 * q] = make_float4(blk[fb][4 * q + 0], blk[fb][4 * q + 1], blk[fb][4 * q + 2], blk[fb][4 * q + 3]);
             }
+        // The ReLU mask of this lane's values as bits: value 16 fb + i <-> bit (16 fb + i) & 31 of word fb >> 1 -- 16 bytes per lane,
+        // 32 per row, which the backward chain (csrc/train_wave.hip: the SAME lane owns the same values there) reads back instead of
+        // the 1 KB of activations.  Two instructions per value: min(bits, 1) -- a post-ReLU value is +0 or positive -- and a shift-or.
+        if (a->bits && stage != TAP_PE) {
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int wd = 0; wd < NBLK / 2; ++wd)
+                if (2 * wd < nblk) {
+#pragma unroll
+                    for (int j = 31; j >= 0; --j) {
+                        // (asm: the compiler's own choice is compare + select + shift-or, three instructions, with the 128 selects hoisted
+                        // into registers the kernel does not have)
+                        uint32_t t;
+                        asm volatile("v_min_u32 %1, 1, %2\n\tv_lshl_or_b32 %0, %0, 1, %1" : "+v"(w[wd]), "=&v"(t) : "v"(blk[2 * wd + (j >> 4)][j & 15]));
+                    }
+                }
+            uint4* bp = reinterpret_cast<uint4*>(a->bits + (size_t)stage * (size_t)a->bits_stride + (size_t)row * 8u + 4u * (uint32_t)(lane >> 5));
+            *bp = make_uint4(w[0], w[1], w[2], w[3]);
+        }
     }
 };
 __device__ __forceinline__ NoTap make_tap(const NoTapArgs&, uint32_t, bool) { return NoTap(); }
@@ -242,9 +263,11 @@ int launch_wave_stage(const StageArgs& a_in, bool deep_rgb, int cus, hipStream_t
 }
 
 // One SpaceNet (queue slot 0 of `a`, no MotionNet, not deep_rgb) with every layer's input written out: see StoreTapArgs.
-int launch_wave_stage_store(const StageArgs& a, float* const (&buf)[8], const int32_t (&ld)[8], float* pe, int32_t ld_pe, int cus,
-                            hipStream_t stream) {
+int launch_wave_stage_store(const StageArgs& a, float* const (&buf)[8], const int32_t (&ld)[8], float* pe, int32_t ld_pe, uint32_t* bits,
+                            int64_t bits_stride, int cus, hipStream_t stream) {
     StoreTapArgs t;
+    t.bits = bits;
+    t.bits_stride = bits_stride;
     for (int i = 0; i < 8; ++i) {
         t.buf[i] = buf[i];
         t.ld[i] = ld[i];

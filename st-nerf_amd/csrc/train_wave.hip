@@ -8,9 +8,10 @@
 //                               PE(pos) when the sample points need a gradient), a wave owning 32 rows and carrying the gradient
 //                               from layer to layer in its registers: the accumulator layout of one product is the B-operand
 //                               layout of the next, exactly as in the forward kernel, with the TRANSPOSED weights as the A
-//                               operand (blob sections [out/4][in][4], built by stnerf_amd.modeling.autograd).  At every layer
-//                               boundary the stored activation is read back once as the ReLU mask and the masked gradient -- the
-//                               pre-activation gradient d y_s the weight gradients need -- is written out once.
+//                               operand (blob sections [out/4][in][4], built by stnerf_amd.modeling.autograd).  The ReLU masks come
+//                               as BIT PLANES the forward tap wrote (16 bytes per lane and layer: the same lane owns the same
+//                               values in both kernels), fetched at the start of an item; at every layer boundary the masked
+//                               gradient -- the pre-activation gradient d y_s the weight gradients need -- is written out once.
 //
 // What is left to per-layer launches are the weight gradients dW_s = d y_s^T x_s (csrc/train.hip: a reduction over ALL rows that
 // no 128-row item can finish on its own) and the encodings' chain rule.
@@ -23,8 +24,9 @@ namespace stnerf {
 struct DxArgs {
     const float* wt;          // transposed sections, see the offsets below (floats)
     const float* d_raw;       // [rows][4]: dLoss / d {r, g, b, sigma} (raw network outputs)
-    const float* act[8];      // act[s], s = 0 .. 6: stage1.0 .. stage2.4's post-ReLU output [rows][ld] (256 wide); act[7]: rgb_net.1's (128)
-    int32_t ld_act[8];
+    int64_t bits_stride;      // uint32 words between two stages' planes of `bits`
+    const uint32_t* bits;     // [8][.. bits_stride ..], rows x 8 words per stage: bit (16 fb + i) & 31 of word (fb >> 1) + 4 h of row r, stage s = [act_s > 0] for the value the lane
+                              // (h, r & 31) holds in register i of block fb (stage s = 0 .. 6: stage1.0 .. stage2.4's output; 7: rgb_net.1's)
     float* dy[8];             // dy[s]: dLoss / d (pre-activation of that layer), same widths
     int32_t ld_dy[8];
     float* dpe;               // [rows][ld_dpe]: dLoss / d PE(pos) (64 wide: feature 63 is the pad) -- only read with DPOS
@@ -37,74 +39,22 @@ struct DxArgs {
     uint32_t o_wrgb2;         // the colour head: [3][128]
 };
 
-// One block (16 values of this lane's row) of a stored activation -> blk: the ReLU mask of the next boundary.
-__device__ __forceinline__ void load_x_block(f32x16& blk, const float4* xp, int fb, bool valid) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 v = valid ? xp[fb * 8 + 2 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        blk[4 * q + 0] = v.x;
-        blk[4 * q + 1] = v.y;
-        blk[4 * q + 2] = v.z;
-        blk[4 * q + 3] = v.w;
-    }
-}
-
-// segment_r (mlp_wave_core.h) whose B operand `blk` is overwritten AS IT IS CONSUMED with the stored activation the following
-// boundary masks with: block j is dead after K step 4 j + 3, its 4 loads go out right behind that step, so that a boundary starts
-// with seven eighths of its mask on chip.  Blocks >= NBLK are not operands of this product: loaded up front.
-// Measured (profiles/r05_training_kernels.md): the boundaries stay the kernel's loss -- 64 MB of mask reads and gradient writes per
-// boundary over the chip, and the memory counter is in order: a mask load anywhere in the K loop makes the next operand wait (L2) wait
-// for HBM.  One piece per K step behind the operand fetch, with the workgroups staggered by an eighth of a product, was SLOWER
-// (3.27 ms against 2.72 ms for 262,144 samples; the plain boundary: 2.81 ms).
-// The block of the LAST K steps is left to the boundary (its UNLOADED bit).
-template <int NFB, int NBLK, int STEPS, int NFB_NEXT, int XBLK>
-__device__ __forceinline__ void segment_x(f32x16 (&acc)[8], f32x16 (&blk)[8], float4 (&wa)[8], float4 (&wb)[8], __amdgpu_buffer_rsrc_t rsrc,
-                                          const LaneOfs& wlane, uint32_t soff, uint32_t wstep, const NextOfs& next_wlane, uint32_t next_soff,
-                                          const float* x, bool valid) {
-    static_assert(STEPS == 4 * NBLK && (STEPS & 1) == 0, "segment_x: whole blocks, an even number of steps");
-    const float4* xp = reinterpret_cast<const float4*>(x);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int fb = NBLK; fb < XBLK; ++fb) load_x_block(blk[fb], xp, fb, valid);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s + 1 < STEPS; ++s) {
-        float4 (&wc)[8] = (s & 1) ? wb : wa;
-        float4 (&wn)[8] = (s & 1) ? wa : wb;
-        load_w<NFB>(wn, rsrc, wlane, soff + (uint32_t)(s + 1) * wstep);
-        step_r<NFB, NFB>(acc, wc, blk[s >> 2][4 * (s & 3) + 0], blk[s >> 2][4 * (s & 3) + 1], blk[s >> 2][4 * (s & 3) + 2],
-                         blk[s >> 2][4 * (s & 3) + 3]);
-        if ((s & 3) == 3 && (s >> 2) < XBLK) {
-            load_x_block(blk[s >> 2], xp, s >> 2, valid);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    {
-        constexpr int s = STEPS - 1;
-        float4 (&wc)[8] = (s & 1) ? wb : wa;
-        float4 (&wn)[8] = (s & 1) ? wa : wb;
-        load_w_next<NFB_NEXT>(wn, rsrc, next_wlane, next_soff);
-        step_r<NFB, NFB_NEXT>(acc, wc, blk[s >> 2][4 * (s & 3) + 0], blk[s >> 2][4 * (s & 3) + 1], blk[s >> 2][4 * (s & 3) + 2],
-                              blk[s >> 2][4 * (s & 3) + 3]);
-    }
-}
-
-// Layer boundary of the backward chain: in = (x > 0) ? acc : 0 for this lane's 16 x NFB values of its row, written to dy as well;
-// acc = 0 for the next product.  x / dy: the row's base + 4 h floats; register 4 q + r of block fb <-> column 32 fb + 8 q + 4 h + r.
-// Bit fb of UNLOADED: block fb of `in` does not hold x yet (segment_x leaves the block of its last K steps) and is loaded here.
-template <int NFB, unsigned UNLOADED>
-__device__ __forceinline__ void mask_boundary(f32x16 (&acc)[8], f32x16 (&in)[8], const float* x, float* dy, bool valid) {
-    const float4* xp = reinterpret_cast<const float4*>(x);
+// Layer boundary of the backward chain: in = mask ? acc : 0 for this lane's 16 x NFB values of its row (threshold_backward), written to
+// dy as well (row base + 4 h floats; register 4 q + r of block fb <-> column 32 fb + 8 q + 4 h + r); acc = 0 for the next product.
+// mask: the lane's 128 bits of this layer (value 16 fb + i <-> bit (16 fb + i) & 31 of component fb >> 1): one v_bfe_i32 spreads a bit
+// over a word, one v_and applies it -- no load, no compare.  (Rounds' history: the masks used to be the stored fp32 activations, 1 KB
+// per row and layer read back here -- 32 MB per boundary over the chip with the matrix pipes idle; profiles/r05_training_kernels.md.)
+template <int NFB>
+__device__ __forceinline__ void mask_boundary(f32x16 (&acc)[8], f32x16 (&in)[8], const uint4& mask, float* dy, bool valid) {
     float4* yp = reinterpret_cast<float4*>(dy);
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb)
-        if (UNLOADED >> fb & 1u) load_x_block(in[fb], xp, fb, valid);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
     for (int fb = 0; fb < NFB; ++fb) {
+        const uint32_t word = (fb >> 1) == 0 ? mask.x : (fb >> 1) == 1 ? mask.y : (fb >> 1) == 2 ? mask.z : mask.w;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            in[fb][i] = in[fb][i] > 0.f ? acc[fb][i] : 0.f;     // threshold_backward: the stored post-ReLU value is > 0 or exactly 0
+            int m;     // 0 or -1 (asm: the compiler's own choice is and + compare + select)
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(word), "n"((fb & 1) * 16 + i));
+            in[fb][i] = __int_as_float(__float_as_int(acc[fb][i]) & m);
             acc[fb][i] = 0.f;
         }
         if (valid) {
@@ -140,14 +90,17 @@ __global__ __launch_bounds__(WV_THREADS, 1) void train_space_dx_kernel(DxArgs a)
         const int64_t row = item * WV_ITEM + wave * WV_ROWS + c;
         const bool valid = row < a.rows;
         const int64_t r = valid ? row : 0;
-        auto xrow = [&](int s) { return a.act[s] + r * a.ld_act[s] + 4 * h; };
         auto yrow = [&](int s) { return a.dy[s] + r * a.ld_dy[s] + 4 * h; };
         // the first operands of the first product and the first mask, in flight behind the heads' vector work
         load_w<8>(wa, rsrc, wl256, a.o_rgb1 * 4u);
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid) g = *reinterpret_cast<const float4*>(a.d_raw + r * 4);
+        // the item's eight ReLU masks: 16 bytes per lane and layer, the wave's 32 rows contiguous (1 KB per load)
+        uint4 bw[8];
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb) load_x_block(in[fb], reinterpret_cast<const float4*>(xrow(7)), fb, valid);
+        for (int sidx = 0; sidx < 8; ++sidx)
+            bw[sidx] = valid ? *reinterpret_cast<const uint4*>(a.bits + (size_t)sidx * (size_t)a.bits_stride + (size_t)r * 8u + 4u * (uint32_t)h)
+                             : make_uint4(0u, 0u, 0u, 0u);
         // ---- the colour head backwards: d act7[f] = sum_o d rgb[o] W[o][f] (rgb_net.3, modeling/spacenet.py:84-85), masked by act7 > 0
         {
             const float4* w4 = reinterpret_cast<const float4*>(heads + 256) + h;   // quad 2 s + h of each of the three rows
@@ -162,7 +115,7 @@ __global__ __launch_bounds__(WV_THREADS, 1) void train_space_dx_kernel(DxArgs a)
                     acc[fb][4 * q + 3] = g.x * w0.w + g.y * w1.w + g.z * w2.w;
                 }
         }
-        mask_boundary<4, 0u>(acc, in, xrow(7), yrow(7), valid);
+        mask_boundary<4>(acc, in, bw[7], yrow(7), valid);
         // ---- d act6 = d y7 W_rgb1[:, :256] + d sigma w_sigma: the density head's rank-1 term is the product's C operand
         {
             const float4* w4 = reinterpret_cast<const float4*>(heads) + h;
@@ -177,13 +130,12 @@ __global__ __launch_bounds__(WV_THREADS, 1) void train_space_dx_kernel(DxArgs a)
                     acc[fb][4 * q + 3] = g.w * w.w;
                 }
         }
-        // (every product below prefetches the mask of the boundary behind it into the operand blocks it has consumed)
-        segment_x<8, 4, 16, 8, 8>(acc, in, wa, wb, rsrc, wl256, a.o_rgb1 * 4u, WSTEP256, nx256, a.o_l[6] * 4u, xrow(6), valid);
-        mask_boundary<8, 0x08u>(acc, in, xrow(6), yrow(6), valid);
-        segment_x<8, 8, 32, 8, 8>(acc, in, wa, wb, rsrc, wl256, a.o_l[6] * 4u, WSTEP256, nx256, a.o_l[5] * 4u, xrow(5), valid);     // stage2.4
-        mask_boundary<8, 0x80u>(acc, in, xrow(5), yrow(5), valid);
-        segment_x<8, 8, 32, 8, 8>(acc, in, wa, wb, rsrc, wl256, a.o_l[5] * 4u, WSTEP256, nx320, a.o_l[4] * 4u, xrow(4), valid);     // stage2.2
-        mask_boundary<8, 0x80u>(acc, in, xrow(4), yrow(4), valid);
+        segment_r<8, 4, 16, 0, 8>(acc, reinterpret_cast<const f32x16 (&)[4]>(in[0]), wa, wb, rsrc, wl256, a.o_rgb1 * 4u, WSTEP256, nx256, a.o_l[6] * 4u);
+        mask_boundary<8>(acc, in, bw[6], yrow(6), valid);
+        segment_r<8, 8, 32, 0, 8>(acc, in, wa, wb, rsrc, wl256, a.o_l[6] * 4u, WSTEP256, nx256, a.o_l[5] * 4u);     // stage2.4
+        mask_boundary<8>(acc, in, bw[5], yrow(5), valid);
+        segment_r<8, 8, 32, 0, 8>(acc, in, wa, wb, rsrc, wl256, a.o_l[5] * 4u, WSTEP256, nx320, a.o_l[4] * 4u);     // stage2.2
+        mask_boundary<8>(acc, in, bw[4], yrow(4), valid);
         // stage2.0: the h4 columns (blocks 0 .. 7), then -- only if the points need a gradient -- the PE columns (blocks 8, 9)
         f32x16 accp[8];   // (only [0], [1] are live)
         if constexpr (DPOS) {
@@ -194,20 +146,19 @@ __global__ __launch_bounds__(WV_THREADS, 1) void train_space_dx_kernel(DxArgs a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) accp[fb][i] = 0.f;
             const LaneOfs wl320b = lane_offsets(nx320b.base);
-            segment_x<2, 8, 32, 8, 8>(accp, in, wa, wb, rsrc, wl320b, a.o_l[4] * 4u, WSTEP320, nx256, a.o_l[3] * 4u, xrow(3), valid);
+            segment_r<2, 8, 32, 0, 8>(accp, in, wa, wb, rsrc, wl320b, a.o_l[4] * 4u, WSTEP320, nx256, a.o_l[3] * 4u);
         } else {
             const LaneOfs wl320 = lane_offsets(nx320.base);
-            segment_x<8, 8, 32, 8, 8>(acc, in, wa, wb, rsrc, wl320, a.o_l[4] * 4u, WSTEP320, nx256, a.o_l[3] * 4u, xrow(3), valid);
+            segment_r<8, 8, 32, 0, 8>(acc, in, wa, wb, rsrc, wl320, a.o_l[4] * 4u, WSTEP320, nx256, a.o_l[3] * 4u);
         }
-        mask_boundary<8, 0x80u>(acc, in, xrow(3), yrow(3), valid);
-        segment_x<8, 8, 32, 8, 8>(acc, in, wa, wb, rsrc, wl256, a.o_l[3] * 4u, WSTEP256, nx256, a.o_l[2] * 4u, xrow(2), valid);     // stage1.6
-        mask_boundary<8, 0x80u>(acc, in, xrow(2), yrow(2), valid);
-        segment_x<8, 8, 32, 8, 8>(acc, in, wa, wb, rsrc, wl256, a.o_l[2] * 4u, WSTEP256, nx256, a.o_l[1] * 4u, xrow(1), valid);     // stage1.4
-        mask_boundary<8, 0x80u>(acc, in, xrow(1), yrow(1), valid);
+        mask_boundary<8>(acc, in, bw[3], yrow(3), valid);
+        segment_r<8, 8, 32, 0, 8>(acc, in, wa, wb, rsrc, wl256, a.o_l[3] * 4u, WSTEP256, nx256, a.o_l[2] * 4u);     // stage1.6
+        mask_boundary<8>(acc, in, bw[2], yrow(2), valid);
+        segment_r<8, 8, 32, 0, 8>(acc, in, wa, wb, rsrc, wl256, a.o_l[2] * 4u, WSTEP256, nx256, a.o_l[1] * 4u);     // stage1.4
+        mask_boundary<8>(acc, in, bw[1], yrow(1), valid);
         // stage1.2 (the fetch behind it: stage1.0's section when the points need a gradient, else discarded)
-        segment_x<8, 8, 32, 8, 8>(acc, in, wa, wb, rsrc, wl256, a.o_l[1] * 4u, WSTEP256, DPOS ? nx64 : nx256, (DPOS ? a.o_l[0] : a.o_l[1]) * 4u,
-                                  xrow(0), valid);
-        mask_boundary<8, 0x80u>(acc, in, xrow(0), yrow(0), valid);
+        segment_r<8, 8, 32, 0, 8>(acc, in, wa, wb, rsrc, wl256, a.o_l[1] * 4u, WSTEP256, DPOS ? nx64 : nx256, (DPOS ? a.o_l[0] : a.o_l[1]) * 4u);
+        mask_boundary<8>(acc, in, bw[0], yrow(0), valid);
         if constexpr (DPOS) {
             // d PE = d y4 W_2.0[:, 256:] + d y0 W_1.0: stage1.0's product continues in the skip connection's accumulators
             const LaneOfs wl64 = lane_offsets(nx64.base);
@@ -231,7 +182,7 @@ using namespace stnerf;
 extern "C" int stnerf_train_spacenet_fwd(int kind, const void* packed, int64_t n_rays, int ns, const float* xyz, int64_t xyz_ray_stride,
                                          const float* dirs, int64_t dirs_ray_stride, const float* times, int64_t times_ray_stride,
                                          float* raw, int64_t raw_ray_stride, float* const* act_host, const int32_t* ld_act_host, float* pe,
-                                         int32_t ld_pe, uint32_t* queue, float* ray_bias, stnerf_stream_t stream) {
+                                         int32_t ld_pe, uint32_t* relu_bits, int64_t relu_bits_stride, uint32_t* queue, float* ray_bias, stnerf_stream_t stream) {
     STNERF_REQUIRE(packed && xyz && dirs && raw && act_host && ld_act_host && pe && queue && ray_bias, "train_spacenet_fwd: null pointer");
     STNERF_REQUIRE(kind == STNERF_NET_SPACE || kind == STNERF_NET_SPACE_TIME, "train_spacenet_fwd: kind %d (deep_rgb networks take the per-layer path)", kind);
     STNERF_REQUIRE(n_rays >= 0 && ns >= 1 && (raw_ray_stride & 3) == 0, "train_spacenet_fwd: bad shape");
@@ -265,28 +216,30 @@ extern "C" int stnerf_train_spacenet_fwd(int kind, const void* packed, int64_t n
     a.queue = queue;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return launch_wave_stage_store(a, bufs, lds, pe, ld_pe, cus, as_stream(stream));
+    STNERF_REQUIRE(!relu_bits || (((uintptr_t)relu_bits & 15) == 0 && (relu_bits_stride & 3) == 0 && relu_bits_stride >= n_rays * ns * 8),
+                   "train_spacenet_fwd: relu_bits must be 16-byte aligned, its stage stride a multiple of 4 words and >= 8 x rows");
+    return launch_wave_stage_store(a, bufs, lds, pe, ld_pe, relu_bits, relu_bits_stride, cus, as_stream(stream));
 }
 
 extern "C" int stnerf_train_spacenet_dx(const float* wt, const uint32_t* offsets_host /* rgb1, l[0..6], wsigma, wrgb2 */, const float* d_raw,
-                                        int64_t rows, const float* const* act_host, const int32_t* ld_act_host, float* const* dy_host,
+                                        int64_t rows, const uint32_t* relu_bits, int64_t relu_bits_stride, float* const* dy_host,
                                         const int32_t* ld_dy_host, float* dpe, int32_t ld_dpe, stnerf_stream_t stream) {
-    STNERF_REQUIRE(wt && offsets_host && d_raw && act_host && ld_act_host && dy_host && ld_dy_host, "train_spacenet_dx: null pointer");
+    STNERF_REQUIRE(wt && offsets_host && d_raw && relu_bits && dy_host && ld_dy_host, "train_spacenet_dx: null pointer");
     STNERF_REQUIRE(rows >= 0 && rows <= 0x7fffff00ll, "train_spacenet_dx: %lld rows (split the batch)", (long long)rows);
-    STNERF_REQUIRE((((uintptr_t)wt | (uintptr_t)d_raw) & 15) == 0, "train_spacenet_dx: weights and d_raw must be 16-byte aligned");
+    STNERF_REQUIRE((((uintptr_t)wt | (uintptr_t)d_raw | (uintptr_t)relu_bits) & 15) == 0 && (relu_bits_stride & 3) == 0 && relu_bits_stride >= rows * 8,
+                   "train_spacenet_dx: weights, d_raw and relu_bits must be 16-byte aligned (stage stride: a multiple of 4 words, >= 8 x rows)");
     if (rows == 0) return STNERF_OK;
     DxArgs a;
     memset(&a, 0, sizeof(a));
     a.wt = wt;
     a.d_raw = d_raw;
     a.rows = rows;
+    a.bits = relu_bits;
+    a.bits_stride = relu_bits_stride;
     for (int i = 0; i < 8; ++i) {
         const int width = i == 7 ? 128 : 256;
-        STNERF_REQUIRE(act_host[i] && dy_host[i] && (((uintptr_t)act_host[i] | (uintptr_t)dy_host[i]) & 15) == 0 && (ld_act_host[i] & 3) == 0 &&
-                           (ld_dy_host[i] & 3) == 0 && ld_act_host[i] >= width && ld_dy_host[i] >= width,
+        STNERF_REQUIRE(dy_host[i] && ((uintptr_t)dy_host[i] & 15) == 0 && (ld_dy_host[i] & 3) == 0 && ld_dy_host[i] >= width,
                        "train_spacenet_dx: matrix %d must be 16-byte aligned with a row stride that is a multiple of 4 floats", i);
-        a.act[i] = act_host[i];
-        a.ld_act[i] = ld_act_host[i];
         a.dy[i] = dy_host[i];
         a.ld_dy[i] = ld_dy_host[i];
     }

@@ -32,7 +32,7 @@ FUSED_BACKWARD = os.environ.get("STNERF_TRAIN_FUSED", "1") != "0"
 # samples fit this budget -- as the reference's autograd does, and what 288 GB of HBM are for: the backward then starts without any
 # recomputation.  Above the budget (or with STNERF_TRAIN_KEEP_GB=0) nothing is kept and the backward recomputes chunk by chunk.
 KEEP_BYTES = int(float(os.environ.get("STNERF_TRAIN_KEEP_GB", "32")) * (1 << 30))
-ACT_FLOATS_PER_SAMPLE = 320 + 5 * 256 + 304 + 128
+ACT_FLOATS_PER_SAMPLE = 320 + 5 * 256 + 304 + 128 + 64
 CHUNK_SAMPLES = min(max(int(os.environ.get("STNERF_TRAIN_CHUNK_SAMPLES", 1 << 18)), 1024), (1 << 29) // 320)
 
 
@@ -81,14 +81,16 @@ def transposed_spacenet(module, params) -> tuple:
 
 def _activation_buffers(rows: int, tail: int, device) -> List[torch.Tensor]:
     """Row-major storage of a SpaceNet's layer inputs for `rows` samples: [h4 | PE(pos) + pad] (320), the outputs of stage1.0, 1.2, 1.4
-    and stage2.0, 2.2 (256 each), [g3 | relu PE(dir) | relu PE(t)] (256 + tail, padded), rgb_net.1's output (128)."""
-    return [_buf(rows, 320, device)] + [_buf(rows, 256, device) for _ in range(5)] + [_buf(rows, 256 + tail, device), _buf(rows, 128, device)]
+    and stage2.0, 2.2 (256 each), [g3 | relu PE(dir) | relu PE(t)] (256 + tail, padded), rgb_net.1's output (128); and, last, the eight
+    ReLU masks as bit planes (8, rows, 8) int32 -- what the backward chain reads instead of the activations."""
+    return ([_buf(rows, 320, device)] + [_buf(rows, 256, device) for _ in range(5)] + [_buf(rows, 256 + tail, device), _buf(rows, 128, device)]
+            + [torch.empty(8, rows, 8, dtype=torch.int32, device=device)])
 
 
 def _act_views(bufs: List[torch.Tensor]) -> List[torch.Tensor]:
     """The eight matrices stnerf_train_spacenet_fwd writes / stnerf_train_spacenet_dx masks with (the post-ReLU outputs of
     stage1.0 .. stage2.4 and rgb_net.1), as views of ``_activation_buffers``."""
-    Cc, h0, h1, h2, g0, g1, R, t0 = bufs
+    Cc, h0, h1, h2, g0, g1, R, t0 = bufs[:8]
     return [h0[:, :256], h1[:, :256], h2[:, :256], Cc[:, :256], g0[:, :256], g1[:, :256], R[:, :256], t0[:, :128]]
 
 
@@ -108,7 +110,7 @@ class SpaceNetFunction(torch.autograd.Function):
             packed = module._packed("fp32")
             if fused and n * ns * ACT_FLOATS_PER_SAMPLE * 4 <= KEEP_BYTES:
                 kept = _activation_buffers(n * ns, 27 + (21 if module.use_time else 0), dev)
-                ops.train_spacenet_fwd(packed, pos.detach(), dirs.detach(), times, raw, _act_views(kept), kept[0][:, 256:320])
+                ops.train_spacenet_fwd(packed, pos.detach(), dirs.detach(), times, raw, _act_views(kept), kept[0][:, 256:320], kept[8])
             else:
                 ops.spacenet_fwd(packed, pos.detach().contiguous(), dirs.detach(), times, raw)
         ctx.module, ctx.has_times, ctx.kept = module, times is not None, bool(kept)
@@ -122,7 +124,7 @@ class SpaceNetFunction(torch.autograd.Function):
         pos, dirs, times, *params = ctx.saved_tensors
         kept = []
         if ctx.kept:
-            params, kept = params[:-8], list(params[-8:])
+            params, kept = params[:-9], list(params[-9:])
         m_ = ctx.module
         inc, use_dir, use_time, deep = m_.include_input, m_.use_dir, m_.use_time, m_.deep_rgb
         n, ns = pos.shape[0], pos.shape[1]
@@ -150,12 +152,12 @@ class SpaceNetFunction(torch.autograd.Function):
                 M = (r1 - r0) * ns
                 x = flat_pos[r0 * ns:r1 * ns]
                 if kept:
-                    bufs = [b[r0 * ns:r1 * ns] for b in kept]
+                    bufs = [b[r0 * ns:r1 * ns] for b in kept[:8]] + [kept[8][:, r0 * ns:r1 * ns]]
                 else:
                     bufs = _activation_buffers(M, dir_w + time_w, dev)
                     raw_tmp = torch.empty(r1 - r0, ns, 4, dtype=torch.float32, device=dev)
                     ops.train_spacenet_fwd(packed, pos[r0:r1], dirs[r0:r1], times[r0:r1] if use_time else None, raw_tmp, _act_views(bufs),
-                                           bufs[0][:, 256:320])
+                                           bufs[0][:, 256:320], bufs[8])
                 Cc, R = bufs[0], bufs[6]
                 acts = _act_views(bufs)
                 ops.train_encode(dirs[r0:r1], R[:, 256:256 + dir_w], 4, inc, rows_per_src=ns, relu=True)
@@ -169,7 +171,7 @@ class SpaceNetFunction(torch.autograd.Function):
                     d_raw[:, 3:] = d_sigma[r0:r1].reshape(M, 1)
                 dys = [_buf(M, 256, dev)[:, :256] for _ in range(7)] + [_buf(M, 128, dev)[:, :128]]
                 dpe = _buf(M, 64, dev)[:, :64] if d_pos is not None else None
-                ops.train_spacenet_dx(wt, offsets, d_raw, acts, dys, dpe)
+                ops.train_spacenet_dx(wt, offsets, d_raw, bufs[8], dys, dpe)
                 acc = r0 > 0
                 xin = [Cc[:, 256:256 + pe], acts[0], acts[1], acts[2], Cc[:, :256 + pe], acts[4], acts[5]]
                 for i in range(7):

@@ -613,11 +613,20 @@ def _matrix_list(mats: Sequence[Tensor], name: str):
     return ptrs, lds
 
 
+def _bit_planes(bits: Tensor, rows: int):
+    """(pointer, stage stride in words) of the ReLU bit planes: int32 (8, rows, 8), possibly a row range ``planes[:, a:b]`` of a larger
+    launch's planes (rows and words dense, any stage stride)."""
+    if not bits.is_cuda or bits.dtype != torch.int32 or tuple(bits.shape) != (8, rows, 8) or bits.stride(2) != 1 or bits.stride(1) != 8:
+        raise ValueError(f"relu_bits must be a device int32 (8, {rows}, 8) with dense rows, got {bits.dtype} {tuple(bits.shape)} {bits.stride()}")
+    return C.c_void_p(bits.data_ptr()), bits.stride(0)
+
+
 def train_spacenet_fwd(net: PackedNet, xyz: Tensor, dirs: Tensor, times: Optional[Tensor], raw: Tensor, acts: Sequence[Tensor],
-                       pe: Tensor) -> None:
+                       pe: Tensor, relu_bits: Optional[Tensor] = None) -> None:
     """The exact-f32 stage kernel on one SpaceNet, every ray, writing each layer's input as it goes: acts[0..6] (rows, 256),
-    acts[7] (rows, 128), pe (rows, 64), rows = n * ns in (ray, sample) order -- views into padded row-major storage
-    (stnerf_train_spacenet_fwd).  xyz (n,ns,3), dirs (n,3), times (n,) | None, raw (n,ns,4) out."""
+    acts[7] (rows, 128), pe (rows, 64), rows = n * ns in (ray, sample) order -- views into padded row-major storage -- and
+    relu_bits (8, rows, 8) int32: the ReLU masks as bit planes (stnerf_train_spacenet_fwd).  xyz (n,ns,3), dirs (n,3),
+    times (n,) | None, raw (n,ns,4) out."""
     if net.precision != "fp32":
         raise ValueError("the training kernels are exact f32: pack the network 'fp32'")
     n, ns = xyz.shape[0], xyz.shape[1]
@@ -627,22 +636,24 @@ def train_spacenet_fwd(net: PackedNet, xyz: Tensor, dirs: Tensor, times: Optiona
     tp, ts = _strided_view_ptr(times.reshape(n), (), "times") if times is not None else (C.c_void_p(0), 0)
     ptrs, lds = _matrix_list(acts, "acts")
     pp, ldp = _mat(pe, "pe")
+    bp, bstride = _bit_planes(relu_bits, n * ns) if relu_bits is not None else (C.c_void_p(0), 0)
     queue = torch.zeros(1, dtype=torch.int32, device=xyz.device)
     ray_bias = torch.empty(n, 128, dtype=torch.float32, device=xyz.device)
     hip.check(hip.lib().stnerf_train_spacenet_fwd(net.kind, hip.dptr(net.blob), n, ns, xp, xs, dp, ds, tp, ts, rp, rs, ptrs, lds, pp, ldp,
-                                                  hip.dptr(queue, torch.int32), hip.dptr(ray_bias), hip.stream_ptr()),
-              "stnerf_train_spacenet_fwd")
+                                                  bp, bstride, hip.dptr(queue, torch.int32), hip.dptr(ray_bias),
+                                                  hip.stream_ptr()), "stnerf_train_spacenet_fwd")
 
 
-def train_spacenet_dx(wt: Tensor, offsets: Sequence[int], d_raw: Tensor, acts: Sequence[Tensor], dys: Sequence[Tensor],
-                      dpe: Optional[Tensor]) -> None:
+def train_spacenet_dx(wt: Tensor, offsets: Sequence[int], d_raw: Tensor, relu_bits: Tensor, dys: Sequence[Tensor], dpe: Optional[Tensor]) -> None:
     """The backward chain through one SpaceNet's layers (stnerf_train_spacenet_dx): d_raw (rows,4) -> dys[0..7] (the layers'
-    pre-activation gradients, widths 256 x 7, 128) and, if given, dpe (rows,64) = dLoss / d PE(pos).  wt / offsets: the transposed
-    weight sections (stnerf_amd.modeling.autograd.transposed_spacenet)."""
+    pre-activation gradients, widths 256 x 7, 128) and, if given, dpe (rows,64) = dLoss / d PE(pos).  relu_bits (8, rows, 8) int32:
+    the masks ``train_spacenet_fwd`` wrote for these rows.  wt / offsets: the transposed weight sections
+    (stnerf_amd.modeling.autograd.transposed_spacenet)."""
     rows = d_raw.shape[0]
-    ap, ald = _matrix_list(acts, "acts")
+    bp, bstride = _bit_planes(relu_bits, rows)
     yp, yld = _matrix_list(dys, "dys")
     off = (C.c_uint32 * 10)(*[int(o) for o in offsets])
     pp, ldp = _mat(dpe, "dpe") if dpe is not None else (C.c_void_p(0), 0)
-    hip.check(hip.lib().stnerf_train_spacenet_dx(hip.dptr(wt, name="wt"), off, hip.dptr(d_raw, name="d_raw"), rows, ap, ald, yp, yld, pp, ldp,
-                                                 hip.stream_ptr()), "stnerf_train_spacenet_dx")
+    hip.check(hip.lib().stnerf_train_spacenet_dx(hip.dptr(wt, name="wt"), off, hip.dptr(d_raw, name="d_raw"), rows,
+                                                 bp, bstride, yp, yld, pp, ldp, hip.stream_ptr()),
+              "stnerf_train_spacenet_dx")

@@ -339,7 +339,8 @@ def test_fused_forward_writes_the_activations_the_layerwise_recompute_builds(ops
         b.fill_(float("nan"))
     acts = [Hs[0], Hs[1], Hs[2], Cc[:, :256], Gs[0], Gs[1], R[:, :256], T0]
     raw = torch.empty(n, ns, 4, device="cuda")
-    ops.train_spacenet_fwd(packed, pos, rays[:, 3:6], tm.reshape(n) if use_time else None, raw, acts, Cc[:, 256:320])
+    bits = torch.full((8, M, 8), -1, dtype=torch.int32, device="cuda")
+    ops.train_spacenet_fwd(packed, pos, rays[:, 3:6], tm.reshape(n) if use_time else None, raw, acts, Cc[:, 256:320], bits)
     want = torch.empty(n, ns, 4, device="cuda")
     ops.spacenet_fwd(packed, pos, rays[:, 3:6], tm.reshape(n) if use_time else None, want)
     assert torch.equal(raw, want)
@@ -365,6 +366,16 @@ def test_fused_forward_writes_the_activations_the_layerwise_recompute_builds(ops
         assert torch.allclose(got[:, :256], ref[:, :256], rtol=1e-5, atol=1e-6)
         assert float(got[:, :256].min()) >= 0.0
     assert bool(torch.isfinite(T0).all()) and float(T0.min()) >= 0.0 and float(T0.max()) > 0.0
+    # the ReLU masks as bit planes: row r, stage s: 8 words; the lane (h, r % 32) of the wave that owns the row holds register i of block
+    # fb <-> column 32 fb + 8 (i >> 2) + 4 h + (i & 3), stored as bit (16 fb + i) & 31 of word 4 h + (fb >> 1)
+    fb, i, h = torch.meshgrid(torch.arange(8), torch.arange(16), torch.arange(2), indexing="ij")
+    col = (32 * fb + 8 * (i >> 2) + 4 * h + (i & 3)).reshape(-1)
+    word, bit = (4 * h + (fb >> 1)).reshape(-1), ((16 * fb + i) & 31).reshape(-1)
+    for s_, act in enumerate(acts):
+        width = act.shape[1] if s_ < 7 else 128
+        keep = col < width
+        got = (bits[s_].cpu()[:, word[keep]] >> bit[keep]) & 1
+        assert torch.equal(got.bool(), act[:, :width].cpu()[:, col[keep]] > 0), s_
 
 
 @pytest.mark.parametrize("use_time, want_dpos", [(True, True), (False, True), (True, False)])
