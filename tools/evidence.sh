@@ -18,10 +18,13 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 CMD="python bench.py --steps 1 --warmup 0 --cpu-baseline-rays 0 --eager-gpu-baseline-rays 0 --no-psnr-check --no-second-precision --no-config-legs --detail-out /tmp/d.json"
 for prec in bf16x3 fp32; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $out/trace_$prec -o p -- $CMD --precision $prec > $out/trace_$prec.log 2>&1
+  # (counters in their own runs, never together with a trace: gpurun refuses the combination)
   for ctr in FETCH_SIZE WRITE_SIZE MfmaUtil; do
     timeout 300 rocprofv3 --pmc $ctr -d $out/pmc_${ctr}_$prec -o p -- $CMD --precision $prec > $out/pmc_${ctr}_$prec.log 2>&1
   done
-  timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS -d $out/pmc_SQ_$prec -o p -- $CMD --precision $prec > $out/pmc_SQ_$prec.log 2>&1
+  if [ $prec = bf16x3 ]; then
+    timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS -d $out/pmc_SQ_$prec -o p -- $CMD --precision $prec > $out/pmc_SQ_$prec.log 2>&1
+  fi
 done
 # ---- 4. the other BASELINE configurations on the same build (one bench line each, both arithmetics)
 W="--cpu-baseline-rays 0 --eager-gpu-baseline-rays 0 --no-psnr-check --no-config-legs"
@@ -29,6 +32,7 @@ timeout 300 python bench.py --workload single-512-64+64 --steps 5 --warmup 1 $W 
 timeout 300 python bench.py --workload taekwondo-1080p-90+30 --steps 3 --warmup 1 $W --detail-out $out/bench_c3_90_30_detail.json > $out/bench_c3_90_30.json 2> $out/bench_c3_90_30.err
 timeout 500 python bench.py --workload walking-1080p-L4-64+64 --steps 2 --warmup 1 --emulate-share 2,4,8 $W --detail-out $out/bench_c4_detail.json > $out/bench_c4.json 2> $out/bench_c4.err
 timeout 900 python bench.py --workload synthetic-4k-L8-128+64 --steps 1 --warmup 1 --rays-per-launch 131072 --emulate-share 2,4,8 $W --detail-out $out/bench_c5_detail.json > $out/bench_c5.json 2> $out/bench_c5.err
+if [ -n "$EVIDENCE_FULL" ]; then
 # ---- 4b. compositor / resampler at C4 and C5 on counter bytes: kernel trace + FETCH_SIZE + WRITE_SIZE of one step each
 CMDX="python bench.py --steps 1 --warmup 0 --cpu-baseline-rays 0 --eager-gpu-baseline-rays 0 --no-psnr-check --no-second-precision --no-config-legs --precision bf16x3 --detail-out /tmp/d.json"
 for cfg in "c4 walking-1080p-L4-64+64" "c5 synthetic-4k-L8-128+64 --rays-per-launch 131072"; do
@@ -38,6 +42,7 @@ for cfg in "c4 walking-1080p-L4-64+64" "c5 synthetic-4k-L8-128+64 --rays-per-lau
     timeout 400 rocprofv3 --pmc $ctr -d $out/pmc_${ctr}_$tagc -o p -- $CMDX --workload "$@" > $out/pmc_${ctr}_$tagc.log 2>&1
   done
 done
+fi
 # ---- 5. N ranks on this one GPU through bench.py itself (gloo; the code path a node runs, not a measurement)
 timeout 300 python bench.py --gpus 2 --debug-single-device --steps 2 --warmup 1 $W --no-second-precision --detail-out $out/bench_2ranks_one_device_detail.json > $out/bench_2ranks_one_device.json 2> $out/bench_2ranks_one_device.err
 # ---- 6. the training kernels: GEMM flavours, whole backward, kernel trace
