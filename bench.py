@@ -572,8 +572,8 @@ def main():
                     help="N>1 with every rank on cuda:0 over gloo: exercises the multi-rank code path on a 1-GPU box (not a measurement)")
     ap.add_argument("--no-psnr-check", action="store_true",
                     help="skip the PSNR-vs-reference check of the device RNG mode (a 128x128 view, ~0.1 s)")
-    ap.add_argument("--eager-gpu-baseline-rays", type=int, default=3584,
-                    help=">0 (default: one reference chunk): also time the oracle restatement through eager PyTorch-ROCm on this GPU -- "
+    ap.add_argument("--eager-gpu-baseline-rays", type=int, default=16 * 3584,
+                    help=">0 (default: 16 reference chunks, ~0.5 s): also time the oracle restatement through eager PyTorch-ROCm on this GPU -- "
                          "the 'stock ATen on the same GPU' figure of BASELINE.md 3.5 (informative); 0 skips it")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
                     help="arithmetic of the headline leg: split-bf16 (the library default: three bf16 pieces per fp32 operand, six MFMAs, "

@@ -53,5 +53,10 @@ def _dssim(img1, img2, window_size=3, reduction="mean", max_val=1.0):
 
 
 def ssim(image_pred, image_gt, reduction="mean"):
-    """utils/metrics.py:19-24: image_pred, image_gt (3,H,W) -> structural similarity in [-1, 1]."""
+    """utils/metrics.py:19-24: image_pred, image_gt (3,H,W) -> structural similarity in [-1, 1].
+
+    PARITY UNPINNED: the reference delegates to ``kornia.losses.ssim`` (an unpinned, un-vendored dependency that is absent from the
+    build container), so there is no reference output to compare with -- ``_dssim`` restates kornia's published window-3 algorithm and
+    is checked against its own definition only.  ``mse`` / ``mae`` / ``psnr`` are pinned to the reference's own functions
+    (tests/test_host_cpu.py)."""
     return 1 - 2 * _dssim(image_pred.unsqueeze(0), image_gt.unsqueeze(0), 3, reduction)

@@ -570,6 +570,9 @@ def g_train_step(name, L, n1, n2, st, dt, seed, n_rays=96, only_coarse=False, re
     the same expressions."""
     from layers import make_loss
     from solver import make_optimizer
+    # ATen's CPU weight-gradient reductions depend on the thread count in their last bits (2e-8 of a tensor's largest entry between
+    # 2 threads and the container's default): pinned, so that the fixture regenerates byte for byte on any host
+    torch.set_num_threads(4)
     model = build_ref_model(L, n1, n2, st, dt, seed)
     cfg = types.SimpleNamespace(SOLVER=types.SimpleNamespace(OPTIMIZER_NAME="Adam", BASE_LR=0.0004, WEIGHT_DECAY=0.0))
     loss_fn = make_loss(cfg)
