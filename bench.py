@@ -45,8 +45,8 @@ from stnerf_amd import parallel                         # noqa: E402
 from stnerf_amd.parallel import gather_tiles, render_view  # noqa: E402
 
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
-MEASURED_HBM_JSON = os.path.join(REPO, "profiles", "r04_hbm_copy_microbench.json")   # tools/micro/hbm_copy on the GPU box
-PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r04_pmc_hbm_traffic.json")         # tools/r04_summarise.py (pose 0 of the sweep)
+MEASURED_HBM_JSON = os.path.join(REPO, "profiles", "r05_hbm_copy_microbench.json")   # tools/micro/hbm_copy on the GPU box
+PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r05_pmc_hbm_traffic.json")         # tools/summarise.py (pose 0 of the sweep)
 
 # Algorithmic work per network evaluation: 2 * MACs of every nn.Linear.
 FLOP_SPACE, FLOP_SPACE_TIME, FLOP_MOTION = 924_672, 930_048, 153_344

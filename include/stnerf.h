@@ -133,6 +133,11 @@ int stnerf_compact_rays(const uint8_t* mask, int64_t n, int l, int32_t* ray_list
 
 /* Bytes of the packed (kernel-layout) weight blob of one network. */
 int64_t stnerf_packed_bytes(int kind);
+/* stnerf_pack_net with every tensor and the destination IN DEVICE MEMORY (weights_dev / biases_dev: host arrays of device pointers;
+ * same tensors, same blob, bit for bit): one memset + one kernel on `stream`, no host round trip -- what a training loop calls after
+ * every optimizer.step() (round 5). */
+int stnerf_pack_net_device(int kind, const float* const* weights_dev, const float* const* biases_dev, int n_tensors, void* dst_dev,
+                           int64_t dst_bytes, stnerf_stream_t stream);
 /* Repack reference-layout tensors (nn.Linear: weight (out,in) row-major, bias (out)) into the
  * kernel layout.  HOST -> HOST; the caller uploads `dst` to the device (any allocator).
  * SpaceNet order (10 tensors): stage1.{0,2,4,6}, stage2.{0,2,4}, density_net.0, rgb_net.{1,3};
@@ -193,9 +198,9 @@ int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32
  *   fp32-subnormal weights are accepted, pieces below 2^-133 flush (absolute error < 2^-133 per weight);
  *   sample points must be FINITE (the sampler's and the resampler's are).  Neither stage kernel propagates NaN / inf the way ATen does:
  *   their ReLU is an integer max on the bit pattern (one instruction; -inf and sign-bit NaNs become 0), and the bf16 split turns what is
- *   left into zero pieces.  A sample with a NaN / inf coordinate therefore gets, in bf16x3, the FINITE outputs of zeroed hidden units
- *   (sigma = the density head's bias ...) where ATen returns NaN; the exact-f32 kernel returns NaN for NaN / +inf coordinates and the
- *   same finite values for -inf.  Likewise activations that overflow fp32 (|x| > 3.4e38: ATen carries +-inf / NaN on) give unspecified
+ *   left into zero pieces.  A sample with a NaN / inf coordinate therefore gets, in bf16x3, the FINITE outputs of a network whose first
+ *   layer's activations are zero (the biases' response: the same values for every such sample) where ATen returns NaN; the exact-f32
+ *   kernel returns NaN for NaN / +inf coordinates and those finite values for -inf.  Likewise activations that overflow fp32 (|x| > 3.4e38: ATen carries +-inf / NaN on) give unspecified
  *   values for that sample.  In every case ONLY that sample is affected: every other sample of the launch, of the same wave included,
  *   is bit-identical to a launch without it.  Subnormal activations and products behave as in the exact-f32 kernel up to the flush. */
 int64_t stnerf_packed_bytes_bf16x3(int kind);

@@ -453,6 +453,94 @@ extern "C" int stnerf_pack_net(int kind, const float* const* W, const float* con
     return STNERF_EINVAL;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The exact-f32 packing ON THE DEVICE: the same blob as stnerf_pack_net from tensors that live in HBM -- what a training loop needs
+// after every optimizer.step() (the host packer costs a D2H of the weights, a CPU loop and an H2D per network: 165 ms per
+// iteration for the eight networks of a C3 model against 40 ms of kernels).  One launch per network: a table of segments, each
+// either a linear layer's [Kq][N][4] re-blocking (zero padded) or a plain copy; blockIdx.y = the segment.
+// ---------------------------------------------------------------------------------------------
+namespace stnerf {
+struct PackSeg {
+    const float* src;
+    int64_t dst_off;   // floats
+    int32_t n, in_f, kq;   // kq > 0: W[n][in_f] -> [kq][n][4];  kq == 0: copy `n` floats
+};
+struct PackTable {
+    PackSeg seg[26];
+    int32_t count;
+};
+__global__ void pack_net_device_kernel(PackTable t, float* dst) {
+    const PackSeg sg = t.seg[blockIdx.y];
+    const int64_t total = sg.kq > 0 ? (int64_t)sg.kq * sg.n * 4 : sg.n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float v;
+        if (sg.kq > 0) {
+            const int r = (int)(i & 3);
+            const int64_t q = i >> 2;
+            const int n = (int)(q % sg.n), k = 4 * (int)(q / sg.n) + r;
+            v = k < sg.in_f ? sg.src[(int64_t)n * sg.in_f + k] : 0.f;
+        } else {
+            v = sg.src[i];
+        }
+        dst[sg.dst_off + i] = v;
+    }
+}
+}  // namespace stnerf
+
+extern "C" int stnerf_pack_net_device(int kind, const float* const* W, const float* const* B, int n_tensors, void* dst_dev, int64_t dst_bytes,
+                                      stnerf_stream_t stream) {
+    STNERF_REQUIRE(W && B && dst_dev, "pack_net_device: null pointer");
+    PackTable t;
+    memset(&t, 0, sizeof(t));
+    auto lin = [&](const float* w, int n, int in_f, int kq, int64_t off) { t.seg[t.count++] = PackSeg{w, off, n, in_f, kq}; };
+    auto cpy = [&](const float* src, int count, int64_t off) { t.seg[t.count++] = PackSeg{src, off, count, 0, 0}; };
+    int64_t total = 0;
+    if (STNERF_NET_IS_SPACE(kind)) {
+        const bool ut = STNERF_NET_USES_TIME(kind), deep = STNERF_NET_IS_DEEP(kind);
+        const SpaceLayout L = space_layout(ut, deep);
+        const int nt = deep ? 12 : 10;
+        STNERF_REQUIRE(n_tensors == nt, "pack_net_device: this SpaceNet kind takes %d tensors, got %d", nt, n_tensors);
+        for (int i = 0; i < nt; ++i) STNERF_REQUIRE(W[i] && B[i], "pack_net_device: tensor %d is null", i);
+        total = L.total;
+        const int in_f[7] = {63, 256, 256, 256, 319, 256, 256};
+        for (int i = 0; i < 7; ++i) {
+            lin(W[i], 256, in_f[i], L.kq[i], L.w[i]);
+            cpy(B[i], 256, L.b[i]);
+        }
+        cpy(W[7], 256, L.w_sigma);
+        cpy(B[7], 1, L.b_sigma);
+        lin(W[8], 128, 256 + 27 + (ut ? 21 : 0), L.kq_rgb1, L.w_rgb1);
+        cpy(B[8], 128, L.b_rgb1);
+        for (int i = 0; i < 2 && deep; ++i) {
+            lin(W[9 + i], 128, 128, 32, L.w_deep[i]);
+            cpy(B[9 + i], 128, L.b_deep[i]);
+        }
+        cpy(W[nt - 1], 3 * 128, L.w_rgb2);
+        cpy(B[nt - 1], 3, L.b_rgb2);
+    } else if (kind == STNERF_NET_MOTION) {
+        const MotionLayout L = motion_layout();
+        STNERF_REQUIRE(n_tensors == 6, "pack_net_device: MotionNet takes 6 tensors, got %d", n_tensors);
+        for (int i = 0; i < 6; ++i) STNERF_REQUIRE(W[i] && B[i], "pack_net_device: tensor %d is null", i);
+        total = L.total;
+        const int in_f[5] = {84, 128, 128, 128, 128};
+        for (int i = 0; i < 5; ++i) {
+            lin(W[i], 128, in_f[i], L.kq[i], L.w[i]);
+            cpy(B[i], 128, L.b[i]);
+        }
+        cpy(W[5], 3 * 128, L.w_out);
+        cpy(B[5], 3, L.b_out);
+    } else {
+        set_error("pack_net_device: unknown net kind %d", kind);
+        return STNERF_EINVAL;
+    }
+    STNERF_REQUIRE(dst_bytes >= total * 4, "pack_net_device: dst too small");
+    // (the pads between the sections: the host packer zeroes the whole blob first)
+    if (hipMemsetAsync(dst_dev, 0, (size_t)total * 4, as_stream(stream)) != hipSuccess) return STNERF_ELAUNCH;
+    hipLaunchKernelGGL(pack_net_device_kernel, dim3(64, t.count), dim3(256), 0, as_stream(stream), t, static_cast<float*>(dst_dev));
+    STNERF_CHECK_LAUNCH("pack_net_device");
+    return STNERF_OK;
+}
+
 extern "C" int stnerf_encode(const float* x, int64_t n, int dim, int n_freq, int include_input, float* y,
                              stnerf_stream_t stream) {
     STNERF_REQUIRE(x && y, "encode: null pointer");

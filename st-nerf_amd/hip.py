@@ -81,6 +81,7 @@ _PROTOS = {
     "stnerf_compact_rays": (C.c_int, [C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "stnerf_packed_bytes": (c_i64, [C.c_int]),
     "stnerf_pack_net": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, c_i64]),
+    "stnerf_pack_net_device": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, c_i64, C.c_void_p]),
     "stnerf_spacenet_fwd": (C.c_int, [C.c_int, C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_i64,
                                       c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, C.c_void_p]),
     "stnerf_rgb_ray_bias": (C.c_int, [C.c_int, C.c_void_p, c_i64, C.c_void_p, C.c_void_p, c_f32p, c_i64, c_f32p, c_i64,

@@ -164,6 +164,18 @@ def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cud
     nbytes = size_fn(kind)
     if nbytes < 0:
         hip.check(int(nbytes), "stnerf_packed_bytes")
+    if precision == "fp32" and all(t.is_cuda for t in list(weights) + list(biases)):
+        # tensors that live on the GPU are packed there (stnerf_pack_net_device): no D2H / CPU loop / H2D per network -- a training loop
+        # repacks after every optimizer.step()
+        dev = weights[0].device
+        ws = [w.detach().to(torch.float32).contiguous() for w in weights]
+        bs = [b.detach().to(torch.float32).contiguous() for b in biases]
+        blob = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        wp = (C.c_void_p * len(ws))(*(w.data_ptr() for w in ws))
+        bp = (C.c_void_p * len(bs))(*(b.data_ptr() for b in bs))
+        with torch.cuda.device(dev):
+            hip.check(lib.stnerf_pack_net_device(kind, wp, bp, len(ws), hip.dptr(blob), nbytes, hip.stream_ptr()), "stnerf_pack_net_device")
+        return PackedNet(kind, blob, precision)
     ws = [w.detach().to("cpu", torch.float32).contiguous() for w in weights]
     bs = [b.detach().to("cpu", torch.float32).contiguous() for b in biases]
     host = torch.empty(nbytes // 4, dtype=torch.float32)
@@ -199,7 +211,8 @@ def pack_spacenet(state: dict, prefix: str, device="cuda", precision: str = "fp3
     (use_time, use_dir, include_input, deep_rgb: modeling/spacenet.py:16-86) is read off the tensor shapes."""
     deep = f"{prefix}.rgb_net.7.weight" in state          # deep_rgb: rgb_net.{1,3,5,7} (modeling/spacenet.py:68-79)
     keys = SPACENET_KEYS + (["rgb_net.5", "rgb_net.7"] if deep else [])
-    ws = [state[f"{prefix}.{k}.weight"].detach().float().cpu() for k in keys]
+    on_device = precision == "fp32" and all(state[f"{prefix}.{k}.weight"].is_cuda for k in keys)     # (packed where they live)
+    ws = [state[f"{prefix}.{k}.weight"].detach().float() if on_device else state[f"{prefix}.{k}.weight"].detach().float().cpu() for k in keys]
     bs = [state[f"{prefix}.{k}.bias"] for k in keys]
     pos_w = ws[0].shape[1]
     if pos_w not in (63, 60):
@@ -224,7 +237,8 @@ def pack_spacenet(state: dict, prefix: str, device="cuda", precision: str = "fp3
 
 
 def pack_motionnet(state: dict, prefix: str, device="cuda", precision: str = "fp32") -> PackedNet:
-    ws = [state[f"{prefix}.{k}.weight"].detach().float().cpu() for k in MOTIONNET_KEYS]
+    on_device = precision == "fp32" and all(state[f"{prefix}.{k}.weight"].is_cuda for k in MOTIONNET_KEYS)
+    ws = [state[f"{prefix}.{k}.weight"].detach().float() if on_device else state[f"{prefix}.{k}.weight"].detach().float().cpu() for k in MOTIONNET_KEYS]
     bs = [state[f"{prefix}.{k}.bias"] for k in MOTIONNET_KEYS]
     if ws[0].shape[1] not in (84, 80):
         raise ValueError(f"{prefix}.motion_net.0 has in-width {ws[0].shape[1]}: only c_input=4 with PE_10 is supported")

@@ -393,8 +393,9 @@ def test_fused_backward_matches_the_layerwise_backward(ops, monkeypatch, use_tim
                                              tm.cpu().double() if use_time else None)).reshape(301, 23, 1).cuda()
     c_rgb, c_sig = torch.randn(301, 23, 3, generator=g).cuda() * safe, torch.randn(301, 23, 1, generator=g).cuda() * safe
     grads = {}
-    for fused in (True, False):
-        monkeypatch.setattr(A, "FUSED_BACKWARD", fused)
+    for fused in (True, "recompute", False):      # activations kept by the forward / recomputed chunk by chunk / the per-layer GEMM chain
+        monkeypatch.setattr(A, "FUSED_BACKWARD", bool(fused))
+        monkeypatch.setattr(A, "KEEP_BYTES", 0 if fused == "recompute" else 1 << 35)
         net.zero_grad(set_to_none=True)
         p = pos.clone().requires_grad_(want_dpos)
         rgb, sig = net(p, rays, tm)
@@ -402,8 +403,26 @@ def test_fused_backward_matches_the_layerwise_backward(ops, monkeypatch, use_tim
         grads[fused] = {k: v.grad.clone() for k, v in net.named_parameters()}
         grads[fused]["pos"] = p.grad.clone() if want_dpos else None
     for k, a in grads[True].items():
-        b = grads[False][k]
+        b, r = grads[False][k], grads["recompute"][k]
         if a is None:
-            assert b is None
+            assert b is None and r is None
             continue
         assert float((a - b).abs().max()) <= GRAD_RTOL * float(b.abs().max()), k
+        assert torch.equal(a, r), k                     # the same kernels on the same rows: bit-identical
+
+
+@pytest.mark.parametrize("kind", ["space", "space_time", "space_time_deep", "space_noinc", "motion"])
+def test_device_packer_writes_the_host_packers_blob(ops, kind):
+    """stnerf_pack_net_device (what a training loop calls after every optimizer.step(): no host round trip) writes the exact-f32
+    blob of stnerf_pack_net bit for bit, for every network flavour."""
+    rs = np.random.RandomState(11)
+    if kind == "motion":
+        sd = syn.motionnet_state("net", rs)
+        pack = ops.pack_motionnet
+    else:
+        sd = syn.spacenet_state("net", rs, "time" in kind, deep_rgb="deep" in kind, include_input="noinc" not in kind)
+        pack = ops.pack_spacenet
+    host = pack(sd, "net", "cuda", "fp32")
+    dev = pack({k: v.cuda() for k, v in sd.items()}, "net", "cuda", "fp32")
+    assert host.kind == dev.kind and host.blob.shape == dev.blob.shape
+    assert torch.equal(host.blob.view(torch.int32), dev.blob.view(torch.int32))

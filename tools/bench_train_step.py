@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""One iteration of the reference trainer's inner loop (engine/layered_trainer.py:186-283: model.train(), forward, MSE of both mixed
+colours, loss.backward(), Adam step) on the MI355X at the reference's batch size (SOLVER.BUNCH = 4096 rays, config/defaults.py:131):
+ms per iteration, rays/s (the figure the trainer logs, :307-309) and where the GPU time goes.  `python tools/bench_train_step.py
+[--rays 4096] [--workload taekwondo-1080p-64+64] [--iters 5]`."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench                                             # noqa: E402  (scene construction)
+from stnerf_amd import ops, synthetic as syn             # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rays", type=int, default=4096)
+ap.add_argument("--workload", default="taekwondo-1080p-64+64")
+ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--fused", type=int, default=1)
+args = ap.parse_args()
+from stnerf_amd.modeling import autograd as A            # noqa: E402
+A.FUSED_BACKWARD = bool(args.fused)
+dev = torch.device("cuda")
+model, (H, W, L, n1, n2, st, dt) = bench.build_scene(args.workload, dev)
+model.train()
+K, T = syn.camera(H, W, 10.0)
+g = torch.Generator().manual_seed(0)
+# training-style rays: 7 columns, one integer frame id per ray (data/datasets/ray_dataset.py), drawn from all over the view
+all_rays = ops.generate_rays(K, T, H, W, frame_ids=[1.0], device=dev)[:, :6]
+pick = torch.randperm(H * W, generator=g)[:args.rays].to(dev)
+rays = torch.cat([all_rays[pick], torch.randint(1, 4, (args.rays, 1), generator=g).float().to(dev)], 1).contiguous()
+rgbs = torch.rand(args.rays, 3, generator=g).to(dev)
+opt = torch.optim.Adam(model.parameters(), lr=4e-4, betas=(0.9, 0.999))
+mse = torch.nn.MSELoss()
+
+
+def iteration():
+    opt.zero_grad()
+    stage2, stage1, _, _, masks = model(rays, None, None, False)
+    loss = mse(stage1[0], rgbs) + mse(stage2[0], rgbs)
+    loss.backward()
+    opt.step()
+    return loss, masks
+
+
+loss, masks = iteration()
+torch.cuda.synchronize()
+hits = [float(m.float().mean()) for m in masks]
+evals = args.rays * sum(hits) * (2 * n1 + n2)
+t0 = time.perf_counter()
+for _ in range(args.iters):
+    loss, _ = iteration()
+torch.cuda.synchronize()
+dt_s = (time.perf_counter() - t0) / args.iters
+flop = 3 * evals * ((bench.FLOP_SPACE_TIME if st else bench.FLOP_SPACE) + (bench.FLOP_MOTION if dt else 0) * (sum(hits[1:]) / max(sum(hits), 1e-9)))
+print(f"{args.workload}: {args.rays} rays per iteration (hit fractions {[round(h, 3) for h in hits]}), {'fused' if args.fused else 'per-layer'} backward: "
+      f"{1e3 * dt_s:.1f} ms per iteration = {args.rays / dt_s:.0f} rays/s, {evals / dt_s / 1e6:.1f} M network evaluations/s trained, "
+      f"~{flop / dt_s / 1e12:.1f} TF/s of forward + dX + dW work; loss {float(loss):.5f}")
