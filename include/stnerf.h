@@ -350,6 +350,25 @@ int stnerf_train_linear_dx(const float* dy, int64_t lddy, const float* w, int64_
 int64_t stnerf_train_dw_workspace_bytes(int64_t m, int n, int k);
 int stnerf_train_linear_dw(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t m, int n, int k, float* dw, int64_t lddw,
                            float* db, int accumulate, void* workspace, int64_t workspace_bytes, stnerf_stream_t stream);
+/* Every weight and bias gradient of a network in ONE launch (+ one for the reduction): `count` (<= 16) layers whose dy / x have
+ * the same m rows -- what loss.backward() accumulates into the .grad of every nn.Linear of modeling/spacenet.py:45-86 or
+ * modeling/motion_net.py:20-32 --, same operand rules and the same result contract as stnerf_train_linear_dw (dw[n][k] (+)= dy^T
+ * x, db[n] (+)= column sums of dy, db may be NULL; n <= 256 where db is given), sliced over the samples once for all layers
+ * (<= 256 slices of >= 256 rows, partials summed in slice order: deterministic).  The work items of all layers fill the chip
+ * together, the bias sums run beside the MFMA items instead of in launches of their own. */
+typedef struct stnerf_dw_problem {
+    const float* dy;   /* [m][lddy], n columns */
+    int64_t lddy;
+    const float* x;    /* [m][ldx], k columns */
+    int64_t ldx;
+    float* dw;         /* [n][lddw] */
+    int64_t lddw;
+    float* db;         /* [n] or NULL */
+    int32_t n, k;
+} stnerf_dw_problem;
+int64_t stnerf_train_dw_batch_workspace_bytes(const stnerf_dw_problem* problems, int32_t count, int64_t m);
+int stnerf_train_dw_batch(const stnerf_dw_problem* problems, int32_t count, int64_t m, int32_t accumulate, void* workspace,
+                          int64_t workspace_bytes, stnerf_stream_t stream);
 /* Positional encoding (utils/dimension_kernel.py:54-73) of x[src][0..dim) into columns [col0, col0 + dim (include_input + 2
  * n_freq)) of y[rows][ldy] (a column block of a layer's input matrix: the skip connection of modeling/spacenet.py:128 and
  * rgb_net's input :141-151 are assembled in place).  rows_per_src = ns repeats a ray's encoding on its ns samples (:115,118);

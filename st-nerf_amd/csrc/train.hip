@@ -135,20 +135,14 @@ __device__ __forceinline__ void store_tile(float* lds, const float4 (&v)[ROWS / 
 // C = A' B' with A'[m][k], B'[k][n] read as the template flags say; MODE 0: forward epilogue (bias, ReLU), 1: dX epilogue
 // (mask, accumulate), 2: dW partial tile.  BN = 256 where the output is wider than 128: the A' operand (the large,
 // sample-major matrix in every flavour but dW's) is then read once instead of twice.
-// (two workgroups per CU at least -- <= 256 registers: while one stores its tile, the other multiplies)
+// One workgroup's tile: rows m0 .. m0 + 127, columns n0 .. n0 + BN - 1 of the output, reduction range [k_begin, k_end) (k_begin a
+// multiple of 32), written to out[m][ldc].
 template <bool A_KC, bool B_KC, int MODE, int BN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void train_gemm_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem_gemm[];
+__device__ __forceinline__ void gemm_tile(const GemmArgs& a, float* smem_gemm, int m0, int n0, int k_begin, int k_end, float* out, int64_t ldc) {
     float* As = smem_gemm;
     float* Bs = smem_gemm + GBM * GLD;
     constexpr int NJ = BN / 64;                // 32-column MFMA tiles per wave
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, c = lane & 31;
-    const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * BN;   // (row tiles on x: a grid's y extent ends at 65535 blocks)
-    int k_begin = 0, k_end = a.K;
-    if (MODE == 2) {                           // (k_per_split is a multiple of 32: a slice never straddles two splits)
-        k_begin = blockIdx.z * a.k_per_split;
-        k_end = min(a.K, k_begin + a.k_per_split);
-    }
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
     f32x16 acc[2][NJ];
 #pragma unroll
@@ -226,8 +220,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
         multiply();
     }
     // accumulator register 4 q + r of lane (h, c): row 8 q + 4 h + r, column c of the 32 x 32 tile
-    float* out = MODE == 2 ? a.C + (int64_t)blockIdx.z * a.M * a.N : a.C;
-    const int64_t ldc = MODE == 2 ? a.N : a.ldc;
     const bool inside = m0 + GBM <= a.M && n0 + BN <= a.N;       // (uniform) no edge of the matrix in this tile
     // ---- the usual case -- a tile inside the matrix, 16-byte aligned rows: the wave turns its 64 x BN/2 accumulators around
     // through LDS, 16 rows at a time (the operand tiles are dead: every wave has its own 8.5 KB there), and bias / ReLU / mask
@@ -313,6 +305,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
                 }
         }
 }
+
+// (two workgroups per CU at least -- <= 256 registers: while one stores its tile, the other multiplies)
+template <bool A_KC, bool B_KC, int MODE, int BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void train_gemm_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_gemm[];
+    int k_begin = 0, k_end = a.K;
+    if (MODE == 2) {                           // (k_per_split is a multiple of 32: a slice never straddles two splits)
+        k_begin = blockIdx.z * a.k_per_split;
+        k_end = min(a.K, k_begin + a.k_per_split);
+    }
+    // (row tiles on x: a grid's y extent ends at 65535 blocks)
+    gemm_tile<A_KC, B_KC, MODE, BN>(a, smem_gemm, blockIdx.x * GBM, blockIdx.y * BN, k_begin, k_end,
+                                    MODE == 2 ? a.C + (int64_t)blockIdx.z * a.M * a.N : a.C, MODE == 2 ? (int64_t)a.N : a.ldc);
+}
 template <bool A_KC, bool B_KC, int MODE>
 int launch_gemm(const GemmArgs& a, int row_tiles, int grid_z, hipStream_t st, const char* what) {
     if (a.N > 128) {
@@ -343,13 +349,11 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int sp
 // beyond N land in outputs nobody stores) and every 256 / CG-th row of the block's slice, four rows in flight; the row lanes
 // are folded through LDS.  HBM-bound: the matrix is read once.
 template <int CG>   // column groups (of 4) per block: 64 (N >= 256), 32, 16, ... -- 256 / CG row lanes
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y, int64_t ld, int M, int N, int rows_per_block,
-                                                     float* __restrict__ partial) {
+__device__ __forceinline__ void colsum_rows(const float* __restrict__ y, int64_t ld, int N, int col_block, int m_begin, int m_end,
+                                            float* __restrict__ out, float4* red) {
     constexpr int RL = 256 / CG;
-    __shared__ float4 red[RL][CG];
     const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
-    const int col = 4 * (blockIdx.x * CG + cg);
-    const int m_begin = blockIdx.y * rows_per_block, m_end = min(M, m_begin + rows_per_block);
+    const int col = 4 * (col_block * CG + cg);
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
     if (col < N) {
         const float* p = y + col;
@@ -367,20 +371,105 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y
             s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
         }
     }
-    red[rl][cg] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+    red[rl * CG + cg] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
     __syncthreads();
     if (rl == 0 && col < N) {
-        float4 t = red[0][cg];
+        float4 t = red[cg];
         for (int r = 1; r < RL; ++r) {
-            const float4 u = red[r][cg];
+            const float4 u = red[r * CG + cg];
             t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
-        float* o = partial + (int64_t)blockIdx.y * N + col;
+        float* o = out + col;
         o[0] = t.x;
         if (col + 1 < N) o[1] = t.y;
         if (col + 2 < N) o[2] = t.z;
         if (col + 3 < N) o[3] = t.w;
     }
+}
+template <int CG>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y, int64_t ld, int M, int N, int rows_per_block,
+                                                     float* __restrict__ partial) {
+    __shared__ float4 red[256];
+    const int m_begin = blockIdx.y * rows_per_block;
+    colsum_rows<CG>(y, ld, N, blockIdx.x, m_begin, min(M, m_begin + rows_per_block), partial + (int64_t)blockIdx.y * N, red);
+}
+
+// ---- every weight and bias gradient of a network in ONE launch (stnerf_train_dw_batch) -------------------------------------
+// The layers' dW = dY^T X share the contraction (the samples), so they share the slicing: slice z = rows [z kps, (z + 1) kps) of
+// every layer's dY and X.  A work item is (slice, tile) -- a 128 x 256 or 128 x 128 piece of one layer's dW reduced over the
+// slice into a partial tile -- or (slice, bias): the column sums of one layer's dY over the slice (HBM-bound vector code that
+// runs NEXT to the MFMA items of other workgroups instead of in a launch of its own).  Items are ordered slice-major and dealt
+// to the XCDs in contiguous ranges (hardware workgroup b runs on XCD b % 8): the tiles that read the same rows of X and dY
+// are neighbours on one XCD's L2.  The widths 319 / 304 of stage2.0 / rgb_net.1 take a 256- and a 128-column item (launched
+// alone they were two 256-column tiles).  The partials are summed in slice order by dw_reduce_kernel: deterministic, no atomics.
+constexpr int DW_MAX_PROBLEMS = 16, DW_MAX_TILES = 64, DW_MAX_SEGMENTS = 2 * DW_MAX_PROBLEMS;
+struct DwProblem {
+    const float* dy;
+    const float* x;
+    int64_t lddy, ldx;
+    int64_t partial_off, bias_off;   // floats into the workspace: [slice][n][k] and [slice][n]
+    int32_t n, k;
+};
+struct DwTile {
+    uint16_t problem, m0, n0, wide;
+};
+struct DwBatchArgs {
+    DwProblem p[DW_MAX_PROBLEMS];
+    DwTile tile[DW_MAX_TILES];
+    uint8_t bias_problem[DW_MAX_PROBLEMS];
+    int32_t n_tiles, n_bias, slices, kps, m;
+    uint32_t items, items_per_xcd;
+    float* workspace;
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void train_dw_batch_kernel(DwBatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_gemm[];
+    const uint32_t w = (blockIdx.x & 7u) * a.items_per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= a.items_per_xcd || w >= a.items) return;
+    const int per_slice = a.n_tiles + a.n_bias;
+    const int z = (int)(w / (uint32_t)per_slice), i = (int)(w % (uint32_t)per_slice);
+    const int k_begin = z * a.kps, k_end = min(a.m, k_begin + a.kps);
+    if (i < a.n_tiles) {
+        const DwTile tl = a.tile[i];
+        const DwProblem& p = a.p[tl.problem];
+        const GemmArgs g{p.dy, p.x, nullptr, p.lddy, p.ldx, 0, p.n, p.k, a.m, nullptr, nullptr, 0, 0, 0, a.kps};
+        float* out = a.workspace + p.partial_off + (int64_t)z * p.n * p.k;
+        if (tl.wide)
+            gemm_tile<false, false, 2, 256>(g, smem_gemm, tl.m0, tl.n0, k_begin, k_end, out, p.k);
+        else
+            gemm_tile<false, false, 2, 128>(g, smem_gemm, tl.m0, tl.n0, k_begin, k_end, out, p.k);
+    } else {
+        const DwProblem& p = a.p[a.bias_problem[i - a.n_tiles]];
+        float* out = a.workspace + p.bias_off + (int64_t)z * p.n;
+        float4* red = reinterpret_cast<float4*>(smem_gemm);
+        if (p.n > 128)
+            colsum_rows<64>(p.dy, p.lddy, p.n, 0, k_begin, k_end, out, red);
+        else if (p.n > 32)
+            colsum_rows<32>(p.dy, p.lddy, p.n, 0, k_begin, k_end, out, red);
+        else
+            colsum_rows<8>(p.dy, p.lddy, p.n, 0, k_begin, k_end, out, red);
+    }
+}
+// dst[i] (+)= sum_z partial[z][i] in z order, for every weight and bias gradient of the batch (blockIdx.y = segment).
+struct DwSegment {
+    float* dst;
+    int64_t ld_dst, partial_off;
+    int32_t count, cols;
+};
+struct DwReduceArgs {
+    DwSegment seg[DW_MAX_SEGMENTS];
+    const float* workspace;
+    int32_t slices, accumulate;
+};
+__global__ void dw_reduce_kernel(DwReduceArgs a) {
+    const DwSegment& sg = a.seg[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sg.count) return;
+    const float* partial = a.workspace + sg.partial_off + i;
+    float s = 0.f;
+#pragma unroll 8
+    for (int z = 0; z < a.slices; ++z) s += partial[(int64_t)z * sg.count];
+    float* d = sg.dst + (int64_t)(i / sg.cols) * sg.ld_dst + (i % sg.cols);
+    *d = a.accumulate ? *d + s : s;
 }
 
 // ---- positional encodings ------------------------------------------------------------------------------------------------
@@ -553,6 +642,93 @@ extern "C" int stnerf_train_linear_dw(const float* dy, int64_t lddy, const float
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bpart, row_blocks, (int64_t)n, n, db, (int64_t)n, accumulate);
         STNERF_CHECK_LAUNCH("train_linear_dw (bias reduce)");
     }
+    return STNERF_OK;
+}
+
+// The batch's slicing: at most 256 slices of at least 256 samples (a multiple of 32).
+static int dw_batch_kps(int64_t m) {
+    int64_t kps = (m + 255) / 256;
+    if (kps < 256) kps = 256;
+    return (int)((kps + GBK - 1) / GBK * GBK);
+}
+static int check_dw_batch(const stnerf_dw_problem* pr, int32_t count, int64_t m) {
+    STNERF_REQUIRE(pr && count >= 1 && count <= DW_MAX_PROBLEMS, "train_dw_batch: 1 .. %d problems", DW_MAX_PROBLEMS);
+    STNERF_REQUIRE(m >= 0 && m < (1ll << 31), "train_dw_batch: bad sample count %lld", (long long)m);
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        const stnerf_dw_problem& q = pr[i];
+        STNERF_REQUIRE(q.dy && q.x && q.dw, "train_dw_batch: null pointer in problem %d", i);
+        STNERF_REQUIRE(q.n >= 1 && q.n <= 65535 && q.k >= 1 && q.k <= 65535, "train_dw_batch: bad shape n=%d k=%d in problem %d", q.n, q.k, i);
+        STNERF_REQUIRE((q.lddy & 3) == 0 && (q.ldx & 3) == 0 && q.lddy >= ((q.n + 3) & ~3) && q.ldx >= ((q.k + 3) & ~3) && q.lddw >= q.k &&
+                           aligned16(q.dy) && aligned16(q.x),
+                       "train_dw_batch: dy / x need 16-byte aligned rows (ld %% 4 == 0) of at least round4(n) / round4(k) floats (problem %d)", i);
+        STNERF_REQUIRE(m * q.lddy < (1ll << 29) && m * q.ldx < (1ll << 29), "train_dw_batch: operands of 2 GiB and more: split the batch");
+        STNERF_REQUIRE(!q.db || q.n <= 256, "train_dw_batch: bias gradients of at most 256 outputs (problem %d has %d)", i, q.n);
+        tiles += ((q.n + GBM - 1) / GBM) * ((q.k + 255) / 256);
+    }
+    STNERF_REQUIRE(tiles <= DW_MAX_TILES, "train_dw_batch: %d tiles, at most %d", tiles, DW_MAX_TILES);
+    return STNERF_OK;
+}
+static int64_t dw_batch_floats(const stnerf_dw_problem* pr, int32_t count, int64_t m) {
+    const int kps = dw_batch_kps(m);
+    const int64_t slices = m <= 0 ? 1 : (m + kps - 1) / kps;
+    int64_t floats = 0;
+    for (int i = 0; i < count; ++i) floats += slices * ((int64_t)pr[i].n * pr[i].k + ((pr[i].n + 3) & ~3));
+    return floats;
+}
+
+extern "C" int64_t stnerf_train_dw_batch_workspace_bytes(const stnerf_dw_problem* problems, int32_t count, int64_t m) {
+    if (check_dw_batch(problems, count, m)) return STNERF_EINVAL;
+    return 4 * dw_batch_floats(problems, count, m) + 512;
+}
+
+extern "C" int stnerf_train_dw_batch(const stnerf_dw_problem* problems, int32_t count, int64_t m, int32_t accumulate, void* workspace,
+                                     int64_t workspace_bytes, stnerf_stream_t stream) {
+    if (const int rc = check_dw_batch(problems, count, m)) return rc;
+    STNERF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= 4 * dw_batch_floats(problems, count, m) + 512,
+                   "train_dw_batch: workspace too small");
+    if (m == 0) return STNERF_OK;
+    hipStream_t st = as_stream(stream);
+    DwBatchArgs a{};
+    DwReduceArgs r{};
+    a.kps = dw_batch_kps(m);
+    a.slices = (int)((m + a.kps - 1) / a.kps);
+    a.m = (int)m;
+    a.workspace = static_cast<float*>(workspace);
+    int64_t off = 0;
+    int segs = 0, max_count = 0;
+    for (int i = 0; i < count; ++i) {
+        const stnerf_dw_problem& q = problems[i];
+        DwProblem& p = a.p[i];
+        p = DwProblem{q.dy, q.x, q.lddy, q.ldx, off, 0, q.n, q.k};
+        r.seg[segs++] = DwSegment{q.dw, q.lddw, off, q.n * q.k, q.k};
+        max_count = q.n * q.k > max_count ? q.n * q.k : max_count;
+        off += (int64_t)a.slices * q.n * q.k;
+        // a 256-column item while more than 128 columns are left, then a 128-column one
+        for (int m0 = 0; m0 < q.n; m0 += GBM)
+            for (int n0 = 0; n0 < q.k;) {
+                const bool wide = q.k - n0 > 128;
+                a.tile[a.n_tiles++] = DwTile{(uint16_t)i, (uint16_t)m0, (uint16_t)n0, (uint16_t)wide};
+                n0 += wide ? 256 : 128;
+            }
+    }
+    for (int i = 0; i < count; ++i)
+        if (problems[i].db) {
+            a.p[i].bias_off = off;
+            a.bias_problem[a.n_bias++] = (uint8_t)i;
+            r.seg[segs++] = DwSegment{problems[i].db, (int64_t)problems[i].n, off, problems[i].n, problems[i].n};
+            off += (int64_t)a.slices * ((problems[i].n + 3) & ~3);
+        }
+    // (bias partials are [slice][n] with the slice stride n: the padding above is slack for the last slice only)
+    a.items = (uint32_t)a.slices * (uint32_t)(a.n_tiles + a.n_bias);
+    a.items_per_xcd = (a.items + 7) / 8;
+    hipLaunchKernelGGL(train_dw_batch_kernel, dim3(8 * a.items_per_xcd), dim3(256), (GBM + 256) * GLD * 4, st, a);
+    STNERF_CHECK_LAUNCH("train_dw_batch");
+    r.workspace = a.workspace;
+    r.slices = a.slices;
+    r.accumulate = accumulate;
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((max_count + 255) / 256, segs), dim3(256), 0, st, r);
+    STNERF_CHECK_LAUNCH("train_dw_batch (reduce)");
     return STNERF_OK;
 }
 

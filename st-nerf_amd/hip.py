@@ -61,6 +61,12 @@ class RenderParams(C.Structure):
 MOTION_ADD_TO_XYZ, MOTION_PLAIN_TIME = 1, 2   # STNERF_MOTION_* bits of stnerf_motionnet_fwd's add_to_xyz argument
 
 
+class DwProblem(C.Structure):
+    """stnerf_dw_problem (include/stnerf.h): one layer of stnerf_train_dw_batch."""
+    _fields_ = [("dy", C.c_void_p), ("lddy", C.c_int64), ("x", C.c_void_p), ("ldx", C.c_int64), ("dw", C.c_void_p), ("lddw", C.c_int64),
+                ("db", C.c_void_p), ("n", C.c_int32), ("k", C.c_int32)]
+
+
 class ProfileRecord(C.Structure):
     _fields_ = [("kernel", C.c_int32), ("kind", C.c_int32), ("ns", C.c_int32), ("tag", C.c_int32),
                 ("n_rays", C.c_int64), ("bytes_per_ray", C.c_int64), ("ms", C.c_float), ("pad_", C.c_int32)]
@@ -99,6 +105,8 @@ _PROTOS = {
     "stnerf_train_dw_workspace_bytes": (c_i64, [c_i64, C.c_int, C.c_int]),
     "stnerf_train_linear_dw": (C.c_int, [c_f32p, c_i64, c_f32p, c_i64, c_i64, C.c_int, C.c_int, c_f32p, c_i64, c_f32p, C.c_int, C.c_void_p,
                                          c_i64, C.c_void_p]),
+    "stnerf_train_dw_batch_workspace_bytes": (c_i64, [C.POINTER(DwProblem), C.c_int32, c_i64]),
+    "stnerf_train_dw_batch": (C.c_int, [C.POINTER(DwProblem), C.c_int32, c_i64, C.c_int32, C.c_void_p, c_i64, C.c_void_p]),
     "stnerf_train_encode": (C.c_int, [c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, c_i64, C.c_int,
                                       C.c_void_p]),
     "stnerf_train_encode_bwd": (C.c_int, [c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_i64, c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p,

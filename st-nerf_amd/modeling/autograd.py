@@ -36,6 +36,19 @@ ACT_FLOATS_PER_SAMPLE = 320 + 5 * 256 + 304 + 128 + 64
 CHUNK_SAMPLES = min(max(int(os.environ.get("STNERF_TRAIN_CHUNK_SAMPLES", 1 << 18)), 1024), (1 << 29) // 320)
 
 
+# every weight / bias gradient of a network in one launch (stnerf_train_dw_batch); "0": one launch group per layer (the A/B of
+# tools/bench_backward.py)
+DW_BATCH = os.environ.get("STNERF_TRAIN_DW_BATCH", "1") != "0"
+
+
+def _weight_gradients(layers, accumulate: bool) -> None:
+    if DW_BATCH:
+        ops.train_dw_batch(layers, accumulate)
+    else:
+        for dy, x, dw, db in layers:
+            ops.train_linear_dw(dy, x, dw, db, accumulate)
+
+
 def _pad4(n: int) -> int:
     return (n + 3) // 4 * 4
 
@@ -132,8 +145,10 @@ class SpaceNetFunction(torch.autograd.Function):
         fused = ctx.kept or (FUSED_BACKWARD and inc and use_dir and not deep)
         W = [] if fused else [_padded_weight(params[2 * i]) for i in range(len(params) // 2)]
         B = [] if fused else [params[2 * i + 1].detach().float().contiguous() for i in range(len(params) // 2)]
-        gW = [torch.zeros_like(params[2 * i], dtype=torch.float32) for i in range(len(params) // 2)]
-        gB = [torch.zeros_like(params[2 * i + 1], dtype=torch.float32) for i in range(len(params) // 2)]
+        # (the fused path's first chunk writes every gradient whole: nothing to clear -- 20 fill launches less per backward)
+        fresh = torch.empty_like if fused and n > 0 else torch.zeros_like
+        gW = [fresh(params[2 * i], dtype=torch.float32) for i in range(len(params) // 2)]
+        gB = [fresh(params[2 * i + 1], dtype=torch.float32) for i in range(len(params) // 2)]
         d_pos = torch.zeros(n * ns, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         pe = 3 * (int(inc) + 20)
         dir_w = 3 * (int(inc) + 8) if use_dir else 0
@@ -174,13 +189,12 @@ class SpaceNetFunction(torch.autograd.Function):
                 ops.train_spacenet_dx(wt, offsets, d_raw, bufs[8], dys, dpe)
                 acc = r0 > 0
                 xin = [Cc[:, 256:256 + pe], acts[0], acts[1], acts[2], Cc[:, :256 + pe], acts[4], acts[5]]
-                for i in range(7):
-                    ops.train_linear_dw(dys[i], xin[i], gW[i], gB[i], acc)
                 dS = _buf(M, 1, dev)
                 dS[:, :1] = d_raw[:, 3:]
-                ops.train_linear_dw(dS[:, :1], acts[6], gW[7], gB[7], acc)
-                ops.train_linear_dw(dys[7], R[:, :256 + dir_w + time_w], gW[8], gB[8], acc)
-                ops.train_linear_dw(d_raw[:, :3], acts[7], gW[9], gB[9], acc)
+                # every weight and bias gradient of the network: one launch + one reduction (stnerf_train_dw_batch)
+                _weight_gradients([(dys[i], xin[i], gW[i], gB[i]) for i in range(7)] +
+                                  [(dS[:, :1], acts[6], gW[7], gB[7]), (dys[7], R[:, :256 + dir_w + time_w], gW[8], gB[8]),
+                                   (d_raw[:, :3], acts[7], gW[9], gB[9])], acc)
                 if d_pos is not None:
                     ops.train_encode_bwd(x, dpe[:, :pe], d_pos[r0 * ns:r1 * ns], 10, inc)
         for r0 in ([] if fused else range(0, n, rays_per_chunk)):
@@ -290,8 +304,9 @@ class MotionNetFunction(torch.autograd.Function):
         L = len(params) // 2
         W = [_padded_weight(params[2 * i]) for i in range(L)]
         B = [params[2 * i + 1].detach().float().contiguous() for i in range(L)]
-        gW = [torch.zeros_like(params[2 * i], dtype=torch.float32) for i in range(L)]
-        gB = [torch.zeros_like(params[2 * i + 1], dtype=torch.float32) for i in range(L)]
+        fresh = torch.empty_like if rows > 0 else torch.zeros_like     # (the first chunk writes every gradient whole)
+        gW = [fresh(params[2 * i], dtype=torch.float32) for i in range(L)]
+        gB = [fresh(params[2 * i + 1], dtype=torch.float32) for i in range(L)]
         d_xt = torch.zeros(rows, 4, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         pe = m_.pos_dim
         x4 = xt.float().contiguous()
@@ -310,9 +325,10 @@ class MotionNetFunction(torch.autograd.Function):
             dO = _buf(M, 3, dev)
             dO[:, :3] = d_flow[r0:r1]
             dy = dO[:, :3]
+            layers = []
             for j in range(L - 1, -1, -1):
                 xin = A[j - 1][:, :128] if j > 0 else E[:, :pe]
-                ops.train_linear_dw(dy, xin, gW[j], gB[j], acc)
+                layers.append((dy, xin, gW[j], gB[j]))
                 if j > 0:
                     d_prev = _buf(M, 128, dev)
                     ops.train_linear_dx(dy, W[j], d_prev[:, :128], mask=A[j - 1][:, :128])
@@ -322,6 +338,7 @@ class MotionNetFunction(torch.autograd.Function):
                     ops.train_linear_dx(dy, W[0], dE[:, :pe])
                     # (the frame-id column gets no gradient: the lerp weights are data)
                     ops.train_encode_bwd(x, dE[:, :pe], d_xt[r0:r1, :3], 10, inc)
+            _weight_gradients(layers, acc)
         grads: List[Optional[torch.Tensor]] = []
         for i in range(L):
             grads += [gW[i] if ctx.needs_input_grad[2 + 2 * i] else None, gB[i] if ctx.needs_input_grad[3 + 2 * i] else None]

@@ -579,15 +579,48 @@ def train_linear_dw(dy: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], acc
     wp, lddw = _mat(dw, "dw")
     if x.shape[0] != m or tuple(dw.shape) != (n, k) or (db is not None and tuple(db.shape) != (n,)):
         raise ValueError(f"train_linear_dw: dy {tuple(dy.shape)}, x {tuple(x.shape)}, dw {tuple(dw.shape)}")
-    need = int(hip.lib().stnerf_train_dw_workspace_bytes(m, n, k))
-    # one workspace per device and stream, grown on demand (a backward issues ~10 of these calls per chunk on one stream: they run
-    # in order, so the partial tiles of one may overwrite the previous call's; up to 64 MB each -- ADVICE r04)
-    key = (dy.device, torch.cuda.current_stream(dy.device).cuda_stream)
-    ws = _DW_WORKSPACE.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _DW_WORKSPACE[key] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=dy.device)
+    ws = _dw_workspace(int(hip.lib().stnerf_train_dw_workspace_bytes(m, n, k)), dy.device)
     hip.check(hip.lib().stnerf_train_linear_dw(dp, lddy, xp, ldx, m, n, k, wp, lddw, hip.dptr(db, name="db"), int(accumulate),
                                                hip.dptr(ws, torch.uint8, "workspace"), ws.numel(), hip.stream_ptr()), "stnerf_train_linear_dw")
+
+
+def _dw_workspace(need: int, device) -> Tensor:
+    # one workspace per device and stream, grown on demand (a backward's calls run in order on one stream, so the partial tiles of
+    # one may overwrite the previous call's -- ADVICE r04)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _DW_WORKSPACE.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _DW_WORKSPACE[key] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+    return ws
+
+
+DW_BATCH_MAX = 16
+
+
+def train_dw_batch(layers: Sequence[Tuple[Tensor, Tensor, Tensor, Optional[Tensor]]], accumulate: bool) -> None:
+    """For every (dy (m,n), x (m,k), dw (n,k), db (n,) | None) of `layers` (the same m): dw (+)= dy.T @ x, db (+)= dy.sum(0) --
+    stnerf_train_dw_batch: all weight and bias gradients of a network in one launch and one deterministic reduction."""
+    if not layers:
+        return
+    if len(layers) > DW_BATCH_MAX:
+        raise ValueError(f"train_dw_batch: {len(layers)} layers, at most {DW_BATCH_MAX}")
+    m = layers[0][0].shape[0]
+    arr = (hip.DwProblem * len(layers))()
+    for i, (dy, x, dw, db) in enumerate(layers):
+        n, k = dy.shape[1], x.shape[1]
+        dp, lddy = _mat(dy, f"dy[{i}]", True)
+        xp, ldx = _mat(x, f"x[{i}]", True)
+        wp, lddw = _mat(dw, f"dw[{i}]")
+        if dy.shape[0] != m or x.shape[0] != m or tuple(dw.shape) != (n, k) or (db is not None and tuple(db.shape) != (n,)):
+            raise ValueError(f"train_dw_batch: layer {i}: dy {tuple(dy.shape)}, x {tuple(x.shape)}, dw {tuple(dw.shape)}, m = {m}")
+        bp = hip.dptr(db, name=f"db[{i}]")
+        arr[i] = hip.DwProblem(dp.value, lddy, xp.value, ldx, wp.value, lddw, bp.value if bp is not None else None, n, k)
+    need = int(hip.lib().stnerf_train_dw_batch_workspace_bytes(arr, len(layers), m))
+    if need < 0:
+        hip.check(need, "stnerf_train_dw_batch_workspace_bytes")
+    ws = _dw_workspace(need, layers[0][0].device)
+    hip.check(hip.lib().stnerf_train_dw_batch(arr, len(layers), m, int(accumulate), hip.dptr(ws, torch.uint8, "workspace"), ws.numel(),
+                                              hip.stream_ptr()), "stnerf_train_dw_batch")
 
 
 def train_encode(x: Tensor, y: Tensor, n_freq: int, include_input: bool = True, rows_per_src: int = 1, relu: bool = False,
