@@ -78,15 +78,20 @@ __device__ __forceinline__ Operand make_operand(const float* src, int64_t ld, in
     o.step = k_contig ? GBK * 4u : (uint32_t)(GBK * ld * 4);
     return o;
 }
+// 16-byte vectors per thread and slice.  (A row-contiguous tile moves in units of 4 k x 4 rows = four vectors: 2 ROWS units, so a
+// 64-row tile -- the narrow items of stnerf_train_dw_batch -- keeps only threads t < 128 busy: tile_active.)
+constexpr int tile_vecs(bool k_contig, int rows) { return k_contig || rows >= 128 ? rows / 32 : 4; }
 template <bool K_CONTIG, int ROWS>
-__device__ __forceinline__ void lane_offsets(uint32_t (&off)[ROWS / 32], int64_t ld, int r0, int t) {
+__device__ __forceinline__ bool tile_active(int t) { return K_CONTIG || ROWS >= 128 || t < 2 * ROWS; }
+template <bool K_CONTIG, int ROWS>
+__device__ __forceinline__ void lane_offsets(uint32_t (&off)[tile_vecs(K_CONTIG, ROWS)], int64_t ld, int r0, int t) {
     if (K_CONTIG) {
 #pragma unroll
         for (int i = 0; i < ROWS / 32; ++i) off[i] = (uint32_t)(((int64_t)(r0 + (t >> 3) + 32 * i) * ld + 4 * (t & 7)) * 4);
     } else {
         constexpr int RQ = ROWS / 4;
 #pragma unroll
-        for (int u = 0; u < ROWS / 128; ++u) {
+        for (int u = 0; u < tile_vecs(false, ROWS) / 4; ++u) {
             const int f = t + 256 * u;
 #pragma unroll
             for (int j = 0; j < 4; ++j) off[4 * u + j] = (uint32_t)(((int64_t)(4 * (f / RQ) + j) * ld + r0 + 4 * (f % RQ)) * 4);
@@ -104,7 +109,7 @@ __device__ __forceinline__ void load_tile(float4 (&v)[NV], const Operand& op, co
 // ... and into LDS.  k_left = elements of the reduction range left from this slice's first k: only the k-contiguous flavour
 // can see a range end inside its rows (K % 32 != 0: the last slice), and only then (TAIL) are the elements selected.
 template <bool K_CONTIG, int ROWS, bool TAIL>
-__device__ __forceinline__ void store_tile(float* lds, const float4 (&v)[ROWS / 32], int k_left, int t) {
+__device__ __forceinline__ void store_tile(float* lds, const float4 (&v)[tile_vecs(K_CONTIG, ROWS)], int k_left, int t) {
     if (K_CONTIG) {
 #pragma unroll
         for (int i = 0; i < ROWS / 32; ++i) {
@@ -121,7 +126,7 @@ __device__ __forceinline__ void store_tile(float* lds, const float4 (&v)[ROWS / 
     } else {
         constexpr int RQ = ROWS / 4;
 #pragma unroll
-        for (int u = 0; u < ROWS / 128; ++u) {
+        for (int u = 0; u < tile_vecs(false, ROWS) / 4; ++u) {
             const int f = t + 256 * u, q = f / RQ, row = 4 * (f % RQ);
             const float4 x0 = v[4 * u], x1 = v[4 * u + 1], x2 = v[4 * u + 2], x3 = v[4 * u + 3];
             *reinterpret_cast<float4*>(lds + lds_quad(row, q)) = make_float4(x0.x, x1.x, x2.x, x3.x);
@@ -142,7 +147,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, float* smem_gemm, i
     float* As = smem_gemm;
     float* Bs = smem_gemm + GBM * GLD;
     constexpr int NJ = BN / 64;                // 32-column MFMA tiles per wave
+    constexpr int NVA = tile_vecs(A_KC, GBM), NVB = tile_vecs(B_KC, BN);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, c = lane & 31;
+    const bool b_active = tile_active<B_KC, BN>(t);   // (wave-uniform; constant true but for the 64-column items)
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
     f32x16 acc[2][NJ];
 #pragma unroll
@@ -154,13 +161,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, float* smem_gemm, i
     // A' = [M rows][K] (k-contiguous) or [K rows][M] (row-contiguous); B' likewise with N
     const Operand opa = make_operand(a.A, a.lda, A_KC ? a.M : a.K, A_KC ? a.K : a.M, A_KC);
     const Operand opb = make_operand(a.B, a.ldb, B_KC ? a.N : a.K, B_KC ? a.K : a.N, B_KC);
-    uint32_t offa[GBM / 32], offb[BN / 32];
+    uint32_t offa[NVA], offb[NVB];
     lane_offsets<A_KC, GBM>(offa, a.lda, m0, t);
     lane_offsets<B_KC, BN>(offb, a.ldb, n0, t);
     uint32_t sa = (uint32_t)(k_begin / GBK) * opa.step, sb = (uint32_t)(k_begin / GBK) * opb.step;   // this slice's scalar offsets
-    float4 ra[GBM / 32], rb[BN / 32];
+    float4 ra[NVA], rb[NVB];
     load_tile(ra, opa, offa, sa);
-    load_tile(rb, opb, offb, sb);
+    if (b_active) load_tile(rb, opb, offb, sb);
     // this lane's operand rows (the swizzle term (row >> 2) & 7 = (c >> 2) & 7 is the same for every 32-row block)
     const float* arow = As + (wm + c) * GLD;
     const float* brow = Bs + (wn + c) * GLD;
@@ -205,17 +212,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, float* smem_gemm, i
         __syncthreads();                       // the previous slice has been consumed
         if (tail) {
             store_tile<A_KC, GBM, true>(As, ra, k_end - k0, t);
-            store_tile<B_KC, BN, true>(Bs, rb, k_end - k0, t);
+            if (b_active) store_tile<B_KC, BN, true>(Bs, rb, k_end - k0, t);
         } else {
             store_tile<A_KC, GBM, false>(As, ra, 0, t);
-            store_tile<B_KC, BN, false>(Bs, rb, 0, t);
+            if (b_active) store_tile<B_KC, BN, false>(Bs, rb, 0, t);
         }
         __syncthreads();
         if (k0 + GBK < k_end) {                // the next slice's loads fly under this slice's MFMAs
             sa += opa.step;
             sb += opb.step;
             load_tile(ra, opa, offa, sa);
-            load_tile(rb, opb, offb, sb);
+            if (b_active) load_tile(rb, opb, offb, sb);
         }
         multiply();
     }
@@ -394,14 +401,64 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y
     colsum_rows<CG>(y, ld, N, blockIdx.x, m_begin, min(M, m_begin + rows_per_block), partial + (int64_t)blockIdx.y * N, red);
 }
 
+// A layer of at most four outputs (the density and colour heads, MotionNet's last layer): dW[j][c] = sum_m dy[m][j] x[m][c] is
+// four weighted column sums of X -- HBM-bound vector code like colsum_rows, where a 128-row MFMA tile would multiply 124 rows of
+// nothing.  dy rows are read as one 16-byte vector (the caller guarantees round4(n) readable floats), only rows j < n are stored.
+template <int CG>
+__device__ __forceinline__ void thin_rows(const float* __restrict__ dy, int64_t lddy, int n, const float* __restrict__ x, int64_t ldx, int K,
+                                          int col_block, int m_begin, int m_end, float* __restrict__ out, float4* red) {
+    constexpr int RL = 256 / CG;
+    const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+    const int col = 4 * (col_block * CG + cg);
+    float4 s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < K) {
+        const float* p = x + col;
+        auto row = [&](const float4& w, const float4& v) {
+            s[0].x += w.x * v.x; s[0].y += w.x * v.y; s[0].z += w.x * v.z; s[0].w += w.x * v.w;
+            s[1].x += w.y * v.x; s[1].y += w.y * v.y; s[1].z += w.y * v.z; s[1].w += w.y * v.w;
+            s[2].x += w.z * v.x; s[2].y += w.z * v.y; s[2].z += w.z * v.z; s[2].w += w.z * v.w;
+            s[3].x += w.w * v.x; s[3].y += w.w * v.y; s[3].z += w.w * v.z; s[3].w += w.w * v.w;
+        };
+        int m = m_begin + rl;
+        for (; m + 3 * RL < m_end; m += 4 * RL) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)m * ldx), v1 = *reinterpret_cast<const float4*>(p + (int64_t)(m + RL) * ldx);
+            const float4 v2 = *reinterpret_cast<const float4*>(p + (int64_t)(m + 2 * RL) * ldx), v3 = *reinterpret_cast<const float4*>(p + (int64_t)(m + 3 * RL) * ldx);
+            const float4 w0 = *reinterpret_cast<const float4*>(dy + (int64_t)m * lddy), w1 = *reinterpret_cast<const float4*>(dy + (int64_t)(m + RL) * lddy);
+            const float4 w2 = *reinterpret_cast<const float4*>(dy + (int64_t)(m + 2 * RL) * lddy), w3 = *reinterpret_cast<const float4*>(dy + (int64_t)(m + 3 * RL) * lddy);
+            row(w0, v0); row(w1, v1); row(w2, v2); row(w3, v3);
+        }
+        for (; m < m_end; m += RL) row(*reinterpret_cast<const float4*>(dy + (int64_t)m * lddy), *reinterpret_cast<const float4*>(p + (int64_t)m * ldx));
+    }
+    for (int j = 0; j < n; ++j) {                       // (n is uniform; the row lanes fold through LDS in lane order, one output row at a time)
+        __syncthreads();
+        red[rl * CG + cg] = j == 0 ? s[0] : j == 1 ? s[1] : j == 2 ? s[2] : s[3];
+        __syncthreads();
+        if (rl == 0 && col < K) {
+            float4 t = red[cg];
+            for (int r = 1; r < RL; ++r) {
+                const float4 u = red[r * CG + cg];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            float* o = out + (int64_t)j * K + col;
+            o[0] = t.x;
+            if (col + 1 < K) o[1] = t.y;
+            if (col + 2 < K) o[2] = t.z;
+            if (col + 3 < K) o[3] = t.w;
+        }
+    }
+}
+
 // ---- every weight and bias gradient of a network in ONE launch (stnerf_train_dw_batch) -------------------------------------
 // The layers' dW = dY^T X share the contraction (the samples), so they share the slicing: slice z = rows [z kps, (z + 1) kps) of
 // every layer's dY and X.  A work item is (slice, tile) -- a 128 x 256 or 128 x 128 piece of one layer's dW reduced over the
 // slice into a partial tile -- or (slice, bias): the column sums of one layer's dY over the slice (HBM-bound vector code that
-// runs NEXT to the MFMA items of other workgroups instead of in a launch of its own).  Items are ordered slice-major and dealt
+// runs NEXT to the MFMA items of other workgroups instead of in a launch of its own) -- or (slice, thin layer, 256 columns): a layer
+// of <= 4 outputs as weighted column sums (thin_rows).  Items are ordered slice-major and dealt
 // to the XCDs in contiguous ranges (hardware workgroup b runs on XCD b % 8): the tiles that read the same rows of X and dY
-// are neighbours on one XCD's L2.  The widths 319 / 304 of stage2.0 / rgb_net.1 take a 256- and a 128-column item (launched
-// alone they were two 256-column tiles).  The partials are summed in slice order by dw_reduce_kernel: deterministic, no atomics.
+// are neighbours on one XCD's L2.  The widths 319 / 304 of stage2.0 / rgb_net.1 take a 256- and a 64-column item (launched
+// alone they were two 256-column tiles), the 63 columns of stage1.0 one 64-column item per row tile.  The partials are summed in slice order by dw_reduce_kernel: deterministic, no atomics.
 constexpr int DW_MAX_PROBLEMS = 16, DW_MAX_TILES = 64, DW_MAX_SEGMENTS = 2 * DW_MAX_PROBLEMS;
 struct DwProblem {
     const float* dy;
@@ -411,20 +468,21 @@ struct DwProblem {
     int32_t n, k;
 };
 struct DwTile {
-    uint16_t problem, m0, n0, wide;
+    uint16_t problem, m0, n0, kind;   // kind 0: 128 x 128 MFMA item, 1: 128 x 256, 3: 128 x 64, 2: thin layer, 256 columns from n0
 };
 struct DwBatchArgs {
     DwProblem p[DW_MAX_PROBLEMS];
     DwTile tile[DW_MAX_TILES];
     uint8_t bias_problem[DW_MAX_PROBLEMS];
     int32_t n_tiles, n_bias, slices, kps, m;
+    int32_t plain_order;             // development: work items in launch order instead of dealt to the XCDs (STNERF_DEV_DW_PLAIN_ORDER=1)
     uint32_t items, items_per_xcd;
     float* workspace;
 };
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void train_dw_batch_kernel(DwBatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem_gemm[];
-    const uint32_t w = (blockIdx.x & 7u) * a.items_per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= a.items_per_xcd || w >= a.items) return;
+    const uint32_t w = a.plain_order ? blockIdx.x : (blockIdx.x & 7u) * a.items_per_xcd + (blockIdx.x >> 3);
+    if (w >= a.items) return;
     const int per_slice = a.n_tiles + a.n_bias;
     const int z = (int)(w / (uint32_t)per_slice), i = (int)(w % (uint32_t)per_slice);
     const int k_begin = z * a.kps, k_end = min(a.m, k_begin + a.kps);
@@ -433,10 +491,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
         const DwProblem& p = a.p[tl.problem];
         const GemmArgs g{p.dy, p.x, nullptr, p.lddy, p.ldx, 0, p.n, p.k, a.m, nullptr, nullptr, 0, 0, 0, a.kps};
         float* out = a.workspace + p.partial_off + (int64_t)z * p.n * p.k;
-        if (tl.wide)
+        if (tl.kind == 1)
             gemm_tile<false, false, 2, 256>(g, smem_gemm, tl.m0, tl.n0, k_begin, k_end, out, p.k);
-        else
+        else if (tl.kind == 0)
             gemm_tile<false, false, 2, 128>(g, smem_gemm, tl.m0, tl.n0, k_begin, k_end, out, p.k);
+        else if (tl.kind == 3)
+            gemm_tile<false, false, 2, 64>(g, smem_gemm, tl.m0, tl.n0, k_begin, k_end, out, p.k);
+        else
+            thin_rows<64>(p.dy, p.lddy, p.n, p.x, p.ldx, p.k, tl.n0 / 256, k_begin, k_end, out, reinterpret_cast<float4*>(smem_gemm));
     } else {
         const DwProblem& p = a.p[a.bias_problem[i - a.n_tiles]];
         float* out = a.workspace + p.bias_off + (int64_t)z * p.n;
@@ -664,7 +726,7 @@ static int check_dw_batch(const stnerf_dw_problem* pr, int32_t count, int64_t m)
                        "train_dw_batch: dy / x need 16-byte aligned rows (ld %% 4 == 0) of at least round4(n) / round4(k) floats (problem %d)", i);
         STNERF_REQUIRE(m * q.lddy < (1ll << 29) && m * q.ldx < (1ll << 29), "train_dw_batch: operands of 2 GiB and more: split the batch");
         STNERF_REQUIRE(!q.db || q.n <= 256, "train_dw_batch: bias gradients of at most 256 outputs (problem %d has %d)", i, q.n);
-        tiles += ((q.n + GBM - 1) / GBM) * ((q.k + 255) / 256);
+        tiles += q.n <= 4 ? (q.k + 255) / 256 : ((q.n + GBM - 1) / GBM) * ((q.k + 255) / 256);
     }
     STNERF_REQUIRE(tiles <= DW_MAX_TILES, "train_dw_batch: %d tiles, at most %d", tiles, DW_MAX_TILES);
     return STNERF_OK;
@@ -704,12 +766,16 @@ extern "C" int stnerf_train_dw_batch(const stnerf_dw_problem* problems, int32_t 
         r.seg[segs++] = DwSegment{q.dw, q.lddw, off, q.n * q.k, q.k};
         max_count = q.n * q.k > max_count ? q.n * q.k : max_count;
         off += (int64_t)a.slices * q.n * q.k;
-        // a 256-column item while more than 128 columns are left, then a 128-column one
+        if (q.n <= 4) {                         // a thin layer: weighted column sums, 256 columns per item
+            for (int n0 = 0; n0 < q.k; n0 += 256) a.tile[a.n_tiles++] = DwTile{(uint16_t)i, 0, (uint16_t)n0, 2};
+            continue;
+        }
+        // a 256-column item while more than 128 columns are left, then a 128- or a 64-column one
         for (int m0 = 0; m0 < q.n; m0 += GBM)
             for (int n0 = 0; n0 < q.k;) {
-                const bool wide = q.k - n0 > 128;
-                a.tile[a.n_tiles++] = DwTile{(uint16_t)i, (uint16_t)m0, (uint16_t)n0, (uint16_t)wide};
-                n0 += wide ? 256 : 128;
+                const int left = q.k - n0, kind = left > 128 ? 1 : left > 64 ? 0 : 3;
+                a.tile[a.n_tiles++] = DwTile{(uint16_t)i, (uint16_t)m0, (uint16_t)n0, (uint16_t)kind};
+                n0 += kind == 1 ? 256 : kind == 0 ? 128 : 64;
             }
     }
     for (int i = 0; i < count; ++i)
@@ -722,6 +788,8 @@ extern "C" int stnerf_train_dw_batch(const stnerf_dw_problem* problems, int32_t 
     // (bias partials are [slice][n] with the slice stride n: the padding above is slack for the last slice only)
     a.items = (uint32_t)a.slices * (uint32_t)(a.n_tiles + a.n_bias);
     a.items_per_xcd = (a.items + 7) / 8;
+    static const bool plain = getenv("STNERF_DEV_DW_PLAIN_ORDER") && getenv("STNERF_DEV_DW_PLAIN_ORDER")[0] == '1';
+    a.plain_order = plain;
     hipLaunchKernelGGL(train_dw_batch_kernel, dim3(8 * a.items_per_xcd), dim3(256), (GBM + 256) * GLD * 4, st, a);
     STNERF_CHECK_LAUNCH("train_dw_batch");
     r.workspace = a.workspace;

@@ -100,7 +100,8 @@ def test_dw_batch_matches_fp64_matmuls_layer_by_layer(ops, m):
     g = torch.Generator().manual_seed(m)
     space = [(256, 63), (256, 256), (256, 256), (256, 256), (256, 319), (256, 256), (256, 256), (1, 256), (128, 304), (3, 128)]
     motion = [(128, 84), (128, 128), (128, 128), (128, 128), (128, 128), (3, 128)]
-    for shapes in (space, motion):
+    odd = [(4, 319), (2, 63), (1, 4), (5, 130), (130, 5)]      # thin layers (<= 4 outputs: weighted column sums) of every width, and neighbours
+    for shapes in (space, motion, odd):
         dys = [torch.randn(m, n, generator=g) for n, _ in shapes]
         xs = [torch.relu(torch.randn(m, k, generator=g)) for _, k in shapes]
         dyd, xd = [_padded(t) for t in dys], [_padded(t, 4) for t in xs]
