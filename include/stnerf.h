@@ -408,6 +408,27 @@ int stnerf_train_spacenet_dx(const float* wt, const uint32_t* offsets_host, cons
                              int64_t relu_bits_stride, float* const* dy_host, const int32_t* ld_dy_host, float* dpe, int32_t ld_dpe,
                              stnerf_stream_t stream);
 
+/* The MotionNet's backward (modeling/motion_net.py:20-71 under loss.backward()) as the same two launches (csrc/train_wave.hip):
+ *
+ * stnerf_train_motionnet_fwd: flow[row][3] = MotionNet(xt[row] = {x, y, z, frame id}) with the arithmetic of the inference kernels'
+ * MotionNet (exact f32; motion_flags: STNERF_MOTION_PLAIN_TIME or 0, as stnerf_motionnet_fwd), writing what the backward needs as
+ * the rows pass through the registers: enc[row][ld_enc] = the 84 encoded features (+ 4 zeros; fractional frame ids blended as
+ * motion_net.py:52-60 does), act[s][row][ld_act[s]] = the post-ReLU outputs of motion_net.0, .2, .4, .6, .8 (128 columns), and
+ * relu_bits: stage s's plane at relu_bits + s * relu_bits_stride, 4 words per row (the masks [act_s > 0], 16 bytes per row and layer,
+ * in the lane order of the wave kernels).
+ *
+ * stnerf_train_motionnet_dx: from d_flow[rows][4] (dLoss / d flow in columns 0 .. 2) back through the five hidden layers with the
+ * gradient in registers: dy[s][row][ld_dy[s]] = dLoss / d (pre-activation of motion_net.{0,2,4,6,8}[s]) (128 columns), the left
+ * operands of the weight gradients, and denc[row][ld_denc] (may be NULL; 96 columns written, 84 meaningful) = dLoss / d encoding
+ * for stnerf_train_encode_bwd.  wt: transposed sections [128 / 4][128][4] of motion_net.0 (its 84 inputs zero-padded to 128) and
+ * .2 .. .8 at offsets_host[0 .. 4], the flow head's [3][128] as it is at [5] (float offsets, multiples of 4). */
+int stnerf_train_motionnet_fwd(const void* packed, const float* xt, int64_t rows, int motion_flags, float* flow, float* enc, int32_t ld_enc,
+                               float* const* act_host, const int32_t* ld_act_host, uint32_t* relu_bits, int64_t relu_bits_stride,
+                               stnerf_stream_t stream);
+int stnerf_train_motionnet_dx(const float* wt, const uint32_t* offsets_host, const float* d_flow, int64_t rows, const uint32_t* relu_bits,
+                              int64_t relu_bits_stride, float* const* dy_host, const int32_t* ld_dy_host, float* denc, int32_t ld_denc,
+                              stnerf_stream_t stream);
+
 /* The whole chunk pipeline of LayeredRFRender.forward (modeling/layered_rfrender.py:141-734) behind one call:
  * coarse sampler -> mask compaction -> [MotionNet] -> SpaceNets -> composite/merge -> resample -> [MotionNet] ->
  * fine SpaceNets -> composite/merge, all enqueued on `stream` into a caller-provided workspace.  Host-side

@@ -392,6 +392,7 @@ constexpr int TAP_PE = 100;
 struct NoTap {
     template <int NBLK>
     __device__ __forceinline__ void blocks(int, const f32x16 (&)[NBLK], int, int) const {}
+    __device__ __forceinline__ void flow(const float (&)[3], int) const {}
 };
 template <bool DEEP, class Mid, class Tap = NoTap>
 __device__ __forceinline__ float4 space_wave(const float* net, const bool use_time, float* encw, const float (&p)[3],
@@ -519,8 +520,12 @@ __device__ __forceinline__ float4 space_wave(const float* net, const bool use_ti
 // ---------------------------------------------------------------------------------------------
 // MotionNet on the wave's 32 samples: p += flow (modeling/layered_rfrender.py:356,510).
 // ---------------------------------------------------------------------------------------------
+// `tap` (training, csrc/train_wave.hip): stage TAP_PE = the staged encoding (3 blocks, 11 K steps), 0 .. 4 = the post-ReLU outputs of
+// motion_net.0 .. .8 (4 blocks), and the flow itself.
+template <class Tap = NoTap>
 __device__ __forceinline__ void motion_wave(const float* net, float* encw, float (&p)[3], float tv, int flags, int lane,
-                                            f32x16 (&acc)[8], f32x16 (&in)[8], float4 (&wa)[8], float4 (&wb)[8] WV_DBG_PARAM WP_PARAM) {
+                                            f32x16 (&acc)[8], f32x16 (&in)[8], float4 (&wa)[8], float4 (&wb)[8] WV_DBG_PARAM WP_PARAM,
+                                            const Tap& tap = Tap()) {
     const MotionLayout L = motion_layout();
     const __amdgpu_buffer_rsrc_t rsrc = weight_rsrc(net);
     const int h = lane >> 5, c = lane & 31;
@@ -550,6 +555,7 @@ __device__ __forceinline__ void motion_wave(const float* net, float* encw, float
         stage_bias_issue<2>(hst, rsrc, lane, ho, 32);
     }
     WV_DBG(199, me, 3);
+    tap.template blocks<3>(TAP_PE, me, 3, lane);
     WP(WP_M_ENC);
     // motion_net.0: 11 K steps (22 quads) = 5 step pairs + a half pair (every layer here runs in step pairs)
     segment_p<3, 11, 0, 8>(acc, me, wa, wb, rsrc, wl128p, (uint32_t)L.w[0] * 4u, WSTEP128, nx128p, (uint32_t)L.w[1] * 4u);
@@ -558,6 +564,7 @@ __device__ __forceinline__ void motion_wave(const float* net, float* encw, float
     for (int li = 1; li <= 4; ++li) {
         relu_rebias<4, 4>(acc, in, biasw + (li - 1) * 256, lane);  // the previous layer's ReLU, this layer's bias
         WV_DBG(199 + li, in, 4);
+        tap.template blocks<8>(li - 1, in, 4, lane);
         const uint32_t soff = (uint32_t)L.w[1] * 4u + (uint32_t)(li - 1) * (32u * 128u * 16u + 512u);
         const uint32_t next_w = soff + 32u * 128u * 16u + 512u;
         // (behind motion_net.8 nothing follows: the fetch is discarded, so it re-reads this layer's first rows -- a full
@@ -567,9 +574,11 @@ __device__ __forceinline__ void motion_wave(const float* net, float* encw, float
     }
     relu_rebias<4, 0>(acc, in, biasw, lane);
     WV_DBG(204, in, 4);
+    tap.template blocks<8>(4, in, 4, lane);
     WP(WP_M_LAYERS);
     float fl[3];
     head3(in, biasw + 4 * 256, net + L.b_out, lane, fl);
+    tap.flow(fl, lane);
 #pragma unroll
     for (int c3 = 0; c3 < 3; ++c3) p[c3] = p[c3] + fl[c3];
     WP(WP_M_HEAD);

@@ -175,6 +175,175 @@ __global__ __launch_bounds__(WV_THREADS, 1) void train_space_dx_kernel(DxArgs a)
     }
 }
 
+// ---- MotionNet (modeling/motion_net.py:20-71): the same two launches ---------------------------------------------------------
+// Forward = motion_wave, the inference kernel's MotionNet, on rows [xyz | t], with a tap that writes the staged encoding (the right
+// operand of motion_net.0's weight gradient), the five post-ReLU outputs and their masks as bit planes (8 bytes per lane and layer:
+// two words for the lane's 64 values), and the flow.
+struct MotionTapArgs {
+    float* enc;          // [rows][ld_enc]: the 84 encoded features + 4 zeros
+    int32_t ld_enc;
+    float* act[5];       // the post-ReLU outputs of motion_net.0 .. .8: [rows][ld_act[s]], 128 columns
+    int32_t ld_act[5];
+    uint32_t* bits;      // [5][.. bits_stride ..], rows x 4 words per stage: value 16 fb + i of lane (h, row & 31) <-> bit (16 fb + i) & 31 of word (fb >> 1) + 2 h
+    int64_t bits_stride;
+    float* flow;         // [rows][3]
+};
+struct MotionStoreTap {
+    const MotionTapArgs* a;
+    uint32_t row;
+    bool valid;
+    template <int NBLK>
+    __device__ __forceinline__ void blocks(int stage, const f32x16 (&blk)[NBLK], int, int lane) const {
+        if (!valid) return;
+        const int h = lane >> 5;
+        if constexpr (NBLK == 3) {      // the encoding: K steps 0 .. 10 = quads 2 s + h
+            float4* p = reinterpret_cast<float4*>(a->enc + (size_t)row * (size_t)a->ld_enc + 4 * h);
+#pragma unroll
+            for (int s = 0; s < 11; ++s)
+                p[2 * s] = make_float4(blk[s >> 2][4 * (s & 3) + 0], blk[s >> 2][4 * (s & 3) + 1], blk[s >> 2][4 * (s & 3) + 2], blk[s >> 2][4 * (s & 3) + 3]);
+        } else {
+            float4* p = reinterpret_cast<float4*>(a->act[stage] + (size_t)row * (size_t)a->ld_act[stage] + 4 * h);
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    p[fb * 8 + 2 * q] = make_float4(blk[fb][4 * q + 0], blk[fb][4 * q + 1], blk[fb][4 * q + 2], blk[fb][4 * q + 3]);
+            uint32_t w[2] = {0u, 0u};
+#pragma unroll
+            for (int wd = 0; wd < 2; ++wd)
+#pragma unroll
+                for (int j = 31; j >= 0; --j) {
+                    uint32_t t;     // (see StoreTap in mlp_wave.hip: min(bits, 1), shift-or)
+                    asm volatile("v_min_u32 %1, 1, %2\n\tv_lshl_or_b32 %0, %0, 1, %1" : "+v"(w[wd]), "=&v"(t) : "v"(blk[2 * wd + (j >> 4)][j & 15]));
+                }
+            *reinterpret_cast<uint2*>(a->bits + (size_t)stage * (size_t)a->bits_stride + (size_t)row * 4u + 2u * (uint32_t)h) = make_uint2(w[0], w[1]);
+        }
+    }
+    __device__ __forceinline__ void flow(const float (&fl)[3], int lane) const {
+        if (valid && lane < 32) {
+            float* o = a->flow + (size_t)row * 3u;
+            o[0] = fl[0];
+            o[1] = fl[1];
+            o[2] = fl[2];
+        }
+    }
+};
+struct MotionFwdArgs {
+    const float* net;    // packed MotionNet (exact f32)
+    const float* xt;     // [rows][4]: x, y, z, frame id
+    int64_t rows;
+    int32_t flags;       // STNERF_MOTION_PLAIN_TIME
+    MotionTapArgs tap;
+};
+__global__ __launch_bounds__(WV_THREADS, 1) void train_motion_fwd_kernel(MotionFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem_mf[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* encw = reinterpret_cast<float*>(smem_mf) + wave * WV_WAVE_FLOATS;
+    f32x16 acc[8], in[8];
+    float4 wa[8], wb[8];
+#ifdef STNERF_WAVE_DEBUG
+    const WaveDbg dbg{nullptr, 0, -1};
+#endif
+#ifdef STNERF_WAVE_PROF
+    WaveProf wp;
+    for (int i = 0; i < 16; ++i) wp.acc[i] = 0;
+    wp.t = clock64();
+#endif
+    const int64_t items = (a.rows + WV_ITEM - 1) / WV_ITEM;
+    for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const int64_t row = item * WV_ITEM + wave * WV_ROWS + (lane & 31);
+        const bool valid = row < a.rows;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) x = *reinterpret_cast<const float4*>(a.xt + row * 4);
+        float p[3] = {x.x, x.y, x.z};
+        const MotionStoreTap tap{&a.tap, (uint32_t)row, valid};
+        motion_wave(a.net, encw, p, x.w, a.flags, lane, acc, in, wa, wb WV_DBG_ARG WP_ARG, tap);
+    }
+}
+
+// Backward chain: d a_{l-1} = (d a_l * [a_l > 0]) W_l from the flow head back to motion_net.0's input, the gradient in the wave's
+// registers between layers (128-wide products in K-step pairs like the forward), every masked gradient written once (the left
+// operands of the weight gradients), and -- DX -- d enc = d y_0 W_0 for the encodings' chain rule.
+struct MotionDxArgs {
+    const float* wt;          // sections [128/4][128][4] of motion_net.0 (inputs 84 padded to 128), .2, .4, .6, .8; then the head [3][128]
+    const float* d_flow;      // [rows][4]: dLoss / d flow in columns 0 .. 2
+    const uint32_t* bits;
+    int64_t bits_stride;
+    float* dy[5];
+    int32_t ld_dy[5];
+    float* denc;              // [rows][ld_denc], 96 columns written (84 used) -- DX only
+    int32_t ld_denc;
+    int64_t rows;
+    uint32_t o_l[5], o_head;
+};
+template <bool DX>
+__global__ __launch_bounds__(WV_THREADS, 1) void train_motion_dx_kernel(MotionDxArgs a) {
+    __shared__ __attribute__((aligned(16))) float heads[3 * 128];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    for (int i = tid; i < 384; i += WV_THREADS) heads[i] = a.wt[a.o_head + i];
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rsrc = weight_rsrc(a.wt);
+    constexpr uint32_t WSTEP128 = 2u * 128u * 16u;
+    const LaneOfs wl128p = lane_offsets_paired((uint32_t)(h * 128 + c) * 16u, WSTEP128);
+    const NextOfs nx128p{(uint32_t)(h * 128 + c) * 16u, true, WSTEP128};
+    f32x16 acc[8], in[8];
+    float4 wa[8], wb[8];
+    const int64_t items = (a.rows + WV_ITEM - 1) / WV_ITEM;
+    for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const int64_t row = item * WV_ITEM + wave * WV_ROWS + c;
+        const bool valid = row < a.rows;
+        const int64_t r = valid ? row : 0;
+        auto yrow = [&](int s) { return a.dy[s] + r * a.ld_dy[s] + 4 * h; };
+        load_w<8>(wa, rsrc, wl128p, a.o_l[4] * 4u);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) g = *reinterpret_cast<const float4*>(a.d_flow + r * 4);
+        uint4 bw[5];
+#pragma unroll
+        for (int sidx = 0; sidx < 5; ++sidx) {
+            uint2 t = make_uint2(0u, 0u);
+            if (valid) t = *reinterpret_cast<const uint2*>(a.bits + (size_t)sidx * (size_t)a.bits_stride + (size_t)r * 4u + 2u * (uint32_t)h);
+            bw[sidx] = make_uint4(t.x, t.y, 0u, 0u);
+        }
+        // the flow head backwards: d a4[f] = sum_o d flow[o] W[o][f] (motion_net.10)
+        {
+            const float4* w4 = reinterpret_cast<const float4*>(heads) + h;
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w0 = w4[2 * (fb * 4 + q)], w1 = w4[32 + 2 * (fb * 4 + q)], w2 = w4[64 + 2 * (fb * 4 + q)];
+                    acc[fb][4 * q + 0] = g.x * w0.x + g.y * w1.x + g.z * w2.x;
+                    acc[fb][4 * q + 1] = g.x * w0.y + g.y * w1.y + g.z * w2.y;
+                    acc[fb][4 * q + 2] = g.x * w0.z + g.y * w1.z + g.z * w2.z;
+                    acc[fb][4 * q + 3] = g.x * w0.w + g.y * w1.w + g.z * w2.w;
+                }
+        }
+        mask_boundary<4>(acc, in, bw[4], yrow(4), valid);
+#pragma unroll
+        for (int l = 4; l >= 1; --l) {     // through motion_net.8 .. .2
+            const uint32_t next = l > 1 ? a.o_l[l - 1] : (DX ? a.o_l[0] : a.o_l[4]);
+            segment_p<8, 16, 0, 8>(acc, in, wa, wb, rsrc, wl128p, a.o_l[l] * 4u, WSTEP128, nx128p, next * 4u);
+            mask_boundary<4>(acc, in, bw[l - 1], yrow(l - 1), valid);
+        }
+        if constexpr (DX) {
+            segment_p<8, 16, 0, 8>(acc, in, wa, wb, rsrc, wl128p, a.o_l[0] * 4u, WSTEP128, nx128p, a.o_l[4] * 4u);
+            if (valid) {
+                float4* yp = reinterpret_cast<float4*>(a.denc + r * a.ld_denc + 4 * h);
+#pragma unroll
+                for (int fb = 0; fb < 3; ++fb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        yp[fb * 8 + 2 * q] = make_float4(acc[fb][4 * q + 0], acc[fb][4 * q + 1], acc[fb][4 * q + 2], acc[fb][4 * q + 3]);
+            }
+        }
+    }
+}
+
 }  // namespace stnerf
 
 using namespace stnerf;
@@ -260,5 +429,83 @@ extern "C" int stnerf_train_spacenet_dx(const float* wt, const uint32_t* offsets
     else
         hipLaunchKernelGGL(train_space_dx_kernel<false>, dim3(grid), dim3(WV_THREADS), 0, as_stream(stream), a);
     STNERF_CHECK_LAUNCH("train_spacenet_dx");
+    return STNERF_OK;
+}
+
+extern "C" int stnerf_train_motionnet_fwd(const void* packed, const float* xt, int64_t rows, int motion_flags, float* flow, float* enc,
+                                          int32_t ld_enc, float* const* act_host, const int32_t* ld_act_host, uint32_t* relu_bits,
+                                          int64_t relu_bits_stride, stnerf_stream_t stream) {
+    STNERF_REQUIRE(packed && xt && flow && enc && act_host && ld_act_host && relu_bits, "train_motionnet_fwd: null pointer");
+    STNERF_REQUIRE(rows >= 0 && rows <= 0x7fffff00ll, "train_motionnet_fwd: %lld rows (split the batch)", (long long)rows);
+    STNERF_REQUIRE((((uintptr_t)packed | (uintptr_t)xt | (uintptr_t)enc) & 15) == 0 && (ld_enc & 3) == 0 && ld_enc >= 88,
+                   "train_motionnet_fwd: weights, rows and the encoding matrix (>= 88 columns, a multiple of 4) must be 16-byte aligned");
+    STNERF_REQUIRE(((uintptr_t)relu_bits & 7) == 0 && (relu_bits_stride & 1) == 0 && relu_bits_stride >= rows * 4,
+                   "train_motionnet_fwd: relu_bits must be 8-byte aligned, its stage stride even and >= 4 x rows");
+    STNERF_REQUIRE((motion_flags & ~STNERF_MOTION_PLAIN_TIME) == 0, "train_motionnet_fwd: flags %d", motion_flags);
+    if (rows == 0) return STNERF_OK;
+    MotionFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.net = static_cast<const float*>(packed);
+    a.xt = xt;
+    a.rows = rows;
+    a.flags = motion_flags;
+    a.tap.enc = enc;
+    a.tap.ld_enc = ld_enc;
+    for (int i = 0; i < 5; ++i) {
+        STNERF_REQUIRE(act_host[i] && ((uintptr_t)act_host[i] & 15) == 0 && (ld_act_host[i] & 3) == 0 && ld_act_host[i] >= 128,
+                       "train_motionnet_fwd: activation matrix %d must be 16-byte aligned with a row stride that is a multiple of 4 floats", i);
+        a.tap.act[i] = act_host[i];
+        a.tap.ld_act[i] = ld_act_host[i];
+    }
+    a.tap.bits = relu_bits;
+    a.tap.bits_stride = relu_bits_stride;
+    a.tap.flow = flow;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t items = (rows + WV_ITEM - 1) / WV_ITEM;
+    const int grid = (int)(items < cus ? items : cus);
+    if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(train_motion_fwd_kernel), WV_LDS, "train_motionnet_fwd")) return rc;
+    hipLaunchKernelGGL(train_motion_fwd_kernel, dim3(grid), dim3(WV_THREADS), WV_LDS, as_stream(stream), a);
+    STNERF_CHECK_LAUNCH("train_motionnet_fwd");
+    return STNERF_OK;
+}
+
+extern "C" int stnerf_train_motionnet_dx(const float* wt, const uint32_t* offsets_host /* motion_net.0, .2, .4, .6, .8, head */, const float* d_flow,
+                                         int64_t rows, const uint32_t* relu_bits, int64_t relu_bits_stride, float* const* dy_host,
+                                         const int32_t* ld_dy_host, float* denc, int32_t ld_denc, stnerf_stream_t stream) {
+    STNERF_REQUIRE(wt && offsets_host && d_flow && relu_bits && dy_host && ld_dy_host, "train_motionnet_dx: null pointer");
+    STNERF_REQUIRE(rows >= 0 && rows <= 0x7fffff00ll, "train_motionnet_dx: %lld rows (split the batch)", (long long)rows);
+    STNERF_REQUIRE((((uintptr_t)wt | (uintptr_t)d_flow) & 15) == 0 && ((uintptr_t)relu_bits & 7) == 0 && (relu_bits_stride & 1) == 0 &&
+                       relu_bits_stride >= rows * 4,
+                   "train_motionnet_dx: weights and d_flow must be 16-byte aligned, relu_bits 8-byte (stage stride: even, >= 4 x rows)");
+    if (rows == 0) return STNERF_OK;
+    MotionDxArgs a;
+    memset(&a, 0, sizeof(a));
+    a.wt = wt;
+    a.d_flow = d_flow;
+    a.bits = relu_bits;
+    a.bits_stride = relu_bits_stride;
+    a.rows = rows;
+    for (int i = 0; i < 5; ++i) {
+        STNERF_REQUIRE(dy_host[i] && ((uintptr_t)dy_host[i] & 15) == 0 && (ld_dy_host[i] & 3) == 0 && ld_dy_host[i] >= 128,
+                       "train_motionnet_dx: matrix %d must be 16-byte aligned with a row stride that is a multiple of 4 floats", i);
+        a.dy[i] = dy_host[i];
+        a.ld_dy[i] = ld_dy_host[i];
+        a.o_l[i] = offsets_host[i];
+    }
+    a.o_head = offsets_host[5];
+    for (int i = 0; i < 6; ++i) STNERF_REQUIRE((offsets_host[i] & 3) == 0, "train_motionnet_dx: section %d is not 16-byte aligned", i);
+    a.denc = denc;
+    a.ld_denc = ld_denc;
+    STNERF_REQUIRE(!denc || (((uintptr_t)denc & 15) == 0 && (ld_denc & 3) == 0 && ld_denc >= 96), "train_motionnet_dx: d enc needs 96 columns, 16-byte aligned");
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t items = (rows + WV_ITEM - 1) / WV_ITEM;
+    const int grid = (int)(items < cus ? items : cus);
+    if (denc)
+        hipLaunchKernelGGL(train_motion_dx_kernel<true>, dim3(grid), dim3(WV_THREADS), 0, as_stream(stream), a);
+    else
+        hipLaunchKernelGGL(train_motion_dx_kernel<false>, dim3(grid), dim3(WV_THREADS), 0, as_stream(stream), a);
+    STNERF_CHECK_LAUNCH("train_motionnet_dx");
     return STNERF_OK;
 }

@@ -115,6 +115,10 @@ _PROTOS = {
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_int32), c_f32p, C.c_int32, C.c_void_p, c_i64, C.c_void_p, c_f32p, C.c_void_p]),
     "stnerf_train_spacenet_dx": (C.c_int, [c_f32p, C.POINTER(C.c_uint32), c_f32p, c_i64, C.c_void_p, c_i64, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                            c_f32p, C.c_int32, C.c_void_p]),
+    "stnerf_train_motionnet_fwd": (C.c_int, [C.c_void_p, c_f32p, c_i64, C.c_int, c_f32p, c_f32p, C.c_int32, C.POINTER(C.c_void_p),
+                                             C.POINTER(C.c_int32), C.c_void_p, c_i64, C.c_void_p]),
+    "stnerf_train_motionnet_dx": (C.c_int, [c_f32p, C.POINTER(C.c_uint32), c_f32p, c_i64, C.c_void_p, c_i64, C.POINTER(C.c_void_p),
+                                            C.POINTER(C.c_int32), c_f32p, C.c_int32, C.c_void_p]),
     "stnerf_encode": (C.c_int, [c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "stnerf_gen_weight": (C.c_int, [c_f32p, c_f32p, c_i64, C.c_int, c_f32p, C.c_void_p]),
     "stnerf_composite": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_i64, C.c_int, C.c_int, C.POINTER(CompositeParams),

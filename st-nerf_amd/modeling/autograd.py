@@ -279,29 +279,108 @@ class SpaceNetFunction(torch.autograd.Function):
         return (None, d_pos.reshape(n, ns, 3) if d_pos is not None else None, None, None, *grads)
 
 
+MOTION_ACT_FLOATS_PER_SAMPLE = 96 + 5 * 128 + 5 * 4
+
+
+def transposed_motionnet(module, params) -> tuple:
+    """(wt, offsets): the A operands of the MotionNet's backward chain (stnerf_train_motionnet_dx): sections [128 / 4][128][4] of
+    motion_net.0 (84 inputs zero-padded to 128), .2, .4, .6, .8, then the flow head [3][128] as it is.  Cached per parameter version."""
+    key = tuple((p.data_ptr(), p._version) for p in params)
+    cache = getattr(module, "_wt_cache", None)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+
+    def section(w):
+        out, k = w.shape
+        wp = torch.zeros(out, 128, dtype=torch.float32, device=w.device)
+        wp[:, :k] = w.detach().float()
+        return wp.reshape(out // 4, 4, 128).permute(0, 2, 1).contiguous().reshape(-1)
+    W = [params[2 * i] for i in range(6)]
+    parts = [section(W[i]) for i in range(5)] + [W[5].detach().float().reshape(-1)]
+    offsets, off = [], 0
+    for part in parts:
+        offsets.append(off)
+        off += part.numel()
+    wt = torch.cat(parts + [torch.zeros(4096, dtype=torch.float32, device=parts[0].device)])   # (slack for the operand prefetches)
+    module._wt_cache = (key, wt, offsets)
+    return wt, offsets
+
+
+def _motion_buffers(rows: int, device) -> List[torch.Tensor]:
+    """The staged encoding (rows, 96), the five post-ReLU outputs (rows, 128) and the masks as bit planes (5, rows, 4) int32."""
+    return ([_buf(rows, 96, device)] + [_buf(rows, 128, device) for _ in range(5)] + [torch.empty(5, rows, 4, dtype=torch.int32, device=device)])
+
+
 class MotionNetFunction(torch.autograd.Function):
     """flow = MotionNet([xyz, t]) (modeling/motion_net.py:34-71).  ``params`` = weight, bias of motion_net.{0,2,4,6,8,10}."""
 
     @staticmethod
     def forward(ctx, module, xt, *params):
         rows = xt.shape[0]
-        xyz = xt[:, :3].detach().reshape(rows, 1, 3).contiguous()
-        flow = torch.empty_like(xyz)
+        fused = FUSED_BACKWARD and module.pos_dim == 84
+        kept = []
         with torch.no_grad():
-            ops.motionnet_fwd(module._packed("fp32"), xyz, xt[:, 3].detach().contiguous(), flow=flow, add_to_xyz=False,
-                              plain_time=not module.input_time)
-        ctx.module = module
-        ctx.save_for_backward(xt.detach(), *[p.detach() for p in params])
+            if fused and 0 < rows * MOTION_ACT_FLOATS_PER_SAMPLE * 4 <= KEEP_BYTES:
+                # the forward itself keeps what the backward needs (3 KB per row): no recomputation
+                kept = _motion_buffers(rows, xt.device)
+                flow = torch.empty(rows, 3, dtype=torch.float32, device=xt.device)
+                ops.train_motionnet_fwd(module._packed("fp32"), xt.detach().float().contiguous(), flow, kept[0], [b[:, :128] for b in kept[1:6]],
+                                        kept[6], plain_time=not module.input_time)
+            else:
+                xyz = xt[:, :3].detach().reshape(rows, 1, 3).contiguous()
+                flow = torch.empty_like(xyz)
+                ops.motionnet_fwd(module._packed("fp32"), xyz, xt[:, 3].detach().contiguous(), flow=flow, add_to_xyz=False,
+                                  plain_time=not module.input_time)
+        ctx.module, ctx.kept = module, bool(kept)
+        ctx.save_for_backward(xt.detach(), *[p.detach() for p in params], *kept)
         return flow.reshape(rows, 3)
 
     @staticmethod
     def backward(ctx, d_flow):
         xt, *params = ctx.saved_tensors
+        kept = []
+        if ctx.kept:
+            params, kept = params[:-7], list(params[-7:])
         m_ = ctx.module
         inc = m_.pos_dim == 84
         dev = xt.device
         rows = xt.shape[0]
         L = len(params) // 2
+        fused = ctx.kept or (FUSED_BACKWARD and inc)
+        if fused:
+            # ---- two fused launches (csrc/train_wave.hip) + one for every weight gradient: the layers' inputs come from the forward
+            # (kept) or from one more run of it per chunk; the d x chain carries the gradient in registers
+            fresh = torch.empty_like if rows > 0 else torch.zeros_like
+            gW = [fresh(params[2 * i], dtype=torch.float32) for i in range(L)]
+            gB = [fresh(params[2 * i + 1], dtype=torch.float32) for i in range(L)]
+            d_xt = torch.zeros(rows, 4, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+            wt, offsets = transposed_motionnet(m_, params)
+            x4 = xt.float().contiguous()
+            for r0 in range(0, rows, CHUNK_SAMPLES):
+                r1 = min(rows, r0 + CHUNK_SAMPLES)
+                M = r1 - r0
+                x = x4[r0:r1]
+                if kept:
+                    bufs = [b[r0:r1] for b in kept[:6]] + [kept[6][:, r0:r1]]
+                else:
+                    bufs = _motion_buffers(M, dev)
+                    ops.train_motionnet_fwd(m_._packed("fp32"), x, torch.empty(M, 3, dtype=torch.float32, device=dev), bufs[0],
+                                            [b[:, :128] for b in bufs[1:6]], bufs[6], plain_time=not m_.input_time)
+                E, A = bufs[0], [b[:, :128] for b in bufs[1:6]]
+                dO = _buf(M, 3, dev)
+                dO[:, :3] = d_flow[r0:r1]
+                dys = [_buf(M, 128, dev)[:, :128] for _ in range(5)]
+                dE = _buf(M, 96, dev) if d_xt is not None else None
+                ops.train_motionnet_dx(wt, offsets, dO[:, :3], bufs[6], dys, dE)
+                _weight_gradients([(dys[0], E[:, :84], gW[0], gB[0])] + [(dys[j], A[j - 1], gW[j], gB[j]) for j in range(1, 5)] +
+                                  [(dO[:, :3], A[4], gW[5], gB[5])], r0 > 0)
+                if d_xt is not None:
+                    # (the frame-id column gets no gradient: the lerp weights are data)
+                    ops.train_encode_bwd(x, dE[:, :84], d_xt[r0:r1, :3], 10, inc)
+            grads: List[Optional[torch.Tensor]] = []
+            for i in range(L):
+                grads += [gW[i] if ctx.needs_input_grad[2 + 2 * i] else None, gB[i] if ctx.needs_input_grad[3 + 2 * i] else None]
+            return (None, d_xt, *grads)
         W = [_padded_weight(params[2 * i]) for i in range(L)]
         B = [params[2 * i + 1].detach().float().contiguous() for i in range(L)]
         fresh = torch.empty_like if rows > 0 else torch.zeros_like     # (the first chunk writes every gradient whole)

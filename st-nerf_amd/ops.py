@@ -704,3 +704,48 @@ def train_spacenet_dx(wt: Tensor, offsets: Sequence[int], d_raw: Tensor, relu_bi
     hip.check(hip.lib().stnerf_train_spacenet_dx(hip.dptr(wt, name="wt"), off, hip.dptr(d_raw, name="d_raw"), rows,
                                                  bp, bstride, yp, yld, pp, ldp, hip.stream_ptr()),
               "stnerf_train_spacenet_dx")
+
+
+def _motion_bit_planes(bits: Tensor, rows: int):
+    """(pointer, stage stride in words) of a MotionNet's ReLU bit planes: int32 (5, rows, 4), possibly a row range of a larger launch's."""
+    if not bits.is_cuda or bits.dtype != torch.int32 or tuple(bits.shape) != (5, rows, 4) or bits.stride(2) != 1 or bits.stride(1) != 4:
+        raise ValueError(f"relu_bits must be a device int32 (5, {rows}, 4) with dense rows, got {bits.dtype} {tuple(bits.shape)} {bits.stride()}")
+    return C.c_void_p(bits.data_ptr()), bits.stride(0)
+
+
+def train_motionnet_fwd(net: PackedNet, xt: Tensor, flow: Tensor, enc: Tensor, acts: Sequence[Tensor], relu_bits: Tensor,
+                        plain_time: bool = False) -> None:
+    """flow (rows,3) = MotionNet(xt (rows,4) = [xyz | frame id]) with the inference kernels' exact-f32 arithmetic, writing the staged
+    encoding enc (rows, >= 88), the five post-ReLU outputs acts[0..4] (rows,128) -- views into padded row-major storage -- and their
+    masks as bit planes relu_bits (5, rows, 4) int32 (stnerf_train_motionnet_fwd)."""
+    if net.kind != hip.NET_MOTION or net.precision != "fp32":
+        raise ValueError("train_motionnet_fwd wants an exact-f32 packed MotionNet")
+    rows = xt.shape[0]
+    if tuple(xt.shape) != (rows, 4) or not xt.is_contiguous() or tuple(flow.shape) != (rows, 3) or not flow.is_contiguous() or len(acts) != 5:
+        raise ValueError(f"train_motionnet_fwd: xt {tuple(xt.shape)}, flow {tuple(flow.shape)}, {len(acts)} activation matrices")
+    ap, ald = _matrix_list(acts, "acts")
+    ep, lde = _mat(enc, "enc", True)
+    if enc.shape != (rows, enc.shape[1]) or enc.shape[1] < 88 or any(tuple(m.shape) != (rows, 128) for m in acts):
+        raise ValueError("train_motionnet_fwd: enc needs >= 88 columns, the activation matrices 128, one row per sample")
+    bp, bstride = _motion_bit_planes(relu_bits, rows)
+    hip.check(hip.lib().stnerf_train_motionnet_fwd(hip.dptr(net.blob), hip.dptr(xt, name="xt"), rows, hip.MOTION_PLAIN_TIME if plain_time else 0,
+                                                   hip.dptr(flow, name="flow"), ep, lde, ap, ald, bp, bstride, hip.stream_ptr()),
+              "stnerf_train_motionnet_fwd")
+
+
+def train_motionnet_dx(wt: Tensor, offsets: Sequence[int], d_flow: Tensor, relu_bits: Tensor, dys: Sequence[Tensor], denc: Optional[Tensor]) -> None:
+    """The backward chain through one MotionNet (stnerf_train_motionnet_dx): d_flow (rows,3) as a view of (rows,4) storage -> dys[0..4]
+    (rows,128), the layers' pre-activation gradients, and, if given, denc (rows, >= 96) = dLoss / d encoding.  wt / offsets:
+    stnerf_amd.modeling.autograd.transposed_motionnet."""
+    rows = d_flow.shape[0]
+    dp, ldf = _mat(d_flow, "d_flow", True)
+    if d_flow.shape[1] != 3 or ldf != 4 or len(dys) != 5 or any(tuple(m.shape) != (rows, 128) for m in dys):
+        raise ValueError(f"train_motionnet_dx: d_flow {tuple(d_flow.shape)} (row stride {ldf}), {len(dys)} gradient matrices")
+    bp, bstride = _motion_bit_planes(relu_bits, rows)
+    yp, yld = _matrix_list(dys, "dys")
+    off = (C.c_uint32 * 6)(*[int(o) for o in offsets])
+    pp, ldp = _mat(denc, "denc", True) if denc is not None else (C.c_void_p(0), 0)
+    if denc is not None and (denc.shape[0] != rows or denc.shape[1] < 96):
+        raise ValueError(f"train_motionnet_dx: denc {tuple(denc.shape)} needs {rows} rows of >= 96 columns")
+    hip.check(hip.lib().stnerf_train_motionnet_dx(hip.dptr(wt, name="wt"), off, dp, rows, bp, bstride, yp, yld, pp, ldp, hip.stream_ptr()),
+              "stnerf_train_motionnet_dx")

@@ -464,6 +464,88 @@ def test_fused_backward_matches_the_layerwise_backward(ops, monkeypatch, use_tim
         assert torch.equal(a, r), k                     # the same kernels on the same rows: bit-identical
 
 
+def _motion_case(input_time, rows=1237, seed=4):
+    from stnerf_amd.modeling.motion_net import MotionNet
+    sd = syn.motionnet_state("net", np.random.RandomState(seed))
+    net = MotionNet(c_input=4, input_time=input_time)
+    net.load_state_dict({k[4:]: v for k, v in sd.items()})
+    net = net.cuda()
+    g = torch.Generator().manual_seed(seed)
+    xyz = (torch.rand(rows, 3, generator=g) - 0.5) * 4.0
+    t = torch.where(torch.rand(rows, 1, generator=g) < 0.5, torch.floor(torch.rand(rows, 1, generator=g) * 30), torch.rand(rows, 1, generator=g) * 30) + 1
+    net.oracle_state = sd
+    return net, torch.cat([xyz, t], -1).cuda()
+
+
+@pytest.mark.parametrize("input_time", [True, False])
+def test_fused_motionnet_forward_writes_what_the_layerwise_recompute_builds(ops, input_time):
+    """stnerf_train_motionnet_fwd: the flow of stnerf_motionnet_fwd (same arithmetic: within fp32 rounding of the stand-alone kernel's
+    different summation order), and every matrix it writes -- the staged encoding with the fractional-time blend, the five post-ReLU
+    outputs, their masks as bit planes -- against the per-layer recomputation (train_encode + train_linear_fwd)."""
+    from stnerf_amd.modeling import autograd as A
+    net, xt = _motion_case(input_time)
+    rows = xt.shape[0]
+    packed = net._packed("fp32")
+    bufs = A._motion_buffers(rows, "cuda")
+    for b in bufs[:6]:
+        b.fill_(float("nan"))
+    bufs[6].fill_(-1)
+    flow = torch.full((rows, 3), float("nan"), device="cuda")
+    acts = [b[:, :128] for b in bufs[1:6]]
+    ops.train_motionnet_fwd(packed, xt, flow, bufs[0], acts, bufs[6], plain_time=not input_time)
+    want = net(xt.detach())
+    assert torch.allclose(flow, want, rtol=1e-5, atol=2e-7)
+    params = [p.detach() for p in net.parameters()]
+    W = [A._padded_weight(params[2 * i]) for i in range(6)]
+    B = [params[2 * i + 1].float().contiguous() for i in range(6)]
+    E = A._buf(rows, 84, "cuda")
+    ops.train_encode(xt, E[:, :84], 10, True, lerp_col=3 if input_time else -1)
+    assert torch.allclose(bufs[0][:, :84], E[:, :84], rtol=0, atol=2e-7) and float(bufs[0][:, 84:88].abs().max()) == 0.0
+    src = E[:, :84]
+    for j in range(5):
+        ref = A._buf(rows, 128, "cuda")
+        ops.train_linear_fwd(src, W[j], B[j], ref[:, :128], True)
+        assert torch.allclose(acts[j], ref[:, :128], rtol=1e-5, atol=1e-6), j
+        assert float(acts[j].min()) >= 0.0 and float(acts[j].max()) > 0.0
+        src = ref[:, :128]
+    # bit (16 fb + i) & 31 of word 2 h + (fb >> 1) <-> column 32 fb + 8 (i >> 2) + 4 h + (i & 3)
+    fb, i, h = torch.meshgrid(torch.arange(4), torch.arange(16), torch.arange(2), indexing="ij")
+    col = (32 * fb + 8 * (i >> 2) + 4 * h + (i & 3)).reshape(-1)
+    word, bit = (2 * h + (fb >> 1)).reshape(-1), ((16 * fb + i) & 31).reshape(-1)
+    for s_, act in enumerate(acts):
+        got = (bufs[6][s_].cpu()[:, word] >> bit) & 1
+        assert torch.equal(got.bool(), act.cpu()[:, col] > 0), s_
+
+
+@pytest.mark.parametrize("input_time, want_dx", [(True, True), (False, True), (True, False)])
+def test_fused_motionnet_backward_matches_the_layerwise_backward(ops, monkeypatch, input_time, want_dx):
+    """Same gradients from the fused launches as from the per-layer GEMM chain (every weight, bias and the points), several chunks with
+    a ragged last one; activations kept by the forward and recomputed: the same bits."""
+    from stnerf_amd.modeling import autograd as A
+    net, xt = _motion_case(input_time, rows=5003, seed=6)
+    monkeypatch.setattr(A, "CHUNK_SAMPLES", 2048)
+    g = torch.Generator().manual_seed(2)
+    sd64 = {k: v.double() for k, v in net.oracle_state.items()}
+    safe = _safe_samples(lambda: O.motion_net(sd64, "net", xt.cpu().double(), input_time=input_time)).reshape(-1, 1).cuda()
+    cot = torch.randn(xt.shape[0], 3, generator=g).cuda() * safe
+    grads = {}
+    for fused in (True, "recompute", False):
+        monkeypatch.setattr(A, "FUSED_BACKWARD", bool(fused))
+        monkeypatch.setattr(A, "KEEP_BYTES", 0 if fused == "recompute" else 1 << 35)
+        net.zero_grad(set_to_none=True)
+        x = xt.clone().requires_grad_(want_dx)
+        (net(x) * cot).sum().backward()
+        grads[fused] = {k: v.grad.clone() for k, v in net.named_parameters()}
+        grads[fused]["x"] = x.grad.clone() if want_dx else None
+    for k, a in grads[True].items():
+        b, r = grads[False][k], grads["recompute"][k]
+        if a is None:
+            assert b is None and r is None
+            continue
+        assert float((a - b).abs().max()) <= GRAD_RTOL * float(b.abs().max()), k
+        assert torch.equal(a, r), k
+
+
 @pytest.mark.parametrize("kind", ["space", "space_time", "space_time_deep", "space_noinc", "motion"])
 def test_device_packer_writes_the_host_packers_blob(ops, kind):
     """stnerf_pack_net_device (what a training loop calls after every optimizer.step(): no host round trip) writes the exact-f32

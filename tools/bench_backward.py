@@ -65,7 +65,7 @@ for name, net, flop in [("SpaceNet (time)", SpaceNet(use_time=True), 930_048), (
         t_layers = timed(step, 3)
         A.DW_BATCH = True
         print(f"{name}: weight gradients per layer (STNERF_TRAIN_DW_BATCH=0) {1e3 * t_layers:.2f} ms; batched {1e3 * t:.2f} ms")
-    if "Space" in name and not os.environ.get("ONLY_FUSED"):     # A/B: the round-4 per-layer backward
+    if not os.environ.get("ONLY_FUSED"):     # A/B: the round-4 per-layer backward
         from stnerf_amd.modeling import autograd as A
         A.FUSED_BACKWARD = False
         t_old = timed(step, 3)
