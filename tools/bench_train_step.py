@@ -20,6 +20,8 @@ ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--workload", default="taekwondo-1080p-64+64")
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--fused", type=int, default=1)
+ap.add_argument("--eager", action="store_true", help="also time the same iteration through eager PyTorch-ROCm on this GPU (the oracle "
+                "restatement of the reference's modules under torch.autograd: what pointing the reference's own code at the GPU gives)")
 args = ap.parse_args()
 from stnerf_amd.modeling import autograd as A            # noqa: E402
 A.FUSED_BACKWARD = bool(args.fused)
@@ -59,3 +61,33 @@ flop = 3 * evals * ((bench.FLOP_SPACE_TIME if st else bench.FLOP_SPACE) + (bench
 print(f"{args.workload}: {args.rays} rays per iteration (hit fractions {[round(h, 3) for h in hits]}), {'fused' if args.fused else 'per-layer'} backward: "
       f"{1e3 * dt_s:.1f} ms per iteration = {args.rays / dt_s:.0f} rays/s, {evals / dt_s / 1e6:.1f} M network evaluations/s trained, "
       f"~{flop / dt_s / 1e12:.1f} TF/s of forward + dX + dW work; loss {float(loss):.5f}")
+
+if args.eager:
+    # Informative baseline (like bench.py's eager_gpu_baseline): the reference's algorithm op by op through ATen / rocBLAS with
+    # torch.autograd, same weights, same rays, same loss, same optimiser.  (oracle/ is test infrastructure: it is the thing measured
+    # AGAINST here, never part of the product path.)
+    from oracle import stnerf_oracle as O
+    bk, per = syn.scene_boxes(L)
+    sd = {k: v.to(dev).requires_grad_(True) for k, v in syn.make_state_dict(L, st, dt, seed=0).items()}
+    m = O.OracleModel(layer_num=L, n_coarse=n1, n_fine=n2, params=sd, use_deform_time=dt, use_space_time=st, bkgd_bbox=bk.to(dev),
+                      bboxes=per.to(dev))
+    opt_e = torch.optim.Adam(list(sd.values()), lr=4e-4, betas=(0.9, 0.999))
+
+    def eager_iteration():
+        opt_e.zero_grad()
+        with torch.device(dev):
+            out = O.render_chunk(m, rays)
+        loss = mse(out[1][0], rgbs) + mse(out[0][0], rgbs)
+        loss.backward()
+        opt_e.step()
+        return loss
+
+    eager_iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(max(2, args.iters // 2)):
+        le = eager_iteration()
+    torch.cuda.synchronize()
+    de = (time.perf_counter() - t0) / max(2, args.iters // 2)
+    print(f"  eager PyTorch-ROCm on the same GPU (oracle restatement, torch.autograd, rocBLAS): {1e3 * de:.1f} ms per iteration = {args.rays / de:.0f} rays/s "
+          f"({de / dt_s:.1f} x this library's iteration); peak memory {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB; loss {float(le):.5f}")
