@@ -541,6 +541,47 @@ extern "C" int stnerf_pack_net_device(int kind, const float* const* W, const flo
     return STNERF_OK;
 }
 
+// The transposed sections the fused backward chains read (csrc/train_wave.hip): out x in (row stride ldw) -> [out / 4][n_pad][4], zero
+// for the padded inputs; n_pad == 0: a plain copy of out * in floats (the heads).  One launch for a network: blockIdx.y = section.
+namespace stnerf {
+struct TransposeTable {
+    stnerf_transpose_section seg[12];
+};
+__global__ void pack_transposed_kernel(TransposeTable t, float* dst) {
+    const stnerf_transpose_section sg = t.seg[blockIdx.y];
+    const int64_t total = sg.n_pad > 0 ? (int64_t)sg.out * sg.n_pad : (int64_t)sg.out * sg.in;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float v;
+        if (sg.n_pad > 0) {
+            const int r = (int)(i & 3);
+            const int64_t q = i >> 2;
+            const int n = (int)(q % sg.n_pad), o = 4 * (int)(q / sg.n_pad) + r;
+            v = n < sg.in ? sg.w[(int64_t)o * sg.ldw + n] : 0.f;
+        } else {
+            v = sg.w[(i / sg.in) * sg.ldw + (i % sg.in)];
+        }
+        dst[sg.dst_off + i] = v;
+    }
+}
+}  // namespace stnerf
+
+extern "C" int stnerf_pack_transposed(const stnerf_transpose_section* sections, int count, float* dst_dev, int64_t dst_floats, stnerf_stream_t stream) {
+    STNERF_REQUIRE(sections && dst_dev && count >= 1 && count <= 12, "pack_transposed: 1 .. 12 sections");
+    TransposeTable t;
+    memset(&t, 0, sizeof(t));
+    for (int i = 0; i < count; ++i) {
+        const stnerf_transpose_section& q = sections[i];
+        STNERF_REQUIRE(q.w && q.out >= 1 && q.in >= 1 && q.ldw >= q.in && q.dst_off >= 0, "pack_transposed: bad section %d", i);
+        STNERF_REQUIRE(q.n_pad == 0 || ((q.out & 3) == 0 && q.n_pad >= q.in), "pack_transposed: section %d: out %% 4 == 0 and n_pad >= in", i);
+        const int64_t floats = q.n_pad > 0 ? (int64_t)q.out * q.n_pad : (int64_t)q.out * q.in;
+        STNERF_REQUIRE(q.dst_off + floats <= dst_floats, "pack_transposed: section %d ends beyond the destination", i);
+        t.seg[i] = q;
+    }
+    hipLaunchKernelGGL(pack_transposed_kernel, dim3(64, count), dim3(256), 0, as_stream(stream), t, dst_dev);
+    STNERF_CHECK_LAUNCH("pack_transposed");
+    return STNERF_OK;
+}
+
 extern "C" int stnerf_encode(const float* x, int64_t n, int dim, int n_freq, int include_input, float* y,
                              stnerf_stream_t stream) {
     STNERF_REQUIRE(x && y, "encode: null pointer");

@@ -67,6 +67,11 @@ class DwProblem(C.Structure):
                 ("db", C.c_void_p), ("n", C.c_int32), ("k", C.c_int32)]
 
 
+class TransposeSection(C.Structure):
+    """stnerf_transpose_section (include/stnerf.h)."""
+    _fields_ = [("w", C.c_void_p), ("ldw", C.c_int64), ("dst_off", C.c_int64), ("out", C.c_int32), ("in_", C.c_int32), ("n_pad", C.c_int32)]
+
+
 class ProfileRecord(C.Structure):
     _fields_ = [("kernel", C.c_int32), ("kind", C.c_int32), ("ns", C.c_int32), ("tag", C.c_int32),
                 ("n_rays", C.c_int64), ("bytes_per_ray", C.c_int64), ("ms", C.c_float), ("pad_", C.c_int32)]
@@ -115,6 +120,7 @@ _PROTOS = {
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_int32), c_f32p, C.c_int32, C.c_void_p, c_i64, C.c_void_p, c_f32p, C.c_void_p]),
     "stnerf_train_spacenet_dx": (C.c_int, [c_f32p, C.POINTER(C.c_uint32), c_f32p, c_i64, C.c_void_p, c_i64, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                            c_f32p, C.c_int32, C.c_void_p]),
+    "stnerf_pack_transposed": (C.c_int, [C.POINTER(TransposeSection), C.c_int, c_f32p, c_i64, C.c_void_p]),
     "stnerf_train_motionnet_fwd": (C.c_int, [C.c_void_p, c_f32p, c_i64, C.c_int, c_f32p, c_f32p, C.c_int32, C.POINTER(C.c_void_p),
                                              C.POINTER(C.c_int32), C.c_void_p, c_i64, C.c_void_p]),
     "stnerf_train_motionnet_dx": (C.c_int, [c_f32p, C.POINTER(C.c_uint32), c_f32p, c_i64, C.c_void_p, c_i64, C.POINTER(C.c_void_p),

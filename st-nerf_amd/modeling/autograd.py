@@ -65,31 +65,32 @@ def _buf(m: int, cols: int, device) -> torch.Tensor:
     return torch.empty(m, _pad4(cols), dtype=torch.float32, device=device)
 
 
+def _transposed(module, params, sections) -> tuple:
+    """(wt, offsets) of `sections` = [(W view, n_pad)] in one launch (stnerf_pack_transposed) into the module's own blob, rebuilt when a
+    parameter changed (every optimizer.step(): ~40 torch launches per network when this was zeros / copy / permute / cat)."""
+    key = tuple((p.data_ptr(), p._version) for p in params)
+    cache = getattr(module, "_wt_cache", None)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    views = [(w.detach(), n_pad) for w, n_pad in sections]
+    if any(w.dtype != torch.float32 for w, _ in views):
+        views = [(w.float(), n_pad) for w, n_pad in views]
+    total = sum(w.shape[0] * (n_pad if n_pad else w.shape[1]) for w, n_pad in views)
+    wt = cache[1] if cache is not None and cache[1].numel() == total + 4096 and cache[1].device == views[0][0].device else \
+        torch.zeros(total + 4096, dtype=torch.float32, device=views[0][0].device)     # (slack: operand prefetches run past a section's end)
+    offsets = ops.pack_transposed(views, wt)
+    module._wt_cache = (key, wt, offsets)
+    return wt, offsets
+
+
 def transposed_spacenet(module, params) -> tuple:
     """(wt, offsets): the A operands of the fused backward chain (csrc/train_wave.hip), one section [out / 4][N][4] per product
     d x = d y W -- wt[(o // 4), n, o % 4] = W[o][n], N = the layer's inputs padded to a multiple of 32 -- in the order
     stnerf_train_spacenet_dx takes them: rgb_net.1's 256 backbone columns, stage1.0 .. stage2.4, then density_net.0's weights and
     the colour head as they are.  Cached on the module until a parameter changes."""
-    key = tuple((p.data_ptr(), p._version) for p in params)
-    cache = getattr(module, "_wt_cache", None)
-    if cache is not None and cache[0] == key:
-        return cache[1], cache[2]
-
-    def section(w):
-        out, k = w.shape
-        n = (k + 31) // 32 * 32
-        wp = torch.zeros(out, n, dtype=torch.float32, device=w.device)
-        wp[:, :k] = w.detach().float()
-        return wp.reshape(out // 4, 4, n).permute(0, 2, 1).contiguous().reshape(-1)
     W = [params[2 * i] for i in range(len(params) // 2)]
-    parts = [section(W[8][:, :256])] + [section(W[i]) for i in range(7)] + [W[7].detach().float().reshape(-1), W[9].detach().float().reshape(-1)]
-    offsets, off = [], 0
-    for part in parts:
-        offsets.append(off)
-        off += part.numel()
-    wt = torch.cat(parts + [torch.zeros(4096, dtype=torch.float32, device=parts[0].device)])   # (slack: operand prefetches run past a section's end)
-    module._wt_cache = (key, wt, offsets)
-    return wt, offsets
+    pad32 = lambda w: (w.shape[1] + 31) // 32 * 32
+    return _transposed(module, params, [(W[8][:, :256], 256)] + [(W[i], pad32(W[i])) for i in range(7)] + [(W[7], 0), (W[9], 0)])
 
 
 def _activation_buffers(rows: int, tail: int, device) -> List[torch.Tensor]:
@@ -285,25 +286,8 @@ MOTION_ACT_FLOATS_PER_SAMPLE = 96 + 5 * 128 + 5 * 4
 def transposed_motionnet(module, params) -> tuple:
     """(wt, offsets): the A operands of the MotionNet's backward chain (stnerf_train_motionnet_dx): sections [128 / 4][128][4] of
     motion_net.0 (84 inputs zero-padded to 128), .2, .4, .6, .8, then the flow head [3][128] as it is.  Cached per parameter version."""
-    key = tuple((p.data_ptr(), p._version) for p in params)
-    cache = getattr(module, "_wt_cache", None)
-    if cache is not None and cache[0] == key:
-        return cache[1], cache[2]
-
-    def section(w):
-        out, k = w.shape
-        wp = torch.zeros(out, 128, dtype=torch.float32, device=w.device)
-        wp[:, :k] = w.detach().float()
-        return wp.reshape(out // 4, 4, 128).permute(0, 2, 1).contiguous().reshape(-1)
     W = [params[2 * i] for i in range(6)]
-    parts = [section(W[i]) for i in range(5)] + [W[5].detach().float().reshape(-1)]
-    offsets, off = [], 0
-    for part in parts:
-        offsets.append(off)
-        off += part.numel()
-    wt = torch.cat(parts + [torch.zeros(4096, dtype=torch.float32, device=parts[0].device)])   # (slack for the operand prefetches)
-    module._wt_cache = (key, wt, offsets)
-    return wt, offsets
+    return _transposed(module, params, [(W[i], 128) for i in range(5)] + [(W[5], 0)])
 
 
 def _motion_buffers(rows: int, device) -> List[torch.Tensor]:

@@ -13,8 +13,8 @@ hit rays of a layer (index_select / index_copy: data movement) and strings the `
 
 Gradients reach every weight and bias of the SpaceNets and MotionNets; rays, boxes, depths and frame ids get none, as in the
 reference (its POSE_REFINEMENT / USE_DEFORM_VIEW paths are outside SURVEY section 8).  The training forward runs the exact-f32
-MFMA kernels whatever ``model.set_precision`` says for rendering: the backward recomputes the activations in fp32, and the
-ReLU masks of forward and backward must be the same ones.
+MFMA kernels whatever ``model.set_precision`` says for rendering: the backward walks back through the ReLU masks of the evaluation
+that produced the loss (the forward kernels write them out as bit planes).
 """
 from __future__ import annotations
 
@@ -49,7 +49,7 @@ class CompositeFunction(torch.autograd.Function):
         return None, ops.composite_bwd(t, raw, mask, order, ctx.params, gl, gm), None, None
 
 
-def _stage(model, rays, xyz, mask01, times_col, fine: bool):
+def _stage(model, rays, xyz, hit, times_col, fine: bool):
     """MotionNet + SpaceNet of every layer on a stage's points xyz (n,l,ns,3) -> raw (n,l,ns,4) with autograd history.
     modeling/layered_rfrender.py:340-418 (coarse) / :495-576 (fine)."""
     n, l, ns = xyz.shape[0], xyz.shape[1], xyz.shape[2]
@@ -66,7 +66,7 @@ def _stage(model, rays, xyz, mask01, times_col, fine: bool):
     raws.append(torch.cat([rgb, sig], -1))
     for i in range(1, l):
         zero = torch.zeros(n, ns, 4, dtype=torch.float32, device=xyz.device)      # the reference's zero tensors (:398-399)
-        idx = mask01[:, i].nonzero(as_tuple=True)[0]
+        idx = hit[i]
         if idx.numel() == 0 or not model.is_shown_layer(i):
             raws.append(zero)
             continue
@@ -113,7 +113,9 @@ def render_rays_train(model, rays, boxes, pivot, retiming: bool, only_coarse: bo
     # (the 0 / 1 mask, without the sampler's "missed" hints: with hints the resampler leaves a missed pair's fine depths
     # unwritten, and the backward walks the merged list through every source sample's depth)
     mask01 = mask
-    raw_c = _stage(model, rays, xyz_c, mask01, times_col, False)
+    # the hit rays of every performer, once for both stages (a nonzero is a host synchronisation: the output's size is data)
+    hit = [None] + [mask01[:, i].nonzero(as_tuple=True)[0] for i in range(1, l)]
+    raw_c = _stage(model, rays, xyz_c, hit, times_col, False)
     layer_c, mixed_c, w_c = CompositeFunction.apply(t_c, raw_c, mask, _composite_params(model, False, retiming, thr, bthr))
     if only_coarse:
         # layered_rfrender.py:704-723: the "fine" entries are the coarse ones
@@ -122,6 +124,6 @@ def render_rays_train(model, rays, boxes, pivot, retiming: bool, only_coarse: bo
         t_f, xyz_f = ops.resample(t_c, w_c, n2, rays, u=replay.get("u") if replay else None, seed=int(model.seed),
                                   ray_index_base=first, edits=ef, pivot=pivot, ray_index_stripe=stripe, ray_index_period=period,
                                   mask=None)
-    raw_f = _stage(model, rays, xyz_f, mask01, times_col, True)
+    raw_f = _stage(model, rays, xyz_f, hit, times_col, True)
     layer_f, mixed_f, _ = CompositeFunction.apply(t_f, raw_f, mask, _composite_params(model, True, retiming, thr, bthr))
     return mixed_f, mixed_c, layer_f, layer_c, mask01

@@ -749,3 +749,22 @@ def train_motionnet_dx(wt: Tensor, offsets: Sequence[int], d_flow: Tensor, relu_
         raise ValueError(f"train_motionnet_dx: denc {tuple(denc.shape)} needs {rows} rows of >= 96 columns")
     hip.check(hip.lib().stnerf_train_motionnet_dx(hip.dptr(wt, name="wt"), off, dp, rows, bp, bstride, yp, yld, pp, ldp, hip.stream_ptr()),
               "stnerf_train_motionnet_dx")
+
+
+def pack_transposed(sections: Sequence[Tuple[Tensor, int]], dst: Tensor) -> List[int]:
+    """The A operands of the fused backward chains in one launch (stnerf_pack_transposed): for every (W (out, in) fp32 device view with
+    dense columns, n_pad) a section [out / 4][n_pad][4] of `dst` (n_pad = 0: W copied as it is), packed back to back from offset 0.
+    -> the sections' float offsets."""
+    arr = (hip.TransposeSection * len(sections))()
+    offsets, off = [], 0
+    for i, (w, n_pad) in enumerate(sections):
+        wp, ldw = _mat(w, f"w[{i}]")
+        out, k = w.shape
+        arr[i] = hip.TransposeSection(wp.value, ldw, off, out, k, n_pad)
+        offsets.append(off)
+        off += out * (n_pad if n_pad else k)
+    if dst.dtype != torch.float32 or not dst.is_contiguous() or dst.numel() < off:
+        raise ValueError(f"pack_transposed: the destination needs {off} contiguous fp32 values")
+    hip.check(hip.lib().stnerf_pack_transposed(arr, len(sections), hip.dptr(dst, name="dst"), dst.numel(), hip.stream_ptr()),
+              "stnerf_pack_transposed")
+    return offsets

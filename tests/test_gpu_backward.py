@@ -546,6 +546,32 @@ def test_fused_motionnet_backward_matches_the_layerwise_backward(ops, monkeypatc
         assert torch.equal(a, r), k
 
 
+def test_pack_transposed_builds_the_sections_torch_builds(ops):
+    """stnerf_pack_transposed (one launch per network after every optimizer.step()): [out / 4][n_pad][4] sections with zero padding, a
+    column block of a wider weight as the source, heads copied as they are -- against zeros / copy / permute in torch."""
+    g = torch.Generator().manual_seed(5)
+    wide = torch.randn(128, 304, generator=g).cuda()
+    ws = [(wide[:, :256], 256), (torch.randn(256, 63, generator=g).cuda(), 64), (torch.randn(256, 319, generator=g).cuda(), 320),
+          (torch.randn(128, 84, generator=g).cuda(), 128), (torch.randn(1, 256, generator=g).cuda(), 0), (torch.randn(3, 128, generator=g).cuda(), 0)]
+    total = sum(w.shape[0] * (p if p else w.shape[1]) for w, p in ws)
+    dst = torch.full((total + 64,), float("nan"), device="cuda")
+    offsets = ops.pack_transposed(ws, dst)
+    off = 0
+    for (w, p), o in zip(ws, offsets):
+        assert o == off
+        if p:
+            wp = torch.zeros(w.shape[0], p, device="cuda")
+            wp[:, :w.shape[1]] = w
+            want = wp.reshape(w.shape[0] // 4, 4, p).permute(0, 2, 1).contiguous().reshape(-1)
+        else:
+            want = w.reshape(-1)
+        assert torch.equal(dst[off:off + want.numel()], want)
+        off += want.numel()
+    assert bool(torch.isnan(dst[off:]).all())
+    with pytest.raises(ValueError):
+        ops.pack_transposed(ws, dst[:100])
+
+
 @pytest.mark.parametrize("kind", ["space", "space_time", "space_time_deep", "space_noinc", "motion"])
 def test_device_packer_writes_the_host_packers_blob(ops, kind):
     """stnerf_pack_net_device (what a training loop calls after every optimizer.step(): no host round trip) writes the exact-f32

@@ -52,11 +52,26 @@ loss, masks = iteration()
 torch.cuda.synchronize()
 hits = [float(m.float().mean()) for m in masks]
 evals = args.rays * sum(hits) * (2 * n1 + n2)
-t0 = time.perf_counter()
-for _ in range(args.iters):
+each = []
+import gc                                                # noqa: E402
+gc_log = []
+gc.callbacks.append(lambda phase, info: gc_log.append((phase, info.get("generation"), time.perf_counter())))
+for it in range(args.iters):
+    before = torch.cuda.memory_stats()
+    n_gc = len(gc_log)
+    t0 = time.perf_counter()
     loss, _ = iteration()
-torch.cuda.synchronize()
-dt_s = (time.perf_counter() - t0) / args.iters
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    each.append(time.perf_counter() - t0)
+    if each[-1] > 1.5 * min(each):                       # an outlier: where did it go?
+        after = torch.cuda.memory_stats()
+        gcs = [(g, round(1e3 * (e[2] - s_[2]), 1)) for s_, e in zip(gc_log[n_gc::2], gc_log[n_gc + 1::2]) for g in [s_[1]]]
+        print(f"  outlier iteration {it}: {1e3 * each[-1]:.1f} ms, host part {1e3 * (t1 - t0):.1f} ms; hipMallocs {after['num_device_alloc'] - before['num_device_alloc']}, "
+              f"hipFrees {after['num_device_free'] - before['num_device_free']}, alloc retries {after['num_alloc_retries'] - before['num_alloc_retries']}; "
+              f"python gc (generation, ms): {gcs}")
+dt_s = sorted(each)[len(each) // 2]                       # the median iteration (the first ones still grow the allocator's pools)
+print("  iterations, ms:", " ".join(f"{1e3 * t:.1f}" for t in each))
 flop = 3 * evals * ((bench.FLOP_SPACE_TIME if st else bench.FLOP_SPACE) + (bench.FLOP_MOTION if dt else 0) * (sum(hits[1:]) / max(sum(hits), 1e-9)))
 print(f"{args.workload}: {args.rays} rays per iteration (hit fractions {[round(h, 3) for h in hits]}), {'fused' if args.fused else 'per-layer'} backward: "
       f"{1e3 * dt_s:.1f} ms per iteration = {args.rays / dt_s:.0f} rays/s, {evals / dt_s / 1e6:.1f} M network evaluations/s trained, "
