@@ -47,7 +47,17 @@ fi
 timeout 300 python bench.py --gpus 2 --debug-single-device --steps 2 --warmup 1 $W --no-second-precision --detail-out $out/bench_2ranks_one_device_detail.json > $out/bench_2ranks_one_device.json 2> $out/bench_2ranks_one_device.err
 # ---- 6. the training kernels: GEMM flavours, whole backward, kernel trace
 timeout 200 python tools/bench_backward.py > $out/bench_backward.txt 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $out/trace_backward -o p -- python tools/bench_backward.py > $out/trace_backward.log 2>&1
+ONLY_NETS=1 ONLY_FUSED=1 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $out/trace_backward -o p -- python tools/bench_backward.py > $out/trace_backward.log 2>&1
+python tools/trace_top.py $out/trace_backward 30 > $out/trace_backward_top.txt 2>&1
+for ctr in FETCH_SIZE WRITE_SIZE MfmaUtil; do
+  ONLY_NETS=1 ONLY_FUSED=1 timeout 200 rocprofv3 --pmc $ctr -d $out/pmc_train/pmc_$ctr -o p -- python tools/bench_backward.py > /dev/null 2>&1
+done
+python tools/pmc_training.py $out/pmc_train > $out/pmc_training.md 2>&1
+# one iteration of the reference trainer's inner loop: the bench scene at 4096 rays, the reference's own batch configuration, both against eager PyTorch-ROCm
+{ timeout 300 python tools/bench_train_step.py --iters 12 --eager; timeout 300 python tools/bench_train_step.py --iters 12 --rays 2000 --workload taekwondo-1080p-90+30 --eager;
+  timeout 300 python tools/bench_train_step.py --iters 8 --rays 16384; } 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|float(loss)" > $out/train_step.txt
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $out/trace_step -o p -- python tools/bench_train_step.py --iters 3 > $out/trace_step.log 2>&1
+python tools/trace_top.py $out/trace_step 30 > $out/trace_step_top.txt 2>&1
 # ---- 7. stage kernels alone, A/B of the bf16x3 variants, compositor and resampler alone, microbenchmarks
 STAGE_ONLY=1 timeout 200 python tools/bench_stage.py > $out/bench_stage.txt 2>&1
 timeout 200 python tools/bench_composite.py > $out/bench_composite.txt 2>&1
@@ -56,6 +66,6 @@ timeout 100 tools/micro/hbm_copy > $out/hbm_copy.json 2>/dev/null
 # ---- 8. summarise here (the rocprofv3 databases are too large to travel), then drop them
 python tools/summarise.py $out $rnd > $out/summarise.log 2>&1; echo rc=$? >> $out/summarise.log
 find $out -name "*.db" -delete; find $out -type d -empty -delete
-rm -rf $out/trace_* $out/pmc_* 2>/dev/null
+rm -rf $out/trace_*/ $out/pmc_*/ 2>/dev/null
 tail -3 $out/pytest.log; tail -2 $out/smoke.log; tail -40 $out/summarise.log; for f in c2 c3_90_30 c4 c5 2ranks_one_device; do tail -c 200 $out/bench_$f.err; done
 du -sh $out
