@@ -139,14 +139,14 @@ int64_t stnerf_packed_bytes(int kind);
 int stnerf_pack_net_device(int kind, const float* const* weights_dev, const float* const* biases_dev, int n_tensors, void* dst_dev,
                            int64_t dst_bytes, stnerf_stream_t stream);
 /* The A operands of the fused backward chains (stnerf_train_spacenet_dx / stnerf_train_motionnet_dx): `count` (<= 12) sections of one
- * destination blob, each an nn.Linear weight W (out x in, row stride ldw floats, device memory) as [out / 4][n_pad][4] --
- * dst[dst_off + ((o / 4) n_pad + n) 4 + o % 4] = W[o][n], zero for in <= n < n_pad -- or, n_pad == 0, a plain copy of its out x in
+ * destination blob, each an nn.Linear weight W (n_out x n_in, row stride ldw floats, device memory) as [n_out / 4][n_pad][4] --
+ * dst[dst_off + ((o / 4) n_pad + n) 4 + o % 4] = W[o][n], zero for n_in <= n < n_pad -- or, n_pad == 0, a plain copy of its n_out x n_in
  * floats (the heads).  One launch, no host round trip: a training loop rebuilds them after every optimizer.step(). */
 typedef struct stnerf_transpose_section {
     const float* w;
     int64_t ldw;
     int64_t dst_off;   /* floats */
-    int32_t out, in, n_pad;
+    int32_t n_out, n_in, n_pad;
 } stnerf_transpose_section;
 int stnerf_pack_transposed(const stnerf_transpose_section* sections, int count, float* dst_dev, int64_t dst_floats, stnerf_stream_t stream);
 /* Repack reference-layout tensors (nn.Linear: weight (out,in) row-major, bias (out)) into the

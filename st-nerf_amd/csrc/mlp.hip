@@ -549,16 +549,16 @@ struct TransposeTable {
 };
 __global__ void pack_transposed_kernel(TransposeTable t, float* dst) {
     const stnerf_transpose_section sg = t.seg[blockIdx.y];
-    const int64_t total = sg.n_pad > 0 ? (int64_t)sg.out * sg.n_pad : (int64_t)sg.out * sg.in;
+    const int64_t total = sg.n_pad > 0 ? (int64_t)sg.n_out * sg.n_pad : (int64_t)sg.n_out * sg.n_in;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         float v;
         if (sg.n_pad > 0) {
             const int r = (int)(i & 3);
             const int64_t q = i >> 2;
             const int n = (int)(q % sg.n_pad), o = 4 * (int)(q / sg.n_pad) + r;
-            v = n < sg.in ? sg.w[(int64_t)o * sg.ldw + n] : 0.f;
+            v = n < sg.n_in ? sg.w[(int64_t)o * sg.ldw + n] : 0.f;
         } else {
-            v = sg.w[(i / sg.in) * sg.ldw + (i % sg.in)];
+            v = sg.w[(i / sg.n_in) * sg.ldw + (i % sg.n_in)];
         }
         dst[sg.dst_off + i] = v;
     }
@@ -571,9 +571,9 @@ extern "C" int stnerf_pack_transposed(const stnerf_transpose_section* sections, 
     memset(&t, 0, sizeof(t));
     for (int i = 0; i < count; ++i) {
         const stnerf_transpose_section& q = sections[i];
-        STNERF_REQUIRE(q.w && q.out >= 1 && q.in >= 1 && q.ldw >= q.in && q.dst_off >= 0, "pack_transposed: bad section %d", i);
-        STNERF_REQUIRE(q.n_pad == 0 || ((q.out & 3) == 0 && q.n_pad >= q.in), "pack_transposed: section %d: out %% 4 == 0 and n_pad >= in", i);
-        const int64_t floats = q.n_pad > 0 ? (int64_t)q.out * q.n_pad : (int64_t)q.out * q.in;
+        STNERF_REQUIRE(q.w && q.n_out >= 1 && q.n_in >= 1 && q.ldw >= q.n_in && q.dst_off >= 0, "pack_transposed: bad section %d", i);
+        STNERF_REQUIRE(q.n_pad == 0 || ((q.n_out & 3) == 0 && q.n_pad >= q.n_in), "pack_transposed: section %d: out %% 4 == 0 and n_pad >= in", i);
+        const int64_t floats = q.n_pad > 0 ? (int64_t)q.n_out * q.n_pad : (int64_t)q.n_out * q.n_in;
         STNERF_REQUIRE(q.dst_off + floats <= dst_floats, "pack_transposed: section %d ends beyond the destination", i);
         t.seg[i] = q;
     }

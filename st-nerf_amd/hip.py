@@ -69,7 +69,7 @@ class DwProblem(C.Structure):
 
 class TransposeSection(C.Structure):
     """stnerf_transpose_section (include/stnerf.h)."""
-    _fields_ = [("w", C.c_void_p), ("ldw", C.c_int64), ("dst_off", C.c_int64), ("out", C.c_int32), ("in_", C.c_int32), ("n_pad", C.c_int32)]
+    _fields_ = [("w", C.c_void_p), ("ldw", C.c_int64), ("dst_off", C.c_int64), ("n_out", C.c_int32), ("n_in", C.c_int32), ("n_pad", C.c_int32)]
 
 
 class ProfileRecord(C.Structure):

@@ -117,7 +117,8 @@ def test_ctypes_structs_agree_with_the_c_compiler(tmp_path):
     if gcc is None:
         pytest.skip("no gcc")
     pairs = {"stnerf_layer_edit": hip.LayerEdit, "stnerf_composite_params": hip.CompositeParams, "stnerf_nets": hip.Nets,
-             "stnerf_render_params": hip.RenderParams, "stnerf_profile_record": hip.ProfileRecord}
+             "stnerf_render_params": hip.RenderParams, "stnerf_profile_record": hip.ProfileRecord, "stnerf_dw_problem": hip.DwProblem,
+             "stnerf_transpose_section": hip.TransposeSection}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "stnerf.h"', 'int main(void){']
     for cname, cls in pairs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -186,6 +187,37 @@ def test_render_workspace_query_and_argument_errors(lib):
     assert lib.stnerf_render_workspace_bytes(10, 99, 64, 64, 0) == hip.EINVAL
     null = C.c_void_p(0)
     assert lib.stnerf_render_rays(null, 4, null, 0, None, None, null, null, null, 0, null, null, null, null, null, null) == hip.EINVAL
+
+
+def test_training_batch_entries_check_their_arguments_on_the_host(lib):
+    """stnerf_train_dw_batch_workspace_bytes / stnerf_train_dw_batch / stnerf_pack_transposed: host arithmetic and argument errors
+    before any launch (no GPU here): the workspace of a SpaceNet's ten layers, the limits (16 layers, 64 tiles, bias gradients of at
+    most 256 outputs, 16-byte aligned rows), the section table's bounds."""
+    fake = 1 << 20                                     # (never dereferenced)
+    def problems(shapes, db=True, lddy=None):
+        arr = (hip.DwProblem * len(shapes))()
+        for i, (n, k) in enumerate(shapes):
+            arr[i] = hip.DwProblem(fake, lddy or (n + 3) // 4 * 4, fake, (k + 3) // 4 * 4, fake, k, fake if db else None, n, k)
+        return arr
+    space = [(256, 63), (256, 256), (256, 256), (256, 256), (256, 319), (256, 256), (256, 256), (1, 256), (128, 304), (3, 128)]
+    m = 262144
+    nb = lib.stnerf_train_dw_batch_workspace_bytes(problems(space), len(space), m)
+    slices = 256                                       # <= 256 slices of >= 256 rows
+    assert nb == 4 * slices * sum(n * k + (n + 3) // 4 * 4 for n, k in space) + 512
+    assert lib.stnerf_train_dw_batch_workspace_bytes(problems(space), len(space), 100) == 4 * sum(n * k + (n + 3) // 4 * 4 for n, k in space) + 512
+    assert lib.stnerf_train_dw_batch_workspace_bytes(problems([(8, 8)] * 17), 17, m) == hip.EINVAL
+    assert "16 problems" in hip.last_error()
+    assert lib.stnerf_train_dw_batch_workspace_bytes(problems([(512, 4096)] * 2), 2, m) == hip.EINVAL      # 2 x 4 x 16 tiles
+    assert lib.stnerf_train_dw_batch_workspace_bytes(problems([(300, 8)]), 1, m) == hip.EINVAL             # db of 300 outputs
+    assert lib.stnerf_train_dw_batch_workspace_bytes(problems([(300, 8)], db=False), 1, m) > 0
+    assert lib.stnerf_train_dw_batch_workspace_bytes(problems([(8, 8)], lddy=6), 1, m) == hip.EINVAL       # rows not 16-byte aligned
+    assert lib.stnerf_train_dw_batch(problems(space), len(space), m, 0, fake, 1024, None) == hip.EINVAL
+    assert "workspace too small" in hip.last_error()
+    sec = (hip.TransposeSection * 2)(hip.TransposeSection(fake, 63, 0, 256, 63, 64), hip.TransposeSection(fake, 128, 256 * 64, 3, 128, 0))
+    assert lib.stnerf_pack_transposed(sec, 2, fake, 256 * 64 + 383, None) == hip.EINVAL                  # the last section ends beyond dst
+    assert lib.stnerf_pack_transposed(sec, 0, fake, 1 << 20, None) == hip.EINVAL
+    sec[0].n_pad = 32                                                                                      # narrower than the inputs
+    assert lib.stnerf_pack_transposed(sec, 2, fake, 1 << 20, None) == hip.EINVAL
 
 
 def test_composite_launch_plan(lib):
