@@ -660,6 +660,10 @@ def g_train_cases():
     g_train_step("train_c3", 2, 40, 40, True, True, 41)
     # the coarse-only epochs (:199-200, :274-275) of a deform-only single performer
     g_train_step("train_coarse_only", 1, 24, 8, False, True, 42, n_rays=64, only_coarse=True)
+    # C4-shaped (four performers, deformation nets, SpaceNets WITHOUT the time input: configs/config_walking.yml), both stages: five
+    # layers in the merged list, the fine stage's alpha on layer 2, rays that hit 0 .. 3 performers
+    if "--c4" in sys.argv or "--all-grads" in sys.argv:
+        g_train_step("train_c4", 4, 24, 16, False, True, 43, n_rays=96)
 
 
 

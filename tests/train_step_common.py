@@ -1,6 +1,6 @@
 """One iteration of the reference trainer's inner loop (engine/layered_trainer.py:186-283), restated for the tests that compare
 a training step with the fixtures tests/golden/make_golden.py --grads recorded from the reference's own model, loss and optimiser
-(train_c3.npz, train_coarse_only.npz)."""
+(train_c3.npz, train_coarse_only.npz, train_c4.npz)."""
 import json
 import os
 
