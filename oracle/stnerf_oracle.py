@@ -193,7 +193,10 @@ def space_net(params: Dict[str, Tensor], prefix: str, pos: Tensor, dirs: Tensor,
     if use_dir:
         feat.append(positional_encoding(dirs.unsqueeze(1).repeat(1, s, 1).reshape(-1, 3), 4, inc))
     if use_time:
-        feat.append(positional_encoding(times.reshape(n, 1, 1).repeat(1, s, 1).reshape(-1, 1), 10, inc))
+        # (n, 1): a ray's frame id on each of its samples (:117-118).  (n, S, 1): one time per SAMPLE -- only the background's call
+        # site produces that, see render_chunk's run_nets
+        per_sample = times if times.dim() == 3 else times.reshape(n, 1, 1).repeat(1, s, 1)
+        feat.append(positional_encoding(per_sample.reshape(-1, 1), 10, inc))
     x = F.relu(torch.cat(feat, dim=1))
     x = F.relu(_linear(params, f"{prefix}.rgb_net.1", x))
     if f"{prefix}.rgb_net.7.weight" in params:      # deep_rgb (:68-79): 128 -> 128 -> 128 -> 3
@@ -439,7 +442,12 @@ def render_chunk(m: OracleModel, rays: Tensor, only_coarse: bool = False,
         rgbs, sig = [], []
         # :382-394 / :531-549: the frame id is handed over whenever use_space_time is on; the network uses it
         # only if it was built with use_time (BKGD_USE_SPACE_TIME)
-        t0 = fid(0).reshape(-1, 1) if m.use_space_time else None
+        # The BACKGROUND's call sites (:380, :385 / :531-537) hand the frame ids over as a 1-D tensor (rays[:, -1] or
+        # rays_frame_id[:, 0]) where the performers' reshape theirs to (n, 1) (:403, :405): SpaceNet.forward's
+        # `times.unsqueeze(1).repeat(1, L, 1).reshape(-1, 1)` (modeling/spacenet.py:117-118) then TILES the batch's ids -- sample j of
+        # ray i gets the frame id of ray (i S + j) mod n.  Invisible when every ray of the call has the same background frame id (any
+        # rendered frame); a training batch with BKGD_USE_SPACE_TIME mixes the ids across rays.  Restated as the reference does it.
+        t0 = fid(0).reshape(-1).repeat(ns).reshape(n, ns, 1) if m.use_space_time else None
         c0, s0 = space_net(P, "bkgd_spacenet" + sfx, x[0], d, t0)
         if fine and retiming:
             s0[s0 < bkgd_density_threshold] = 0                           # :538-547

@@ -313,6 +313,13 @@ class LayeredRFRender(nn.Module):
             raise RuntimeError("set_bkgd_bbox / set_bboxes must be called before rendering")
         if N == 0:  # the reference dereferences row 0 (rays_frame_id[0, i+1], layered_rfrender.py:200)
             raise IndexError("empty ray batch: LayeredRFRender needs at least one ray")
+        if self.bkgd_use_space_time and self.use_space_time and bool((rays[:, 6] != rays[0, 6]).any()):
+            # The reference hands the background net its frame ids as a 1-D tensor (layered_rfrender.py:380,385), which
+            # modeling/spacenet.py:117-118 tiles over the samples: sample j of ray i gets the id of ray (i S + j) mod n.  With one
+            # background frame id per call (every rendered frame) that is the identity and this path is exact; a batch that mixes
+            # them (training rays with BKGD_USE_SPACE_TIME -- off in both shipped ymls) would need that scramble reproduced.
+            raise NotImplementedError("BKGD_USE_SPACE_TIME with different background frame ids in one call: the reference assigns "
+                                      "them to the wrong samples there (modeling/spacenet.py:117-118 with 1-D times); not reproduced")
         # Training: model.train() + autograd enabled + trainable parameters = what engine/layered_trainer.py:186-194
         # sets up -> the same stages launched op by op with autograd history (stnerf_amd.modeling.training).  In eval() mode the
         # inference kernels run and the outputs carry no history, as under torch.no_grad() (render/layered_neural_renderer.py:377).

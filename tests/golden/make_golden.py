@@ -467,6 +467,10 @@ def g_model_flag_cases():
     # plain-time encoding differs from the lerp) + background space-time
     g_forward("fwd_bkgd_time", 2, 12, 6, True, True, 29, 8, 8, bkgd_frame=1.25,
               flags=dict(BKGD_USE_DEFORM_TIME=True, BKGD_USE_SPACE_TIME=True))
+    # ... and the same flags on training-style rays (one integer frame id per RAY, mixed over the batch): the background call sites
+    # pass the ids 1-D, SpaceNet.forward tiles them over the samples (modeling/spacenet.py:117-118) -- pins the oracle's restatement
+    g_forward("fwd_bkgd_time_mixed_ids", 1, 8, 4, True, True, 36, 6, 8, per_ray_frames=True,
+              flags=dict(BKGD_USE_SPACE_TIME=True))
     # fine performer nets shared with the coarse ones
     g_forward("fwd_same_spacenet", 2, 12, 6, True, True, 32, 6, 8, flags=dict(SAME_SPACENET=True))
     # config/defaults.py:39 has DEEP_RGB = True: any USE_SPACE_TIME config that does not switch it off gets the
@@ -561,7 +565,7 @@ def grad_digest(name, g):
     return {name: syn.tensor_digest(name.split("|", 1)[1], g.detach(), GRAD_SAMPLES)}
 
 
-def g_train_step(name, L, n1, n2, st, dt, seed, n_rays=96, only_coarse=False, remove_outliers=True, h=40, w=64):
+def g_train_step(name, L, n1, n2, st, dt, seed, n_rays=96, only_coarse=False, remove_outliers=True, h=40, w=64, flags=None):
     """One iteration of do_train's inner loop (engine/layered_trainer.py:178-282) with the reference's OWN model, loss
     (layers/loss.py:4) and optimiser (solver/build.py:10-27, Adam as configs/config_taekwondo.yml:3-5), on a batch of
     training-style rays (7 columns: one integer frame id per ray, data/datasets/ray_dataset.py): the loss, every parameter's
@@ -573,7 +577,7 @@ def g_train_step(name, L, n1, n2, st, dt, seed, n_rays=96, only_coarse=False, re
     # ATen's CPU weight-gradient reductions depend on the thread count in their last bits (2e-8 of a tensor's largest entry between
     # 2 threads and the container's default): pinned, so that the fixture regenerates byte for byte on any host
     torch.set_num_threads(4)
-    model = build_ref_model(L, n1, n2, st, dt, seed)
+    model = build_ref_model(L, n1, n2, st, dt, seed, flags)
     cfg = types.SimpleNamespace(SOLVER=types.SimpleNamespace(OPTIMIZER_NAME="Adam", BASE_LR=0.0004, WEIGHT_DECAY=0.0))
     loss_fn = make_loss(cfg)
     optimizer = make_optimizer(cfg, model)
@@ -649,7 +653,7 @@ def g_train_step(name, L, n1, n2, st, dt, seed, n_rays=96, only_coarse=False, re
         arrays[f"draw{i}"] = dr
     meta = dict(L=L, n1=n1, n2=n2, space_time=st, deform_time=dt, weight_seed=seed, n_rays=n_rays, only_coarse=only_coarse,
                 remove_outliers=remove_outliers, n_draws=len(rr.draws), without_grad=without_grad, lr=0.0004,
-                grad_samples=GRAD_SAMPLES, scalar=100000, penalty=1,
+                grad_samples=GRAD_SAMPLES, scalar=100000, penalty=1, **({"flags": dict(flags)} if flags else {}),
                 hit_fraction=[float(mk.float().mean()) for mk in ray_mask])
     save(name, meta, **arrays)
 
@@ -664,6 +668,11 @@ def g_train_cases():
     # layers in the merged list, the fine stage's alpha on layer 2, rays that hit 0 .. 3 performers
     if "--c4" in sys.argv or "--all-grads" in sys.argv:
         g_train_step("train_c4", 4, 24, 16, False, True, 43, n_rays=96)
+    # the model flags both shipped ymls leave off, under autograd: the 4-layer colour head (config/defaults.py:39 DEEP_RGB) and a
+    # background with its own deformation net (MotionNet(input_time=False)).  (Not BKGD_USE_SPACE_TIME: on a batch with mixed frame
+    # ids the reference tiles the background's ids over the samples, see fwd_bkgd_time_mixed_ids)
+    if "--flags" in sys.argv or "--all-grads" in sys.argv:
+        g_train_step("train_flags", 1, 16, 8, True, True, 44, n_rays=64, flags=dict(DEEP_RGB=True, BKGD_USE_DEFORM_TIME=True))
 
 
 

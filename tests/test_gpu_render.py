@@ -264,6 +264,24 @@ def test_empty_ray_batch_raises_like_the_reference():
         model(a["rays"][:0].cuda(), None, None)
 
 
+def test_background_space_time_with_mixed_frame_ids_is_refused_not_approximated():
+    """BKGD_USE_SPACE_TIME (off in both shipped ymls): the reference tiles the background's frame ids over the samples when they
+    differ across the rays of a call (modeling/spacenet.py:117-118 with the 1-D ids of layered_rfrender.py:380; the oracle restates
+    it and matches fwd_bkgd_time_mixed_ids on CPU).  The HIP path feeds a ray's own id -- identical whenever a call has ONE
+    background frame id (every rendered frame: fwd_bkgd_time above) -- and refuses the mixed case instead of rendering something else."""
+    meta, a = load_golden("fwd_bkgd_time_mixed_ids")
+    model = build_model(meta)
+    rays = a["rays"].cuda()
+    assert rays.shape[1] == 7 and len(set(rays[:, 6].tolist())) > 1
+    with pytest.raises(NotImplementedError, match="BKGD_USE_SPACE_TIME"):
+        model(rays, None, None)
+    same = rays.clone()
+    same[:, 6] = rays[0, 6]
+    model.replay = None
+    out = model(same, None, None)                       # one id for the whole call: renders
+    assert bool(torch.isfinite(out[0][0]).all())
+
+
 def test_cpu_tensors_are_refused():
     meta, a = load_golden("fwd_c1")
     model = build_model(meta)

@@ -131,8 +131,10 @@ def _model_for(meta, device="cuda"):
                               POSE_REFINEMENT=False, USE_DIR=True, USE_DEFORM_VIEW=False, USE_DEFORM_TIME=meta["deform_time"],
                               USE_SPACE_TIME=meta["space_time"], BKGD_USE_DEFORM_TIME=False, BKGD_USE_SPACE_TIME=False, DEEP_RGB=False,
                               COARSE_RAY_SAMPLING=meta["n1"], FINE_RAY_SAMPLING=meta["n2"])
+    for k, v in meta.get("flags", {}).items():
+        setattr(m, k, v)
     model = build_layered_model(types.SimpleNamespace(MODEL=m, DATASETS=types.SimpleNamespace(LAYER_NUM=meta["L"])), camera_num=1)
-    model.load_state_dict(syn.make_state_dict(meta["L"], meta["space_time"], meta["deform_time"], seed=meta["weight_seed"]))
+    model.load_state_dict(syn.state_dict_for_flags(meta["L"], meta["space_time"], meta["deform_time"], meta["weight_seed"], meta.get("flags", {})))
     bk, per = syn.scene_boxes(meta["L"])
     model.set_bkgd_bbox(bk)
     model.set_bboxes(per)
@@ -161,7 +163,7 @@ FP32_NOISE_FACTOR = 3.0
 CONDITIONED_RTOL = 1e-3   # networks behind a MotionNet or the resampler: see the test's docstring (the conditioning of sin(2^9 x), not of the kernels)
 
 
-@pytest.mark.parametrize("name", ["train_c3", "train_coarse_only", "train_c4"])
+@pytest.mark.parametrize("name", ["train_c3", "train_coarse_only", "train_c4", "train_flags"])
 def test_training_step_matches_the_reference_fixture(ops, name):
     """Bar: every parameter's gradient within GRAD_RTOL of the REFERENCE's fp32 autograd (the fixture).  Where the reference's own
     autograd departs from an fp64 evaluation of the same graph by more than that -- a ReLU'(0) event: train_c3 has ONE hidden unit
@@ -202,12 +204,13 @@ def test_training_step_matches_the_reference_fixture(ops, name):
             d64 = digest(pname, sd64[pname].grad)
             ref_vs_64 = compare_digest(pname, torch.from_numpy(z["grad|" + pname]), d64, rel=GRAD_RTOL)
             hip_vs_64 = compare_digest(pname, digest(pname, named[pname].grad), d64, rel=GRAD_RTOL)
-            conditioned = not pname.startswith("bkgd_spacenet.")      # behind a MotionNet and / or the resampler
+            # behind a MotionNet and / or the resampler (with BKGD_USE_DEFORM_TIME the coarse background net is, too)
+            conditioned = not pname.startswith("bkgd_spacenet.") or bool(meta.get("flags", {}).get("BKGD_USE_DEFORM_TIME"))
             bar = max(1.0, FP32_NOISE_FACTOR * ref_vs_64, CONDITIONED_RTOL / GRAD_RTOL if conditioned else 0.0)
             # (ref_vs_64 is measured ON the reference run's sample positions: for a conditioned network it does not contain the
             # position noise the HIP run has against both -- train_c4's fine networks: reference 6e-6 from fp64, HIP 8e-5 from either)
             assert (ref_vs_64 > 1.0 or conditioned) and hip_vs_64 <= bar, (pname, vs_ref[pname], hip_vs_64, ref_vs_64)
-        assert name in ("train_c3", "train_c4"), off      # (train_c4: deformation nets and a fine stage, no ReLU'(0) event)
+        assert name in ("train_c3", "train_c4", "train_flags"), off      # (train_c4: deformation nets and a fine stage, no ReLU'(0) event)
     for pname in meta["without_grad"]:       # the fine networks of a coarse-only epoch
         assert named[pname].grad is None or float(named[pname].grad.abs().max()) == 0.0, pname
     # optimizer.step() (:283; solver/build.py:18).  Adam's first step moves every entry by lr * sign(g) whatever |g| is: the stepped

@@ -10,7 +10,7 @@ from stnerf_amd import synthetic as syn
 
 FWD_CASES = ["fwd_c1", "fwd_c3", "fwd_edit", "fwd_hide", "fwd_nonretime", "fwd_only_coarse",
              "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet", "fwd_deep_rgb", "fwd_no_raw_no_dir", "fwd_c4", "fwd_c5",
-             "fwd_c3_90_30", "fwd_c3_90_30_chunked", "fwd_c3_64_64", "fwd_grazing"]
+             "fwd_c3_90_30", "fwd_c3_90_30_chunked", "fwd_c3_64_64", "fwd_grazing", "fwd_bkgd_time_mixed_ids"]
 
 
 def test_generate_rays():

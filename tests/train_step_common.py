@@ -1,6 +1,6 @@
 """One iteration of the reference trainer's inner loop (engine/layered_trainer.py:186-283), restated for the tests that compare
 a training step with the fixtures tests/golden/make_golden.py --grads recorded from the reference's own model, loss and optimiser
-(train_c3.npz, train_coarse_only.npz, train_c4.npz)."""
+(train_c3.npz, train_coarse_only.npz, train_c4.npz, train_flags.npz)."""
 import json
 import os
 
@@ -74,11 +74,13 @@ def oracle_step(z, meta, dtype, sample_dtype=None):
     from oracle import stnerf_oracle as O
     from stnerf_amd import synthetic as syn
     L = meta["L"]
-    sd = {k: v.to(dtype).requires_grad_(True) for k, v in syn.make_state_dict(L, meta["space_time"], meta["deform_time"],
-                                                                             seed=meta["weight_seed"]).items()}
+    fl = meta.get("flags", {})
+    sd = {k: v.to(dtype).requires_grad_(True) for k, v in syn.state_dict_for_flags(L, meta["space_time"], meta["deform_time"],
+                                                                                  meta["weight_seed"], fl).items()}
     bk, per = syn.scene_boxes(L)
     m = O.OracleModel(layer_num=L, n_coarse=meta["n1"], n_fine=meta["n2"], params=sd, use_deform_time=meta["deform_time"],
-                      use_space_time=meta["space_time"], bkgd_bbox=bk.to(dtype), bboxes=per.to(dtype))
+                      use_space_time=meta["space_time"], bkgd_use_deform_time=fl.get("BKGD_USE_DEFORM_TIME", False),
+                      bkgd_use_space_time=fl.get("BKGD_USE_SPACE_TIME", False), bkgd_bbox=bk.to(dtype), bboxes=per.to(dtype))
     draws, _ = replay_of(z, meta, dtype)
     it = iter(draws)
     out = O.render_chunk(m, torch.from_numpy(z["rays"]).to(dtype), only_coarse=meta["only_coarse"], rand=lambda shape: next(it),
