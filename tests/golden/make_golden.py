@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by running the REFERENCE's own code (build container only).
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py        # the base set
+    ... make_golden.py --round2 | --model-flags | --more-layers | --teacher | --psnr-view | --grads      # one group each; every file
+    regenerates byte for byte (--grads: train_c3 / train_coarse_only / train_c4 / train_flags, one iteration of the reference's
+    do_train inner loop each, with the thread count pinned)
 
 Imports ``/root/reference`` (a pure-Python/PyTorch repo) on CPU with the three shims of
 SURVEY.md section 8(c): a SimpleNamespace cfg (yacs is absent), ``Tensor.cuda`` = identity (no
@@ -666,13 +669,11 @@ def g_train_cases():
     g_train_step("train_coarse_only", 1, 24, 8, False, True, 42, n_rays=64, only_coarse=True)
     # C4-shaped (four performers, deformation nets, SpaceNets WITHOUT the time input: configs/config_walking.yml), both stages: five
     # layers in the merged list, the fine stage's alpha on layer 2, rays that hit 0 .. 3 performers
-    if "--c4" in sys.argv or "--all-grads" in sys.argv:
-        g_train_step("train_c4", 4, 24, 16, False, True, 43, n_rays=96)
+    g_train_step("train_c4", 4, 24, 16, False, True, 43, n_rays=96)
     # the model flags both shipped ymls leave off, under autograd: the 4-layer colour head (config/defaults.py:39 DEEP_RGB) and a
     # background with its own deformation net (MotionNet(input_time=False)).  (Not BKGD_USE_SPACE_TIME: on a batch with mixed frame
     # ids the reference tiles the background's ids over the samples, see fwd_bkgd_time_mixed_ids)
-    if "--flags" in sys.argv or "--all-grads" in sys.argv:
-        g_train_step("train_flags", 1, 16, 8, True, True, 44, n_rays=64, flags=dict(DEEP_RGB=True, BKGD_USE_DEFORM_TIME=True))
+    g_train_step("train_flags", 1, 16, 8, True, True, 44, n_rays=64, flags=dict(DEEP_RGB=True, BKGD_USE_DEFORM_TIME=True))
 
 
 
