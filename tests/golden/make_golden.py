@@ -3,7 +3,7 @@
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py        # the base set
     ... make_golden.py --round2 | --model-flags | --more-layers | --teacher | --psnr-view | --grads      # one group each; every file
-    regenerates byte for byte (--grads: train_c3 / train_coarse_only / train_c4 / train_flags, one iteration of the reference's
+    regenerates byte for byte (--grads: train_c3 / train_coarse_only / train_c4 / train_flags / train_same_spacenet, one iteration of the reference's
     do_train inner loop each, with the thread count pinned)
 
 Imports ``/root/reference`` (a pure-Python/PyTorch repo) on CPU with the three shims of
@@ -674,6 +674,12 @@ def g_train_cases():
     # background with its own deformation net (MotionNet(input_time=False)).  (Not BKGD_USE_SPACE_TIME: on a batch with mixed frame
     # ids the reference tiles the background's ids over the samples, see fwd_bkgd_time_mixed_ids)
     g_train_step("train_flags", 1, 16, 8, True, True, 44, n_rays=64, flags=dict(DEEP_RGB=True, BKGD_USE_DEFORM_TIME=True))
+    # SAME_SPACENET: the fine stage runs the COARSE performer networks again (layered_rfrender.py:70-71) -- one nn.Module called twice
+    # per iteration, its gradients the sum of both calls
+    # (weight seed 48: with seed 45 the background density head's gradient -- the SUM of the signed density cotangents over all
+    # samples -- cancelled 76-fold, so that fp32 rounding of the terms was 1e-4 of the sum, in the reference's autograd as in any
+    # other; the fixtures' bars are relative to a tensor's largest entry and want sums that are not differences: 1 - 8 x here)
+    g_train_step("train_same_spacenet", 2, 16, 8, True, True, 48, n_rays=64, flags=dict(SAME_SPACENET=True))
 
 
 

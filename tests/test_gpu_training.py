@@ -163,7 +163,7 @@ FP32_NOISE_FACTOR = 3.0
 CONDITIONED_RTOL = 1e-3   # networks behind a MotionNet or the resampler: see the test's docstring (the conditioning of sin(2^9 x), not of the kernels)
 
 
-@pytest.mark.parametrize("name", ["train_c3", "train_coarse_only", "train_c4", "train_flags"])
+@pytest.mark.parametrize("name", ["train_c3", "train_coarse_only", "train_c4", "train_flags", "train_same_spacenet"])
 def test_training_step_matches_the_reference_fixture(ops, name):
     """Bar: every parameter's gradient within GRAD_RTOL of the REFERENCE's fp32 autograd (the fixture).  Where the reference's own
     autograd departs from an fp64 evaluation of the same graph by more than that -- a ReLU'(0) event: train_c3 has ONE hidden unit
@@ -210,7 +210,7 @@ def test_training_step_matches_the_reference_fixture(ops, name):
             # (ref_vs_64 is measured ON the reference run's sample positions: for a conditioned network it does not contain the
             # position noise the HIP run has against both -- train_c4's fine networks: reference 6e-6 from fp64, HIP 8e-5 from either)
             assert (ref_vs_64 > 1.0 or conditioned) and hip_vs_64 <= bar, (pname, vs_ref[pname], hip_vs_64, ref_vs_64)
-        assert name in ("train_c3", "train_c4", "train_flags"), off      # (train_c4: deformation nets and a fine stage, no ReLU'(0) event)
+        assert name in ("train_c3", "train_c4", "train_flags", "train_same_spacenet"), off      # (train_c4: deformation nets and a fine stage, no ReLU'(0) event)
     for pname in meta["without_grad"]:       # the fine networks of a coarse-only epoch
         assert named[pname].grad is None or float(named[pname].grad.abs().max()) == 0.0, pname
     # optimizer.step() (:283; solver/build.py:18).  Adam's first step moves every entry by lr * sign(g) whatever |g| is: the stepped

@@ -13,7 +13,7 @@ from stnerf_amd import synthetic as syn                  # noqa: E402
 from train_step_common import compare_digest, load_fixture, oracle_step   # noqa: E402
 
 
-@pytest.mark.parametrize("name", ["train_c3", "train_coarse_only", "train_c4", "train_flags"])
+@pytest.mark.parametrize("name", ["train_c3", "train_coarse_only", "train_c4", "train_flags", "train_same_spacenet"])
 def test_oracle_training_step_matches_the_reference(name):
     z, meta = load_fixture(name)
     sd, out, loss, parts = oracle_step(z, meta, torch.float32)
