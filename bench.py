@@ -45,8 +45,15 @@ from stnerf_amd import parallel                         # noqa: E402
 from stnerf_amd.parallel import gather_tiles, render_view  # noqa: E402
 
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
-MEASURED_HBM_JSON = os.path.join(REPO, "profiles", "r05_hbm_copy_microbench.json")   # tools/micro/hbm_copy on the GPU box
-PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r05_pmc_hbm_traffic.json")         # tools/summarise.py (pose 0 of the sweep)
+def _latest_profile(suffix):
+    """The newest round's profiles/rNN_<suffix> (tools/summarise.py writes one per round)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_" + suffix)))
+    return found[-1] if found else os.path.join(REPO, "profiles", "r00_" + suffix)
+
+
+MEASURED_HBM_JSON = _latest_profile("hbm_copy_microbench.json")   # tools/micro/hbm_copy on the GPU box
+PMC_TRAFFIC_JSON = _latest_profile("pmc_hbm_traffic.json")         # tools/summarise.py (pose 0 of the sweep; carries the build it ran on)
 
 # Algorithmic work per network evaluation (SURVEY.md section 8d): 2 * MACs of every nn.Linear.
 FLOP_SPACE, FLOP_SPACE_TIME, FLOP_MOTION = 924_672, 930_048, 153_344
@@ -315,10 +322,24 @@ def emulate_share(model, dims, rank_counts, stripe_rows, device, steps):
             "t1_ms": t1_ms, "steps": steps, "stripe_rows": stripe_rows, "shares": out}
 
 
+def fail(message, code=2):
+    """A run that cannot measure anything still ends with ONE parsable JSON line as the last stdout line (rank 0 only), and a
+    non-zero exit status."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps({"error": message, "metric": "rendered rays/s (and ray-samples/s) per GPU, 1080p x 128-sample layered render",
+                          "value": None}))
+        sys.stdout.flush()
+    sys.stderr.write("bench.py: " + message + "\n")
+    sys.exit(code)
+
+
 def _self_launch(args):
     """`python bench.py --gpus N` (N > 1) without torch.distributed.run's environment: become the launcher of N ranks of
     this very command (one process per GPU, rendezvous on 127.0.0.1, a free port)."""
     import socket
+    if not args.debug_single_device and torch.cuda.device_count() < args.gpus:
+        fail(f"--gpus {args.gpus} but this node exposes {torch.cuda.device_count()} GPU(s): one process per GPU "
+             "(check HIP_VISIBLE_DEVICES / the compute partition mode)")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -341,7 +362,7 @@ EXECUTED_TERMS = {"fp32": 1.0, "bf16x3": 6.0}     # MFMA products executed per a
 STAGE_KERNEL = {
     "bf16x3": "stnerf::mlp_bf16x3_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, a wave owns 32 "
               "samples and keeps their activations in registers as three bf16 planes, weights through an LDS-DMA ring, "
-              "v_mfma_f32_32x32x16_bf16; achieved = EXECUTED MFMA rate = 6 x algorithmic)",
+              "v_mfma_f32_32x32x16_bf16; achieved = algorithmic rate, executed MFMA rate = 6 x that)",
     "fp32": "stnerf::mlp_wave_stage_kernel (one persistent launch per stage: MotionNet + SpaceNet of every layer, a wave owns 32 "
             "samples and keeps their activations in registers, v_mfma_f32_32x32x2_f32)"}
 
@@ -363,30 +384,53 @@ def _stage_of(leg):
     return leg["ksum"]["mlp_stage"] if "mlp_stage" in leg["ksum"] else leg["ksum"]["spacenet"]
 
 
+def pmc_matches_loaded_library(pmc):
+    """Counter bytes are a property of the kernels they were measured on: the committed PMC file names the build
+    (`fatbin_sha256` of libstnerf_hip.so's .hip_fatbin, `rev`); anything else loaded -> no traffic figure."""
+    from stnerf_amd import hip
+    want = pmc.get("fatbin_sha256")
+    return bool(want) and want == hip.fatbin_sha256()
+
+
 def roofline_of(leg, workload, ctx):
-    """MFMA roofline of the stage kernel of one leg: EXECUTED MFMA rate (what the matrix pipe does) over the dense peak
-    of the instruction it issues, and the algorithmic rate (network FLOPs of the reference's arithmetic) beside it."""
+    """MFMA roofline of the stage kernel of one leg, as SURVEY.md section 8(d) defines it: achieved = ALGORITHMIC FLOPs (network
+    evaluations x FLOPs per evaluation of the reference's arithmetic) / the kernel's time; peak = the ceiling for the arithmetic that
+    is delivered -- fp32-faithful products: the f32 MFMA peak for the exact kernel, the dense bf16 MFMA peak / 6 for bf16x3 (six bf16
+    terms per product is the minimum for 24-bit significands on an 8-bit-significand MFMA).  The EXECUTED MFMA rate (what the matrix
+    pipe does) stays beside it under names that say so."""
     prec = leg["precision"]
     pmc, world = ctx["pmc"], ctx["world"]
     sp = _stage_of(leg)
     alg = sp["flop"] / (sp["ms"] * 1e-3) / 1e12
-    executed = EXECUTED_TERMS[prec] * alg
-    peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    terms = EXECUTED_TERMS[prec]
+    executed = terms * alg
+    instr_peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    peak = instr_peak / terms
     sustained = SUSTAINED_F32_MFMA_TFLOPS if prec == "fp32" else SUSTAINED_16BIT_MFMA_TFLOPS
-    # HBM traffic cannot be counted inside this process: it comes from the committed rocprofv3 PMC passes
-    # of the same command (profiles/), per launch, with the gfx950 FETCH_SIZE correction applied.
+    # HBM traffic cannot be counted inside this process: it comes from the committed rocprofv3 PMC passes of the same command
+    # (profiles/), per launch, with the gfx950 FETCH_SIZE correction applied -- and only when those passes ran on the kernels
+    # that are loaded now (the .hip_fatbin digest recorded beside them), on this workload, on one GPU.
     pk = pmc.get({"bf16x3": "kernels_bf16x3", "fp32": "kernels"}.get(prec, "-"), {})
     dom = "mlp_stage" if "mlp_stage" in leg["ksum"] else "spacenet"
-    traffic = pk[dom]["hbm_bytes_per_launch"] if (pmc.get("workload") == workload and world == 1 and dom in pk) else None
+    same_build = ctx.get("pmc_same_build")
+    if same_build is None:
+        same_build = pmc_matches_loaded_library(pmc)
+    usable = pmc.get("workload") == workload and world == 1 and dom in pk
+    traffic = pk[dom]["hbm_bytes_per_launch"] if (usable and same_build) else None
     return {"kernel": STAGE_KERNEL[prec] if dom == "mlp_stage" else "stnerf::spacenet_kernel (fused PE + 9-layer MLP)",
-            "bound": "mfma", "achieved": executed, "peak": peak, "unit": "TFLOP/s", "frac": executed / peak,
-            "executed_mfma_tflops": executed, "algorithmic_tflops": alg, "mfma_terms_per_product": EXECUTED_TERMS[prec],
+            "bound": "mfma", "achieved": alg, "peak": peak, "unit": "TFLOP/s", "frac": alg / peak,
+            "peak_note": (f"{instr_peak:g} dense bf16 MFMA / {terms:g} bf16x3 terms per fp32-faithful product = {peak:.1f}" if prec == "bf16x3"
+                          else f"{instr_peak:g} v_mfma_f32_32x32x2_f32"),
+            "algorithmic_tflops": alg, "executed_mfma_tflops": executed, "mfma_terms_per_product": terms,
+            "executed_frac_of_instruction_peak": executed / instr_peak, "instruction_peak": instr_peak,
             "measured_sustained_peak": sustained, "frac_of_measured_sustained_peak": executed / sustained,
             "measured_sustained_peak_source": "profiles/r01_mfma_rate_microbench.md: register-only MFMA loop, all 256 CUs, ~3 s, random operands "
                                               "(16-bit MFMA: power-bound at 1.3 kW; f32 MFMA: issue-bound)",
-            "traffic": traffic,
+            "traffic": traffic, "traffic_rev": pmc.get("rev") if usable else None, "traffic_pose": pmc.get("pose_short") if usable else None,
+            "traffic_same_build": bool(same_build) if usable else None,
             "traffic_source": ("profiles/" + os.path.basename(PMC_TRAFFIC_JSON) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over ONE "
-                               "step of this workload at pose 0 of the sweep (the timed steps sweep the orbit: +- 10 % evaluations)") if traffic else None,
+                               "step of this workload at pose 0 of the sweep (the timed steps sweep the orbit: +- 10 % evaluations), on the build "
+                               "whose .hip_fatbin digest the file records; null when another build is loaded") if usable else None,
             "algorithmic_bytes_per_launch": 28 * sp["evals"] / sp["launches"],   # 12 B point in + 16 B raw out per SpaceNet evaluation
             "launches": sp["launches"], "avg_launch_ms": sp["ms"] / sp["launches"],
             "algorithmic_flop_per_launch": sp["flop"] / sp["launches"],
@@ -467,18 +511,22 @@ def build_records(head, second, config_legs, ctx):
         "ray_samples_per_s": hr["ray_samples_per_s"],
         "roofline": {"kernel": KERNEL_SHORT[head["precision"]] if "mlp_stage" in head["ksum"] else "stnerf::spacenet_kernel",
                      "bound": "mfma", "achieved": roof["achieved"], "peak": roof["peak"], "unit": "TFLOP/s", "frac": roof["frac"],
-                     "algorithmic_tflops": roof["algorithmic_tflops"], "mfma_terms_per_product": roof["mfma_terms_per_product"],
-                     "traffic": roof["traffic"], "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"],
+                     "peak_note": roof["peak_note"], "algorithmic_tflops": roof["algorithmic_tflops"],
+                     "executed_mfma_tflops": roof["executed_mfma_tflops"], "mfma_terms_per_product": roof["mfma_terms_per_product"],
+                     "executed_frac_of_instruction_peak": roof["executed_frac_of_instruction_peak"],
+                     "traffic": roof["traffic"], "traffic_rev": roof["traffic_rev"], "traffic_pose": roof["traffic_pose"],
+                     "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"],
                      "avg_launch_ms": roof["avg_launch_ms"], "launches": roof["launches"]},
         "cpu_baseline": None if cpu is None else {
             "value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
-            "sample": cpu.get("sample_short", cpu["sample"])[:200], "seconds": cpu["seconds"], "cpu": cpu["host"]["cpu"][:64]},
+            "sample": cpu.get("sample_short", cpu["sample"])[:200], "chunks": len(cpu.get("chunks") or []),
+            "chunks_asked_by_baseline_md": ">= 8 (BASELINE.md 3.3)", "seconds": cpu["seconds"], "cpu": cpu["host"]["cpu"][:64]},
     }
     if second is not None:
         sr = leg_record(second, workload, ctx)
         final["other_precision"] = {"precision": second["precision"], "value": sr["value"], "ms_per_step": sr["ms_per_step"],
                                     "steps": second["steps"], "warmup": second["warmup"], "frac": sr["roofline"]["frac"],
-                                    "algorithmic_tflops": sr["roofline"]["algorithmic_tflops"]}
+                                    "peak": sr["roofline"]["peak"], "algorithmic_tflops": sr["roofline"]["algorithmic_tflops"]}
     if ctx.get("psnr"):
         p = ctx["psnr"]
         final["psnr_vs_reference_dB"] = {"reference_seed_b_vs_a": p.get("reference_seed_b_vs_seed_a_dB"),
@@ -555,9 +603,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="taekwondo-1080p-64+64", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-baseline-rays", type=int, default=5 * 3584,
-                    help="0 disables the CPU baseline leg; default = 5 reference chunks spread over the image, ~28 s of host work "
-                         "(BASELINE.md 3.3; a chunk's rate varies by 3 %% over the image)")
+    ap.add_argument("--cpu-baseline-rays", type=int, default=8 * 3584,
+                    help="0 disables the CPU baseline leg; default = 8 reference chunks spread over the image, ~50 s of host work "
+                         "(what BASELINE.md 3.3 asks for: >= 8 chunks; the driver's run is ~3.5 min with it)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline leg (0 = min(32, host cores))")
     ap.add_argument("--rays-per-launch", type=int, default=1 << 19)
     ap.add_argument("--partition", default="stripes", choices=["views", "stripes"],
@@ -598,14 +646,19 @@ def main():
         _self_launch(args)                               # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if rank != 0:
+        # the record is rank 0's LAST stdout line: whatever another rank (or a library under it: RCCL / torchrun notices) writes to
+        # stdout goes to stderr instead, under the driver's own torch.distributed.run as under _self_launch
+        sys.stdout.flush()
+        os.dup2(2, 1)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        fail(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (the render path has no CPU fallback)")
+        fail("bench.py needs an MI355X (the render path has no CPU fallback)")
     try:
         parallel.init_from_env(single_device=args.debug_single_device)   # cuda:LOCAL_RANK, RCCL (gloo in the one-device debug mode)
     except RuntimeError as e:
-        raise SystemExit(str(e))
+        fail(str(e))
     device = torch.device("cuda", torch.cuda.current_device())
     dist = None
     if world > 1:

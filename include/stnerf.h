@@ -364,9 +364,13 @@ int stnerf_train_linear_dw(const float* dy, int64_t lddy, const float* x, int64_
 /* Every weight and bias gradient of a network in ONE launch (+ one for the reduction): `count` (<= 16) layers whose dy / x have
  * the same m rows -- what loss.backward() accumulates into the .grad of every nn.Linear of modeling/spacenet.py:45-86 or
  * modeling/motion_net.py:20-32 --, same operand rules and the same result contract as stnerf_train_linear_dw (dw[n][k] (+)= dy^T
- * x, db[n] (+)= column sums of dy, db may be NULL; n <= 256 where db is given), sliced over the samples once for all layers
- * (<= 256 slices of >= 256 rows, partials summed in slice order: deterministic).  The work items of all layers fill the chip
- * together, the bias sums run beside the MFMA items instead of in launches of their own. */
+ * x, db[n] (+)= column sums of dy, db may be NULL).  csrc/train_dw.hip: a WAVE keeps a 128 x 128 tile of one dw in its
+ * accumulator registers (row blocks of 128 -- one block of 32 for a layer of <= 4 outputs --, column pieces of 128, the last piece
+ * 96 / 64 / 32 wide) and streams a range of samples past it, operands straight from the row-major matrices (no LDS); sample ranges
+ * are sized by a tile's MFMA count so that the launch's <= 1024 waves finish together (>= 64 samples each); partial tiles are summed
+ * in range order: deterministic, no atomics.  At most 64 tiles and 100 reduction segments (tiles + bias row blocks) per call.
+ * Columns of dy / x beyond n / k may be read (up to the tile's width: into the row's padding, the next row, never beyond the last
+ * row's round4 end); they only reach outputs that are not stored. */
 typedef struct stnerf_dw_problem {
     const float* dy;   /* [m][lddy], n columns */
     int64_t lddy;

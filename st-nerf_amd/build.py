@@ -30,10 +30,14 @@ SOURCES = [
     ("stage_entry.hip", []),
     ("pipeline.hip", []),
     ("train.hip", []),
+    ("train_dw.hip", []),
     ("render_bwd.hip", []),
     ("train_wave.hip", []),
 ]
 EXTRA = os.environ.get("STNERF_EXTRA_FLAGS", "").split()   # e.g. -DSTNERF_PHASE_PROF (development only)
+# STNERF_FLAGS_<source stem> (development): extra flags for ONE source of a variant build, e.g.
+# STNERF_LIB_TAG=noslp STNERF_FLAGS_mlp_bf16x3=-fno-slp-vectorize (the A/B of profiles/retired_designs.md)
+SOURCES = [(s, f + os.environ.get("STNERF_FLAGS_" + s[:-4], "").split()) for s, f in SOURCES]
 COMMON = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-I" + os.path.join(REPO, "include"), "-I" + CSRC]
 

@@ -401,139 +401,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y
     colsum_rows<CG>(y, ld, N, blockIdx.x, m_begin, min(M, m_begin + rows_per_block), partial + (int64_t)blockIdx.y * N, red);
 }
 
-// A layer of at most four outputs (the density and colour heads, MotionNet's last layer): dW[j][c] = sum_m dy[m][j] x[m][c] is
-// four weighted column sums of X -- HBM-bound vector code like colsum_rows, where a 128-row MFMA tile would multiply 124 rows of
-// nothing.  dy rows are read as one 16-byte vector (the caller guarantees round4(n) readable floats), only rows j < n are stored.
-template <int CG>
-__device__ __forceinline__ void thin_rows(const float* __restrict__ dy, int64_t lddy, int n, const float* __restrict__ x, int64_t ldx, int K,
-                                          int col_block, int m_begin, int m_end, float* __restrict__ out, float4* red) {
-    constexpr int RL = 256 / CG;
-    const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
-    const int col = 4 * (col_block * CG + cg);
-    float4 s[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col < K) {
-        const float* p = x + col;
-        auto row = [&](const float4& w, const float4& v) {
-            s[0].x += w.x * v.x; s[0].y += w.x * v.y; s[0].z += w.x * v.z; s[0].w += w.x * v.w;
-            s[1].x += w.y * v.x; s[1].y += w.y * v.y; s[1].z += w.y * v.z; s[1].w += w.y * v.w;
-            s[2].x += w.z * v.x; s[2].y += w.z * v.y; s[2].z += w.z * v.z; s[2].w += w.z * v.w;
-            s[3].x += w.w * v.x; s[3].y += w.w * v.y; s[3].z += w.w * v.z; s[3].w += w.w * v.w;
-        };
-        int m = m_begin + rl;
-        for (; m + 3 * RL < m_end; m += 4 * RL) {
-            const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)m * ldx), v1 = *reinterpret_cast<const float4*>(p + (int64_t)(m + RL) * ldx);
-            const float4 v2 = *reinterpret_cast<const float4*>(p + (int64_t)(m + 2 * RL) * ldx), v3 = *reinterpret_cast<const float4*>(p + (int64_t)(m + 3 * RL) * ldx);
-            const float4 w0 = *reinterpret_cast<const float4*>(dy + (int64_t)m * lddy), w1 = *reinterpret_cast<const float4*>(dy + (int64_t)(m + RL) * lddy);
-            const float4 w2 = *reinterpret_cast<const float4*>(dy + (int64_t)(m + 2 * RL) * lddy), w3 = *reinterpret_cast<const float4*>(dy + (int64_t)(m + 3 * RL) * lddy);
-            row(w0, v0); row(w1, v1); row(w2, v2); row(w3, v3);
-        }
-        for (; m < m_end; m += RL) row(*reinterpret_cast<const float4*>(dy + (int64_t)m * lddy), *reinterpret_cast<const float4*>(p + (int64_t)m * ldx));
-    }
-    for (int j = 0; j < n; ++j) {                       // (n is uniform; the row lanes fold through LDS in lane order, one output row at a time)
-        __syncthreads();
-        red[rl * CG + cg] = j == 0 ? s[0] : j == 1 ? s[1] : j == 2 ? s[2] : s[3];
-        __syncthreads();
-        if (rl == 0 && col < K) {
-            float4 t = red[cg];
-            for (int r = 1; r < RL; ++r) {
-                const float4 u = red[r * CG + cg];
-                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-            }
-            float* o = out + (int64_t)j * K + col;
-            o[0] = t.x;
-            if (col + 1 < K) o[1] = t.y;
-            if (col + 2 < K) o[2] = t.z;
-            if (col + 3 < K) o[3] = t.w;
-        }
-    }
-}
-
-// ---- every weight and bias gradient of a network in ONE launch (stnerf_train_dw_batch) -------------------------------------
-// The layers' dW = dY^T X share the contraction (the samples), so they share the slicing: slice z = rows [z kps, (z + 1) kps) of
-// every layer's dY and X.  A work item is (slice, tile) -- a 128 x 256 or 128 x 128 piece of one layer's dW reduced over the
-// slice into a partial tile -- or (slice, bias): the column sums of one layer's dY over the slice (HBM-bound vector code that
-// runs NEXT to the MFMA items of other workgroups instead of in a launch of its own) -- or (slice, thin layer, 256 columns): a layer
-// of <= 4 outputs as weighted column sums (thin_rows).  Items are ordered slice-major and dealt
-// to the XCDs in contiguous ranges (hardware workgroup b runs on XCD b % 8): the tiles that read the same rows of X and dY
-// are neighbours on one XCD's L2.  The widths 319 / 304 of stage2.0 / rgb_net.1 take a 256- and a 64-column item (launched
-// alone they were two 256-column tiles), the 63 columns of stage1.0 one 64-column item per row tile.  The partials are summed in slice order by dw_reduce_kernel: deterministic, no atomics.
-constexpr int DW_MAX_PROBLEMS = 16, DW_MAX_TILES = 64, DW_MAX_SEGMENTS = 2 * DW_MAX_PROBLEMS;
-struct DwProblem {
-    const float* dy;
-    const float* x;
-    int64_t lddy, ldx;
-    int64_t partial_off, bias_off;   // floats into the workspace: [slice][n][k] and [slice][n]
-    int32_t n, k;
-};
-struct DwTile {
-    uint16_t problem, m0, n0, kind;   // kind 0: 128 x 128 MFMA item, 1: 128 x 256, 3: 128 x 64, 2: thin layer, 256 columns from n0
-};
-struct DwBatchArgs {
-    DwProblem p[DW_MAX_PROBLEMS];
-    DwTile tile[DW_MAX_TILES];
-    uint8_t bias_problem[DW_MAX_PROBLEMS];
-    int32_t n_tiles, n_bias, slices, kps, m;
-    int32_t plain_order;             // development: work items in launch order instead of dealt to the XCDs (STNERF_DEV_DW_PLAIN_ORDER=1)
-    uint32_t items, items_per_xcd;
-    float* workspace;
-};
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void train_dw_batch_kernel(DwBatchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem_gemm[];
-    const uint32_t w = a.plain_order ? blockIdx.x : (blockIdx.x & 7u) * a.items_per_xcd + (blockIdx.x >> 3);
-    if (w >= a.items) return;
-    const int per_slice = a.n_tiles + a.n_bias;
-    const int z = (int)(w / (uint32_t)per_slice), i = (int)(w % (uint32_t)per_slice);
-    const int k_begin = z * a.kps, k_end = min(a.m, k_begin + a.kps);
-    if (i < a.n_tiles) {
-        const DwTile tl = a.tile[i];
-        const DwProblem& p = a.p[tl.problem];
-        const GemmArgs g{p.dy, p.x, nullptr, p.lddy, p.ldx, 0, p.n, p.k, a.m, nullptr, nullptr, 0, 0, 0, a.kps};
-        float* out = a.workspace + p.partial_off + (int64_t)z * p.n * p.k;
-        if (tl.kind == 1)
-            gemm_tile<false, false, 2, 256>(g, smem_gemm, tl.m0, tl.n0, k_begin, k_end, out, p.k);
-        else if (tl.kind == 0)
-            gemm_tile<false, false, 2, 128>(g, smem_gemm, tl.m0, tl.n0, k_begin, k_end, out, p.k);
-        else if (tl.kind == 3)
-            gemm_tile<false, false, 2, 64>(g, smem_gemm, tl.m0, tl.n0, k_begin, k_end, out, p.k);
-        else
-            thin_rows<64>(p.dy, p.lddy, p.n, p.x, p.ldx, p.k, tl.n0 / 256, k_begin, k_end, out, reinterpret_cast<float4*>(smem_gemm));
-    } else {
-        const DwProblem& p = a.p[a.bias_problem[i - a.n_tiles]];
-        float* out = a.workspace + p.bias_off + (int64_t)z * p.n;
-        float4* red = reinterpret_cast<float4*>(smem_gemm);
-        if (p.n > 128)
-            colsum_rows<64>(p.dy, p.lddy, p.n, 0, k_begin, k_end, out, red);
-        else if (p.n > 32)
-            colsum_rows<32>(p.dy, p.lddy, p.n, 0, k_begin, k_end, out, red);
-        else
-            colsum_rows<8>(p.dy, p.lddy, p.n, 0, k_begin, k_end, out, red);
-    }
-}
-// dst[i] (+)= sum_z partial[z][i] in z order, for every weight and bias gradient of the batch (blockIdx.y = segment).
-struct DwSegment {
-    float* dst;
-    int64_t ld_dst, partial_off;
-    int32_t count, cols;
-};
-struct DwReduceArgs {
-    DwSegment seg[DW_MAX_SEGMENTS];
-    const float* workspace;
-    int32_t slices, accumulate;
-};
-__global__ void dw_reduce_kernel(DwReduceArgs a) {
-    const DwSegment& sg = a.seg[blockIdx.y];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= sg.count) return;
-    const float* partial = a.workspace + sg.partial_off + i;
-    float s = 0.f;
-#pragma unroll 8
-    for (int z = 0; z < a.slices; ++z) s += partial[(int64_t)z * sg.count];
-    float* d = sg.dst + (int64_t)(i / sg.cols) * sg.ld_dst + (i % sg.cols);
-    *d = a.accumulate ? *d + s : s;
-}
-
 // ---- positional encodings ------------------------------------------------------------------------------------------------
 struct EncodeArgs {
     const float* x;       // [n_src][ldx]: dim input columns per source row
@@ -707,98 +574,7 @@ extern "C" int stnerf_train_linear_dw(const float* dy, int64_t lddy, const float
     return STNERF_OK;
 }
 
-// The batch's slicing: at most 256 slices of at least 256 samples (a multiple of 32).
-static int dw_batch_kps(int64_t m) {
-    int64_t kps = (m + 255) / 256;
-    if (kps < 256) kps = 256;
-    return (int)((kps + GBK - 1) / GBK * GBK);
-}
-static int check_dw_batch(const stnerf_dw_problem* pr, int32_t count, int64_t m) {
-    STNERF_REQUIRE(pr && count >= 1 && count <= DW_MAX_PROBLEMS, "train_dw_batch: 1 .. %d problems", DW_MAX_PROBLEMS);
-    STNERF_REQUIRE(m >= 0 && m < (1ll << 31), "train_dw_batch: bad sample count %lld", (long long)m);
-    int tiles = 0;
-    for (int i = 0; i < count; ++i) {
-        const stnerf_dw_problem& q = pr[i];
-        STNERF_REQUIRE(q.dy && q.x && q.dw, "train_dw_batch: null pointer in problem %d", i);
-        STNERF_REQUIRE(q.n >= 1 && q.n <= 65535 && q.k >= 1 && q.k <= 65535, "train_dw_batch: bad shape n=%d k=%d in problem %d", q.n, q.k, i);
-        STNERF_REQUIRE((q.lddy & 3) == 0 && (q.ldx & 3) == 0 && q.lddy >= ((q.n + 3) & ~3) && q.ldx >= ((q.k + 3) & ~3) && q.lddw >= q.k &&
-                           aligned16(q.dy) && aligned16(q.x),
-                       "train_dw_batch: dy / x need 16-byte aligned rows (ld %% 4 == 0) of at least round4(n) / round4(k) floats (problem %d)", i);
-        STNERF_REQUIRE(m * q.lddy < (1ll << 29) && m * q.ldx < (1ll << 29), "train_dw_batch: operands of 2 GiB and more: split the batch");
-        STNERF_REQUIRE(!q.db || q.n <= 256, "train_dw_batch: bias gradients of at most 256 outputs (problem %d has %d)", i, q.n);
-        tiles += q.n <= 4 ? (q.k + 255) / 256 : ((q.n + GBM - 1) / GBM) * ((q.k + 255) / 256);
-    }
-    STNERF_REQUIRE(tiles <= DW_MAX_TILES, "train_dw_batch: %d tiles, at most %d", tiles, DW_MAX_TILES);
-    return STNERF_OK;
-}
-static int64_t dw_batch_floats(const stnerf_dw_problem* pr, int32_t count, int64_t m) {
-    const int kps = dw_batch_kps(m);
-    const int64_t slices = m <= 0 ? 1 : (m + kps - 1) / kps;
-    int64_t floats = 0;
-    for (int i = 0; i < count; ++i) floats += slices * ((int64_t)pr[i].n * pr[i].k + ((pr[i].n + 3) & ~3));
-    return floats;
-}
-
-extern "C" int64_t stnerf_train_dw_batch_workspace_bytes(const stnerf_dw_problem* problems, int32_t count, int64_t m) {
-    if (check_dw_batch(problems, count, m)) return STNERF_EINVAL;
-    return 4 * dw_batch_floats(problems, count, m) + 512;
-}
-
-extern "C" int stnerf_train_dw_batch(const stnerf_dw_problem* problems, int32_t count, int64_t m, int32_t accumulate, void* workspace,
-                                     int64_t workspace_bytes, stnerf_stream_t stream) {
-    if (const int rc = check_dw_batch(problems, count, m)) return rc;
-    STNERF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= 4 * dw_batch_floats(problems, count, m) + 512,
-                   "train_dw_batch: workspace too small");
-    if (m == 0) return STNERF_OK;
-    hipStream_t st = as_stream(stream);
-    DwBatchArgs a{};
-    DwReduceArgs r{};
-    a.kps = dw_batch_kps(m);
-    a.slices = (int)((m + a.kps - 1) / a.kps);
-    a.m = (int)m;
-    a.workspace = static_cast<float*>(workspace);
-    int64_t off = 0;
-    int segs = 0, max_count = 0;
-    for (int i = 0; i < count; ++i) {
-        const stnerf_dw_problem& q = problems[i];
-        DwProblem& p = a.p[i];
-        p = DwProblem{q.dy, q.x, q.lddy, q.ldx, off, 0, q.n, q.k};
-        r.seg[segs++] = DwSegment{q.dw, q.lddw, off, q.n * q.k, q.k};
-        max_count = q.n * q.k > max_count ? q.n * q.k : max_count;
-        off += (int64_t)a.slices * q.n * q.k;
-        if (q.n <= 4) {                         // a thin layer: weighted column sums, 256 columns per item
-            for (int n0 = 0; n0 < q.k; n0 += 256) a.tile[a.n_tiles++] = DwTile{(uint16_t)i, 0, (uint16_t)n0, 2};
-            continue;
-        }
-        // a 256-column item while more than 128 columns are left, then a 128- or a 64-column one
-        for (int m0 = 0; m0 < q.n; m0 += GBM)
-            for (int n0 = 0; n0 < q.k;) {
-                const int left = q.k - n0, kind = left > 128 ? 1 : left > 64 ? 0 : 3;
-                a.tile[a.n_tiles++] = DwTile{(uint16_t)i, (uint16_t)m0, (uint16_t)n0, (uint16_t)kind};
-                n0 += kind == 1 ? 256 : kind == 0 ? 128 : 64;
-            }
-    }
-    for (int i = 0; i < count; ++i)
-        if (problems[i].db) {
-            a.p[i].bias_off = off;
-            a.bias_problem[a.n_bias++] = (uint8_t)i;
-            r.seg[segs++] = DwSegment{problems[i].db, (int64_t)problems[i].n, off, problems[i].n, problems[i].n};
-            off += (int64_t)a.slices * ((problems[i].n + 3) & ~3);
-        }
-    // (bias partials are [slice][n] with the slice stride n: the padding above is slack for the last slice only)
-    a.items = (uint32_t)a.slices * (uint32_t)(a.n_tiles + a.n_bias);
-    a.items_per_xcd = (a.items + 7) / 8;
-    static const bool plain = getenv("STNERF_DEV_DW_PLAIN_ORDER") && getenv("STNERF_DEV_DW_PLAIN_ORDER")[0] == '1';
-    a.plain_order = plain;
-    hipLaunchKernelGGL(train_dw_batch_kernel, dim3(8 * a.items_per_xcd), dim3(256), (GBM + 256) * GLD * 4, st, a);
-    STNERF_CHECK_LAUNCH("train_dw_batch");
-    r.workspace = a.workspace;
-    r.slices = a.slices;
-    r.accumulate = accumulate;
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((max_count + 255) / 256, segs), dim3(256), 0, st, r);
-    STNERF_CHECK_LAUNCH("train_dw_batch (reduce)");
-    return STNERF_OK;
-}
+// (stnerf_train_dw_batch -- every weight and bias gradient of a network in one launch -- lives in train_dw.hip since round 6)
 
 extern "C" int stnerf_train_encode(const float* x, int64_t ldx, int dim, int n_freq, int include_input, int64_t rows, int rows_per_src,
                                    int relu, int lerp_col, float* y, int64_t ldy, int col0, stnerf_stream_t stream) {

@@ -194,6 +194,36 @@ def dptr(t: Optional[torch.Tensor], dtype=torch.float32, name: str = "tensor") -
     return C.c_void_p(t.data_ptr())
 
 
+def fatbin_sha256(path: Optional[str] = None) -> Optional[str]:
+    """sha256 of the library's ``.hip_fatbin`` section (the device code objects): what identifies the KERNELS of a build
+    independently of where it was linked.  bench.py prints committed PMC counter bytes only when they were measured on
+    exactly these kernels (tools/summarise.py records the digest beside them).  None when the file is not an ELF64 with
+    that section."""
+    import hashlib
+    import struct
+    try:
+        with open(path or LIB_PATH, "rb") as f:
+            ident = f.read(64)
+            if ident[:4] != b"\x7fELF" or ident[4] != 2:
+                return None
+            shoff, = struct.unpack_from("<Q", ident, 0x28)
+            shentsize, shnum, shstrndx = struct.unpack_from("<HHH", ident, 0x3A)
+            f.seek(shoff)
+            table = f.read(shentsize * shnum)
+            sec = lambda i: struct.unpack_from("<IIQQQQ", table, i * shentsize)   # name, type, flags, addr, offset, size
+            _, _, _, _, str_off, str_size = sec(shstrndx)
+            f.seek(str_off)
+            names = f.read(str_size)
+            for i in range(shnum):
+                name, _, _, _, off, size = sec(i)
+                if names[name:names.index(b"\0", name)] == b".hip_fatbin":
+                    f.seek(off)
+                    return hashlib.sha256(f.read(size)).hexdigest()
+    except (OSError, struct.error, ValueError):
+        pass
+    return None
+
+
 def device_info() -> dict:
     cu, lds, clk = C.c_int(0), C.c_int(0), C.c_int(0)
     arch = C.create_string_buffer(64)

@@ -191,8 +191,8 @@ def test_render_workspace_query_and_argument_errors(lib):
 
 def test_training_batch_entries_check_their_arguments_on_the_host(lib):
     """stnerf_train_dw_batch_workspace_bytes / stnerf_train_dw_batch / stnerf_pack_transposed: host arithmetic and argument errors
-    before any launch (no GPU here): the workspace of a SpaceNet's ten layers, the limits (16 layers, 64 tiles, bias gradients of at
-    most 256 outputs, 16-byte aligned rows), the section table's bounds."""
+    before any launch (no GPU here): the workspace of a SpaceNet's ten layers, the limits (16 layers, 64 tiles, 16-byte aligned rows),
+    the section table's bounds."""
     fake = 1 << 20                                     # (never dereferenced)
     def problems(shapes, db=True, lddy=None):
         arr = (hip.DwProblem * len(shapes))()
@@ -201,15 +201,34 @@ def test_training_batch_entries_check_their_arguments_on_the_host(lib):
         return arr
     space = [(256, 63), (256, 256), (256, 256), (256, 256), (256, 319), (256, 256), (256, 256), (1, 256), (128, 304), (3, 128)]
     m = 262144
+
+    def tiles(shapes, db=True):
+        """csrc/train_dw.hip's tiling: (rows, cols, carries the bias sums) per wave tile."""
+        out = []
+        for n, k in shapes:
+            rows = 32 if n <= 4 else 128
+            for n0 in range(0, n, rows):
+                for k0 in range(0, k, 128):
+                    left = k - k0
+                    out.append((rows, 32 * (4 if left > 96 else 3 if left > 64 else 2 if left > 32 else 1), db and k0 == 0))
+        return out
+    one_range = lambda shapes, db=True: sum(r * c + (2 * r if b else 0) for r, c, b in tiles(shapes, db))
     nb = lib.stnerf_train_dw_batch_workspace_bytes(problems(space), len(space), m)
-    slices = 256                                       # <= 256 slices of >= 256 rows
-    assert nb == 4 * slices * sum(n * k + (n + 3) // 4 * 4 for n, k in space) + 512
-    assert lib.stnerf_train_dw_batch_workspace_bytes(problems(space), len(space), 100) == 4 * sum(n * k + (n + 3) // 4 * 4 for n, k in space) + 512
+    # <= 1024 wave tiles x ranges in all (one wave per SIMD), ~36 ranges per 128 x 128 tile of a SpaceNet: tens of MB, not round 5's 476
+    t = tiles(space)
+    assert len(t) == 34 and (nb - 512) % 16 == 0
+    assert 20 * 4 * one_range(space) < nb - 512 <= 4 * 1024 * (128 * 128 + 256) and nb < 80e6
+    # ranges are not cut below 64 samples: 64 samples = one range per tile, 100 = two
+    assert lib.stnerf_train_dw_batch_workspace_bytes(problems(space), len(space), 64) == 4 * one_range(space) + 512
+    assert lib.stnerf_train_dw_batch_workspace_bytes(problems(space), len(space), 100) == 2 * 4 * one_range(space) + 512
+    assert lib.stnerf_train_dw_batch_workspace_bytes(problems(space, db=False), len(space), 64) == 4 * one_range(space, False) + 512
+    assert lib.stnerf_train_dw_batch_workspace_bytes(problems(space), len(space), 0) == 4 * one_range(space) + 512
     assert lib.stnerf_train_dw_batch_workspace_bytes(problems([(8, 8)] * 17), 17, m) == hip.EINVAL
     assert "16 problems" in hip.last_error()
-    assert lib.stnerf_train_dw_batch_workspace_bytes(problems([(512, 4096)] * 2), 2, m) == hip.EINVAL      # 2 x 4 x 16 tiles
-    assert lib.stnerf_train_dw_batch_workspace_bytes(problems([(300, 8)]), 1, m) == hip.EINVAL             # db of 300 outputs
-    assert lib.stnerf_train_dw_batch_workspace_bytes(problems([(300, 8)], db=False), 1, m) > 0
+    assert lib.stnerf_train_dw_batch_workspace_bytes(problems([(512, 4096)] * 2), 2, m) == hip.EINVAL      # operands of 4 GiB
+    assert lib.stnerf_train_dw_batch_workspace_bytes(problems([(512, 4096)] * 2), 2, 1000) == hip.EINVAL   # 2 x 4 x 32 tiles
+    assert "tiles" in hip.last_error()
+    assert lib.stnerf_train_dw_batch_workspace_bytes(problems([(300, 8)]), 1, m) > 0                       # (no limit on the bias width any more)
     assert lib.stnerf_train_dw_batch_workspace_bytes(problems([(8, 8)], lddy=6), 1, m) == hip.EINVAL       # rows not 16-byte aligned
     assert lib.stnerf_train_dw_batch(problems(space), len(space), m, 0, fake, 1024, None) == hip.EINVAL
     assert "workspace too small" in hip.last_error()

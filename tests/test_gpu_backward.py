@@ -94,14 +94,14 @@ def test_dw_reduction_over_many_samples_is_deterministic_and_accurate(ops):
 @pytest.mark.parametrize("m", [1, 300, 7001, 300_000])
 def test_dw_batch_matches_fp64_matmuls_layer_by_layer(ops, m):
     """stnerf_train_dw_batch: every layer shape of the two networks (SpaceNet's ten, then MotionNet's six) in one launch each -- 319-
-    and 304-wide inputs (a 256- and a 128-column item), 1- and 3-row heads, layers without a bias gradient, dw as a column block of
+    and 304-wide inputs (two 128-column tiles and a 64-column one), 84 (a 96-column tile), 1- and 3-row heads, layers without a bias gradient, dw as a column block of
     a wider matrix, accumulate -- against fp64 matmuls; the same bits on every run and under accumulate = False after a dirty
     destination; the per-layer entry point's result within rounding."""
     g = torch.Generator().manual_seed(m)
     space = [(256, 63), (256, 256), (256, 256), (256, 256), (256, 319), (256, 256), (256, 256), (1, 256), (128, 304), (3, 128)]
     motion = [(128, 84), (128, 128), (128, 128), (128, 128), (128, 128), (3, 128)]
-    # thin layers (<= 4 outputs: weighted column sums) of every width, and neighbours; full 256 x 256 tiles (the eight-wave kernel) with
-    # remainders on both sides
+    # thin layers (<= 4 outputs: one 32-row block) of every width, and neighbours; several row blocks with remainders on both sides;
+    # bias sums of more than 256 outputs
     odd = [(4, 319), (2, 63), (1, 4), (5, 130), (130, 5), (512, 520), (300, 300)]
     for shapes in (space, motion, odd):
         dys = [torch.randn(m, n, generator=g) for n, _ in shapes]
@@ -109,7 +109,7 @@ def test_dw_batch_matches_fp64_matmuls_layer_by_layer(ops, m):
         dyd, xd = [_padded(t) for t in dys], [_padded(t, 4) for t in xs]
         wide = [torch.full((n, k + 5), 0.5, device="cuda") for n, k in shapes]
         dws = [w[:, 2:2 + k] for w, (_, k) in zip(wide, shapes)]
-        dbs = [None if i == 2 or n > 256 else torch.full((n,), -0.25, device="cuda") for i, (n, _) in enumerate(shapes)]
+        dbs = [None if i == 2 else torch.full((n,), -0.25, device="cuda") for i, (n, _) in enumerate(shapes)]
         ops.train_dw_batch(list(zip(dyd, xd, dws, dbs)), accumulate=True)
         tol = 4e-6 if m < 100_000 else 1e-5
         for i, (n, k) in enumerate(shapes):
@@ -120,15 +120,15 @@ def test_dw_batch_matches_fp64_matmuls_layer_by_layer(ops, m):
                 assert _rel(dbs[i], -0.25 + dys[i].double().sum(0)) <= max(tol, 2e-5 if m > 100_000 else 0), (i, n)
         a = [torch.full((n, k), float("nan"), device="cuda") for n, k in shapes]
         b = [torch.empty(n, k, device="cuda") for n, k in shapes]
-        da = [torch.full((n,), float("nan"), device="cuda") if n <= 256 else None for n, _ in shapes]
-        db_ = [torch.empty(n, device="cuda") if n <= 256 else None for n, _ in shapes]
+        da = [torch.full((n,), float("nan"), device="cuda") for n, _ in shapes]
+        db_ = [torch.empty(n, device="cuda") for n, _ in shapes]
         ops.train_dw_batch(list(zip(dyd, xd, a, da)), accumulate=False)
         ops.train_dw_batch(list(zip(dyd, xd, b, db_)), accumulate=False)
         for i, (n, k) in enumerate(shapes):
             assert torch.equal(a[i], b[i]) and (da[i] is None or torch.equal(da[i], db_[i])), i
             one, one_b = torch.empty(n, k, device="cuda"), torch.empty(n, device="cuda")
             ops.train_linear_dw(dyd[i], xd[i], one, one_b, False)
-            assert _rel(a[i], one.double().cpu()) <= 2e-6, i
+            assert _rel(a[i], one.double().cpu()) <= (2e-6 if m < 100_000 else 5e-6), i    # (two fp32 summation orders of m terms)
             assert da[i] is None or _rel(da[i], one_b.double().cpu()) <= (2e-6 if m < 100_000 else 2e-5), i
 
 
@@ -142,9 +142,9 @@ def test_dw_batch_refuses_what_it_cannot_run(ops):
     with pytest.raises(RuntimeError):
         ops.train_dw_batch([(dy.cpu(), x, dw, None)], False)
     ops.train_dw_batch([], False)
-    wide_dy = torch.zeros(8, 260, device="cuda")
-    with pytest.raises(ValueError, match="256 outputs"):
-        ops.train_dw_batch([(wide_dy, x, torch.zeros(260, 4, device="cuda"), torch.zeros(260, device="cuda"))], False)
+    wide = torch.zeros(8, 1024, device="cuda")
+    with pytest.raises(ValueError, match="tiles"):                                     # 8 x 8 + 8 x 1 tiles of 128 x 128
+        ops.train_dw_batch([(wide, wide, torch.zeros(1024, 1024, device="cuda"), None), (wide, x, torch.zeros(1024, 4, device="cuda"), None)], False)
 
 
 def test_encode_and_its_chain_rule(ops):

@@ -29,6 +29,7 @@ def _run_bench(extra, dump):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 2 and len(lines[-1]) < 3072, r.stdout[-2000:]      # the detail digest, then the contract record LAST
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()][-1] == lines[-1], r.stdout[-2000:]   # nothing of any rank behind it on stdout
     rec = json.loads(lines[-1])
     side = json.load(open(dump + ".detail.json"))
     assert side["final"] == rec
@@ -45,7 +46,8 @@ def _flat(d):
 
 @pytest.mark.parametrize("workload, precision, world", [("taekwondo-192x256-32+32", "bf16x3", 2),
                                                         ("taekwondo-192x256-32+32", "fp32", 3),
-                                                        ("single-512-64+64", "bf16x3", 2)])
+                                                        ("single-512-64+64", "bf16x3", 2),
+                                                        ("taekwondo-192x256-32+32", "bf16x3", 8)])
 def test_bench_launches_its_own_ranks_and_matches_one_rank(tmp_path, workload, precision, world):
     """`python bench.py --gpus N` (no torchrun) = N ranks of the same step function as N = 1; the gathered 5-tuple of the
     last step is the 1-rank one, bit for bit; both lines carry the same partition and scaling label."""

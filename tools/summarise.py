@@ -125,7 +125,8 @@ def leg_line(tag, e):
     r = e["roofline"]
     return (f"* {tag} **{e['precision']}**: **{e['value']:.4g} rays/s, {e['ray_samples_per_s']:.4g} ray-samples/s, {e['ms_per_step']:.1f} ms per frame** "
             f"({e['steps']} timed poses, {e['warmup']} warm-up); stage kernel {r['launches']} launches, avg {r['avg_launch_ms']:.2f} ms, "
-            f"{r['algorithmic_tflops']:.2f} algorithmic TF/s, {r['executed_mfma_tflops']:.1f} executed MFMA TF/s = **{r['frac']:.4f}** of {r['peak']} TF/s"
+            f"**{r['achieved']:.2f} algorithmic TF/s = {r['frac']:.4f} of {r['peak']:.1f} TF/s** ({r.get('peak_note', '')}); {r['executed_mfma_tflops']:.1f} executed MFMA TF/s = "
+            f"{r['executed_frac_of_instruction_peak']:.4f} of the instruction's dense peak"
             + (f"; HBM traffic {r['traffic'] / 1e9:.2f} GB per launch (counters) vs {r['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic" if r.get("traffic") else ""))
 
 
@@ -141,7 +142,7 @@ if "value" in b:
                           + (f"; counter / algorithmic bytes {h['counter_over_algorithmic']:.2f}" if "counter_over_algorithmic" in h else ""))
     for wl_, e in b.get("config_legs", {}).items():
         md.append(f"* config leg {wl_} ({e['precision']}, {e['steps']} poses): {e['value']:.4g} rays/s, {e['ray_samples_per_s']:.4g} ray-samples/s, "
-                  f"{e['ms_per_step']:.1f} ms per frame, stage {e['roofline']['algorithmic_tflops']:.1f} algorithmic TF/s = {e['roofline']['frac']:.3f} of its MFMA peak (executed)")
+                  f"{e['ms_per_step']:.1f} ms per frame, stage {e['roofline']['algorithmic_tflops']:.1f} algorithmic TF/s = {e['roofline']['frac']:.3f} of {e['roofline']['peak']:.1f} (SURVEY 8(d))")
     cb, eg = b.get("cpu_baseline"), b.get("eager_gpu_baseline")
     if cb:
         md.append(f"* cpu_baseline: {cb['value']:.1f} rays/s on {cb['cores']} threads ({cb['host']['cpu']}); frame extrapolates to {cb['extrapolated_frame_seconds']:.0f} s")
@@ -150,7 +151,22 @@ if "value" in b:
     if b.get("psnr_vs_reference"):
         md.append("* PSNR of the device-RNG render vs the reference: " + json.dumps(b["psnr_vs_reference"]))
     md.append("")
-traffic = {"workload": "taekwondo-1080p-64+64", "pose": "pose 0 of the bench's sweep (orbit 10 deg), one step", "gfx950_fetch_correction": 2.0,
+def _build_identity():
+    """(rev, .hip_fatbin sha256) of the library the passes ran on: bench.py prints roofline.traffic only when the loaded library's
+    kernels are these (tools/evidence.sh writes .git_rev into the snapshot; the digest is read from the .so itself)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from stnerf_amd import hip
+    rev = None
+    for cand in (os.path.join(src, "git_rev.txt"), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".git_rev")):
+        if os.path.exists(cand):
+            rev = open(cand).read().strip()[:12]
+            break
+    return rev, hip.fatbin_sha256()
+
+
+_rev, _sha = _build_identity()
+traffic = {"workload": "taekwondo-1080p-64+64", "pose": "pose 0 of the bench's sweep (orbit 10 deg), one step", "pose_short": "pose 0 (orbit 10 deg), 1 step",
+           "rev": _rev, "fatbin_sha256": _sha, "gfx950_fetch_correction": 2.0,
            "note": "hbm bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE), MI355X_MICROARCH.md section HBM; separate rocprofv3 --pmc runs", "kernels": {}, "kernels_bf16x3": {}}
 for prec in ("bf16x3", "fp32"):
     db = os.path.join(src, f"trace_{prec}", "p_results.db")
@@ -229,7 +245,7 @@ power_report(src, dst)
 open(os.path.join(dst, RND + "_final.md"), "w").write("\n".join(md) + "\n")
 
 wl = ["# " + RND + ": every BASELINE configuration on the round's build (1 x MI355X, `tools/evidence.sh`)\n",
-      "| config | workload | arithmetic | rays/s | ray-samples/s | s per frame | stage kernel TF/s (algorithmic) | frac of its MFMA peak (executed) | composite ms | resample ms | sample_coarse ms |",
+      "| config | workload | arithmetic | rays/s | ray-samples/s | s per frame | stage kernel TF/s (algorithmic) | frac (SURVEY 8(d): of 416.7 bf16x3 / 157.3 f32) | composite ms | resample ms | sample_coarse ms |",
       "|---|---|---|---|---|---|---|---|---|---|---|"]
 for cfg, fn in (("C2", "bench_c2.json"), ("C3", "bench.json"), ("C3 (yml 90+30)", "bench_c3_90_30.json"), ("C4", "bench_c4.json"), ("C5 (one GPU)", "bench_c5.json"),
                 ("C3-small, 2 ranks on ONE GPU (gloo; code path only)", "bench_2ranks_one_device.json")):
