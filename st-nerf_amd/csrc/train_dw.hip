@@ -41,7 +41,10 @@ constexpr int DWW_WAVES = 1024;         // wave slots of the part: 256 CUs x 4 S
 constexpr int DWW_U = 8;                // K steps per rotation of the operand registers
 constexpr int DWW_BLOCK = 2 * DWW_U;    // samples per unrolled block
 constexpr int DWW_MIN_SLICE = 64;       // samples: a shorter range is not worth its partial tile
-constexpr int DWW_MAX_PROBLEMS = 16, DWW_MAX_TILES = 64, DWW_MAX_GROUPS = 64;
+constexpr int DWW_MAX_PROBLEMS = 16, DWW_MAX_TILES = 64, DWW_MAX_GROUPS = 40;
+// bundles: four tiles that read the same rows get them through LDS (see dwb_run)
+constexpr int DWB_RING = 4;             // ring slots of one 16-sample block each: fetched three blocks (~10 us) ahead
+constexpr int DWB_MAX_PIECES = 3, DWB_MAX_BUNDLES = 12;
 
 struct DwwProblem {
     const float* dy;
@@ -62,12 +65,27 @@ struct DwwGroup {                  // tiles first .. first + count - 1 share `sl
     uint16_t pad_;
     uint32_t len;
 };
+struct DwbPiece {                  // one DMA instruction per sample row: `units` 16-byte units of a matrix row -> the slot row at lds_off
+    uint8_t problem, is_x;
+    uint16_t col0, units, lds_off; // floats; units <= 64
+};
+struct DwbWave {                   // what a wave multiplies: A operand at a_off, B operand at b_off of the slot row (floats)
+    uint16_t a_off, b_off;
+    uint8_t tile, kb, active, pad_;
+};
+struct DwbBundle {
+    DwbPiece piece[DWB_MAX_PIECES];
+    DwbWave wave[4];
+    uint16_t n_pieces, row_floats;
+    uint32_t first_wg, slices, len;
+};
 struct DwwArgs {
     DwwProblem p[DWW_MAX_PROBLEMS];
     DwwTile tile[DWW_MAX_TILES];
     DwwGroup group[DWW_MAX_GROUPS];
-    int32_t n_groups, m;
-    uint32_t items;
+    DwbBundle bundle[DWB_MAX_BUNDLES];
+    int32_t n_groups, n_bundles, m;
+    uint32_t items, bundle_wgs;    // workgroups [0, bundle_wgs) run bundles, the rest four wave items each
     float* workspace;
 };
 
@@ -97,6 +115,39 @@ template <> struct OpVec<1> {
 };
 
 constexpr uint32_t DWW_OOB = 0x7FFFFFFCu;   // a per-lane offset past every descriptor's range (num_records < 2^31): the load returns 0
+
+// A wave's partial tile (and bias sums) to the workspace.  Accumulator register 4 q + rr of block (i, j), lane (h, c): tile row
+// NB (8 q + 4 h + rr) + i, column KB c + j: lanes c hold consecutive columns, a store writes 512 contiguous bytes per half wave.
+template <int NB, int KB, bool BIAS>
+__device__ __forceinline__ void dww_store(const f32x16 (&acc)[NB][KB], const float (&bsum)[NB], float* __restrict__ out, float* __restrict__ bias_out) {
+    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    constexpr int COLS = 32 * KB;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float* o = out + (NB * (8 * q + 4 * h + rr) + i) * COLS + KB * c;
+                if constexpr (KB == 4) {
+                    *reinterpret_cast<float4*>(o) = make_float4(acc[i][0][4 * q + rr], acc[i][1][4 * q + rr], acc[i][2][4 * q + rr], acc[i][3][4 * q + rr]);
+                } else if constexpr (KB == 2) {
+                    *reinterpret_cast<float2*>(o) = make_float2(acc[i][0][4 * q + rr], acc[i][1][4 * q + rr]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KB; ++j) o[j] = acc[i][j][4 * q + rr];
+                }
+            }
+    if (BIAS && bias_out) {   // [parity h][row NB c + i]: the two parities are two more terms of the reduction
+        float* o = bias_out + h * (32 * NB) + NB * c;
+        if constexpr (NB == 4) {
+            *reinterpret_cast<float4*>(o) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) o[i] = bsum[i];
+        }
+    }
+}
 
 // One wave: rows n0 .. of dW (NB blocks: row NB c' + r of the tile = lane c' of block r), columns k0 .. (KB blocks likewise),
 // samples [s0, s1).
@@ -170,39 +221,176 @@ __device__ __forceinline__ void dww_tile(const DwwProblem& p, const DwwTile& tl,
         b.load(rb, in ? vb : DWW_OOB, (uint32_t)s * p.ldx * 4u);
         mma(a, b);
     }
-    // accumulator register 4 q + rr of block (i, j), lane (h, c): tile row NB (8 q + 4 h + rr) + i, column KB c + j
-    constexpr int COLS = 32 * KB;
+    dww_store<NB, KB, BIAS>(acc, bsum, out, bias_out);
+}
+
+// ---- bundles: the tiles of a workgroup share their rows through LDS -------------------------------------------------------
+// Two waves that ask for the same line at the same moment both go to HBM: with the 2 x 2 tiles of a 256 x 256 layer streaming
+// their operands independently the launch moved 1.8 x its unique bytes (PMC), and a staggered start does not survive -- the
+// wave that hits in L2 catches up with the one that waits for HBM.  So a BUNDLE's rows are fetched once per workgroup: every
+// 16-sample block of the bundle's operand columns is copied global -> LDS by DMA (buffer_load_dwordx4 ... lds: one
+// instruction per sample row and matrix piece, 1 KB contiguous on both sides, no registers, no vector instruction; the
+// four waves take the rows of a block in turn) into a ring of four slots, three blocks ahead; a wave reads its A and B
+// operands of a K step with two ds_read_b128 (the same 16 bytes per lane the direct path loads from global memory) one step
+// ahead of the MFMAs.  One s_barrier per block, in the middle of it: "block g + 1 has landed everywhere, block g - 1 is free
+// everywhere", then the DMA of block g + 3 goes into the freed slot.  The ds_reads are asm (the compiler would wait for every
+// DMA in flight before an LDS read it cannot tell apart) with hand-counted waits.
+#define DWW_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 0xf) | (((n) >> 4) << 14) | 0x0f70)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef float dwb_f4 __attribute__((ext_vector_type(4)));
+typedef float dwb_f2 __attribute__((ext_vector_type(2)));
+// (`off` must fold to a constant: the callers sit in fully unrolled loops)
+__device__ __forceinline__ void dwb_read4(dwb_f4& dst, uint32_t addr, int off) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory");
+}
+__device__ __forceinline__ void dwb_read2(dwb_f2& dst, uint32_t addr, int off) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory");
+}
+template <int KB> struct DwbB;
+template <> struct DwbB<4> {
+    dwb_f4 v;
+    __device__ __forceinline__ void read(uint32_t addr, int off) { dwb_read4(v, addr, off); }
+    __device__ __forceinline__ float get(int j) const { return v[j]; }
+};
+template <> struct DwbB<2> {
+    dwb_f2 v;
+    __device__ __forceinline__ void read(uint32_t addr, int off) { dwb_read2(v, addr, off); }
+    __device__ __forceinline__ float get(int j) const { return v[j]; }
+};
+template <> struct DwbB<1> {       // (a wave without a tile)
+    float v;
+    __device__ __forceinline__ void read(uint32_t, int) {}
+    __device__ __forceinline__ float get(int) const { return v; }
+};
+// wait until at most KEEP of the wave's LDS reads are outstanding; names the registers the next MFMAs read
+template <int KEEP, int KB>
+__device__ __forceinline__ void dwb_wait(dwb_f4& a, DwbB<KB>& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b.v) : "i"(KEEP));
+}
+
+// NP pieces per row, ROWF floats per slot row, a wave tile of 4 x KB blocks (KB = 0: a wave without a tile: it copies and
+// keeps the barriers).
+template <int NP, int ROWF, int KB, bool BIAS>
+__device__ __forceinline__ void dwb_run(const DwwArgs& a, const DwbBundle& bd, const DwbWave& wv, int wave, int s0, int s1, float* lds,
+                                        float* __restrict__ out, float* __restrict__ bias_out) {
+    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    constexpr int SLOT = DWW_BLOCK * ROWF;        // floats per ring slot
+    constexpr int IPB = 4 * NP;                   // this wave's DMA instructions per block
+    constexpr int KBA = KB > 0 ? KB : 1;
+    // ---- the copy: rows wave, wave + 4, .. of a block are this wave's
+    __amdgpu_buffer_rsrc_t rs[NP];
+    uint32_t voff[NP], rowb[NP], loff[NP];
+    bool on[NP];
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
+    for (int q = 0; q < NP; ++q) {
+        const DwbPiece& pc = bd.piece[q];
+        const DwwProblem& pr = a.p[pc.problem];
+        rs[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pc.is_x ? pr.x : pr.dy), 0, (int)(pc.is_x ? pr.x_bytes : pr.dy_bytes), 0x00020000);
+        voff[q] = (uint32_t)(pc.col0 + 4 * lane) * 4u;
+        rowb[q] = (pc.is_x ? pr.ldx : pr.lddy) * 4u;
+        loff[q] = pc.lds_off;
+        on[q] = lane < pc.units;
+    }
+    auto issue = [&](int g) {                     // block g -> ring slot g & 3 (rows beyond the matrix: the range check returns zeros)
+        float* slot = lds + (g & (DWB_RING - 1)) * SLOT;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int j = 0; j < 4; ++j) {
+            const int r = wave + 4 * j;
+            const uint32_t row = (uint32_t)(s0 + g * DWW_BLOCK + r);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                float* o = out + (NB * (8 * q + 4 * h + rr) + i) * COLS + KB * c;
-                if (KB == 4) {
-                    *reinterpret_cast<float4*>(o) = make_float4(acc[i][0][4 * q + rr], acc[i][1][4 * q + rr], acc[i][2][4 * q + rr], acc[i][3][4 * q + rr]);
-                } else if (KB == 2) {
-                    *reinterpret_cast<float2*>(o) = make_float2(acc[i][0][4 * q + rr], acc[i][1][4 * q + rr]);
-                } else {
+            for (int q = 0; q < NP; ++q)
+                if (on[q]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[q], (lds_ptr_t)(slot + r * ROWF + loff[q]), 16, voff[q], row * rowb[q], 0, 0);
+        }
+    };
+    const int nblk = (s1 - s0 + DWW_BLOCK - 1) / DWW_BLOCK;
+    issue(0);
+    issue(1);
+    issue(2);
+    f32x16 acc[4][KBA];
+    float bsum[4];
 #pragma unroll
-                    for (int j = 0; j < KB; ++j) o[j] = acc[i][j][4 * q + rr];
-                }
+    for (int i = 0; i < 4; ++i) {
+        bsum[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KBA; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    // the lane's operand addresses in slot 0, step 0 (bytes): row h, A at a_off + 4 c, B at b_off + KB c
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+    const uint32_t a0 = lds0 + (uint32_t)(h * ROWF + wv.a_off + 4 * c) * 4u, b0 = lds0 + (uint32_t)(h * ROWF + wv.b_off + KBA * c) * 4u;
+    dwb_f4 av[2];
+    DwbB<KBA> bv[2];
+    DWW_VMCNT(2 * IPB);                           // this wave's rows of block 0 have landed ...
+    __builtin_amdgcn_s_barrier();                 // ... and everybody else's
+    asm volatile("" ::: "memory");
+    if (KB > 0) {
+        dwb_read4(av[0], a0, 0);
+        bv[0].read(b0, 0);
+    }
+    for (int g = 0; g < nblk; ++g) {
+        const uint32_t so = (uint32_t)(g & (DWB_RING - 1)) * (SLOT * 4u), sn = (uint32_t)((g + 1) & (DWB_RING - 1)) * (SLOT * 4u);
+        const uint32_t ac = a0 + so, bc = b0 + so, an = a0 + sn, bn = b0 + sn;
+#pragma unroll
+        for (int u = 0; u < DWW_U; ++u) {
+            if (u == DWW_U / 2) {
+                // block g + 1 has landed (this wave's rows; the barrier: everyone's), block g - 1 is free: its slot takes block g + 3
+                DWW_VMCNT(IPB);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue(g + 3);
+                __builtin_amdgcn_sched_barrier(0);
             }
-    if (BIAS && bias_out) {   // [parity h][row NB c + i]: the two parities are two more terms of the reduction
-        float* o = bias_out + h * (32 * NB) + NB * c;
-        if (NB == 4) {
-            *reinterpret_cast<float4*>(o) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
-        } else {
+            if (KB > 0) {
+                // the next step's operands (step 0 of the next block behind step 7), then this step's MFMAs
+                if (u + 1 < DWW_U) {
+                    dwb_read4(av[(u + 1) & 1], ac, 2 * (u + 1) * ROWF * 4);
+                    bv[(u + 1) & 1].read(bc, 2 * (u + 1) * ROWF * 4);
+                } else {
+                    dwb_read4(av[(u + 1) & 1], an, 0);
+                    bv[(u + 1) & 1].read(bn, 0);
+                }
+                dwb_wait<2, KBA>(av[u & 1], bv[u & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const dwb_f4 x = av[u & 1];
 #pragma unroll
-            for (int i = 0; i < NB; ++i) o[i] = bsum[i];
+                for (int i = 0; i < 4; ++i) {
+                    const float xa = x[i];
+#pragma unroll
+                    for (int j = 0; j < KBA; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, bv[u & 1].get(j), acc[i][j], 0, 0, 0);
+                    if (BIAS) asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[i]) : "v"(xa));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
+    if (KB > 0) dwb_wait<0, KBA>(av[0], bv[0]);   // (the read ahead of the last step)
+    DWW_VMCNT(0);                                 // nothing may land in LDS after the wave has gone
+    if (KB > 0) dww_store<4, KBA, BIAS>(acc, bsum, out, bias_out);
 }
 
 __global__ __launch_bounds__(256, 1) void train_dw_wave_kernel(DwwArgs a) {
     // (the wave index through readfirstlane: everything derived from it -- tile, descriptors, sample range -- is wave-uniform and
     // stays in scalar registers; as a function of threadIdx the compiler wraps every buffer load in a waterfall loop)
-    const uint32_t g = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (blockIdx.x < a.bundle_wgs) {              // ---- a bundle: the workgroup's four tiles over one sample range, rows through LDS
+        int bi = 0;
+        while (bi + 1 < a.n_bundles && blockIdx.x >= a.bundle[bi + 1].first_wg) ++bi;
+        const DwbBundle& bd = a.bundle[bi];
+        const DwbWave& wv = bd.wave[wave];
+        const uint32_t slice = blockIdx.x - bd.first_wg;
+        const int s0 = (int)(slice * bd.len), s1 = min(a.m, s0 + (int)bd.len);
+        const DwwTile& tl = a.tile[wv.tile];
+        float* out = a.workspace + 4ull * tl.partial_off + (size_t)slice * 128 * (32 * tl.kb);
+        float* bias_out = tl.bias ? a.workspace + 4ull * tl.bias_off + (size_t)slice * 2 * 128 : nullptr;
+        if (bd.n_pieces == 2 && bd.row_floats == 512) {
+            if (tl.bias) dwb_run<2, 512, 4, true>(a, bd, wv, wave, s0, s1, dw_lds, out, bias_out);
+            else dwb_run<2, 512, 4, false>(a, bd, wv, wave, s0, s1, dw_lds, out, bias_out);
+        }
+        return;
+    }
+    const uint32_t g = (blockIdx.x - a.bundle_wgs) * 4u + (uint32_t)wave;
     if (g >= a.items) return;
     int gi = 0;
     while (gi + 1 < a.n_groups && g >= a.group[gi + 1].first_item) ++gi;      // (wave-uniform: scalar loads of the kernel arguments)
@@ -279,7 +467,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 static int dww_check(const stnerf_dw_problem* pr, int32_t count, int64_t m) {
     STNERF_REQUIRE(pr && count >= 1 && count <= DWW_MAX_PROBLEMS, "train_dw_batch: 1 .. %d problems", DWW_MAX_PROBLEMS);
     STNERF_REQUIRE(m >= 0 && m < (1ll << 31), "train_dw_batch: bad sample count %lld", (long long)m);
-    int tiles = 0, segments = 0;
+    int tiles = 0, segments = 0, groups = 0;
     for (int i = 0; i < count; ++i) {
         const stnerf_dw_problem& q = pr[i];
         STNERF_REQUIRE(q.dy && q.x && q.dw, "train_dw_batch: null pointer in problem %d", i);
@@ -291,7 +479,9 @@ static int dww_check(const stnerf_dw_problem* pr, int32_t count, int64_t m) {
         const int row_blocks = q.n <= 4 ? 1 : (q.n + 127) / 128;
         tiles += row_blocks * ((q.k + 127) / 128);
         segments += row_blocks * ((q.k + 127) / 128) + (q.db ? row_blocks : 0);
+        groups += (q.k > 128 ? 1 : 0) + ((q.k & 127) ? 1 : 0) + ((q.k & 127) == 0 && q.k <= 128 ? 1 : 0);
     }
+    STNERF_REQUIRE(groups <= DWW_MAX_GROUPS, "train_dw_batch: %d tile groups, at most %d", groups, DWW_MAX_GROUPS);
     STNERF_REQUIRE(tiles <= DWW_MAX_TILES && segments <= DWW_MAX_SEGMENTS, "train_dw_batch: %d tiles (at most %d), %d reduction segments (at most %d)",
                    tiles, DWW_MAX_TILES, segments, DWW_MAX_SEGMENTS);
     return STNERF_OK;
@@ -299,14 +489,16 @@ static int dww_check(const stnerf_dw_problem* pr, int32_t count, int64_t m) {
 
 // Tiles of a problem: row blocks of 128 (one block of 32 for a layer of <= 4 outputs) x column pieces of 128, the last piece as
 // narrow as its columns allow (96 / 64 / 32).  Groups = a problem's tiles of one width (they cost the same and read the same
-// rows); a group's sample ranges are sized by its tiles' MFMA count so that all waves of the launch finish together.
+// rows).  A group that is exactly the 2 x 2 full tiles of a 256-row, >= 256-column layer becomes a BUNDLE (one workgroup per sample
+// range, rows through LDS); every other group's tiles are independent wave items.  Sample ranges are sized by MFMA count so that
+// all waves of the launch finish together.
 static void dww_plan(const stnerf_dw_problem* pr, int32_t count, int64_t m, DwwPlan& P) {
     P = DwwPlan{};
     DwwArgs& K = P.k;
     K.m = (int)m;
-    struct G { int first, count, cost; };
-    G groups[DWW_MAX_GROUPS];
-    int ng = 0, nt = 0;
+    struct G { int first, count, cost, bundle; };
+    G groups[DWW_MAX_PROBLEMS * 4];
+    int ng = 0, nt = 0, nbundles = 0;
     for (int i = 0; i < count; ++i) {
         const stnerf_dw_problem& q = pr[i];
         K.p[i] = DwwProblem{q.dy, q.x, (uint32_t)q.lddy, (uint32_t)q.ldx,
@@ -324,36 +516,63 @@ static void dww_plan(const stnerf_dw_problem* pr, int32_t count, int64_t m, DwwP
                     t.bias = (uint8_t)(q.db && k0 == 0);
                     t.rows_valid = (uint8_t)(nb == 1 ? q.n : 0);
                 }
-            if (nt > first) groups[ng++] = G{first, nt - first, nb * kb};
+            if (nt == first) continue;
+            G g{first, nt - first, nb * kb, -1};
+            // the 2 x 2 full tiles (n0, k0) = (0, 0), (0, 128), (128, 0), (128, 128) of a layer with exactly 256 outputs
+            static const bool no_bundles = getenv("STNERF_DEV_DW_NO_BUNDLES") && getenv("STNERF_DEV_DW_NO_BUNDLES")[0] == '1';
+            if (!no_bundles && g.count == 4 && nb == 4 && kb == 4 && q.n == 256 && nbundles < DWB_MAX_BUNDLES && m >= 4 * DWW_BLOCK) {
+                DwbBundle& B = K.bundle[nbundles];
+                B = DwbBundle{};
+                B.n_pieces = 2, B.row_floats = 512;
+                B.piece[0] = DwbPiece{(uint8_t)i, 0, 0, 64, 0};                // dy[:, 0:256]  -> slot row floats 0 .. 255
+                B.piece[1] = DwbPiece{(uint8_t)i, 1, 0, 64, 256};              // x[:, 0:256]   -> 256 .. 511
+                for (int w = 0; w < 4; ++w) {
+                    const DwwTile& t = K.tile[first + w];
+                    B.wave[w] = DwbWave{(uint16_t)t.n0, (uint16_t)(256 + t.k0), (uint8_t)(first + w), 4, 1, 0};
+                }
+                g.bundle = nbundles++;
+            }
+            groups[ng++] = g;
         }
     }
     P.n_tiles = nt;
-    // sample ranges: slices_g ~ share of the launch's MFMA work, total <= the part's wave slots
+    K.n_bundles = nbundles;
+    // sample ranges: slices_g ~ share of the launch's MFMA work, wave slots in all <= the part's (a bundle takes four per range)
     int64_t total_cost = 0;
     for (int g = 0; g < ng; ++g) total_cost += (int64_t)groups[g].count * groups[g].cost;
     const int64_t most = m <= 0 ? 1 : (m + DWW_MIN_SLICE - 1) / DWW_MIN_SLICE;
+    uint16_t slices_of[DWW_MAX_PROBLEMS * 4];
     for (int target = DWW_WAVES;; target -= 8) {
-        int64_t items = 0;
+        int64_t items = 0, wgs = 0;
+        int nv = 0;
         for (int g = 0; g < ng; ++g) {
             int64_t s = ((int64_t)target * groups[g].cost + total_cost / 2) / total_cost;
             s = s < 1 ? 1 : s > most ? most : s;
             int64_t len = m <= 0 ? DWW_BLOCK : ((m + s - 1) / s + DWW_BLOCK - 1) / DWW_BLOCK * DWW_BLOCK;
             s = m <= 0 ? 1 : (m + len - 1) / len;
-            K.group[g] = DwwGroup{(uint32_t)items, (uint16_t)groups[g].first, (uint16_t)groups[g].count, (uint16_t)s, 0, (uint32_t)len};
-            items += s * groups[g].count;
+            slices_of[g] = (uint16_t)s;
+            if (groups[g].bundle >= 0) {
+                DwbBundle& B = K.bundle[groups[g].bundle];
+                B.first_wg = (uint32_t)wgs, B.slices = (uint32_t)s, B.len = (uint32_t)len;
+                wgs += s;
+            } else {
+                K.group[nv++] = DwwGroup{(uint32_t)items, (uint16_t)groups[g].first, (uint16_t)groups[g].count, (uint16_t)s, 0, (uint32_t)len};
+                items += s * groups[g].count;
+            }
         }
         K.items = (uint32_t)items;
-        if (items <= DWW_WAVES || target <= 8) break;
+        K.bundle_wgs = (uint32_t)wgs;
+        K.n_groups = nv;
+        if (4 * wgs + items <= DWW_WAVES || target <= 8) break;
     }
-    K.n_groups = ng;
     // workspace: per tile [slices][rows][cols] (+ [slices][2][rows] bias sums), 16-byte aligned pieces
     int64_t off = 0;
     int ns = 0, max_elems = 0;
     for (int g = 0; g < ng; ++g)
-        for (int j = 0; j < K.group[g].count; ++j) {
-            DwwTile& t = K.tile[K.group[g].first_tile + j];
+        for (int j = 0; j < groups[g].count; ++j) {
+            DwwTile& t = K.tile[groups[g].first + j];
             const stnerf_dw_problem& q = pr[t.problem];
-            const int rows = 32 * t.nb, cols = 32 * t.kb, slices = K.group[g].slices;
+            const int rows = 32 * t.nb, cols = 32 * t.kb, slices = slices_of[g];
             t.partial_off = (uint32_t)(off / 4);
             const int rv = q.n - t.n0 < rows ? q.n - t.n0 : rows, cv = q.k - t.k0 < cols ? q.k - t.k0 : cols;
             P.r.seg[ns++] = DwwSegment{q.dw + (int64_t)t.n0 * q.lddw + t.k0, (uint32_t)q.lddw, t.partial_off, (uint32_t)slices, (uint32_t)(rows * cols),
@@ -388,7 +607,16 @@ extern "C" int stnerf_train_dw_batch(const stnerf_dw_problem* problems, int32_t 
     if (m == 0) return STNERF_OK;
     hipStream_t st = as_stream(stream);
     P.k.workspace = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(train_dw_wave_kernel, dim3((P.k.items + 3) / 4), dim3(256), 0, st, P.k);
+    // (a bundle's ring: four slots of 16 rows x 512 floats; the wave-item workgroups of the same launch carry the allocation along --
+    // with 512 registers per wave a CU holds one workgroup either way)
+    const unsigned lds_bytes = P.k.bundle_wgs ? DWB_RING * DWW_BLOCK * 512 * 4 : 0;
+    static bool attr_set = false;
+    if (lds_bytes > 65536 && !attr_set) {
+        STNERF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(train_dw_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           DWB_RING * DWW_BLOCK * 512 * 4) == hipSuccess, "train_dw_batch: cannot reserve the LDS ring");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(train_dw_wave_kernel, dim3(P.k.bundle_wgs + (P.k.items + 3) / 4), dim3(256), lds_bytes, st, P.k);
     STNERF_CHECK_LAUNCH("train_dw_batch");
     P.r.workspace = P.k.workspace;
     P.r.accumulate = accumulate;
