@@ -17,9 +17,14 @@
 //     instruction writes 512 contiguous bytes per half wave.  With a 128 x 128 tile per WAVE the chip's 1024 wave slots hold
 //     every tile of a SpaceNet ~36 times: 36 partial sums per output instead of round 5's 256 (60 MB instead of 476 MB through
 //     HBM), summed in slice order by dw_wave_reduce_kernel: deterministic, no atomics.
-//   * The four waves of a workgroup (one CU) take tiles that read the same rows: the 2 x 2 tiles of a 256 x 256 layer over
-//     one sample range share each operand slab between two waves of ONE CU (vector L1 / the XCD's L2), so a slice's rows of
-//     dY and X cross HBM once.
+//   * Tiles that read the same rows at the same time get them through LDS (a BUNDLE, dwb_run below): the 2 x 2 tiles of a
+//     256 x 256 layer, and the 64-column tiles of two layers on the same narrow input (stage1.0 on PE(pos) and stage2.0's skip
+//     columns).  Streaming independently, two waves that ask for a line at the same moment BOTH go to HBM -- neither the vector
+//     L1 nor the L2 merges a miss into one in flight: 7.5 GB per SpaceNet call on the counters against 4.15 GB of unique
+//     operands.  A bundle's rows are copied global -> LDS once per workgroup by DMA (buffer_load_dwordx4 ... lds, a ring of four
+//     16-sample slots, three blocks ahead) and read from there: 5.1 GB (1.22 x: what is left are the narrow tiles that re-read a
+//     dy, and the density head's second pass over g3).  Time is the same either way (1.94 ms sustained, 0.80 of the f32 MFMA
+//     peak at 2.2 - 2.3 GHz): the launch is bound by its MFMAs, not by HBM.
 //   * Narrow remainders are narrow tiles, not padded ones: 64 columns (stage1.0's 63, the skip connection's 63, rgb_net.1's
 //     48) = 8-byte loads, two column blocks; 96 (MotionNet's 84) = 12-byte loads; a layer of <= 4 outputs (the density and
 //     colour heads, the flow head) one 32-row block whose lanes c >= n read nothing.  Sample ranges are sized by a tile's
@@ -69,7 +74,7 @@ struct DwbPiece {                  // one DMA instruction per sample row: `units
     uint8_t problem, is_x;
     uint16_t col0, units, lds_off; // floats; units <= 64
 };
-struct DwbWave {                   // what a wave multiplies: A operand at a_off, B operand at b_off of the slot row (floats)
+struct DwbWave {                   // what a wave multiplies: A operand at a_off of the slot's dy rows, B operand at b_off of its x rows (floats)
     uint16_t a_off, b_off;
     uint8_t tile, kb, active, pad_;
 };
@@ -257,77 +262,78 @@ template <> struct DwbB<2> {
     __device__ __forceinline__ void read(uint32_t addr, int off) { dwb_read2(v, addr, off); }
     __device__ __forceinline__ float get(int j) const { return v[j]; }
 };
-template <> struct DwbB<1> {       // (a wave without a tile)
-    float v;
-    __device__ __forceinline__ void read(uint32_t, int) {}
-    __device__ __forceinline__ float get(int) const { return v; }
-};
+
 // wait until at most KEEP of the wave's LDS reads are outstanding; names the registers the next MFMAs read
 template <int KEEP, int KB>
 __device__ __forceinline__ void dwb_wait(dwb_f4& a, DwbB<KB>& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b.v) : "i"(KEEP));
 }
 
-// NP pieces per row, ROWF floats per slot row, a wave tile of 4 x KB blocks (KB = 0: a wave without a tile: it copies and
-// keeps the barriers).
-template <int NP, int ROWF, int KB, bool BIAS>
+// A ring slot = [16 rows][NA x 256 floats of dy] then [16 rows][XU x 4 floats of x] (NA = 1 or 2 matrices of 256 columns; XU = 64
+// or 16 sixteen-byte units of x per row); a wave tile of 4 x KB blocks.  DMA instructions of this wave per block: rows wave, wave + 4,
+// wave + 8, wave + 12 of every dy matrix (1 KB each), and of x either the same four rows (XU = 64) or -- XU = 16: 256 bytes per row,
+// rows contiguous in the slot -- rows 4 wave .. 4 wave + 3 in ONE instruction (lane l: row l / 16, unit l % 16).  They go out one
+// behind each of the first MFMAs after the block's barrier: issued in a clump they held the wave's issue port with the matrix pipe
+// idle (measured: the 64-column bundle, whose blocks are half as long, ran 15 % behind the rest of the launch).
+template <int NA, int XU, int KB, bool BIAS>
 __device__ __forceinline__ void dwb_run(const DwwArgs& a, const DwbBundle& bd, const DwbWave& wv, int wave, int s0, int s1, float* lds,
                                         float* __restrict__ out, float* __restrict__ bias_out) {
     const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-    constexpr int SLOT = DWW_BLOCK * ROWF;        // floats per ring slot
-    constexpr int IPB = 4 * NP;                   // this wave's DMA instructions per block
-    constexpr int KBA = KB > 0 ? KB : 1;
-    // ---- the copy: rows wave, wave + 4, .. of a block are this wave's
-    __amdgpu_buffer_rsrc_t rs[NP];
-    uint32_t voff[NP], rowb[NP], loff[NP];
-    bool on[NP];
+    constexpr int RA = NA * 256, RX = XU * 4;                 // floats per slot row of the two regions
+    constexpr int XBASE = DWW_BLOCK * RA;                     // the x region's offset in a slot
+    constexpr int SLOT = DWW_BLOCK * (RA + RX);               // floats per ring slot
+    constexpr int IPB = 4 * NA + (XU == 64 ? 4 : 1);          // this wave's DMA instructions per block
+    static_assert(IPB <= 4 * KB * (DWW_U / 2), "the DMA instructions of a block ride behind the MFMAs of its second half");
+    // ---- the copy
+    __amdgpu_buffer_rsrc_t rs[NA + 1];
+    uint32_t voff[NA + 1], rowb[NA + 1];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const DwbPiece& pc = bd.piece[q];
+    for (int q = 0; q <= NA; ++q) {
+        const DwbPiece& pc = bd.piece[q];                     // pieces 0 .. NA - 1: the dy matrices; piece NA: x
         const DwwProblem& pr = a.p[pc.problem];
         rs[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pc.is_x ? pr.x : pr.dy), 0, (int)(pc.is_x ? pr.x_bytes : pr.dy_bytes), 0x00020000);
-        voff[q] = (uint32_t)(pc.col0 + 4 * lane) * 4u;
         rowb[q] = (pc.is_x ? pr.ldx : pr.lddy) * 4u;
-        loff[q] = pc.lds_off;
-        on[q] = lane < pc.units;
+        voff[q] = (q == NA && XU == 16) ? (uint32_t)(lane >> 4) * rowb[q] + (uint32_t)(pc.col0 + 4 * (lane & 15)) * 4u : (uint32_t)(pc.col0 + 4 * lane) * 4u;
     }
-    auto issue = [&](int g) {                     // block g -> ring slot g & 3 (rows beyond the matrix: the range check returns zeros)
+    auto issue_one = [&](int g, int idx) {        // instruction idx of block g -> ring slot g & 3 (rows beyond the matrix: zeros)
         float* slot = lds + (g & (DWB_RING - 1)) * SLOT;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = wave + 4 * j;
-            const uint32_t row = (uint32_t)(s0 + g * DWW_BLOCK + r);
-#pragma unroll
-            for (int q = 0; q < NP; ++q)
-                if (on[q]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[q], (lds_ptr_t)(slot + r * ROWF + loff[q]), 16, voff[q], row * rowb[q], 0, 0);
+        const uint32_t row0 = (uint32_t)(s0 + g * DWW_BLOCK);
+        if (idx < 4 * NA) {
+            const int j = idx / NA, q = idx % NA, r = wave + 4 * j;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[q], (lds_ptr_t)(slot + r * RA + 256 * q), 16, voff[q], (row0 + r) * rowb[q], 0, 0);
+        } else if (XU == 64) {
+            const int r = wave + 4 * (idx - 4 * NA);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[NA], (lds_ptr_t)(slot + XBASE + r * RX), 16, voff[NA], (row0 + r) * rowb[NA], 0, 0);
+        } else {
+            const int r = 4 * wave;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[NA], (lds_ptr_t)(slot + XBASE + r * RX), 16, voff[NA], (row0 + r) * rowb[NA], 0, 0);
         }
     };
     const int nblk = (s1 - s0 + DWW_BLOCK - 1) / DWW_BLOCK;
-    issue(0);
-    issue(1);
-    issue(2);
-    f32x16 acc[4][KBA];
+#pragma unroll
+    for (int g = 0; g < DWB_RING - 1; ++g)
+#pragma unroll
+        for (int idx = 0; idx < IPB; ++idx) issue_one(g, idx);
+    f32x16 acc[4][KB];
     float bsum[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         bsum[i] = 0.f;
 #pragma unroll
-        for (int j = 0; j < KBA; ++j)
+        for (int j = 0; j < KB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
-    // the lane's operand addresses in slot 0, step 0 (bytes): row h, A at a_off + 4 c, B at b_off + KB c
+    // the lane's operand addresses in slot 0, step 0 (bytes): row h; A at a_off + 4 c of the dy region, B at b_off + KB c of the x region
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
-    const uint32_t a0 = lds0 + (uint32_t)(h * ROWF + wv.a_off + 4 * c) * 4u, b0 = lds0 + (uint32_t)(h * ROWF + wv.b_off + KBA * c) * 4u;
+    const uint32_t a0 = lds0 + (uint32_t)(h * RA + wv.a_off + 4 * c) * 4u, b0 = lds0 + (uint32_t)(XBASE + h * RX + wv.b_off + KB * c) * 4u;
     dwb_f4 av[2];
-    DwbB<KBA> bv[2];
+    DwbB<KB> bv[2];
     DWW_VMCNT(2 * IPB);                           // this wave's rows of block 0 have landed ...
     __builtin_amdgcn_s_barrier();                 // ... and everybody else's
     asm volatile("" ::: "memory");
-    if (KB > 0) {
-        dwb_read4(av[0], a0, 0);
-        bv[0].read(b0, 0);
-    }
+    dwb_read4(av[0], a0, 0);
+    bv[0].read(b0, 0);
     for (int g = 0; g < nblk; ++g) {
         const uint32_t so = (uint32_t)(g & (DWB_RING - 1)) * (SLOT * 4u), sn = (uint32_t)((g + 1) & (DWB_RING - 1)) * (SLOT * 4u);
         const uint32_t ac = a0 + so, bc = b0 + so, an = a0 + sn, bn = b0 + sn;
@@ -338,35 +344,39 @@ __device__ __forceinline__ void dwb_run(const DwwArgs& a, const DwbBundle& bd, c
                 DWW_VMCNT(IPB);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                issue(g + 3);
-                __builtin_amdgcn_sched_barrier(0);
             }
-            if (KB > 0) {
-                // the next step's operands (step 0 of the next block behind step 7), then this step's MFMAs
-                if (u + 1 < DWW_U) {
-                    dwb_read4(av[(u + 1) & 1], ac, 2 * (u + 1) * ROWF * 4);
-                    bv[(u + 1) & 1].read(bc, 2 * (u + 1) * ROWF * 4);
-                } else {
-                    dwb_read4(av[(u + 1) & 1], an, 0);
-                    bv[(u + 1) & 1].read(bn, 0);
-                }
-                dwb_wait<2, KBA>(av[u & 1], bv[u & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                const dwb_f4 x = av[u & 1];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float xa = x[i];
-#pragma unroll
-                    for (int j = 0; j < KBA; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, bv[u & 1].get(j), acc[i][j], 0, 0, 0);
-                    if (BIAS) asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[i]) : "v"(xa));
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            // the next step's operands (step 0 of the next block behind step 7), then this step's MFMAs
+            if (u + 1 < DWW_U) {
+                dwb_read4(av[(u + 1) & 1], ac, 2 * (u + 1) * RA * 4);
+                bv[(u + 1) & 1].read(bc, 2 * (u + 1) * RX * 4);
+            } else {
+                dwb_read4(av[(u + 1) & 1], an, 0);
+                bv[(u + 1) & 1].read(bn, 0);
             }
+            dwb_wait<2, KB>(av[u & 1], bv[u & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const dwb_f4 x = av[u & 1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xa = x[i];
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, bv[u & 1].get(j), acc[i][j], 0, 0, 0);
+                    const int n = (u - DWW_U / 2) * 4 * KB + i * KB + j;      // MFMAs since the barrier
+                    if (u >= DWW_U / 2 && n < IPB) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_one(g + DWB_RING - 1, n);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (BIAS) asm volatile("v_add_f32 %0, %0, %1" : "+v"(bsum[i]) : "v"(xa));
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (KB > 0) dwb_wait<0, KBA>(av[0], bv[0]);   // (the read ahead of the last step)
+    dwb_wait<0, KB>(av[0], bv[0]);                // (the read ahead of the last step)
     DWW_VMCNT(0);                                 // nothing may land in LDS after the wave has gone
-    if (KB > 0) dww_store<4, KBA, BIAS>(acc, bsum, out, bias_out);
+    dww_store<4, KB, BIAS>(acc, bsum, out, bias_out);
 }
 
 __global__ __launch_bounds__(256, 1) void train_dw_wave_kernel(DwwArgs a) {
@@ -381,12 +391,15 @@ __global__ __launch_bounds__(256, 1) void train_dw_wave_kernel(DwwArgs a) {
         const DwbWave& wv = bd.wave[wave];
         const uint32_t slice = blockIdx.x - bd.first_wg;
         const int s0 = (int)(slice * bd.len), s1 = min(a.m, s0 + (int)bd.len);
-        const DwwTile& tl = a.tile[wv.tile];
+        const DwwTile& tl = a.tile[wv.tile];      // (a wave without a tile points at the bundle's first one and stores nothing)
         float* out = a.workspace + 4ull * tl.partial_off + (size_t)slice * 128 * (32 * tl.kb);
         float* bias_out = tl.bias ? a.workspace + 4ull * tl.bias_off + (size_t)slice * 2 * 128 : nullptr;
-        if (bd.n_pieces == 2 && bd.row_floats == 512) {
-            if (tl.bias) dwb_run<2, 512, 4, true>(a, bd, wv, wave, s0, s1, dw_lds, out, bias_out);
-            else dwb_run<2, 512, 4, false>(a, bd, wv, wave, s0, s1, dw_lds, out, bias_out);
+        if (bd.n_pieces == 2) {                   // dy[:, 256], x[:, 256]: the 2 x 2 tiles of a 256 x 256 block
+            if (tl.bias) dwb_run<1, 64, 4, true>(a, bd, wv, wave, s0, s1, dw_lds, out, bias_out);
+            else dwb_run<1, 64, 4, false>(a, bd, wv, wave, s0, s1, dw_lds, out, bias_out);
+        } else {                                  // dy_a[:, 256], dy_b[:, 256], x[:, 64]: two 256-output layers on the same narrow input
+            if (tl.bias) dwb_run<2, 16, 2, true>(a, bd, wv, wave, s0, s1, dw_lds, out, bias_out);
+            else dwb_run<2, 16, 2, false>(a, bd, wv, wave, s0, s1, dw_lds, out, bias_out);
         }
         return;
     }
@@ -517,41 +530,75 @@ static void dww_plan(const stnerf_dw_problem* pr, int32_t count, int64_t m, DwwP
                     t.rows_valid = (uint8_t)(nb == 1 ? q.n : 0);
                 }
             if (nt == first) continue;
-            G g{first, nt - first, nb * kb, -1};
-            // the 2 x 2 full tiles (n0, k0) = (0, 0), (0, 128), (128, 0), (128, 128) of a layer with exactly 256 outputs
-            static const bool no_bundles = getenv("STNERF_DEV_DW_NO_BUNDLES") && getenv("STNERF_DEV_DW_NO_BUNDLES")[0] == '1';
-            if (!no_bundles && g.count == 4 && nb == 4 && kb == 4 && q.n == 256 && nbundles < DWB_MAX_BUNDLES && m >= 4 * DWW_BLOCK) {
-                DwbBundle& B = K.bundle[nbundles];
-                B = DwbBundle{};
-                B.n_pieces = 2, B.row_floats = 512;
-                B.piece[0] = DwbPiece{(uint8_t)i, 0, 0, 64, 0};                // dy[:, 0:256]  -> slot row floats 0 .. 255
-                B.piece[1] = DwbPiece{(uint8_t)i, 1, 0, 64, 256};              // x[:, 0:256]   -> 256 .. 511
-                for (int w = 0; w < 4; ++w) {
-                    const DwwTile& t = K.tile[first + w];
-                    B.wave[w] = DwbWave{(uint16_t)t.n0, (uint16_t)(256 + t.k0), (uint8_t)(first + w), 4, 1, 0};
-                }
-                g.bundle = nbundles++;
-            }
-            groups[ng++] = g;
+            groups[ng++] = G{first, nt - first, nb * kb, -1};
+
         }
+    }
+    // ---- bundles (rows through LDS): groups whose tiles read the same rows at the same time.  Only groups that fill all four waves
+    // of a workgroup with EQUAL work: rgb_net.1's three column tiles (128 + 128 + 48 columns on the same dy) were tried as a bundle
+    // with an idle fourth wave -- 4.79 GB instead of 4.93 per SpaceNet call on the counters, but 2.29 ms instead of 2.04: a bundle's
+    // range is as long as its busiest wave needs, the launch is MFMA-bound, and 24 of 64 slots of that bundle did nothing.
+    static const bool no_bundles = getenv("STNERF_DEV_DW_NO_BUNDLES") && getenv("STNERF_DEV_DW_NO_BUNDLES")[0] == '1';
+    const bool can = !no_bundles && m >= 4 * DWW_BLOCK;
+    auto tile_of = [&](int g, int j) -> DwwTile& { return K.tile[groups[g].first + j]; };
+    for (int g = 0; can && g < ng && nbundles < DWB_MAX_BUNDLES; ++g) {
+        const G& gr = groups[g];
+        if (gr.bundle >= 0) continue;
+        const DwwTile& t0 = K.tile[gr.first];
+        const stnerf_dw_problem& q = pr[t0.problem];
+        if (t0.nb != 4) continue;
+        DwbBundle B{};
+        if (gr.count == 4 && t0.kb == 4 && q.n == 256) {
+            // (a) the 2 x 2 full tiles (n0, k0) = (0, 0), (0, 128), (128, 0), (128, 128) of a layer with 256 outputs
+            B.n_pieces = 2, B.row_floats = 512;
+            B.piece[0] = DwbPiece{t0.problem, 0, 0, 64, 0};                 // dy[:, 0:256]  -> slot row floats 0 .. 255
+            B.piece[1] = DwbPiece{t0.problem, 1, 0, 64, 256};               // x[:, 0:256]   -> 256 .. 511
+            for (int w = 0; w < 4; ++w) B.wave[w] = DwbWave{tile_of(g, w).n0, tile_of(g, w).k0, (uint8_t)(gr.first + w), 4, 1, 0};
+            groups[g].bundle = nbundles;
+        } else if (gr.count == 2 && t0.kb == 2 && q.n == 256) {
+            // (b) two layers of 256 outputs whose 64-column tiles read the SAME columns of the same matrix (stage1.0 on PE(pos) and the
+            // skip connection's columns of stage2.0): one copy of x, both dy
+            for (int g2 = g + 1; g2 < ng; ++g2) {
+                const G& o = groups[g2];
+                const DwwTile& u0 = K.tile[o.first];
+                const stnerf_dw_problem& q2 = pr[u0.problem];
+                if (o.bundle >= 0 || o.count != 2 || u0.nb != 4 || u0.kb != 2 || q2.n != 256 || q2.ldx != q.ldx || q2.x + u0.k0 != q.x + t0.k0) continue;
+                B.n_pieces = 3, B.row_floats = 576;
+                B.piece[0] = DwbPiece{t0.problem, 0, 0, 64, 0};             // dy_a[:, 0:256]
+                B.piece[1] = DwbPiece{u0.problem, 0, 0, 64, 256};           // dy_b[:, 0:256]
+                B.piece[2] = DwbPiece{t0.problem, 1, t0.k0, 16, 512};       // x[:, k0 : k0 + 64]
+                for (int w = 0; w < 2; ++w) {
+                    B.wave[w] = DwbWave{tile_of(g, w).n0, 0, (uint8_t)(gr.first + w), 2, 1, 0};
+                    B.wave[2 + w] = DwbWave{(uint16_t)(256 + tile_of(g2, w).n0), 0, (uint8_t)(o.first + w), 2, 1, 0};
+                }
+                groups[g].bundle = groups[g2].bundle = nbundles;
+                groups[g].cost = 8, groups[g2].cost = 0;
+                break;
+            }
+        }
+        if (groups[g].bundle == nbundles) K.bundle[nbundles++] = B;
     }
     P.n_tiles = nt;
     K.n_bundles = nbundles;
     // sample ranges: slices_g ~ share of the launch's MFMA work, wave slots in all <= the part's (a bundle takes four per range)
+    // (a bundle occupies four wave slots per range whatever its waves do; a group that rides in another group's bundle has cost 0)
     int64_t total_cost = 0;
-    for (int g = 0; g < ng; ++g) total_cost += (int64_t)groups[g].count * groups[g].cost;
+    for (int g = 0; g < ng; ++g) total_cost += groups[g].bundle >= 0 ? (groups[g].cost ? 4 * groups[g].cost : 0) : (int64_t)groups[g].count * groups[g].cost;
     const int64_t most = m <= 0 ? 1 : (m + DWW_MIN_SLICE - 1) / DWW_MIN_SLICE;
     uint16_t slices_of[DWW_MAX_PROBLEMS * 4];
     for (int target = DWW_WAVES;; target -= 8) {
         int64_t items = 0, wgs = 0;
         int nv = 0;
         for (int g = 0; g < ng; ++g) {
+            if (groups[g].bundle >= 0 && groups[g].cost == 0) continue;      // (rides along: below)
             int64_t s = ((int64_t)target * groups[g].cost + total_cost / 2) / total_cost;
             s = s < 1 ? 1 : s > most ? most : s;
             int64_t len = m <= 0 ? DWW_BLOCK : ((m + s - 1) / s + DWW_BLOCK - 1) / DWW_BLOCK * DWW_BLOCK;
             s = m <= 0 ? 1 : (m + len - 1) / len;
             slices_of[g] = (uint16_t)s;
             if (groups[g].bundle >= 0) {
+                for (int g2 = 0; g2 < ng; ++g2)
+                    if (groups[g2].bundle == groups[g].bundle) slices_of[g2] = (uint16_t)s;
                 DwbBundle& B = K.bundle[groups[g].bundle];
                 B.first_wg = (uint32_t)wgs, B.slices = (uint32_t)s, B.len = (uint32_t)len;
                 wgs += s;
@@ -609,11 +656,11 @@ extern "C" int stnerf_train_dw_batch(const stnerf_dw_problem* problems, int32_t 
     P.k.workspace = static_cast<float*>(workspace);
     // (a bundle's ring: four slots of 16 rows x 512 floats; the wave-item workgroups of the same launch carry the allocation along --
     // with 512 registers per wave a CU holds one workgroup either way)
-    const unsigned lds_bytes = P.k.bundle_wgs ? DWB_RING * DWW_BLOCK * 512 * 4 : 0;
+    const unsigned lds_bytes = P.k.bundle_wgs ? DWB_RING * DWW_BLOCK * 576 * 4 : 0;     // (the largest slot: 16 rows x (512 + 64) floats; 144 KB of the CU's 160)
     static bool attr_set = false;
     if (lds_bytes > 65536 && !attr_set) {
         STNERF_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(train_dw_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           DWB_RING * DWW_BLOCK * 512 * 4) == hipSuccess, "train_dw_batch: cannot reserve the LDS ring");
+                                           DWB_RING * DWW_BLOCK * 576 * 4) == hipSuccess, "train_dw_batch: cannot reserve the LDS ring");
         attr_set = true;
     }
     hipLaunchKernelGGL(train_dw_wave_kernel, dim3(P.k.bundle_wgs + (P.k.items + 3) / 4), dim3(256), lds_bytes, st, P.k);
