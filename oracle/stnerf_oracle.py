@@ -388,7 +388,8 @@ def layer_boxes(m: OracleModel, rays: Tensor):
 
 def render_chunk(m: OracleModel, rays: Tensor, only_coarse: bool = False,
                  density_threshold: float = 0.0001, bkgd_density_threshold: float = 0.0,
-                 rand: RandFn = _default_rand, trace: Optional[dict] = None, sample_dtype: Optional[torch.dtype] = None):
+                 rand: RandFn = _default_rand, trace: Optional[dict] = None, sample_dtype: Optional[torch.dtype] = None,
+                 forced: Optional[dict] = None):
     """LayeredRFRender.forward for one chunk (BBOX sampling, no pose refinement / view deform /
     background deform, background net without time: the configuration of both shipped ymls).
 
@@ -399,6 +400,10 @@ def render_chunk(m: OracleModel, rays: Tensor, only_coarse: bool = False,
     ``sample_dtype`` (error analysis only): evaluate the DETACHED parts -- the coarse sampler and the inverse-CDF resampler with
     its sort and point generation (:314-315, :460-465) -- in that dtype and cast the depths / points back, so that an fp64
     evaluation of the differentiable graph sits on the sample positions of the fp32 one.
+    ``forced`` (teacher forcing, error analysis only): {"z": (l, n, N2), "xyz_c" / "xyz_f": per performer the deformed points of its
+    hit rays or None} -- the reference's own new fine depths (the value of sample_pdf at :460) and the points its performer SpaceNets
+    were given (:355-356, :509-510), recorded by tests/golden/make_golden.py --grads --teacher: the networks are evaluated on those
+    (the deformation nets keep their place in the graph: value replaced, gradient passed).
     """
     n, L = rays.shape[0], m.layer_num
     l, N1, N2 = L + 1, m.n_coarse, m.n_fine
@@ -422,7 +427,7 @@ def render_chunk(m: OracleModel, rays: Tensor, only_coarse: bool = False,
             x = (x - pivot) / m.scale[i] + pivot
         return x
 
-    def deform(x, masks, ns):
+    def deform(x, masks, ns, given=None):
         # :340-356 / :495-510: performers only, masked rays only, regardless of visibility
         if m.bkgd_use_deform_time:  # :358-367 / :512-523: every ray, MotionNet(input_time=False)
             tid = fid(0).view(-1, 1, 1).repeat(1, ns, 1)
@@ -435,7 +440,10 @@ def render_chunk(m: OracleModel, rays: Tensor, only_coarse: bool = False,
                 continue
             tid = fid(i)[idx].view(-1, 1, 1).repeat(1, ns, 1)
             flow = motion_net(P, f"time_deform_nets.{i - 1}", torch.cat([x[i][idx], tid], -1))
-            x[i][idx] = x[i][idx] + flow
+            moved = x[i][idx] + flow
+            if given is not None and given[i] is not None:
+                moved = given[i].to(moved.dtype) + (moved - moved.detach())
+            x[i][idx] = moved
 
     def run_nets(x, masks, ns, fine):
         sfx = "_fine" if fine else ""
@@ -480,7 +488,7 @@ def render_chunk(m: OracleModel, rays: Tensor, only_coarse: bool = False,
         ts, xyz = [t_.to(rays.dtype) for t_ in ts], [x_.to(rays.dtype) for x_ in xyz]
     ts, xyz = [t_.detach() for t_ in ts], [x_.detach() for x_ in xyz]      # :314-315 (only matters under autograd)
     xyz = [unedit(xyz[i], i, False) for i in range(l)]
-    deform(xyz, masks, N1)
+    deform(xyz, masks, N1, forced.get("xyz_c") if forced else None)
     rgbs, sig = run_nets(xyz, masks, N1, False)
     sig[0][ts[0][:, :, 0] < m.near, :] = 0.0                              # :422
     t_mix, order = torch.sort(torch.cat(ts, -2), -2)                      # :425
@@ -502,6 +510,8 @@ def render_chunk(m: OracleModel, rays: Tensor, only_coarse: bool = False,
         u = rand((n, N2)).to(rays.dtype)
         sd_ = rays.dtype if sample_dtype is None else sample_dtype
         z = sample_pdf(ts[i].squeeze(-1).to(sd_), coarse_layer[i][3].squeeze(-1)[..., 1:-1].detach().to(sd_), u.to(sd_)).detach()   # :460-461
+        if forced and "z" in forced:
+            z = forced["z"][i].to(sd_)
         zi, _ = torch.sort(torch.cat([ts[i].squeeze(-1).to(sd_), z], -1), -1)
         pts = zi.unsqueeze(-1) * d.to(sd_).unsqueeze(1) + o.to(sd_).unsqueeze(1)
         z, zi, pts = z.to(rays.dtype), zi.to(rays.dtype), pts.to(rays.dtype)
@@ -509,7 +519,7 @@ def render_chunk(m: OracleModel, rays: Tensor, only_coarse: bool = False,
         zs.append(z)
         zf.append(zi)
         xf.append(unedit(pts, i, True))
-    deform(xf, masks, N1 + N2)
+    deform(xf, masks, N1 + N2, forced.get("xyz_f") if forced else None)
     rgbs, sig = run_nets(xf, masks, N1 + N2, True)
     z_mix, order = torch.sort(torch.cat(zf, -1), -1)                      # :587
     z_mix = z_mix.unsqueeze(-1)

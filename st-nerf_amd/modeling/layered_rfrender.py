@@ -84,7 +84,9 @@ class LayeredRFRender(nn.Module):
                                            # sharded / chunked renders and the tests rely on.  dropin.patch_reference
                                            # switches it on for models built through the reference's own code
         self.max_rays_per_launch = 1 << 19 # rays per kernel sequence (workspace bound ~20 KB/ray, not a semantic chunk)
-        self.replay = None                 # {"jitter": (l,N,N1), "u": (l,N,N2)} to replay recorded uniforms
+        self.replay = None                 # {"jitter": (l,N,N1), "u": (l,N,N2)} to replay recorded uniforms (parity tests); the training path
+                                           # also takes "z" (l,N,N2) / "xyz_c" / "xyz_f": the reference's own fine depths and deformed
+                                           # points (teacher forcing, stnerf_amd.modeling.training.render_rays_train)
         self.mlp_schedule = "stage"        # "stage": one persistent MLP launch per stage (stnerf_mlp_stage); "per_net":
                                            # one launch per (layer, network) as in round 1 (A/B measurements)
         self.ray_window = (0, 0, 0)        # (first, stripe, period): which rays of the view `rays` are (include/stnerf.h);
@@ -288,6 +290,17 @@ class LayeredRFRender(nn.Module):
         ray_mask = None if mask is None else [mask[:, i].bool() for i in range(l)]
         return trip(mix_f), trip(mix_c), fine_layer, coarse_layer, ray_mask
 
+    def _warn_if_eval_with_grad(self):
+        """the reference builds an autograd graph in eval() mode too; here training is gated on train() (the inference
+        kernels save nothing), so a fine-tuning script that never calls model.train() would get outputs without history.  Say so once."""
+        if (torch.is_grad_enabled() and not self.training and not getattr(self, "_warned_eval_grad", False)
+                and any(p.requires_grad for p in self.parameters())):
+            import warnings
+            self._warned_eval_grad = True
+            warnings.warn("LayeredRFRender.forward in eval() mode with autograd enabled and trainable parameters: the MI355X inference "
+                          "kernels run and the outputs carry NO autograd history (the reference would build a graph here).  Call "
+                          "model.train() to train, or wrap rendering in torch.no_grad() to silence this.", RuntimeWarning, stacklevel=3)
+
     def advance_seed(self):
         """What a finished call does to ``seed`` (``fresh_draws_per_call``; a rank that owns no ray of a sharded view
         calls this too, so that every rank's stream stays the same)."""
@@ -313,17 +326,20 @@ class LayeredRFRender(nn.Module):
             raise RuntimeError("set_bkgd_bbox / set_bboxes must be called before rendering")
         if N == 0:  # the reference dereferences row 0 (rays_frame_id[0, i+1], layered_rfrender.py:200)
             raise IndexError("empty ray batch: LayeredRFRender needs at least one ray")
-        if self.bkgd_use_space_time and self.use_space_time and bool((rays[:, 6] != rays[0, 6]).any()):
-            # The reference hands the background net its frame ids as a 1-D tensor (layered_rfrender.py:380,385), which
-            # modeling/spacenet.py:117-118 tiles over the samples: sample j of ray i gets the id of ray (i S + j) mod n.  With one
-            # background frame id per call (every rendered frame) that is the identity and this path is exact; a batch that mixes
-            # them (training rays with BKGD_USE_SPACE_TIME -- off in both shipped ymls) would need that scramble reproduced.
-            raise NotImplementedError("BKGD_USE_SPACE_TIME with different background frame ids in one call: the reference assigns "
-                                      "them to the wrong samples there (modeling/spacenet.py:117-118 with 1-D times); not reproduced")
+        # BKGD_USE_SPACE_TIME on a batch that MIXES background frame ids (training rays; off in both shipped ymls): the reference tiles
+        # the ids over the samples (modeling/spacenet.py:117-118 with the 1-D tensor of layered_rfrender.py:380,385), so every sample of
+        # layer 0 has its own time.  The fused pipeline keeps one time per ray; such a call takes the op-by-op path below, which
+        # evaluates the background per sample (stnerf_amd.modeling.training._stage).  One id per call -- every rendered frame -- is the
+        # identity and stays on the fused pipeline.
+        per_sample_bkgd_time = False
+        if self.bkgd_use_space_time and self.use_space_time:
+            from stnerf_amd.modeling import training as _training
+            per_sample_bkgd_time = _training.mixed_bkgd_ids(rays)
         # Training: model.train() + autograd enabled + trainable parameters = what engine/layered_trainer.py:186-194
         # sets up -> the same stages launched op by op with autograd history (stnerf_amd.modeling.training).  In eval() mode the
         # inference kernels run and the outputs carry no history, as under torch.no_grad() (render/layered_neural_renderer.py:377).
         train = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
+        self._warn_if_eval_with_grad()
         step = N if ref_chunk is None else ref_chunk
         groups = []  # (start, end, boxes, pivot)
         if retiming:
@@ -355,8 +371,12 @@ class LayeredRFRender(nn.Module):
                 bx = boxes if boxes.dim() == 3 else boxes[s:e].contiguous()
                 rp = None
                 if self.replay is not None:
-                    rp = {k: v[:, s:e].contiguous() for k, v in self.replay.items()}
-                if train:
+                    # jitter / u / z: (l, N, *) per-ray draws, cut with the rays; xyz_c / xyz_f (teacher forcing, parity tests only): per
+                    # performer the deformed points of its hit rays -- whole-batch lists, one launch piece only
+                    rp = {k: (v[:, s:e].contiguous() if torch.is_tensor(v) else v) for k, v in self.replay.items()}
+                    if any(not torch.is_tensor(v) for v in rp.values()) and (s, e) != (0, N):
+                        raise ValueError("replayed deformed points (xyz_c / xyz_f) need the whole batch in one launch piece")
+                if train or per_sample_bkgd_time:
                     from stnerf_amd.modeling.training import render_rays_train
                     outs.append(render_rays_train(self, rays[s:e], bx, pivot, retiming, only_coarse, density_threshold,
                                                   bkgd_density_threshold, window_at(s), rp))

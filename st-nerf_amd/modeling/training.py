@@ -49,9 +49,16 @@ class CompositeFunction(torch.autograd.Function):
         return None, ops.composite_bwd(t, raw, mask, order, ctx.params, gl, gm), None, None
 
 
-def _stage(model, rays, xyz, hit, times_col, fine: bool):
+def mixed_bkgd_ids(rays) -> bool:
+    """More than one background frame id (column 6) in this call (a host synchronisation; only asked with BKGD_USE_SPACE_TIME)."""
+    return bool((rays[:, 6] != rays[0, 6]).any())
+
+
+def _stage(model, rays, xyz, hit, times_col, fine: bool, forced=None):
     """MotionNet + SpaceNet of every layer on a stage's points xyz (n,l,ns,3) -> raw (n,l,ns,4) with autograd history.
-    modeling/layered_rfrender.py:340-418 (coarse) / :495-576 (fine)."""
+    modeling/layered_rfrender.py:340-418 (coarse) / :495-576 (fine).  ``forced[i]`` (teacher forcing, parity tests): the deformed
+    points the REFERENCE handed performer i's SpaceNet, (hits, ns, 3); the SpaceNet is evaluated on exactly those, the deformation
+    net keeps its place in the graph (its flow's VALUE is replaced, its gradient is the SpaceNet's d pos)."""
     n, l, ns = xyz.shape[0], xyz.shape[1], xyz.shape[2]
     bk, nets = model._nets(fine)
     dirs = rays[:, :6]
@@ -62,7 +69,17 @@ def _stage(model, rays, xyz, hit, times_col, fine: bool):
         tcol = rays[:, times_col(0)].reshape(n, 1, 1).expand(n, ns, 1)
         x0 = x0 + model.bkgd_time_deform_net(torch.cat([x0, tcol], -1))
     tm0 = rays[:, times_col(0)].reshape(n, 1) if model.bkgd_use_space_time else None
-    rgb, sig = bk(x0, dirs, tm0)
+    if tm0 is not None and mixed_bkgd_ids(rays):
+        # The reference hands the background net its frame ids as a 1-D tensor (modeling/layered_rfrender.py:380,385 and the fine
+        # twins) and SpaceNet.forward TILES them over the samples (modeling/spacenet.py:117-118: unsqueeze(1).repeat(1, L, 1) of an
+        # (n,) tensor, then reshape(-1, 1)): sample j of ray i is evaluated at the id of ray (i ns + j) mod n.  With one id per call
+        # that is the identity; on a batch that mixes them (training rays) every sample has its own time, so every sample is
+        # evaluated as a one-sample ray: its own point, its ray's direction, the tiled id.
+        flat = torch.arange(n * ns, device=rays.device)
+        rgb, sig = bk(x0.reshape(n * ns, 1, 3), dirs.index_select(0, flat // ns), tm0.reshape(n).index_select(0, flat % n).reshape(n * ns, 1))
+        rgb, sig = rgb.reshape(n, ns, 3), sig.reshape(n, ns, 1)
+    else:
+        rgb, sig = bk(x0, dirs, tm0)
     raws.append(torch.cat([rgb, sig], -1))
     for i in range(1, l):
         zero = torch.zeros(n, ns, 4, dtype=torch.float32, device=xyz.device)      # the reference's zero tensors (:398-399)
@@ -76,6 +93,8 @@ def _stage(model, rays, xyz, hit, times_col, fine: bool):
         if model.use_deform_time:
             flow = model.time_deform_nets[i - 1](torch.cat([pos, tm.reshape(-1, 1, 1).expand(-1, ns, 1)], -1))   # :340-356
             pos = pos + flow
+            if forced is not None and forced[i] is not None:
+                pos = forced[i] + (pos - pos.detach())       # the recorded points bit for bit (x - x = 0 exactly), d / d flow = identity
         rgb, sig = nets[i - 1](pos, r_i[:, :6], tm if model.use_space_time else None)
         raws.append(zero.index_copy(0, idx, torch.cat([rgb, sig], -1)))
     return torch.stack(raws, 1)
@@ -115,15 +134,25 @@ def render_rays_train(model, rays, boxes, pivot, retiming: bool, only_coarse: bo
     mask01 = mask
     # the hit rays of every performer, once for both stages (a nonzero is a host synchronisation: the output's size is data)
     hit = [None] + [mask01[:, i].nonzero(as_tuple=True)[0] for i in range(1, l)]
-    raw_c = _stage(model, rays, xyz_c, hit, times_col, False)
+    forced = replay or {}
+    raw_c = _stage(model, rays, xyz_c, hit, times_col, False, forced.get("xyz_c"))
     layer_c, mixed_c, w_c = CompositeFunction.apply(t_c, raw_c, mask, _composite_params(model, False, retiming, thr, bthr))
     if only_coarse:
         # layered_rfrender.py:704-723: the "fine" entries are the coarse ones
         return mixed_c, mixed_c, layer_c, layer_c, mask01
     with torch.no_grad():
-        t_f, xyz_f = ops.resample(t_c, w_c, n2, rays, u=replay.get("u") if replay else None, seed=int(model.seed),
-                                  ray_index_base=first, edits=ef, pivot=pivot, ray_index_stripe=stripe, ray_index_period=period,
-                                  mask=None)
-    raw_f = _stage(model, rays, xyz_f, hit, times_col, True)
+        if "z" in forced:
+            # teacher forcing: the reference's own new depths instead of a resampling of THESE coarse weights (whose last bits differ:
+            # utils/sample_pdf.py:58-59 divides by cdf differences down to 1e-5).  The rest as modeling/layered_rfrender.py:462-465:
+            # sort(cat[t, z]), z d + o -- separate IEEE multiplies and adds, the reference's values bit for bit
+            if ef is not None:
+                raise ValueError("replayed fine depths with box edits: not needed by any fixture")
+            t_f = torch.sort(torch.cat([t_c, forced["z"].permute(1, 0, 2).to(t_c.dtype)], -1), -1)[0].contiguous()
+            xyz_f = (t_f.unsqueeze(-1) * rays[:, None, None, 3:6] + rays[:, None, None, 0:3]).contiguous()
+        else:
+            t_f, xyz_f = ops.resample(t_c, w_c, n2, rays, u=replay.get("u") if replay else None, seed=int(model.seed),
+                                      ray_index_base=first, edits=ef, pivot=pivot, ray_index_stripe=stripe, ray_index_period=period,
+                                      mask=None)
+    raw_f = _stage(model, rays, xyz_f, hit, times_col, True, forced.get("xyz_f"))
     layer_f, mixed_f, _ = CompositeFunction.apply(t_f, raw_f, mask, _composite_params(model, True, retiming, thr, bthr))
     return mixed_f, mixed_c, layer_f, layer_c, mask01

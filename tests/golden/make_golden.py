@@ -2,9 +2,10 @@
 """Generate tests/golden/*.npz by running the REFERENCE's own code (build container only).
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py        # the base set
-    ... make_golden.py --round2 | --model-flags | --more-layers | --teacher | --psnr-view | --grads      # one group each; every file
-    regenerates byte for byte (--grads: train_c3 / train_coarse_only / train_c4 / train_flags / train_same_spacenet, one iteration of the reference's
-    do_train inner loop each, with the thread count pinned)
+    ... make_golden.py --round2 | --model-flags | --more-layers | --teacher | --psnr-view | --grads | --grads --teacher     # one group each;
+    every file regenerates byte for byte (--grads: train_c3 / train_coarse_only / train_c4 / train_flags / train_same_spacenet / train_bkgd_time,
+    one iteration of the reference's do_train inner loop each, with the thread count pinned; --grads --teacher: train_tf_c3 and
+    train_tf_trainer -- 2000 rays, 90 + 30 --, the same iteration with the fine depths and deformed points it ran on recorded)
 
 Imports ``/root/reference`` (a pure-Python/PyTorch repo) on CPU with the three shims of
 SURVEY.md section 8(c): a SimpleNamespace cfg (yacs is absent), ``Tensor.cuda`` = identity (no
@@ -568,7 +569,58 @@ def grad_digest(name, g):
     return {name: syn.tensor_digest(name.split("|", 1)[1], g.detach(), GRAD_SAMPLES)}
 
 
-def g_train_step(name, L, n1, n2, st, dt, seed, n_rays=96, only_coarse=False, remove_outliers=True, h=40, w=64, flags=None):
+class SeededDraws:
+    """Replaces torch.rand by draws a test can regenerate: call k returns torch.rand(shape, generator=manual_seed(base + k)) -- for the
+    fixture at the trainer's batch size, whose 720,000 uniforms would otherwise be most of the file.  Records the shapes."""
+
+    def __init__(self, base):
+        self.base, self.shapes, self.draws, self._orig = base, [], [], torch.rand
+
+    def __enter__(self):
+        def rec(*a, **k):
+            shape = tuple(a[0]) if len(a) == 1 and not isinstance(a[0], int) else tuple(a)
+            x = self._orig(shape, generator=torch.Generator().manual_seed(self.base + len(self.shapes)))
+            self.shapes.append(list(shape))
+            self.draws.append(x)
+            return x
+        torch.rand = rec
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self._orig
+
+
+def rays_with_depth_ties(model, rays, seed_base):
+    """Rows of `rays` on which two samples of the merged lists have EXACTLY the same depth (about 1 ray in 1000 at 3 x 90 samples).
+    modeling/layered_rfrender.py:425,587 merge the layers with torch.sort's default stable=False, and ATen's CPU sort is not stable
+    (a probe: 1162 of 2000 rows kept the lower layer first), so on such a ray the reference's own result depends on its sort
+    algorithm -- and differs between its CPU and CUDA runs.  The framework merges in the order of a stable sort (what CUDA's radix
+    sort gives); a fixture that is held to 2e-5 leaves such rays out."""
+    found = []
+    orig = torch.sort
+
+    def sort(*a, **k):
+        out = orig(*a, **k)
+        v = out[0]
+        if v.dim() == 3 and v.shape[-1] == 1:
+            v = v[..., 0]
+        if v.dim() == 2 and v.shape[0] == rays.shape[0] and v.shape[1] > model.coarse_ray_sample + model.fine_ray_sample:   # a merged list
+            tie = ((v[:, 1:] == v[:, :-1]) & (v[:, 1:] > -999.0)).any(-1)
+            found.append(tie)
+        return out
+    n = rays.shape[0]
+    torch.sort = sort
+    try:
+        with SeededDraws(seed_base), torch.no_grad():
+            model(rays, torch.zeros(n), torch.zeros(n, 8, 3), False, near_far=torch.zeros(n, 2))
+    finally:
+        torch.sort = orig
+    assert len(found) == 2, len(found)
+    return (found[0] | found[1]).nonzero().flatten().tolist()
+
+
+def g_train_step(name, L, n1, n2, st, dt, seed, n_rays=96, only_coarse=False, remove_outliers=True, h=40, w=64, flags=None, teacher=False,
+                 seeded_draws=False):
     """One iteration of do_train's inner loop (engine/layered_trainer.py:178-282) with the reference's OWN model, loss
     (layers/loss.py:4) and optimiser (solver/build.py:10-27, Adam as configs/config_taekwondo.yml:3-5), on a batch of
     training-style rays (7 columns: one integer frame id per ray, data/datasets/ray_dataset.py): the loss, every parameter's
@@ -586,19 +638,64 @@ def g_train_step(name, L, n1, n2, st, dt, seed, n_rays=96, only_coarse=False, re
     optimizer = make_optimizer(cfg, model)
     all_rays = view_rays(h, w, L, per_ray_frames=True)
     g = torch.Generator().manual_seed(500 + seed)
-    pick = torch.randperm(all_rays.shape[0], generator=g)[:n_rays]
+    perm = torch.randperm(all_rays.shape[0], generator=g)
+    pick = perm[:n_rays].clone()
     rays = all_rays[pick].contiguous()
+    replaced = []
+    if seeded_draws:
+        # the trainer-sized batch: rays with an exact depth tie in a merged list are swapped for the next unused rays of the view
+        # (rays_with_depth_ties; the draws are seeded per call, so every probe sees the draws of the recorded run)
+        spare = n_rays
+        for _ in range(20):
+            tied = rays_with_depth_ties(model, rays, 9000 + 100 * seed)
+            if not tied:
+                break
+            for r in tied:
+                pick[r] = perm[spare]
+                replaced.append((r, int(perm[spare])))
+                spare += 1
+            rays = all_rays[pick].contiguous()
+        else:
+            raise RuntimeError("depth ties keep turning up")
+        print(f"{name}: {len(replaced)} rays with exact depth ties replaced: {replaced}")
     rgbs = torch.rand(n_rays, 3, generator=g)
     bbox_labels, bboxes, near_far = torch.zeros(n_rays), torch.zeros(n_rays, 8, 3), torch.zeros(n_rays, 2)
     epoch, coarse_stage = (1, 10) if only_coarse else (1, 0)
     torch.manual_seed(600 + seed)
     model.train()                                                       # :186
     optimizer.zero_grad()                                               # :187
-    with RandRecorder() as rr:
-        if epoch < coarse_stage:                                        # :199-202
-            stage2, stage1, stage2_layer, stage1_layer, ray_mask = model(rays, bbox_labels, bboxes, True, near_far=near_far)
-        else:
-            stage2, stage1, stage2_layer, stage1_layer, ray_mask = model(rays, bbox_labels, bboxes, False, near_far=near_far)
+    # teacher forcing (round 6): what the fine stage and the performer networks were evaluated ON -- every layer's new fine depths
+    # (the value of sample_pdf at modeling/layered_rfrender.py:460) and the deformed points handed to the performer SpaceNets
+    # (:355-356 / :509-510 -> :404-411 / :559-566, hit rays only, in ray order)
+    import modeling.layered_rfrender as lr
+    tf = dict(z=[], xyz={})
+    orig_pdf = lr.sample_pdf
+
+    def pdf(bins, weights, N_samples, det=False, pytest=False):
+        zz = orig_pdf(bins, weights, N_samples=N_samples, det=det, pytest=pytest)
+        tf["z"].append(zz.detach().clone())
+        return zz
+    handles = []
+    if teacher:
+        lr.sample_pdf = pdf
+        seen = set()
+        for i in range(L):
+            for net in (model.spacenets[i], model.spacenets_fine[i]):
+                if id(net) in seen:
+                    continue
+                seen.add(id(net))
+                handles.append(net.register_forward_pre_hook(
+                    lambda mod, inputs, i=i: tf["xyz"].setdefault(i + 1, []).append(inputs[0].detach().clone())))
+    try:
+        with (SeededDraws(9000 + 100 * seed) if seeded_draws else RandRecorder()) as rr:
+            if epoch < coarse_stage:                                        # :199-202
+                stage2, stage1, stage2_layer, stage1_layer, ray_mask = model(rays, bbox_labels, bboxes, True, near_far=near_far)
+            else:
+                stage2, stage1, stage2_layer, stage1_layer, ray_mask = model(rays, bbox_labels, bboxes, False, near_far=near_far)
+    finally:
+        lr.sample_pdf = orig_pdf
+        for hd in handles:
+            hd.remove()
     # labels (N,1): 0 = outlier, i = the ray belongs to layer i (the dataset's masks); here: the first performer the ray hits
     labels = torch.zeros(n_rays, 1)
     for i in range(L, 0, -1):
@@ -652,12 +749,28 @@ def g_train_step(name, L, n1, n2, st, dt, seed, n_rays=96, only_coarse=False, re
     for pname, prm in model.named_parameters():
         if prm.grad is not None:
             arrays.update(grad_digest("stepped|" + pname, prm.detach()))
-    for i, dr in enumerate(rr.draws):
-        arrays[f"draw{i}"] = dr
+    if not seeded_draws:
+        for i, dr in enumerate(rr.draws):
+            arrays[f"draw{i}"] = dr
+    extra = {}
+    if seeded_draws:
+        extra.update(draw_seed_base=rr.base, draw_shapes=rr.shapes)
+    if teacher:
+        assert len(tf["z"]) == L + 1 and not only_coarse
+        for i in range(L + 1):
+            arrays[f"tf_z{i}"] = tf["z"][i]                              # (n, n2): layer i's new fine depths
+        for i in range(1, L + 1):
+            calls = tf["xyz"].get(i, [])
+            hits = int(ray_mask[i].sum())
+            assert len(calls) == (2 if hits else 0), (i, len(calls), hits)
+            if hits:                                                     # (hits, n1, 3) and (hits, n1 + n2, 3)
+                assert calls[0].shape == (hits, n1, 3) and calls[1].shape == (hits, n1 + n2, 3)
+                arrays[f"tf_xyz_c{i}"], arrays[f"tf_xyz_f{i}"] = calls[0], calls[1]
+        extra.update(teacher=True)
     meta = dict(L=L, n1=n1, n2=n2, space_time=st, deform_time=dt, weight_seed=seed, n_rays=n_rays, only_coarse=only_coarse,
                 remove_outliers=remove_outliers, n_draws=len(rr.draws), without_grad=without_grad, lr=0.0004,
                 grad_samples=GRAD_SAMPLES, scalar=100000, penalty=1, **({"flags": dict(flags)} if flags else {}),
-                hit_fraction=[float(mk.float().mean()) for mk in ray_mask])
+                hit_fraction=[float(mk.float().mean()) for mk in ray_mask], **extra)
     save(name, meta, **arrays)
 
 
@@ -680,6 +793,19 @@ def g_train_cases():
     # samples -- cancelled 76-fold, so that fp32 rounding of the terms was 1e-4 of the sum, in the reference's autograd as in any
     # other; the fixtures' bars are relative to a tensor's largest entry and want sums that are not differences: 1 - 8 x here)
     g_train_step("train_same_spacenet", 2, 16, 8, True, True, 48, n_rays=64, flags=dict(SAME_SPACENET=True))
+    # BKGD_USE_SPACE_TIME on training rays (one integer frame id per ray, mixed over the batch): the background's ids are tiled over
+    # the samples (modeling/spacenet.py:117-118 with the 1-D tensor of layered_rfrender.py:380,385): every sample has its own time
+    g_train_step("train_bkgd_time", 1, 16, 8, True, True, 55, n_rays=64, flags=dict(BKGD_USE_SPACE_TIME=True))
+
+
+def g_train_teacher_cases():
+    """--grads --teacher (round 6): the same iteration with what the networks were evaluated ON recorded, so that the HIP step can be
+    held to the piecewise bar (2e-5 of a gradient tensor's largest entry) END TO END: with the reference's own fine depths and
+    deformed points every SpaceNet sees the reference's inputs bit for bit, and what is compared is arithmetic, not the conditioning of
+    sin(2^9 x) behind a MotionNet or the resampler."""
+    g_train_step("train_tf_c3", 2, 40, 40, True, True, 53, teacher=True)
+    # the trainer's own batch: 2000 rays (IMS_PER_BATCH), 90 + 30 samples, two performers (configs/config_taekwondo.yml:6,52-53)
+    g_train_step("train_tf_trainer", 2, 90, 30, True, True, 52, n_rays=2000, teacher=True, seeded_draws=True)
 
 
 
@@ -698,6 +824,12 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "--teacher":
         g_teacher_cases()
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "--grads" and sys.argv[2] == "--teacher":
+        g_train_teacher_cases()
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "--grads" and sys.argv[2] == "--bkgd-time":    # (one case, without touching the rest)
+        g_train_step("train_bkgd_time", 1, 16, 8, True, True, 55, n_rays=64, flags=dict(BKGD_USE_SPACE_TIME=True))
         return
     if len(sys.argv) > 1 and sys.argv[1] == "--grads":
         g_train_cases()
@@ -732,6 +864,7 @@ def main():
     g_psnr_view()
     g_teacher_cases()
     g_train_cases()
+    g_train_teacher_cases()
 
 
 if __name__ == "__main__":

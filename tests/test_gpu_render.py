@@ -28,7 +28,7 @@ from stnerf_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 FWD_CASES = ["fwd_c1", "fwd_c3", "fwd_edit", "fwd_hide", "fwd_nonretime", "fwd_only_coarse",
-             "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_same_spacenet", "fwd_deep_rgb", "fwd_no_raw_no_dir", "fwd_c4", "fwd_c5"]
+             "batchify_chunked", "batchify_small", "fwd_bkgd_time", "fwd_bkgd_time_mixed_ids", "fwd_same_spacenet", "fwd_deep_rgb", "fwd_no_raw_no_dir", "fwd_c4", "fwd_c5"]
 COLOR_ATOL, DEPTH_ATOL = 5e-5, 5e-4
 
 
@@ -264,22 +264,31 @@ def test_empty_ray_batch_raises_like_the_reference():
         model(a["rays"][:0].cuda(), None, None)
 
 
-def test_background_space_time_with_mixed_frame_ids_is_refused_not_approximated():
+def test_background_space_time_with_mixed_frame_ids_is_per_sample_time():
     """BKGD_USE_SPACE_TIME (off in both shipped ymls): the reference tiles the background's frame ids over the samples when they
-    differ across the rays of a call (modeling/spacenet.py:117-118 with the 1-D ids of layered_rfrender.py:380; the oracle restates
-    it and matches fwd_bkgd_time_mixed_ids on CPU).  The HIP path feeds a ray's own id -- identical whenever a call has ONE
-    background frame id (every rendered frame: fwd_bkgd_time above) -- and refuses the mixed case instead of rendering something else."""
+    differ across the rays of a call (modeling/spacenet.py:117-118 with the 1-D ids of layered_rfrender.py:380): sample j of ray i is
+    evaluated at the id of ray (i ns + j) mod n.  fwd_bkgd_time_mixed_ids (FWD_CASES, both arithmetics) holds the outputs; here: the
+    scramble is really there (the call differs from one with a ray's own id on every sample), and a call with ONE id stays on the fused
+    pipeline and agrees with the per-sample path fed the same ids."""
     meta, a = load_golden("fwd_bkgd_time_mixed_ids")
-    model = build_model(meta)
+    model = build_model(meta).set_precision("fp32")
     rays = a["rays"].cuda()
+    n = rays.shape[0]
     assert rays.shape[1] == 7 and len(set(rays[:, 6].tolist())) > 1
-    with pytest.raises(NotImplementedError, match="BKGD_USE_SPACE_TIME"):
-        model(rays, None, None)
-    same = rays.clone()
-    same[:, 6] = rays[0, 6]
-    model.replay = None
-    out = model(same, None, None)                       # one id for the whole call: renders
-    assert bool(torch.isfinite(out[0][0]).all())
+    model.replay = assemble_replay(meta, a, n)
+    with torch.no_grad():
+        mixed = model(rays, None, None)
+        same = rays.clone()
+        same[:, 6] = rays[0, 6]
+        one = model(same, None, None)                      # one id for the whole call: the fused pipeline
+        from stnerf_amd.modeling import training as T
+        fused, T.mixed_bkgd_ids = one, (lambda r: True)    # ... and the same call forced through the per-sample path
+        try:
+            per_sample = model(same, None, None)
+        finally:
+            T.mixed_bkgd_ids = lambda r: bool((r[:, 6] != r[0, 6]).any())
+    assert float((mixed[0][0] - one[0][0]).abs().max()) > 1e-3
+    assert torch.allclose(per_sample[1][0], fused[1][0], atol=COLOR_ATOL) and torch.allclose(per_sample[3][0][0], fused[3][0][0], atol=COLOR_ATOL)
 
 
 def test_cpu_tensors_are_refused():

@@ -17,12 +17,24 @@ def load_fixture(name):
 
 
 def replay_of(z, meta, dtype=torch.float32, device="cpu"):
-    """The recorded torch.rand draws in the reference's order: l jitter tensors (n, N1), then l resampling tensors (n, N2)."""
+    """The recorded torch.rand draws in the reference's order: l jitter tensors (n, N1), then l resampling tensors (n, N2).  A fixture
+    made with seeded draws (make_golden.SeededDraws: the trainer-sized one) holds their seeds and shapes instead: call k =
+    torch.rand(shape, generator=manual_seed(base + k)) on the CPU.  A teacher-forced fixture (meta["teacher"]) adds what the reference's
+    networks were evaluated on: "z" (l, n, N2) every layer's new fine depths, "xyz_c" / "xyz_f" per performer the deformed points of
+    its hit rays (None for layer 0 and for performers no ray hits)."""
     l = meta["L"] + 1
-    draws = [torch.from_numpy(z[f"draw{i}"]).to(dtype) for i in range(meta["n_draws"])]
+    if "draw_seed_base" in meta:
+        draws = [torch.rand(tuple(shape), generator=torch.Generator().manual_seed(meta["draw_seed_base"] + k)).to(dtype)
+                 for k, shape in enumerate(meta["draw_shapes"])]
+    else:
+        draws = [torch.from_numpy(z[f"draw{i}"]).to(dtype) for i in range(meta["n_draws"])]
     rp = {"jitter": torch.stack(draws[:l], 0).to(device)}
     if len(draws) > l:
         rp["u"] = torch.stack(draws[l:2 * l], 0).to(device)
+    if meta.get("teacher"):
+        rp["z"] = torch.stack([torch.from_numpy(z[f"tf_z{i}"]) for i in range(l)], 0).to(dtype).to(device)
+        for key in ("xyz_c", "xyz_f"):
+            rp[key] = [None] + [torch.from_numpy(z[f"tf_{key}{i}"]).to(dtype).to(device) if f"tf_{key}{i}" in z.files else None for i in range(1, l)]
     return draws, rp
 
 
@@ -67,10 +79,11 @@ def compare_digest(name, got, want, rel=2e-5):
     return err / (rel * scale)
 
 
-def oracle_step(z, meta, dtype, sample_dtype=None):
+def oracle_step(z, meta, dtype, sample_dtype=None, teacher=False):
     """The same iteration through the CPU oracle (TEST INFRASTRUCTURE: oracle/stnerf_oracle.py, pinned to the reference's own
     gradients by tests/test_train_step_cpu.py) in ``dtype``; -> (params with .grad, outputs, loss, loss parts).  With
-    ``sample_dtype=torch.float32`` an fp64 evaluation sits on the fp32 run's sample positions."""
+    ``sample_dtype=torch.float32`` an fp64 evaluation sits on the fp32 run's sample positions; with ``teacher`` (a fixture of
+    make_golden.py --grads --teacher) also on the reference's own fine depths and deformed points."""
     from oracle import stnerf_oracle as O
     from stnerf_amd import synthetic as syn
     L = meta["L"]
@@ -81,10 +94,11 @@ def oracle_step(z, meta, dtype, sample_dtype=None):
     m = O.OracleModel(layer_num=L, n_coarse=meta["n1"], n_fine=meta["n2"], params=sd, use_deform_time=meta["deform_time"],
                       use_space_time=meta["space_time"], bkgd_use_deform_time=fl.get("BKGD_USE_DEFORM_TIME", False),
                       bkgd_use_space_time=fl.get("BKGD_USE_SPACE_TIME", False), bkgd_bbox=bk.to(dtype), bboxes=per.to(dtype))
-    draws, _ = replay_of(z, meta, dtype)
+    draws, rp = replay_of(z, meta, dtype)
     it = iter(draws)
+    forced = {k: rp[k] for k in ("z", "xyz_c", "xyz_f")} if teacher else None
     out = O.render_chunk(m, torch.from_numpy(z["rays"]).to(dtype), only_coarse=meta["only_coarse"], rand=lambda shape: next(it),
-                         sample_dtype=sample_dtype)
+                         sample_dtype=sample_dtype, forced=forced)
     loss, parts = trainer_loss(out, torch.from_numpy(z["rgbs"]).to(dtype), torch.from_numpy(z["labels"]), meta["only_coarse"],
                                meta["remove_outliers"])
     loss.backward()
