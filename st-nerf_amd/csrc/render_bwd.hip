@@ -71,7 +71,7 @@ __global__ void composite_bwd_kernel(CompositeBwdArgs a) {
     const int LS = a.l * a.S;
     // per workgroup: the per-layer edit table; per wave: dacc[LS] float4 | T, om, gww, q, gw [LS] floats each
     float* tab = reinterpret_cast<float*>(smem_raw);   // thr[16] | scale[16]
-    const int per_wave = LS * 36;
+    const int per_wave = (LS * 36 + 15) & ~15;          // (16-byte aligned regions: dacc is read and written as float4)
     unsigned char* mine = smem_raw + 128 + (size_t)wave * per_wave;
     float4* dacc = reinterpret_cast<float4*>(mine);
     float* sT = reinterpret_cast<float*>(mine + (size_t)LS * 16);
@@ -217,7 +217,7 @@ extern "C" int stnerf_composite_bwd(const float* t, const float* raw, const uint
     STNERF_REQUIRE((((uintptr_t)raw | (uintptr_t)d_raw) & 15) == 0, "composite_bwd: raw and d_raw must be 16-byte aligned");
     STNERF_REQUIRE(!g_mixed || order, "composite_bwd: the merged composite's gradient needs the forward's `order`");
     if (n == 0) return STNERF_OK;
-    const int64_t per_wave = (int64_t)l * S * 36;
+    const int64_t per_wave = ((int64_t)l * S * 36 + 15) & ~(int64_t)15;   // (as in the kernel: rounded up to 16 bytes)
     STNERF_REQUIRE(per_wave + 128 <= 160 * 1024 - 1024, "composite_bwd: %d samples per ray need %lld B of LDS per wave", l * S,
                    (long long)per_wave);
     int wpb = (int)((64 * 1024 - 128) / per_wave);

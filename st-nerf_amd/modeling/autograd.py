@@ -32,6 +32,24 @@ FUSED_BACKWARD = os.environ.get("STNERF_TRAIN_FUSED", "1") != "0"
 # samples fit this budget -- as the reference's autograd does, and what 288 GB of HBM are for: the backward then starts without any
 # recomputation.  Above the budget (or with STNERF_TRAIN_KEEP_GB=0) nothing is kept and the backward recomputes chunk by chunk.
 KEEP_BYTES = int(float(os.environ.get("STNERF_TRAIN_KEEP_GB", "32")) * (1 << 30))
+# ... per CALL; and over all calls of an iteration that hold their activations at the same time (every network of both stages until its
+# backward has run: 2 l SpaceNets + deformation nets) at most this much, after which further calls fall back to recomputation instead
+# of running the 288 GB part out of memory.  The counter follows the kept buffers' lifetime (weakref.finalize).
+KEEP_TOTAL_BYTES = int(float(os.environ.get("STNERF_TRAIN_KEEP_TOTAL_GB", "160")) * (1 << 30))
+_kept_now = [0]
+
+
+def _may_keep(nbytes: int) -> bool:
+    return 0 < nbytes <= KEEP_BYTES and _kept_now[0] + nbytes <= KEEP_TOTAL_BYTES
+
+
+def _account_kept(bufs, nbytes: int) -> None:
+    import weakref
+    _kept_now[0] += nbytes
+
+    def release(n=nbytes):
+        _kept_now[0] -= n
+    weakref.finalize(bufs[0], release)
 ACT_FLOATS_PER_SAMPLE = 320 + 5 * 256 + 304 + 128 + 64
 CHUNK_SAMPLES = min(max(int(os.environ.get("STNERF_TRAIN_CHUNK_SAMPLES", 1 << 18)), 1024), (1 << 29) // 320)
 
@@ -122,9 +140,17 @@ class SpaceNetFunction(torch.autograd.Function):
         with torch.no_grad():
             # exact f32 whatever the module renders with: the backward walks back through the ReLU masks of THIS evaluation
             packed = module._packed("fp32")
-            if fused and n * ns * ACT_FLOATS_PER_SAMPLE * 4 <= KEEP_BYTES:
-                kept = _activation_buffers(n * ns, 27 + (21 if module.use_time else 0), dev)
+            if fused and _may_keep(n * ns * ACT_FLOATS_PER_SAMPLE * 4):
+                dir_w_, time_w_ = 27, (21 if module.use_time else 0)
+                kept = _activation_buffers(n * ns, dir_w_ + time_w_, dev)
+                _account_kept(kept, n * ns * ACT_FLOATS_PER_SAMPLE * 4)
                 ops.train_spacenet_fwd(packed, pos.detach(), dirs.detach(), times, raw, _act_views(kept), kept[0][:, 256:320], kept[8])
+                # rgb_net.1's direction / time columns of its input matrix (the right operand of its weight gradient): written HERE, so
+                # that the backward reads the saved tensors and never writes into them
+                ops.train_encode(dirs.detach(), kept[6][:, 256:256 + dir_w_], 4, True, rows_per_src=ns, relu=True)
+                if module.use_time:
+                    ops.train_encode(times.detach().reshape(-1, 1).float(), kept[6][:, 256 + dir_w_:256 + dir_w_ + time_w_], 10, True,
+                                     rows_per_src=ns, relu=True)
             else:
                 ops.spacenet_fwd(packed, pos.detach().contiguous(), dirs.detach(), times, raw)
         ctx.module, ctx.has_times, ctx.kept = module, times is not None, bool(kept)
@@ -176,10 +202,11 @@ class SpaceNetFunction(torch.autograd.Function):
                                            bufs[0][:, 256:320], bufs[8])
                 Cc, R = bufs[0], bufs[6]
                 acts = _act_views(bufs)
-                ops.train_encode(dirs[r0:r1], R[:, 256:256 + dir_w], 4, inc, rows_per_src=ns, relu=True)
-                if use_time:
-                    ops.train_encode(times[r0:r1].reshape(-1, 1).float(), R[:, 256 + dir_w:256 + dir_w + time_w], 10, inc, rows_per_src=ns,
-                                     relu=True)
+                if not kept:                      # (kept: the forward wrote these columns)
+                    ops.train_encode(dirs[r0:r1], R[:, 256:256 + dir_w], 4, inc, rows_per_src=ns, relu=True)
+                    if use_time:
+                        ops.train_encode(times[r0:r1].reshape(-1, 1).float(), R[:, 256 + dir_w:256 + dir_w + time_w], 10, inc, rows_per_src=ns,
+                                         relu=True)
                 d_raw = torch.zeros(M, 4, dtype=torch.float32, device=dev)
                 if d_rgb is not None:
                     d_raw[:, :3] = d_rgb[r0:r1].reshape(M, 3)
@@ -193,9 +220,11 @@ class SpaceNetFunction(torch.autograd.Function):
                 dS = _buf(M, 1, dev)
                 dS[:, :1] = d_raw[:, 3:]
                 # every weight and bias gradient of the network: one launch + one reduction (stnerf_train_dw_batch)
-                _weight_gradients([(dys[i], xin[i], gW[i], gB[i]) for i in range(7)] +
-                                  [(dS[:, :1], acts[6], gW[7], gB[7]), (dys[7], R[:, :256 + dir_w + time_w], gW[8], gB[8]),
-                                   (d_raw[:, :3], acts[7], gW[9], gB[9])], acc)
+                batch = ([(dys[i], xin[i], gW[i], gB[i]) for i in range(7)] +
+                         [(dS[:, :1], acts[6], gW[7], gB[7]), (dys[7], R[:, :256 + dir_w + time_w], gW[8], gB[8]),
+                          (d_raw[:, :3], acts[7], gW[9], gB[9])])
+                assert len(batch) == len(gW) == len(gB)     # (gW / gB start as torch.empty: the first chunk must write every one whole)
+                _weight_gradients(batch, acc)
                 if d_pos is not None:
                     ops.train_encode_bwd(x, dpe[:, :pe], d_pos[r0 * ns:r1 * ns], 10, inc)
         for r0 in ([] if fused else range(0, n, rays_per_chunk)):
@@ -304,9 +333,10 @@ class MotionNetFunction(torch.autograd.Function):
         fused = FUSED_BACKWARD and module.pos_dim == 84
         kept = []
         with torch.no_grad():
-            if fused and 0 < rows * MOTION_ACT_FLOATS_PER_SAMPLE * 4 <= KEEP_BYTES:
+            if fused and _may_keep(rows * MOTION_ACT_FLOATS_PER_SAMPLE * 4):
                 # the forward itself keeps what the backward needs (3 KB per row): no recomputation
                 kept = _motion_buffers(rows, xt.device)
+                _account_kept(kept, rows * MOTION_ACT_FLOATS_PER_SAMPLE * 4)
                 flow = torch.empty(rows, 3, dtype=torch.float32, device=xt.device)
                 ops.train_motionnet_fwd(module._packed("fp32"), xt.detach().float().contiguous(), flow, kept[0], [b[:, :128] for b in kept[1:6]],
                                         kept[6], plain_time=not module.input_time)
@@ -356,8 +386,10 @@ class MotionNetFunction(torch.autograd.Function):
                 dys = [_buf(M, 128, dev)[:, :128] for _ in range(5)]
                 dE = _buf(M, 96, dev) if d_xt is not None else None
                 ops.train_motionnet_dx(wt, offsets, dO[:, :3], bufs[6], dys, dE)
-                _weight_gradients([(dys[0], E[:, :84], gW[0], gB[0])] + [(dys[j], A[j - 1], gW[j], gB[j]) for j in range(1, 5)] +
-                                  [(dO[:, :3], A[4], gW[5], gB[5])], r0 > 0)
+                batch = ([(dys[0], E[:, :84], gW[0], gB[0])] + [(dys[j], A[j - 1], gW[j], gB[j]) for j in range(1, 5)] +
+                         [(dO[:, :3], A[4], gW[5], gB[5])])
+                assert len(batch) == len(gW) == len(gB)     # (as above: the empty gradient buffers are written whole)
+                _weight_gradients(batch, r0 > 0)
                 if d_xt is not None:
                     # (the frame-id column gets no gradient: the lerp weights are data)
                     ops.train_encode_bwd(x, dE[:, :84], d_xt[r0:r1, :3], 10, inc)

@@ -584,9 +584,16 @@ def train_linear_dw(dy: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], acc
                                                hip.dptr(ws, torch.uint8, "workspace"), ws.numel(), hip.stream_ptr()), "stnerf_train_linear_dw")
 
 
+def free_workspaces() -> None:
+    """Drop the cached weight-gradient workspaces (tens of MB per (device, stream) that ran a backward); they are re-created on demand."""
+    _DW_WORKSPACE.clear()
+
+
 def _dw_workspace(need: int, device) -> Tensor:
     # one workspace per device and stream, grown on demand (a backward's calls run in order on one stream, so the partial tiles of
-    # one may overwrite the previous call's -- ADVICE r04)
+    # one may overwrite the previous call's -- ADVICE r04).  ASSUMES one host thread per stream: two threads that enqueue backwards on
+    # the SAME stream would share the partial tiles (ADVICE r05; the trainer is single-threaded, one process per GPU).  The cache only
+    # grows; free_workspaces() releases it.
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _DW_WORKSPACE.get(key)
     if ws is None or ws.numel() < need:

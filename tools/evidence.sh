@@ -1,14 +1,14 @@
 #!/bin/bash
 # The round's evidence pass on the GPU box (run through gpurun; ~20 GPU-minutes): everything profiles/<rnd>_*.md is built from,
 # measured on ONE build.  Usage: bash tools/evidence.sh [tag] [rnd] ; summaries land in gpurun_out/<tag>/summary/
-tag=${1:-r05}
+tag=${1:-r06}
 rnd=${2:-${tag:0:3}}
 out=gpurun_out/$tag
 mkdir -p $out
 export PYTHONDONTWRITEBYTECODE=1
 { echo "build: $(ls -la --time-style=full-iso st-nerf_amd/libstnerf_hip.so)"; echo "rev: $(cat .git_rev 2>/dev/null)"; rocm-smi --showproductname 2>/dev/null | grep -i "card series\|gfx" | head -3; } > $out/env.txt
 # ---- 1. parity suite + smoke
-timeout 1200 python -m pytest tests -q -m gpu > $out/pytest.log 2>&1; echo rc=$? >> $out/pytest.log
+timeout 1500 python -m pytest tests -q -m gpu > $out/pytest.log 2>&1; echo rc=$? >> $out/pytest.log
 timeout 200 python __graft_entry__.py smoke > $out/smoke.log 2>&1; echo rc=$? >> $out/smoke.log
 # ---- 2. the driver's command with the driver's step counts, socket power / shader clock sampled throughout (>= 60 s per
 #         arithmetic: 25 poses x ~3 s bf16x3, 25 x ~4.8 s f32); bf16x3 = the headline leg, fp32 = the co-equal second leg
@@ -53,6 +53,8 @@ for ctr in FETCH_SIZE WRITE_SIZE MfmaUtil; do
   ONLY_NETS=1 ONLY_FUSED=1 timeout 200 rocprofv3 --pmc $ctr -d $out/pmc_train/pmc_$ctr -o p -- python tools/bench_backward.py > /dev/null 2>&1
 done
 python tools/pmc_training.py $out/pmc_train > $out/pmc_training.md 2>&1
+# stnerf_train_dw_batch alone, on operands laid out as the autograd hands them over: timing, then HBM bytes / MfmaUtil per network
+bash tools/gpu_dw_prof.sh $tag/dw > $out/dw_prof.log 2>&1
 # one iteration of the reference trainer's inner loop: the bench scene at 4096 rays, the reference's own batch configuration, both against eager PyTorch-ROCm
 { timeout 300 python tools/bench_train_step.py --iters 12 --eager; timeout 300 python tools/bench_train_step.py --iters 12 --rays 2000 --workload taekwondo-1080p-90+30 --eager;
   timeout 300 python tools/bench_train_step.py --iters 8 --rays 16384; } 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|float(loss)" > $out/train_step.txt

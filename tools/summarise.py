@@ -299,6 +299,13 @@ if os.path.exists(db):
     trace_table(db, tk)
 else:
     tk.append("(missing)\n")
+for title, rel in (("HBM bytes / MfmaUtil per training kernel (separate `rocprofv3 --pmc` passes of the same command; `tools/pmc_training.py`)", "pmc_training.md"),
+                   ("`stnerf_train_dw_batch` alone (`tools/bench_dw.py`: operands laid out as `modeling/autograd.py` hands them over)", os.path.join("dw", "bench_dw.txt")),
+                   ("... its counters and kernel trace per network (`tools/gpu_dw_prof.sh`)", os.path.join("dw", "pmc.md")),
+                   ("one iteration of the reference trainer's inner loop (`tools/bench_train_step.py`)", "train_step.txt")):
+    q = os.path.join(src, rel)
+    if os.path.exists(q):
+        tk += ["## " + title + "\n", "```" if rel.endswith(".txt") else "", open(q).read().strip(), "```\n" if rel.endswith(".txt") else ""]
 open(os.path.join(dst, RND + "_training_kernels.md"), "w").write("\n".join(tk) + "\n")
 for f in ("hbm_copy.json",):
     p = os.path.join(src, f)
