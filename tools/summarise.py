@@ -293,12 +293,9 @@ open(os.path.join(dst, RND + "_share_emulation.md"), "w").write("\n".join(se) + 
 tk = ["# " + RND + ": the training kernels (csrc/train.hip, SURVEY 8(f)4) on the round's build\n", "## tools/bench_backward.py\n", "```"]
 p = os.path.join(src, "bench_backward.txt")
 tk += [l for l in (open(p).read().strip().splitlines() if os.path.exists(p) else ["(missing)"]) if "amdgpu.ids" not in l] + ["```\n"]
-db = os.path.join(src, "trace_backward", "p_results.db")
-tk.append("## rocprofv3 --kernel-trace --stats of the same command\n")
-if os.path.exists(db):
-    trace_table(db, tk)
-else:
-    tk.append("(missing)\n")
+tk.append("## rocprofv3 --kernel-trace --stats of `ONLY_NETS=1 ONLY_FUSED=1 python tools/bench_backward.py` (4 SpaceNet + 4 MotionNet iterations; `tools/trace_top.py`)\n")
+tt = os.path.join(src, "trace_backward_top.txt")
+tk += ["```", open(tt).read().strip() if os.path.exists(tt) else "(missing)", "```\n"]
 for title, rel in (("HBM bytes / MfmaUtil per training kernel (separate `rocprofv3 --pmc` passes of the same command; `tools/pmc_training.py`)", "pmc_training.md"),
                    ("`stnerf_train_dw_batch` alone (`tools/bench_dw.py`: operands laid out as `modeling/autograd.py` hands them over)", os.path.join("dw", "bench_dw.txt")),
                    ("... its counters and kernel trace per network (`tools/gpu_dw_prof.sh`)", os.path.join("dw", "pmc.md")),
