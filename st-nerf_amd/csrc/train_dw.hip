@@ -50,6 +50,7 @@ constexpr int DWW_MAX_PROBLEMS = 16, DWW_MAX_TILES = 64, DWW_MAX_GROUPS = 40;
 // bundles: four tiles that read the same rows get them through LDS (see dwb_run)
 constexpr int DWB_RING = 4;             // ring slots of one 16-sample block each: fetched three blocks (~10 us) ahead
 constexpr int DWB_MAX_PIECES = 3, DWB_MAX_BUNDLES = 12;
+constexpr int DWW_BX_COST = 7;          // a split-bf16 2 x 2 bundle's time per sample in sixteenths of the f32 bundle's (measured, see dww_plan)
 
 struct DwwProblem {
     const float* dy;
@@ -83,6 +84,7 @@ struct DwbBundle {
     DwbWave wave[4];
     uint16_t n_pieces, row_floats;
     uint32_t first_wg, slices, len;
+    uint32_t bx;                   // the 2 x 2 bundle in split-bf16 (dwb_run_bx)
 };
 struct DwwArgs {
     DwwProblem p[DWW_MAX_PROBLEMS];
@@ -379,6 +381,171 @@ __device__ __forceinline__ void dwb_run(const DwwArgs& a, const DwbBundle& bd, c
     dww_store<4, KB, BIAS>(acc, bsum, out, bias_out);
 }
 
+// ---- the 2 x 2 bundle in split-bf16 ("bf16x3", round 6): fp32-faithful products at the bf16 MFMA's rate -----------------------------
+// Both operands of dW = dY^T X are activations, so both are split on the fly: x = x0 + x1 + x2 (bf16 pieces, round-to-nearest of
+// the remainder: exact; csrc/mlp_bf16x3.hip's split8, 5.5 vector instructions per value) and a b ~ a0 b0 + a0 b1 + a1 b0 + a1 b1 +
+// a0 b2 + a2 b0 on v_mfma_f32_32x32x16_bf16 (bf16 products are exact in fp32; dropped terms <= 2^-24 |a b|), into ONE accumulator per
+// block -- a dW sums thousands of samples: the f32 kernel rounds its running sum as often.  The instruction's contraction index is
+// 16 SAMPLES: lane (h, c) supplies samples 8 h .. 8 h + 7, so a ring slot (16 samples) is exactly one K step, and the lane's raw
+// values are 8 ds_read_b128 per operand (row 8 h + s, columns 4 c .. 4 c + 3 = one value of each of the tile's four row / column blocks).
+// Registers: 256 accumulators (AGPRs); the B planes of this step and of the next (2 x 48), the A planes of two row blocks (2 x 12),
+// the raw values of one step of A and one of B (2 x 32).  A step = four phases, one per A row block r: 24 MFMAs (A_r x B_0..3, six
+// terms each) with, beside them, the split of A_(r+1) (of A_0 of the next step in phase 3) and of B_r of the NEXT step -- 88 vector
+// instructions per 24 MFMAs; the raw B values of the next step are read at the top of the step, the raw A values in phase 3.
+using bx8 = __attribute__((ext_vector_type(8))) __bf16;
+using bx2 = __attribute__((ext_vector_type(2))) __bf16;
+using bxu4 = __attribute__((ext_vector_type(4))) unsigned;
+struct BxPlanes { bx8 p[3]; };
+__device__ __forceinline__ unsigned bx_pk(float a, float b) {
+    dwb_f2 v = {a, b};
+    bx2 hh = __builtin_convertvector(v, bx2);              // v_cvt_pk_bf16_f32
+    return *reinterpret_cast<unsigned*>(&hh);
+}
+__device__ __forceinline__ void bx_split8(const float (&v)[8], BxPlanes& o) {
+    bxu4 w0, w1, w2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = v[2 * i], x1 = v[2 * i + 1];
+        const unsigned u = bx_pk(x0, x1);
+        const float r0 = x0 - __uint_as_float(u << 16), r1 = x1 - __uint_as_float(u & 0xffff0000u);
+        const unsigned m = bx_pk(r0, r1);
+        const float t0 = r0 - __uint_as_float(m << 16), t1 = r1 - __uint_as_float(m & 0xffff0000u);
+        w0[i] = u, w1[i] = m, w2[i] = bx_pk(t0, t1);
+    }
+    o.p[0] = *reinterpret_cast<bx8*>(&w0);
+    o.p[1] = *reinterpret_cast<bx8*>(&w1);
+    o.p[2] = *reinterpret_cast<bx8*>(&w2);
+}
+__device__ __forceinline__ void bx_product(const BxPlanes& a, const BxPlanes& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], b.p[0], c, 0, 0, 0);
+}
+// the lane's 8 raw float4s of one operand of one slot: row 8 h + s at `addr` + s * 1024 bytes
+__device__ __forceinline__ void bx_read8(dwb_f4 (&raw)[8], uint32_t addr) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) dwb_read4(raw[s], addr, s * 256 * 4);
+}
+__device__ __forceinline__ void bx_wait8(dwb_f4 (&raw)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]));
+}
+__device__ __forceinline__ void bx_split_block(const dwb_f4 (&raw)[8], int r, BxPlanes& o) {
+    float v[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) v[s] = raw[s][r];
+    bx_split8(v, o);
+}
+
+template <bool BIAS>
+__device__ __forceinline__ void dwb_run_bx(const DwwArgs& a, const DwbBundle& bd, const DwbWave& wv, int wave, int s0, int s1, float* lds,
+                                           float* __restrict__ out, float* __restrict__ bias_out) {
+    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    constexpr int RA = 256, RX = 256, XBASE = DWW_BLOCK * RA, SLOT = DWW_BLOCK * (RA + RX), IPB = 8;
+    // ---- the copy (as dwb_run<1, 64>): rows wave, wave + 4, .. of a block are this wave's, dy then x
+    __amdgpu_buffer_rsrc_t rs[2];
+    uint32_t voff[2], rowb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const DwbPiece& pc = bd.piece[q];
+        const DwwProblem& pr = a.p[pc.problem];
+        rs[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pc.is_x ? pr.x : pr.dy), 0, (int)(pc.is_x ? pr.x_bytes : pr.dy_bytes), 0x00020000);
+        rowb[q] = (pc.is_x ? pr.ldx : pr.lddy) * 4u;
+        voff[q] = (uint32_t)(pc.col0 + 4 * lane) * 4u;
+    }
+    auto issue_one = [&](int g, int idx) {
+        float* slot = lds + (g & (DWB_RING - 1)) * SLOT;
+        const int q = idx >> 2, r = wave + 4 * (idx & 3);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[q], (lds_ptr_t)(slot + q * XBASE + r * 256), 16, voff[q], (uint32_t)(s0 + g * DWW_BLOCK + r) * rowb[q], 0, 0);
+    };
+    const int nblk = (((s1 - s0 + DWW_BLOCK - 1) / DWW_BLOCK) + 1) & ~1;     // (pairs of steps; a bundle's range is a multiple of 32 samples,
+                                                                             // the last range's extra step reads rows beyond the matrix: zeros)
+#pragma unroll
+    for (int g = 0; g < DWB_RING - 1; ++g)
+#pragma unroll
+        for (int idx = 0; idx < IPB; ++idx) issue_one(g, idx);
+    f32x16 acc[4][4];
+    float bsum[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bsum[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+    const uint32_t a0 = lds0 + (uint32_t)(8 * h * RA + wv.a_off + 4 * c) * 4u, b0 = lds0 + (uint32_t)(XBASE + 8 * h * RX + wv.b_off + 4 * c) * 4u;
+    dwb_f4 rawA[8], rawB[8];
+    BxPlanes pa[2], pb[2][4];
+    auto bias_add = [&](int r) {
+        if (BIAS) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) bsum[r] += rawA[s][r];
+        }
+    };
+    DWW_VMCNT(2 * IPB);                           // block 0 has landed (this wave's rows; the barrier: everyone's)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bx_read8(rawA, a0);
+    bx_read8(rawB, b0);
+    bx_wait8(rawA);
+    bx_wait8(rawB);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bx_split_block(rawB, j, pb[0][j]);
+    bx_split_block(rawA, 0, pa[0]);
+    bias_add(0);
+    for (int g = 0; g < nblk; g += 2) {
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            const int cur = gg, nxt = gg ^ 1;
+            const uint32_t sn = (uint32_t)((g + gg + 1) & (DWB_RING - 1)) * (SLOT * 4u);
+            // block g + gg + 1 has landed everywhere, block g + gg - 1 is free: its slot takes block g + gg + 3
+            DWW_VMCNT(IPB);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            bx_read8(rawB, b0 + sn);              // the next step's raw B
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r == 3) bx_read8(rawA, a0 + sn);                     // the next step's raw A (this step's A_3 planes exist)
+                // 24 MFMAs: A_r x B_0..3 of this step
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bx_product(pa[r & 1], pb[cur][j], acc[r][j]);
+                if (r == 0) {
+#pragma unroll
+                    for (int idx = 0; idx < IPB; ++idx) issue_one(g + gg + DWB_RING - 1, idx);
+                }
+                // beside them: the planes of the next A row block, and of B_r of the next step
+                if (r < 3) {
+                    bx_split_block(rawA, r + 1, pa[(r + 1) & 1]);
+                    bias_add(r + 1);
+                    if (r == 0) bx_wait8(rawB);
+                    bx_split_block(rawB, r, pb[nxt][r]);
+                } else {
+                    bx_split_block(rawB, 3, pb[nxt][3]);
+                    bx_wait8(rawA);
+                    bx_split_block(rawA, 0, pa[0]);
+                    bias_add(0);
+                }
+#pragma unroll
+                for (int k = 0; k < 24; ++k) {                           // one MFMA, then four of the ~90 vector instructions
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (BIAS) {                                   // (the read-ahead's A_0 of the step behind the last was added: take it back)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bsum[0] -= rawA[s][0];
+    }
+    DWW_VMCNT(0);                                 // nothing may land in LDS after the wave has gone
+    dww_store<4, 4, BIAS>(acc, bsum, out, bias_out);
+}
+
 __global__ __launch_bounds__(256, 1) void train_dw_wave_kernel(DwwArgs a) {
     // (the wave index through readfirstlane: everything derived from it -- tile, descriptors, sample range -- is wave-uniform and
     // stays in scalar registers; as a function of threadIdx the compiler wraps every buffer load in a waterfall loop)
@@ -394,7 +561,10 @@ __global__ __launch_bounds__(256, 1) void train_dw_wave_kernel(DwwArgs a) {
         const DwwTile& tl = a.tile[wv.tile];      // (a wave without a tile points at the bundle's first one and stores nothing)
         float* out = a.workspace + 4ull * tl.partial_off + (size_t)slice * 128 * (32 * tl.kb);
         float* bias_out = tl.bias ? a.workspace + 4ull * tl.bias_off + (size_t)slice * 2 * 128 : nullptr;
-        if (bd.n_pieces == 2) {                   // dy[:, 256], x[:, 256]: the 2 x 2 tiles of a 256 x 256 block
+        if (bd.n_pieces == 2 && bd.bx) {          // ... in split-bf16
+            if (tl.bias) dwb_run_bx<true>(a, bd, wv, wave, s0, s1, dw_lds, out, bias_out);
+            else dwb_run_bx<false>(a, bd, wv, wave, s0, s1, dw_lds, out, bias_out);
+        } else if (bd.n_pieces == 2) {            // dy[:, 256], x[:, 256]: the 2 x 2 tiles of a 256 x 256 block
             if (tl.bias) dwb_run<1, 64, 4, true>(a, bd, wv, wave, s0, s1, dw_lds, out, bias_out);
             else dwb_run<1, 64, 4, false>(a, bd, wv, wave, s0, s1, dw_lds, out, bias_out);
         } else {                                  // dy_a[:, 256], dy_b[:, 256], x[:, 64]: two 256-output layers on the same narrow input
@@ -530,7 +700,7 @@ static void dww_plan(const stnerf_dw_problem* pr, int32_t count, int64_t m, DwwP
                     t.rows_valid = (uint8_t)(nb == 1 ? q.n : 0);
                 }
             if (nt == first) continue;
-            groups[ng++] = G{first, nt - first, nb * kb, -1};
+            groups[ng++] = G{first, nt - first, nb * kb * 16, -1};      // (cost in sixteenths of a 32 x 32 block pair per two samples)
 
         }
     }
@@ -554,6 +724,12 @@ static void dww_plan(const stnerf_dw_problem* pr, int32_t count, int64_t m, DwwP
             B.piece[0] = DwbPiece{t0.problem, 0, 0, 64, 0};                 // dy[:, 0:256]  -> slot row floats 0 .. 255
             B.piece[1] = DwbPiece{t0.problem, 1, 0, 64, 256};               // x[:, 0:256]   -> 256 .. 511
             for (int w = 0; w < 4; ++w) B.wave[w] = DwbWave{tile_of(g, w).n0, tile_of(g, w).k0, (uint8_t)(gr.first + w), 4, 1, 0};
+            static const bool no_bx = getenv("STNERF_DEV_DW_BX") && getenv("STNERF_DEV_DW_BX")[0] == '0';   // (development: the f32 bundle)
+            B.bx = no_bx ? 0u : 1u;
+            // a split-bf16 wave gets through its samples faster than an f32 one: its ranges are sized by its measured cost
+            // (DWW_BX_COST sixteenths of the f32 tile's time per sample), so that both kinds of wave finish together
+            static const int bx_cost = getenv("STNERF_DEV_DW_BX_COST") ? atoi(getenv("STNERF_DEV_DW_BX_COST")) : DWW_BX_COST;
+            if (B.bx) groups[g].cost = groups[g].cost * bx_cost / 16;
             groups[g].bundle = nbundles;
         } else if (gr.count == 2 && t0.kb == 2 && q.n == 256) {
             // (b) two layers of 256 outputs whose 64-column tiles read the SAME columns of the same matrix (stage1.0 on PE(pos) and the
@@ -572,7 +748,7 @@ static void dww_plan(const stnerf_dw_problem* pr, int32_t count, int64_t m, DwwP
                     B.wave[2 + w] = DwbWave{(uint16_t)(256 + tile_of(g2, w).n0), 0, (uint8_t)(o.first + w), 2, 1, 0};
                 }
                 groups[g].bundle = groups[g2].bundle = nbundles;
-                groups[g].cost = 8, groups[g2].cost = 0;
+                groups[g].cost = 8 * 16, groups[g2].cost = 0;
                 break;
             }
         }
@@ -593,7 +769,9 @@ static void dww_plan(const stnerf_dw_problem* pr, int32_t count, int64_t m, DwwP
             if (groups[g].bundle >= 0 && groups[g].cost == 0) continue;      // (rides along: below)
             int64_t s = ((int64_t)target * groups[g].cost + total_cost / 2) / total_cost;
             s = s < 1 ? 1 : s > most ? most : s;
-            int64_t len = m <= 0 ? DWW_BLOCK : ((m + s - 1) / s + DWW_BLOCK - 1) / DWW_BLOCK * DWW_BLOCK;
+            // (a split-bf16 bundle works in pairs of 16-sample steps: ranges of a multiple of 32 samples)
+            const int64_t unit = groups[g].bundle >= 0 && K.bundle[groups[g].bundle].bx ? 2 * DWW_BLOCK : DWW_BLOCK;
+            int64_t len = m <= 0 ? unit : ((m + s - 1) / s + unit - 1) / unit * unit;
             s = m <= 0 ? 1 : (m + len - 1) / len;
             slices_of[g] = (uint16_t)s;
             if (groups[g].bundle >= 0) {
