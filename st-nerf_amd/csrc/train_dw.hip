@@ -23,8 +23,12 @@
 //     L1 nor the L2 merges a miss into one in flight: 7.5 GB per SpaceNet call on the counters against 4.15 GB of unique
 //     operands.  A bundle's rows are copied global -> LDS once per workgroup by DMA (buffer_load_dwordx4 ... lds, a ring of four
 //     16-sample slots, three blocks ahead) and read from there: 5.1 GB (1.22 x: what is left are the narrow tiles that re-read a
-//     dy, and the density head's second pass over g3).  Time is the same either way (1.94 ms sustained, 0.80 of the f32 MFMA
-//     peak at 2.2 - 2.3 GHz): the launch is bound by its MFMAs, not by HBM.
+//     dy, and the density head's second pass over g3).  In f32 the time is the same either way (1.94 ms sustained, 0.80 of the f32
+//     MFMA peak at 2.2 - 2.3 GHz): that launch is bound by its MFMAs, not by HBM.
+//   * The 2 x 2 bundles -- 85 % of a SpaceNet's weight-gradient work -- run in SPLIT-BF16 (dwb_run_bx below): both operands split into
+//     three bf16 pieces on the fly, six v_mfma_f32_32x32x16_bf16 per product: fp32-faithful products at 2.3 x the f32 tile's rate per
+//     sample; ranges are sized by that measured cost so that f32 and bf16x3 waves finish together.  SpaceNet's ten dW + db:
+//     1.96 -> 1.43 ms per 262,144 rows = 171 TF/s of fp32-faithful products (1.09 x the f32 MFMA peak).
 //   * Narrow remainders are narrow tiles, not padded ones: 64 columns (stage1.0's 63, the skip connection's 63, rgb_net.1's
 //     48) = 8-byte loads, two column blocks; 96 (MotionNet's 84) = 12-byte loads; a layer of <= 4 outputs (the density and
 //     colour heads, the flow head) one 32-row block whose lanes c >= n read nothing.  Sample ranges are sized by a tile's

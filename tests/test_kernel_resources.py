@@ -211,3 +211,38 @@ def test_fused_backward_kernel_resources(tmp_path):
         assert body.count("v_mfma_f32_32x32x2_f32") == want, (k, body.count("v_mfma_f32_32x32x2_f32"), want)
         assert body.count("global_load_dwordx4") <= 16 and body.count("global_store_dwordx4") >= 7 * 32 + 16
         assert body.count("v_bfe_i32") == (4 + 7 * 8) * 16 and body.count("v_cmp_") < 16
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="no hipcc")
+def test_weight_gradient_kernel_loops_are_what_the_design_says(tmp_path):
+    """csrc/train_dw.hip (round 6): one wave per SIMD, no scratch, and the three inner loops as DESIGN 4.4 describes them --
+    the direct f32 tile: 128 MFMAs + 16 buffer loads per 16 samples and NO vector instruction besides (on gfx950 every VALU instruction
+    takes its cycles out of the f32 MFMA stream); the f32 bundle: 128 MFMAs, 16 LDS reads, 8 LDS-DMA instructions, one barrier per block;
+    the split-bf16 bundle: 192 bf16 MFMAs per two 16-sample steps beside <= 5 vector instructions per MFMA (the two operands' splits),
+    32 LDS reads, 16 LDS-DMA instructions, two barriers."""
+    from collections import Counter
+    text = open(_compile("train_dw.hip", tmp_path)).read()
+    assert [int(v) for v in re.findall(r"; ScratchSize: (\d+)", text)] == [0, 0]          # the tile kernel and the reduction
+    assert "scratch_" not in text
+    assert max(int(v) for v in re.findall(r"; TotalNumVgprs: (\d+)", text)) <= 512
+    assert int(re.findall(r"; Occupancy: (\d+)", text)[0]) == 1
+    lines = text.split("\n")
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    loops = []
+    for i, l in enumerate(lines):
+        m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            body = [x.split()[0] for x in lines[labels[m.group(1)]:i + 1] if x.startswith("\t") and not x.strip().startswith((".", ";"))]
+            loops.append(Counter(body))
+    valu = lambda c: sum(v for k, v in c.items() if k.startswith("v_") and "mfma" not in k)
+    # innermost loops only (a loop that contains another shows up with its sum: take the smallest body per signature)
+    direct = [c for c in loops if c.get("v_mfma_f32_32x32x2_f32") == 128 and c.get("buffer_load_dwordx4") == 16 and not c.get("ds_read_b128")]
+    assert direct and any(valu(c) == 0 for c in direct), [dict(c) for c in direct]          # (the tile without bias sums)
+    assert all(valu(c) in (0, 32) and c.get("s_waitcnt") == 8 for c in direct), [dict(c) for c in direct]   # 8 waits of vmcnt(14): loads stay 8 steps ahead
+    bundle = [c for c in loops if c.get("v_mfma_f32_32x32x2_f32") == 128 and c.get("ds_read_b128") == 16]
+    assert bundle and all(c.get("buffer_load_dwordx4") == 8 and c.get("s_barrier") == 1 and valu(c) <= 40 for c in bundle), [dict(c) for c in bundle]
+    bx = [c for c in loops if c.get("v_mfma_f32_32x32x16_bf16") == 192 and c.get("ds_read_b128") == 32]   # (innermost: an enclosing loop has more)
+    assert len(bx) == 2, [dict(c) for c in bx]                                              # with and without bias sums
+    for c in bx:
+        assert c.get("ds_read_b128") == 32 and c.get("buffer_load_dwordx4") == 16 and c.get("s_barrier") == 2, dict(c)
+        assert c.get("v_cvt_pk_bf16_f32") == 192 and valu(c) <= 5 * 192, (valu(c), dict(c))
