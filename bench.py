@@ -52,6 +52,16 @@ def _latest_profile(suffix):
     return found[-1] if found else os.path.join(REPO, "profiles", "r00_" + suffix)
 
 
+def _load_profile(path):
+    """A committed profile file, or {} when it is missing or unreadable: side information never costs the run its record."""
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d if isinstance(d, dict) else {}
+    except (OSError, ValueError):
+        return {}
+
+
 MEASURED_HBM_JSON = _latest_profile("hbm_copy_microbench.json")   # tools/micro/hbm_copy on the GPU box
 PMC_TRAFFIC_JSON = _latest_profile("pmc_hbm_traffic.json")         # tools/summarise.py (pose 0 of the sweep; carries the build it ran on)
 
@@ -789,8 +799,7 @@ def main():
         ctx = dict(workload=args.workload, precision=args.precision, steps=args.steps, warmup=args.warmup, world=world,
                    partition=partition, stripe_rows=args.stripe_rows, rays_per_launch=args.rays_per_launch, dims=dims,
                    device=info, psnr=psnr_check,
-                   pmc=json.load(open(PMC_TRAFFIC_JSON)) if os.path.exists(PMC_TRAFFIC_JSON) else {},
-                   hbm_microbench=json.load(open(MEASURED_HBM_JSON)) if os.path.exists(MEASURED_HBM_JSON) else {},
+                   pmc=_load_profile(PMC_TRAFFIC_JSON), hbm_microbench=_load_profile(MEASURED_HBM_JSON),
                    eager=(eager_gpu_baseline(args.workload, args.eager_gpu_baseline_rays, device)
                           if world == 1 and args.eager_gpu_baseline_rays > 0 else None),
                    cpu=(cpu_baseline(args.workload, args.cpu_baseline_rays, args.cpu_threads)

@@ -15,6 +15,17 @@ fixtures.  ``tests/test_oracle_golden.py`` replays those fixtures through this f
 All arithmetic is the reference's: ATen ops in the dtype of the inputs (fp32 in production;
 pass float64 tensors to get an fp64 evaluation of the same formulas for error analysis).
 Every function cites the reference file:line it follows (paths relative to /root/reference).
+
+One thing is NOT pinned because the reference does not define it: the order of two samples of DIFFERENT layers
+at exactly the same depth in the merged lists (modeling/layered_rfrender.py:425,587 call torch.sort with its
+default stable=False, and ATen's CPU sort is not stable -- a probe kept the lower layer first on 1162 of 2000
+rows; CUDA's radix sort is).  It happens on about 1 ray in 1000 at 3 x 90 samples and moves that ray's merged
+colour by up to 1e-3.  This file calls torch.sort as the reference does (so on such a ray it follows ATen's CPU
+algorithm); the HIP compositor merges in the order of a stable sort; make_golden.py keeps such rays out of the
+one fixture large enough to contain them (rays_with_depth_ties).
+
+Teacher forcing (``render_chunk(forced=...)``, round 6): the fine depths and deformed points of a recorded
+reference run replace the oracle's own, so that an fp64 evaluation sits on the reference's positions.
 """
 from __future__ import annotations
 
