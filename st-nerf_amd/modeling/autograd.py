@@ -59,6 +59,16 @@ CHUNK_SAMPLES = min(max(int(os.environ.get("STNERF_TRAIN_CHUNK_SAMPLES", 1 << 18
 DW_BATCH = os.environ.get("STNERF_TRAIN_DW_BATCH", "1") != "0"
 
 
+def _dw(dy, x, dw, db, accumulate: bool) -> None:
+    """One layer's dW / db on the per-layer path (deep_rgb, no-raw-input and no-direction networks): through the batch kernel of
+    csrc/train_dw.hip as a batch of one (output-stationary wave tiles; 2 - 3 x the round-4 GEMM's rate), or -- STNERF_TRAIN_DW_BATCH=0 --
+    the round-4 split-K GEMM (stnerf_train_linear_dw)."""
+    if DW_BATCH:
+        ops.train_dw_batch([(dy, x, dw, db)], accumulate)
+    else:
+        ops.train_linear_dw(dy, x, dw, db, accumulate)
+
+
 def _weight_gradients(layers, accumulate: bool) -> None:
     if DW_BATCH:
         ops.train_dw_batch(layers, accumulate)
@@ -267,7 +277,7 @@ class SpaceNetFunction(torch.autograd.Function):
                 dy = dO[:, :3]
                 for j in range(n_tail - 1, -1, -1):            # rgb_net's linear layers, last first
                     xin = T[j - 1][:, :128] if j > 0 else R[:, :256 + dir_w + time_w]
-                    ops.train_linear_dw(dy, xin, gW[8 + j], gB[8 + j], acc)
+                    _dw(dy, xin, gW[8 + j], gB[8 + j], acc)
                     if j > 0:
                         dT = _buf(M, 128, dev)
                         ops.train_linear_dx(dy, W[8 + j], dT[:, :128], mask=T[j - 1][:, :128])
@@ -278,28 +288,28 @@ class SpaceNetFunction(torch.autograd.Function):
             if d_sigma is not None:
                 dS = _buf(M, 1, dev)
                 dS[:, :1] = d_sigma[r0:r1].reshape(M, 1)
-                ops.train_linear_dw(dS[:, :1], g3, gW[7], gB[7], acc)
+                _dw(dS[:, :1], g3, gW[7], gB[7], acc)
                 ops.train_linear_dx(dS[:, :1], W[7], dA[:, :256], mask=g3, accumulate=have)
                 have = True
             if not have:
                 continue
             # stage2 (dA = d pre-activation of stage2.4)
-            ops.train_linear_dw(dA[:, :256], G[1][:, :256], gW[6], gB[6], acc)
+            _dw(dA[:, :256], G[1][:, :256], gW[6], gB[6], acc)
             ops.train_linear_dx(dA[:, :256], W[6], dB_[:, :256], mask=G[1][:, :256])
-            ops.train_linear_dw(dB_[:, :256], G[0][:, :256], gW[5], gB[5], acc)
+            _dw(dB_[:, :256], G[0][:, :256], gW[5], gB[5], acc)
             ops.train_linear_dx(dB_[:, :256], W[5], dA[:, :256], mask=G[0][:, :256])
-            ops.train_linear_dw(dA[:, :256], Cc[:, :256 + pe], gW[4], gB[4], acc)
+            _dw(dA[:, :256], Cc[:, :256 + pe], gW[4], gB[4], acc)
             dP = _buf(M, pe, dev)
             ops.train_linear_dx(dA[:, :256], W[4][:, :256], dB_[:, :256], mask=Cc[:, :256])       # -> h4 (ReLU of stage1.6)
             ops.train_linear_dx(dA[:, :256], W[4][:, 256:256 + pe], dP[:, :pe])                   # -> PE(pos), the skip connection
             # stage1
-            ops.train_linear_dw(dB_[:, :256], H[2][:, :256], gW[3], gB[3], acc)
+            _dw(dB_[:, :256], H[2][:, :256], gW[3], gB[3], acc)
             ops.train_linear_dx(dB_[:, :256], W[3], dA[:, :256], mask=H[2][:, :256])
-            ops.train_linear_dw(dA[:, :256], H[1][:, :256], gW[2], gB[2], acc)
+            _dw(dA[:, :256], H[1][:, :256], gW[2], gB[2], acc)
             ops.train_linear_dx(dA[:, :256], W[2], dB_[:, :256], mask=H[1][:, :256])
-            ops.train_linear_dw(dB_[:, :256], H[0][:, :256], gW[1], gB[1], acc)
+            _dw(dB_[:, :256], H[0][:, :256], gW[1], gB[1], acc)
             ops.train_linear_dx(dB_[:, :256], W[1], dA[:, :256], mask=H[0][:, :256])
-            ops.train_linear_dw(dA[:, :256], P, gW[0], gB[0], acc)
+            _dw(dA[:, :256], P, gW[0], gB[0], acc)
             if d_pos is not None:
                 ops.train_linear_dx(dA[:, :256], W[0], dP[:, :pe], accumulate=True)
                 ops.train_encode_bwd(x, dP[:, :pe], d_pos[r0 * ns:r1 * ns], 10, inc)
