@@ -217,6 +217,12 @@ int stnerf_motionnet_fwd(const void* packed, int64_t n_rays, int ns, const int32
 int64_t stnerf_packed_bytes_bf16x3(int kind);
 int stnerf_pack_net_bf16x3(int kind, const float* const* weights_host, const float* const* biases_host,
                            int n_tensors, void* dst_host, int64_t dst_bytes);
+/* The same blob, bit for bit, from tensors IN DEVICE MEMORY into a 1 KB-aligned device destination (host arrays of device pointers;
+ * one memset + two kernels on `stream`): what a training loop calls after every optimizer.step() when its forward runs in split
+ * bf16 (stnerf_train_spacenet_fwd_bf16x3; round 6).  No finiteness check (no host round trip): a weight stnerf_pack_net_bf16x3 would
+ * refuse gives NaN pieces and NaN outputs. */
+int stnerf_pack_net_bf16x3_device(int kind, const float* const* weights_dev, const float* const* biases_dev, int n_tensors,
+                                  void* dst_dev, int64_t dst_bytes, stnerf_stream_t stream);
 
 /* a8 + a9 for a whole network stage of the pipeline (coarse or fine, modeling/layered_rfrender.py:340-418 / :495-576):
  * ONE persistent launch evaluates every listed layer -- one workgroup per CU pops work items (128 rows of a layer; the
@@ -419,6 +425,15 @@ int stnerf_train_spacenet_fwd(int kind, const void* packed, int64_t n_rays, int 
                               const float* dirs, int64_t dirs_ray_stride, const float* times, int64_t times_ray_stride, float* raw,
                               int64_t raw_ray_stride, float* const* act_host, const int32_t* ld_act_host, float* pe, int32_t ld_pe,
                               uint32_t* relu_bits, int64_t relu_bits_stride, uint32_t* queue, float* ray_bias, stnerf_stream_t stream);
+/* The same launch in split bf16 (round 6): stnerf_mlp_stage's STNERF_STAGE_BF16X3 kernel (csrc/mlp_bf16x3.hip) with the same tap --
+ * raw is bit-identical to what stnerf_mlp_stage / the render pipeline give for these samples in that arithmetic, the stored
+ * activations are that kernel's fp32 layer outputs (fp32-faithful: within a few ulp of the exact-f32 launch's), the masks are
+ * theirs.  `packed`: a blob of stnerf_pack_net_bf16x3[_device], 1 KB aligned.  Everything else as above. */
+int stnerf_train_spacenet_fwd_bf16x3(int kind, const void* packed, int64_t n_rays, int ns, const float* xyz, int64_t xyz_ray_stride,
+                                     const float* dirs, int64_t dirs_ray_stride, const float* times, int64_t times_ray_stride, float* raw,
+                                     int64_t raw_ray_stride, float* const* act_host, const int32_t* ld_act_host, float* pe, int32_t ld_pe,
+                                     uint32_t* relu_bits, int64_t relu_bits_stride, uint32_t* queue, float* ray_bias,
+                                     stnerf_stream_t stream);
 int stnerf_train_spacenet_dx(const float* wt, const uint32_t* offsets_host, const float* d_raw, int64_t rows, const uint32_t* relu_bits,
                              int64_t relu_bits_stride, float* const* dy_host, const int32_t* ld_dy_host, float* dpe, int32_t ld_dpe,
                              stnerf_stream_t stream);

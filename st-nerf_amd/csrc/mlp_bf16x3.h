@@ -54,6 +54,8 @@ __host__ __device__ inline int bx_kmap_enc(int t, int h, int j) { return 16 * t 
 
 // mlp_bf16x3.hip
 struct StageArgs;
+struct StoreTapArgs;
 int launch_bf16x3_stage(const StageArgs& a, bool deep_rgb, int cus, hipStream_t stream);
+int launch_bf16x3_stage_store(const StageArgs& a, const StoreTapArgs& t, int cus, hipStream_t stream);
 
 }  // namespace stnerf

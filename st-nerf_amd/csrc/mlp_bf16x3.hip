@@ -100,6 +100,53 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& p0, bf16x8& 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Training tap (the split-bf16 twin of mlp_wave.hip's StoreTap): every layer's post-ReLU output goes to the row-major
+// matrices of StoreTapArgs on its way into the park, the ReLU masks as bit planes beside them.  Plain global stores from a
+// per-lane pointer (two registers, built where they are used): with BUFFER stores -- descriptor on the scalar ALU, rows past the
+// end of the launch dropped by the range check, one offset register -- the four aligned scalar registers of a descriptor do not
+// exist at a boundary of this kernel, and the allocator answers with ~170 spilled vector registers (round 6; a global store with
+// the same data: none).  Stores count in vmcnt like the weight ring's LDS-DMA: the slot turns behind a boundary that stored wait
+// for `6 + stores` (slot_turn<ST>), or they would wait for the stores too.
+// ---------------------------------------------------------------------------------------------
+struct BxNoTap {
+    static constexpr bool on = false;
+};
+struct BxStoreTap {
+    static constexpr bool on = true;
+    const StoreTapArgs* a;   // the kernel's argument block (scalar loads)
+    uint32_t row0;           // first row of the work item
+    uint32_t nrows;          // rows of the launch in this item (1 .. WV_ITEM)
+    int wave;
+};
+constexpr int BX_TAP_PARK = 18;   // VMEM stores of one park: 16 x 16 B of activations + two mask words
+constexpr int BX_TAP_PE = 8;
+__device__ __forceinline__ uint32_t tap_row_in_item(const BxStoreTap& tap, int lane) { return (uint32_t)(tap.wave * WV_ROWS + (lane & 31)); }
+__device__ __forceinline__ bool tap_valid(const BxStoreTap& tap, int lane) { return tap_row_in_item(tap, lane) < tap.nrows; }
+// this lane's 16 bytes of (stage, column col0) of its row; stage: 0 .. 7 or TAP_PE
+__device__ __forceinline__ float* tap_row(const BxStoreTap& tap, int stage, int col0, int lane) {
+    // (opaque here: the per-lane addresses of all fifteen boundaries are loop invariants of the item loop -- hoisted, they are live
+    // through every K loop of a kernel that has no register to spare)
+    asm volatile("" : "+v"(lane));
+    const bool is_pe = stage == TAP_PE;
+    float* base = is_pe ? tap.a->pe : tap.a->buf[is_pe ? 0 : stage];
+    const uint32_t ld = (uint32_t)(is_pe ? tap.a->ld_pe : tap.a->ld[is_pe ? 0 : stage]);
+    return base + (size_t)(tap.row0 + tap_row_in_item(tap, lane)) * ld + (uint32_t)(col0 + 4 * (lane >> 5));
+}
+// word (col0 / 128) * 2 of this lane's four mask words of its row (null: the caller wants no masks)
+__device__ __forceinline__ uint32_t* tap_bits_row(const BxStoreTap& tap, int stage, int col0, int lane) {
+    asm volatile("" : "+v"(lane));
+    uint32_t* bw = tap.a->bits;
+    if (!bw) return nullptr;
+    return bw + (size_t)stage * (size_t)tap.a->bits_stride + (size_t)(tap.row0 + tap_row_in_item(tap, lane)) * 8u +
+           (uint32_t)(4 * (lane >> 5) + (col0 ? 2 : 0));
+}
+// value i of block fb <-> bit (16 fb + i) & 31 of word fb >> 1 (mlp_wave.hip: StoreTap); a post-ReLU value is +0 or positive
+__device__ __forceinline__ void tap_bit(uint32_t& w, float v, int pos /* a constant once the loops are unrolled */) {
+    uint32_t t;
+    asm volatile("v_min_u32 %1, 1, %2\n\tv_lshl_or_b32 %0, %1, %3, %0" : "+v"(w), "=&v"(t) : "v"(v), "i"(pos));
+}
+
+// ---------------------------------------------------------------------------------------------
 // The weight stream: which global slot the workgroup fetches next (wave-uniform), the ring, the A-operand buffers.
 // ---------------------------------------------------------------------------------------------
 struct Seg {
@@ -256,8 +303,9 @@ __device__ __forceinline__ void unit(Ctx& cx, f32x16& big, f32x16& small, const 
 
 // Between units 5 and 6 of a slot: the next slot has landed everywhere and the previous one is free everywhere (every wave
 // has issued -- and, to get here, completed -- its reads of it); the fetch three slots ahead goes into its place.
+template <int ST = 0>   // ST: VMEM stores this wave issued behind the DMA of the slot it is waiting for (the training tap)
 __device__ __forceinline__ void slot_turn(Ctx& cx, Dma& d) {
-    BX_VMCNT(6);
+    BX_VMCNT(6 + ST);
     __builtin_amdgcn_s_barrier();
     dma_begin(cx, d);
     BX_SB();
@@ -271,7 +319,7 @@ __device__ __forceinline__ void slot_done(Ctx& cx) {
 }
 
 // one ring slot: K steps k0, k1 (their B operands: the three planes of the input) for the pass's four blocks
-template <bool FIRST, bool BIG0 = false, class Hook = NoHook>
+template <bool FIRST, bool BIG0 = false, class Hook = NoHook, int ST = 0>
 __device__ __forceinline__ void slot(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], const bf16x8& k0p0, const bf16x8& k0p1,
                                      const bf16x8& k0p2, const bf16x8& k1p0, const bf16x8& k1p1, const bf16x8& k1p2, Hook* hook = nullptr) {
     unit<0, FIRST, BIG0, -1, Hook>(cx, big[0], small[0], k0p0, k0p1, k0p2, nullptr, hook);
@@ -281,20 +329,23 @@ __device__ __forceinline__ void slot(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[
     unit<4, false, false, -1, Hook>(cx, big[0], small[0], k1p0, k1p1, k1p2, nullptr, hook);
     unit<5, false, false, -1, Hook>(cx, big[1], small[1], k1p0, k1p1, k1p2, nullptr, hook);
     Dma d;
-    slot_turn(cx, d);
+    slot_turn<ST>(cx, d);
     unit<6, false, false, 0, Hook>(cx, big[2], small[2], k1p0, k1p1, k1p2, &d, hook);
     unit<7, false, false, 3, Hook>(cx, big[3], small[3], k1p0, k1p1, k1p2, &d, hook);
     slot_done(cx);
 }
 
 // K steps KS0 .. KS0 + 2 NSLOT - 1 of the activation planes
-template <int KS0, int NSLOT, bool FIRST, bool BIG0 = false>
+// (ST: stores issued in the boundary in front of the pass -- they are younger than the DMA its first TWO slot turns wait for)
+template <int KS0, int NSLOT, bool FIRST, bool BIG0 = false, int ST = 0>
 __device__ __forceinline__ void pass_act(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], const bf16x8 (&act)[3][16]) {
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl) {
         const int k = KS0 + 2 * sl;
         if (sl == 0)
-            slot<FIRST, BIG0>(cx, big, small, act[0][k], act[1][k], act[2][k], act[0][k + 1], act[1][k + 1], act[2][k + 1]);
+            slot<FIRST, BIG0, NoHook, ST>(cx, big, small, act[0][k], act[1][k], act[2][k], act[0][k + 1], act[1][k + 1], act[2][k + 1]);
+        else if (sl == 1)
+            slot<false, false, NoHook, ST>(cx, big, small, act[0][k], act[1][k], act[2][k], act[0][k + 1], act[1][k + 1], act[2][k + 1]);
         else
             slot<false>(cx, big, small, act[0][k], act[1][k], act[2][k], act[0][k + 1], act[1][k + 1], act[2][k + 1]);
     }
@@ -379,6 +430,52 @@ __device__ __forceinline__ void finish_park(f32x16 (&big)[4], const f32x16 (&sma
             BX_SB();  // (group by group: keeps the live values of this straight-line code bounded)
         }
         if (next_c) {  // (uniform; nullptr where the next pass starts from 0: rgb_net.1)
+            load_c_block(big[fb], next_c, fb, lane);
+            BX_SB();
+        }
+    }
+}
+// the same with the training tap: the pass's 128 outputs = columns col0 .. col0 + 127 of stage `stage`'s matrix
+__device__ __forceinline__ void finish_park(f32x16 (&big)[4], const f32x16 (&small)[4], Park& pk, const float* next_c, int lane, const BxNoTap&,
+                                            int, int) {
+    finish_park(big, small, pk, next_c, lane);
+}
+// (Register budget: the kernel's 256 arch registers are full -- 192 of activation planes -- and the park itself runs on two
+// temporaries.  Here: four values at a time (the data of one 16-byte store), one mask word, the row pointer; the kernel's tap
+// variant makes room for them by recomputing per-row values it would otherwise carry through the item, see
+// mlp_bf16x3_stage_kernel.)
+template <bool PARK = true>
+__device__ __forceinline__ void finish_park(f32x16 (&big)[4], const f32x16 (&small)[4], Park& pk, const float* next_c, int lane,
+                                            const BxStoreTap& tap, int stage, int col0) {
+    const bool valid = tap_valid(tap, lane);
+    float4* dst = reinterpret_cast<float4*>(tap_row(tap, stage, col0, lane));
+    uint32_t w = 0u;
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = out_relu(big[fb], small[fb], 4 * q + r);
+                if (PARK) park_put(pk.v[16 * fb + 4 * q + r], v[r]);
+                tap_bit(w, v[r], (16 * fb + 4 * q + r) & 31);
+            }
+            // register 4 q + r of block fb <-> feature 32 fb + 8 q + 4 h + r: 16 bytes per (fb, q), the two lanes of a sample side by side
+            if (valid) dst[fb * 8 + 2 * q] = make_float4(v[0], v[1], v[2], v[3]);
+            if (q & 1) BX_SB();
+        }
+        if (fb & 1) {
+            uint32_t* bw = tap_bits_row(tap, stage, col0, lane);
+            if (valid && bw) bw[fb >> 1] = w;
+            if (stage == 7 && fb == 3 && valid && bw) {   // a 128-wide stage (rgb_net.1's output) owns all four words of the lane
+                bw[2] = 0u;
+                bw[3] = 0u;
+            }
+            w = 0u;
+            BX_SB();
+        }
+        if (next_c) {
             load_c_block(big[fb], next_c, fb, lane);
             BX_SB();
         }
@@ -475,15 +572,16 @@ struct UnparkHook {
 };
 // one slot of a pass (K steps 2 FB, 2 FB + 1 of the half the pass is reading: the upper one for KS_OUT = 0, the lower one for
 // KS_OUT = 8) with block FB of the park converted into the OTHER half of the planes on the way
-template <int FB, int KS_OUT, bool FIRST = false, bool BIG0 = false>
+template <int FB, int KS_OUT, bool FIRST = false, bool BIG0 = false, int ST = 0>
 __device__ __forceinline__ void slot_unpark(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], bf16x8 (&act)[3][16], const Park& pk) {
     constexpr int k = (8 - KS_OUT) + 2 * FB;
     UnparkHook<FB, KS_OUT> hook{pk, act, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
-    slot<FIRST, BIG0, UnparkHook<FB, KS_OUT>>(cx, big, small, act[0][k], act[1][k], act[2][k], act[0][k + 1], act[1][k + 1], act[2][k + 1], &hook);
+    slot<FIRST, BIG0, UnparkHook<FB, KS_OUT>, ST>(cx, big, small, act[0][k], act[1][k], act[2][k], act[0][k + 1], act[1][k + 1], act[2][k + 1], &hook);
 }
 // second pass of a 256-wide layer: 16 K steps, the parked first pass converted on the way
+template <int ST = 0>
 __device__ __forceinline__ void pass_b_unpark(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], bf16x8 (&act)[3][16], const Park& pk) {
-    pass_act<0, 4, true>(cx, big, small, act);
+    pass_act<0, 4, true, false, ST>(cx, big, small, act);
     slot_unpark<0, 0>(cx, big, small, act, pk);
     slot_unpark<1, 0>(cx, big, small, act, pk);
     slot_unpark<2, 0>(cx, big, small, act, pk);
@@ -491,10 +589,10 @@ __device__ __forceinline__ void pass_b_unpark(Ctx& cx, f32x16 (&big)[4], f32x16 
 }
 // K steps 0 .. 7 of a pass whose input's upper half (features 128 .. 255 = the previous layer's second pass) still waits in
 // the park: converted into K steps 8 .. 15 on the way.  The caller continues with pass_act<8, ..., false>.
-template <bool BIG0 = false>
+template <bool BIG0 = false, int ST = 0>
 __device__ __forceinline__ void pass_a_unpark(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], bf16x8 (&act)[3][16], const Park& pk) {
-    slot_unpark<0, 8, true, BIG0>(cx, big, small, act, pk);
-    slot_unpark<1, 8>(cx, big, small, act, pk);
+    slot_unpark<0, 8, true, BIG0, ST>(cx, big, small, act, pk);
+    slot_unpark<1, 8, false, false, ST>(cx, big, small, act, pk);
     slot_unpark<2, 8>(cx, big, small, act, pk);
     slot_unpark<3, 8>(cx, big, small, act, pk);
 }
@@ -530,8 +628,11 @@ __device__ __forceinline__ void head3(const f32x16 (&big)[4], const f32x16 (&sma
 }
 
 // K steps 0 .. STEPS - 1 of the activation planes from the wave's staged encoding (feature 16 t + 8 h + j; NQ quads staged)
-template <int STEPS, int NQ>
-__device__ __forceinline__ void enc_to_act(const float* encw, int lane, bf16x8 (&act)[3][16]) {
+struct NoEncTap {
+    __device__ __forceinline__ void operator()(int, const float (&)[8]) const {}
+};
+template <int STEPS, int NQ, class EncTap = NoEncTap>
+__device__ __forceinline__ void enc_to_act(const float* encw, int lane, bf16x8 (&act)[3][16], EncTap enc_tap = EncTap()) {
     const float4* e4 = reinterpret_cast<const float4*>(encw);
     const int h = lane >> 5, c = lane & 31;
 #pragma unroll
@@ -555,6 +656,7 @@ __device__ __forceinline__ void enc_to_act(const float* encw, int lane, bf16x8 (
             v[4 * qq + 2] = x.z;
             v[4 * qq + 3] = x.w;
         }
+        enc_tap(t, v);
         split8(v, act[0][t], act[1][t], act[2][t]);
         BX_SB();
     }
@@ -591,34 +693,49 @@ __device__ __forceinline__ void motion_bx(Ctx& cx, const float* net, const float
 // SpaceNet on the wave's 32 samples; returns {r, g, b, sigma} (raw) in every lane.  `mid` is called once, in front of the
 // last backbone layer's boundary arithmetic (the caller issues the next work item's HBM loads there).
 // ---------------------------------------------------------------------------------------------
-template <bool DEEP, class Mid>
+// `tap` (training): BxStoreTap writes PE(pos) and every layer's post-ReLU output (stage 0 .. 6 = stage1.0 .. stage2.4, 7 = rgb_net.1)
+// to the caller's matrices as they pass; BxNoTap compiles to the inference kernel.
+template <bool DEEP, class Mid, class Tap>
 __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool use_time, const float* cs, float* encw, const float (&p)[3],
                                            const float* __restrict__ raybias, int32_t ray, int lane, f32x16 (&big)[4], f32x16 (&small)[4],
-                                           bf16x8 (&act)[3][16], Mid mid BXP_PARAM) {
+                                           bf16x8 (&act)[3][16], Mid mid, const Tap& tap BXP_PARAM) {
     const SpaceLayout L = space_layout(use_time, DEEP);
     const int h = lane >> 5;
+    constexpr int ST = Tap::on ? BX_TAP_PARK : 0;   // stores behind every park
     Park pk;
     load_c(big, cs + BXC_B, lane);   // (in front of the encoding arithmetic)
     encode_pos(encw, lane, p);
     wave_lds_sync();
-    enc_to_act<4, 16>(encw, lane, act);
+    if constexpr (Tap::on) {   // feature 16 t + 8 h + j of the staged encoding: 32 bytes per lane and K step
+        const bool valid = tap_valid(tap, lane);
+        // (tap_row's "4 h" is 8 h here: a lane half owns 8 consecutive features of a K step)
+        float4* dst = reinterpret_cast<float4*>(tap_row(tap, TAP_PE, 4 * h, lane));
+        enc_to_act<4, 16>(encw, lane, act, [&](int t, const float (&v)[8]) {
+            if (valid) {
+                dst[4 * t] = make_float4(v[0], v[1], v[2], v[3]);
+                dst[4 * t + 1] = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        });
+    } else {
+        enc_to_act<4, 16>(encw, lane, act);
+    }
     BXP(BXP_PE);
     // ---- stage1.0: 63 (+1) -> 256.  Every pass's C operand (its bias) is read block by block inside the boundary pass in
     // front of it, as soon as a block's accumulators have been consumed.
-    pass_act<0, 2, true>(cx, big, small, act);
+    pass_act<0, 2, true, false, Tap::on ? BX_TAP_PE : 0>(cx, big, small, act);
     BXP(BXP_PASS);
-    finish_park(big, small, pk, cs + BXC_B + 128, lane);
+    finish_park(big, small, pk, cs + BXC_B + 128, lane, tap, 0, 0);
     BXP(BXP_PARK);
-    pass_act<0, 2, true>(cx, big, small, act);
+    pass_act<0, 2, true, false, ST>(cx, big, small, act);
     BXP(BXP_PASS);
     unpark_act(pk, act);                                     // first pass -> K steps 0 .. 7 (in the open: the only layer whose
     BXP(BXP_ACT);                                            // successor's first pass cannot start before it)
-    finish_park(big, small, pk, cs + BXC_B + 256, lane);     // second pass -> park: converted under stage1.2's first K steps
+    finish_park(big, small, pk, cs + BXC_B + 256, lane, tap, 0, 128);   // second pass -> park: converted under stage1.2's first K steps
     BXP(BXP_PARK);
     // ---- stage1.2 .. stage2.4: six 256-wide layers, two passes each; stage2.0 (li == 4) takes PE(pos) again behind its 256
     // features (modeling/spacenet.py:45-57,136-138): four more K steps per pass, their B operands split on the spot from the
     // staged encoding (the activation planes are full)
-    auto pe_slots = [&]() {
+    auto pe_slots = [&]() __attribute__((always_inline)) {
         const float4* e4 = reinterpret_cast<const float4*>(encw);
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
@@ -641,19 +758,19 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     };
     // (stage2.0 is peeled out of the layer loop: inside it, as a conditional block, its extra K steps redefine the
     // accumulators on one of two paths and the register allocator answers with ~200 spills)
-    auto layer = [&](int li, auto with_pe) {
-        pass_a_unpark(cx, big, small, act, pk);              // K steps 0 .. 7, the previous layer's second pass -> K steps 8 .. 15
+    auto layer = [&](int li, auto with_pe) __attribute__((always_inline)) {
+        pass_a_unpark<false, ST>(cx, big, small, act, pk);   // K steps 0 .. 7, the previous layer's second pass -> K steps 8 .. 15
         pass_act<8, 4, false>(cx, big, small, act);
         if constexpr (decltype(with_pe)::value) pe_slots();
         BXP(BXP_PASS);
-        finish_park(big, small, pk, cs + BXC_B + 256 * li + 128, lane);
+        finish_park(big, small, pk, cs + BXC_B + 256 * li + 128, lane, tap, li, 0);
         BXP(BXP_PARK);
-        pass_b_unpark(cx, big, small, act, pk);
+        pass_b_unpark<ST>(cx, big, small, act, pk);
         if constexpr (decltype(with_pe)::value) pe_slots();
         BXP(BXP_PASS);
     };
-    auto layer_end = [&](int li) {   // (+ the next layer's first C operand; behind stage2.4 comes rgb_net.1, which starts from 0)
-        finish_park(big, small, pk, li < 6 ? cs + BXC_B + 256 * (li + 1) : nullptr, lane);
+    auto layer_end = [&](int li) __attribute__((always_inline)) {   // (+ the next layer's first C operand; behind stage2.4 comes rgb_net.1, which starts from 0)
+        finish_park(big, small, pk, li < 6 ? cs + BXC_B + 256 * (li + 1) : nullptr, lane, tap, li, 128);
         BXP(BXP_PARK);
     };
 #pragma unroll 1
@@ -680,7 +797,7 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     // part, and as the C operand it would put every rounding of the a0 b0 chain at its scale (measured: the colour output at
     // 1.3 x the fp32 CPU chain's error instead of 0.5 x).  Its 16 loads go out in front of the pass's last slot (14 of the 16
     // K steps' activation registers are dead by then).
-    pass_a_unpark<true>(cx, big, small, act, pk);            // (stage2.4's second pass is converted under its first K steps)
+    pass_a_unpark<true, ST>(cx, big, small, act, pk);        // (stage2.4's second pass is converted under its first K steps)
     pass_act<8, 3, false>(cx, big, small, act);
     BXP(BXP_PASS);
     {
@@ -706,6 +823,7 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
             BX_SB();
         }
     }
+    if constexpr (Tap::on) finish_park<false>(big, small, pk, nullptr, lane, tap, 7, 0);   // relu(rgb_net.1): rgb_net.3's input
     if constexpr (DEEP) {  // deep_rgb (:68-79): two more 128-wide hidden layers
 #pragma unroll 1
         for (int i = 0; i < 2; ++i) {
@@ -719,8 +837,19 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     return make_float4(rgb[0], rgb[1], rgb[2], sigma);
 }
 
-template <bool DEEP>
-__global__ __launch_bounds__(WV_THREADS, 1) void mlp_bf16x3_stage_kernel(StageArgs a) {
+__device__ __forceinline__ BxNoTap make_bx_tap(const NoTapArgs&, uint32_t, int64_t, int) { return BxNoTap(); }
+__device__ __forceinline__ BxStoreTap make_bx_tap(const StoreTapArgs& t, uint32_t item, int64_t rows, int wave) {
+    // (training launches one network: items of queue slot 0 are rows 128 item ..)
+    const int64_t left = rows - (int64_t)item * WV_ITEM;
+    return BxStoreTap{&t, item * (uint32_t)WV_ITEM, (uint32_t)(left < WV_ITEM ? left : WV_ITEM), wave};
+}
+
+// The tap variant (training: ONE SpaceNet on every ray, no MotionNet, no ray list) gives the tap's stores the registers they need
+// by not carrying per-row values through the item: the next item's (ray, sample) is located where it is fetched, not at the
+// top of the item; this item's output offset is recomputed from its ray at the end; the MotionNet path is compiled out.
+template <bool DEEP, class TapArgs>
+__global__ __launch_bounds__(WV_THREADS, 1) void mlp_bf16x3_stage_kernel(StageArgs a, TapArgs targs) {
+    constexpr bool TAP = !std::is_same<TapArgs, NoTapArgs>::value;
     extern __shared__ __attribute__((aligned(16))) char smem_bx[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -876,7 +1005,13 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_bf16x3_stage_kernel(StageAr
         uint32_t pending = 0;
         if (tid == 0) pending = atomicAdd(a.queue, 1u);
         RowRef rr_next;
-        row_of(it1, rr_next);
+        uint32_t next_ray = 0;   // (tap variant: all that is kept of the next item's row until its inputs are fetched)
+        if constexpr (TAP) {
+            const int64_t row = (int64_t)it1 * WV_ITEM + wave * WV_ROWS + (lane & 31);
+            if (row < a.n_rays * a.ns) next_ray = (uint32_t)row / (uint32_t)a.ns;   // (rows <= 0x7fffff00: stnerf_train_spacenet_fwd)
+        } else {
+            row_of(it1, rr_next);
+        }
         const StageLayer& ly = a.layer[slot_of(it0)];
         // ---- this item's bias vectors / head weights: blob consts -> LDS (12 + 4 chunks of 1 KB over the four waves).  The
         // previous item's last reads of the region are behind the barrier that ended it.
@@ -903,9 +1038,24 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_bf16x3_stage_kernel(StageAr
         // come back from scratch, each reload behind a vmcnt(0) that also drains the weight ring's DMA queue)
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        if (ly.motion) motion_bx(cx, ly.motion, cm, encw, p, cur.tv, ly.motion_flags, ln, big, small, act BXP_ARG);
+        if constexpr (!TAP) {
+            if (ly.motion) motion_bx(cx, ly.motion, cm, encw, p, cur.tv, ly.motion_flags, ln, big, small, act BXP_ARG);
+        }
+        const auto tap = make_bx_tap(targs, it0, a.n_rays * a.ns, wave);
         float4 o = space_bx<DEEP>(cx, ly.space, ly.use_time != 0, cs, encw, p, ly.raybias, cur.ray, ln, big, small, act,
-                                  [&]() { fetch(it1, rr_next, nxt); } BXP_ARG);
+                                  [&]() {
+                                      if constexpr (TAP) {
+                                          const int64_t row = (int64_t)it1 * WV_ITEM + wave * WV_ROWS + (lane & 31);
+                                          rr_next.valid = row < a.n_rays * a.ns;
+                                          rr_next.ray = next_ray;
+                                          rr_next.k = (int)((uint32_t)row - next_ray * (uint32_t)a.ns);
+                                      }
+                                      fetch(it1, rr_next, nxt);
+                                  }, tap BXP_ARG);
+        if constexpr (TAP) {   // (queue slot 0, every ray: row = 128 item + ..., sample k = row - ray * ns)
+            const int64_t row = (int64_t)it0 * WV_ITEM + wave * WV_ROWS + (lane & 31);
+            cur.raw_off = (int64_t)cur.ray * a.raw_ray_stride + 4 * (row - (int64_t)cur.ray * a.ns);
+        }
         if (cur.valid && lane < 32) {
             if (a.sigmoid_rgb) {  // torch.sigmoid(rgb): 1-ulp v_exp_f32 / v_rcp_f32, the same expression the compositor uses
                 o.x = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(o.x * -1.44269504088896340736f));
@@ -940,14 +1090,26 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_bf16x3_stage_kernel(StageAr
 int launch_bf16x3_stage(const StageArgs& a, bool deep_rgb, int cus, hipStream_t stream) {
     const int64_t max_items = ((a.n_rays * a.ns + WV_ITEM - 1) / WV_ITEM) * a.n_layers;
     const int grid = (int)(max_items < cus ? max_items : cus);  // one persistent workgroup per CU
-    const void* kfn = deep_rgb ? reinterpret_cast<const void*>(mlp_bf16x3_stage_kernel<true>)
-                               : reinterpret_cast<const void*>(mlp_bf16x3_stage_kernel<false>);
+    const void* kfn = deep_rgb ? reinterpret_cast<const void*>(mlp_bf16x3_stage_kernel<true, NoTapArgs>)
+                               : reinterpret_cast<const void*>(mlp_bf16x3_stage_kernel<false, NoTapArgs>);
     if (const int rc = reserve_dynamic_lds(kfn, BX_LDS, "mlp_stage (bf16x3)")) return rc;
     if (deep_rgb)
-        hipLaunchKernelGGL(mlp_bf16x3_stage_kernel<true>, dim3(grid), dim3(WV_THREADS), BX_LDS, stream, a);
+        hipLaunchKernelGGL((mlp_bf16x3_stage_kernel<true, NoTapArgs>), dim3(grid), dim3(WV_THREADS), BX_LDS, stream, a, NoTapArgs());
     else
-        hipLaunchKernelGGL(mlp_bf16x3_stage_kernel<false>, dim3(grid), dim3(WV_THREADS), BX_LDS, stream, a);
+        hipLaunchKernelGGL((mlp_bf16x3_stage_kernel<false, NoTapArgs>), dim3(grid), dim3(WV_THREADS), BX_LDS, stream, a, NoTapArgs());
     STNERF_CHECK_LAUNCH("mlp_stage (bf16x3)");
+    return STNERF_OK;
+}
+
+// One SpaceNet (queue slot 0 of `a`, every ray, no MotionNet, not deep_rgb) with every layer's input written out: see StoreTapArgs.
+int launch_bf16x3_stage_store(const StageArgs& a, const StoreTapArgs& t, int cus, hipStream_t stream) {
+    const int64_t max_items = (a.n_rays * a.ns + WV_ITEM - 1) / WV_ITEM;
+    const int grid = (int)(max_items < cus ? max_items : cus);
+    if (const int rc = reserve_dynamic_lds(reinterpret_cast<const void*>(mlp_bf16x3_stage_kernel<false, StoreTapArgs>), BX_LDS,
+                                           "train_space_fwd (bf16x3)"))
+        return rc;
+    hipLaunchKernelGGL((mlp_bf16x3_stage_kernel<false, StoreTapArgs>), dim3(grid), dim3(WV_THREADS), BX_LDS, stream, a, t);
+    STNERF_CHECK_LAUNCH("train_space_fwd (bf16x3)");
     return STNERF_OK;
 }
 
@@ -1082,5 +1244,120 @@ extern "C" int stnerf_pack_net_bf16x3(int kind, const float* const* W, const flo
     }
     STNERF_REQUIRE(off == (int64_t)X.n_slots * BX_SLOT, "pack_net_bf16x3: internal: stream of %lld B, expected %lld", (long long)off,
                    (long long)X.n_slots * BX_SLOT);
+    return STNERF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same blob from tensors in DEVICE memory (training: the weights change with every optimizer step): the f32 section by
+// stnerf_pack_net_device, consts and stream by one kernel -- same split (integer round-to-nearest-even), same order, bit for bit
+// (tests/test_gpu_ops.py).  No finiteness check here (no host round trip): an inf / NaN / > 3.39e38 weight gives NaN pieces and NaN
+// outputs, which a training loop notices; stnerf_pack_net_bf16x3 is the one that refuses.
+// ---------------------------------------------------------------------------------------------
+namespace stnerf {
+struct BxPackPass {
+    const float* src;
+    int64_t dst;        // stream passes: byte offset of the pass in the blob; copies: float offset in the blob
+    int32_t in, n0, ksteps;
+    int32_t mode;       // 0 hidden, 1 staged encoding (limit `lim`), 2 stage2.0 (256 hidden columns, then PE(pos)), 3 plain copy of `ksteps` floats
+    int32_t lim;
+};
+struct BxPackTable {
+    BxPackPass pass[32];
+};
+__device__ __forceinline__ uint32_t bx_bf16_rne_dev(float f) {
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7f800000u) == 0x7f800000u) return u >> 16;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__global__ void pack_bf16x3_device_kernel(BxPackTable t, char* blob) {
+    const BxPackPass ps = t.pass[blockIdx.y];
+    if (ps.mode == 3) {
+        float* d = reinterpret_cast<float*>(blob) + ps.dst;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ps.ksteps; i += gridDim.x * blockDim.x) d[i] = ps.src[i];
+        return;
+    }
+    uint16_t* d = reinterpret_cast<uint16_t*>(blob + ps.dst);
+    const int total = ps.ksteps * 4 * 512;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int j = e & 7, lane = (e >> 3) & 63, fb = (e >> 9) & 3, tt = e >> 11;
+        const int h = lane >> 5, c = lane & 31;
+        int k;
+        if (ps.mode == 0) {
+            k = bx_kmap_hidden(tt, h, j);
+        } else if (ps.mode == 1) {
+            k = bx_kmap_enc(tt, h, j);
+            k = k < ps.lim ? k : -1;
+        } else if (tt < 16) {
+            k = bx_kmap_hidden(tt, h, j);
+        } else {
+            k = bx_kmap_enc(tt - 16, h, j);
+            k = k < ps.lim ? 256 + k : -1;
+        }
+        uint32_t p0 = 0, p1 = 0, p2 = 0;
+        if (k >= 0) {
+            const float w = ps.src[(int64_t)(ps.n0 + 32 * fb + c) * ps.in + k];
+            p0 = bx_bf16_rne_dev(w);
+            const float r1 = w - __uint_as_float(p0 << 16);
+            p1 = bx_bf16_rne_dev(r1);
+            const float r2 = r1 - __uint_as_float(p1 << 16);
+            p2 = bx_bf16_rne_dev(r2);
+        }
+        uint16_t* u = d + (size_t)(tt * 4 + fb) * (BX_UNIT / 2) + lane * 8 + j;
+        u[0] = (uint16_t)p0;
+        u[BX_CHUNK / 2] = (uint16_t)p1;
+        u[BX_CHUNK] = (uint16_t)p2;
+    }
+}
+}  // namespace stnerf
+
+extern "C" int stnerf_pack_net_bf16x3_device(int kind, const float* const* W, const float* const* B, int n_tensors, void* dst_dev,
+                                             int64_t dst_bytes, stnerf_stream_t stream) {
+    STNERF_REQUIRE(W && B && dst_dev, "pack_net_bf16x3_device: null pointer");
+    STNERF_REQUIRE(STNERF_NET_IS_SPACE(kind) || kind == STNERF_NET_MOTION, "pack_net_bf16x3_device: unknown net kind %d", kind);
+    const BxLayout X = bx_layout(kind);
+    STNERF_REQUIRE(dst_bytes >= X.total_bytes, "pack_net_bf16x3_device: dst too small (%lld < %lld)", (long long)dst_bytes, (long long)X.total_bytes);
+    STNERF_REQUIRE(((uintptr_t)dst_dev & 1023) == 0, "pack_net_bf16x3_device: the blob must be 1 KB aligned");
+    // ---- the f32 section (also validates the tensor count), then the pad and the consts cleared
+    if (const int rc = stnerf_pack_net_device(kind, W, B, n_tensors, dst_dev, X.f32_floats * 4, stream)) return rc;
+    if (hipMemsetAsync(static_cast<char*>(dst_dev) + X.f32_floats * 4, 0, (size_t)(X.stream_off - X.f32_floats * 4), as_stream(stream)) != hipSuccess)
+        return STNERF_ELAUNCH;
+    BxPackTable t;
+    memset(&t, 0, sizeof(t));
+    int n = 0;
+    int64_t off = X.stream_off;
+    auto pass = [&](const float* w, int in, int n0, int ksteps, int mode, int lim) {
+        t.pass[n++] = BxPackPass{w, off, in, n0, ksteps, mode, lim};
+        off += (int64_t)ksteps * 4 * BX_UNIT;
+    };
+    auto cpy = [&](const float* src, int count, int cst_off) { t.pass[n++] = BxPackPass{src, X.consts_off / 4 + cst_off, 0, 0, count, 3, 0}; };
+    if (STNERF_NET_IS_SPACE(kind)) {
+        const bool deep = STNERF_NET_IS_DEEP(kind);
+        const int nt = deep ? 12 : 10;
+        const int in_f[7] = {63, 256, 256, 256, 319, 256, 256};
+        for (int i = 0; i < 7; ++i) cpy(B[i], 256, BXC_B + 256 * i);
+        for (int i = 0; i < 2 && deep; ++i) cpy(B[9 + i], 128, BXC_B_DEEP + 128 * i);
+        cpy(W[7], 256, BXC_W_SIGMA);
+        cpy(W[nt - 1], 3 * 128, BXC_W_RGB2);
+        for (int i = 0; i < 7; ++i)
+            for (int half = 0; half < 2; ++half) {
+                if (i == 0)
+                    pass(W[0], 63, 128 * half, 4, 1, 63);
+                else if (i == 4)
+                    pass(W[4], 319, 128 * half, 20, 2, 63);
+                else
+                    pass(W[i], in_f[i], 128 * half, 16, 0, 0);
+            }
+        pass(W[8], 256 + 27 + (STNERF_NET_USES_TIME(kind) ? 21 : 0), 0, 16, 0, 0);
+        for (int i = 0; i < 2 && deep; ++i) pass(W[9 + i], 128, 0, 8, 0, 0);
+    } else {
+        for (int i = 0; i < 5; ++i) cpy(B[i], 128, BXM_B + 128 * i);
+        cpy(W[5], 3 * 128, BXM_W_OUT);
+        pass(W[0], 84, 0, 6, 1, 84);
+        for (int i = 1; i < 5; ++i) pass(W[i], 128, 0, 8, 0, 0);
+    }
+    STNERF_REQUIRE(off == X.total_bytes && n <= 32, "pack_net_bf16x3_device: internal: stream of %lld B, expected %lld", (long long)(off - X.stream_off),
+                   (long long)X.n_slots * BX_SLOT);
+    hipLaunchKernelGGL(pack_bf16x3_device_kernel, dim3(32, n), dim3(256), 0, as_stream(stream), t, static_cast<char*>(dst_dev));
+    STNERF_CHECK_LAUNCH("pack_net_bf16x3_device");
     return STNERF_OK;
 }

@@ -65,6 +65,19 @@ __device__ __forceinline__ float lerp_enc(bool frac, float om, float wgt, float 
     return frac ? om * va + wgt * vb : va;
 }
 
+// Training: where a stage kernel's tap writes every layer's input (mlp_wave.hip: StoreTap, exact f32; mlp_bf16x3.hip:
+// BxStoreTap, split bf16).  Row r of the launch <-> row r of every matrix.
+struct NoTapArgs {};
+constexpr int TAP_PE = 100;   // the taps' stage id of the staged encoding
+struct StoreTapArgs {
+    float* buf[8];     // stage s: the input of stage1.2 .. stage2.4 (0 .. 5), of the heads / rgb_net.1 (6: 256 wide), of rgb_net.3 (7: 128)
+    int32_t ld[8];     // row strides in floats (multiples of 4; 16-byte aligned bases)
+    float* pe;         // PE(pos): 63 features + one zero
+    int32_t ld_pe;
+    uint32_t* bits;    // [8][.. bits_stride ..]: rows x 8 words per stage: the ReLU masks of stages 0 .. 7 as bit planes (see StoreTap), or null
+    int64_t bits_stride;   // uint32 words between two stages' planes
+};
+
 // mlp_wave.hip
 int launch_wave_stage(const StageArgs& a, bool deep_rgb, int cus, hipStream_t stream);
 int launch_wave_stage_store(const StageArgs& a, float* const (&buf)[8], const int32_t (&ld)[8], float* pe, int32_t ld_pe, uint32_t* bits,

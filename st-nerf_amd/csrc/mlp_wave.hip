@@ -37,15 +37,6 @@ namespace stnerf {
 // needs -- to row-major matrices the caller owns, as the item's rows pass through the registers: one launch instead of a
 // chain of per-layer GEMMs through HBM for the recomputation, and the SAME arithmetic as the forward that produced the loss.
 // Slot 0 of the queue only (the training entry point launches one network).  Row r of the launch <-> row r of every matrix.
-struct NoTapArgs {};
-struct StoreTapArgs {
-    float* buf[8];     // stage s: the input of stage1.2 .. stage2.4 (0 .. 5), of the heads / rgb_net.1 (6: 256 wide), of rgb_net.3 (7: 128)
-    int32_t ld[8];     // row strides in floats (multiples of 4; 16-byte aligned bases)
-    float* pe;         // PE(pos): 63 features + one zero
-    int32_t ld_pe;
-    uint32_t* bits;    // [8][.. bits_stride ..]: rows x 8 words per stage: the ReLU masks of stages 0 .. 7 as bit planes (see StoreTap), or null
-    int64_t bits_stride;   // uint32 words between two stages' planes
-};
 struct StoreTap {
     const StoreTapArgs* a;
     uint32_t row;

@@ -388,7 +388,6 @@ __device__ __forceinline__ void head3(const f32x16 (&in)[8], const float* wlds /
 // `tap` sees every layer's input as the layer reads it (training: csrc/mlp_wave.hip's StoreTap writes them out for the backward
 // pass; NoTap compiles to nothing): stage TAP_PE = PE(pos) (2 blocks), 0 .. 5 = the inputs of stage1.2 .. stage2.4 (8 blocks each;
 // 3 = h4, stage2.0's input next to PE), 6 = g3 (the heads' and rgb_net.1's input), 7 = rgb_net.3's input (4 blocks).
-constexpr int TAP_PE = 100;
 struct NoTap {
     template <int NBLK>
     __device__ __forceinline__ void blocks(int, const f32x16 (&)[NBLK], int, int) const {}

@@ -18,6 +18,7 @@
 //
 // Reference: modeling/spacenet.py:45-86,101-160 through ATen's addmm_backward / threshold_backward, engine/layered_trainer.py:281.
 #include "mlp_wave_core.h"
+#include "mlp_bf16x3.h"
 
 namespace stnerf {
 
@@ -348,10 +349,10 @@ __global__ __launch_bounds__(WV_THREADS, 1) void train_motion_dx_kernel(MotionDx
 
 using namespace stnerf;
 
-extern "C" int stnerf_train_spacenet_fwd(int kind, const void* packed, int64_t n_rays, int ns, const float* xyz, int64_t xyz_ray_stride,
-                                         const float* dirs, int64_t dirs_ray_stride, const float* times, int64_t times_ray_stride,
-                                         float* raw, int64_t raw_ray_stride, float* const* act_host, const int32_t* ld_act_host, float* pe,
-                                         int32_t ld_pe, uint32_t* relu_bits, int64_t relu_bits_stride, uint32_t* queue, float* ray_bias, stnerf_stream_t stream) {
+static int train_spacenet_fwd(bool bf16x3, int kind, const void* packed, int64_t n_rays, int ns, const float* xyz, int64_t xyz_ray_stride,
+                              const float* dirs, int64_t dirs_ray_stride, const float* times, int64_t times_ray_stride, float* raw,
+                              int64_t raw_ray_stride, float* const* act_host, const int32_t* ld_act_host, float* pe, int32_t ld_pe,
+                              uint32_t* relu_bits, int64_t relu_bits_stride, uint32_t* queue, float* ray_bias, stnerf_stream_t stream) {
     STNERF_REQUIRE(packed && xyz && dirs && raw && act_host && ld_act_host && pe && queue && ray_bias, "train_spacenet_fwd: null pointer");
     STNERF_REQUIRE(kind == STNERF_NET_SPACE || kind == STNERF_NET_SPACE_TIME, "train_spacenet_fwd: kind %d (deep_rgb networks take the per-layer path)", kind);
     STNERF_REQUIRE(n_rays >= 0 && ns >= 1 && (raw_ray_stride & 3) == 0, "train_spacenet_fwd: bad shape");
@@ -387,7 +388,40 @@ extern "C" int stnerf_train_spacenet_fwd(int kind, const void* packed, int64_t n
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     STNERF_REQUIRE(!relu_bits || (((uintptr_t)relu_bits & 15) == 0 && (relu_bits_stride & 3) == 0 && relu_bits_stride >= n_rays * ns * 8),
                    "train_spacenet_fwd: relu_bits must be 16-byte aligned, its stage stride a multiple of 4 words and >= 8 x rows");
+    if (bf16x3) {
+        // (the stream is fetched by 16-byte LDS-DMA from 1 KB-aligned sections; the tap's buffer descriptors cover one work item's rows)
+        STNERF_REQUIRE(((uintptr_t)packed & 1023) == 0, "train_spacenet_fwd_bf16x3: the packed network must be 1 KB aligned");
+        for (int i = 0; i < 8; ++i) STNERF_REQUIRE(ld_act_host[i] <= (1 << 20), "train_spacenet_fwd_bf16x3: row stride %d of matrix %d", ld_act_host[i], i);
+        STNERF_REQUIRE(ld_pe <= (1 << 20), "train_spacenet_fwd_bf16x3: row stride %d of the PE matrix", ld_pe);
+        StoreTapArgs t;
+        t.bits = relu_bits;
+        t.bits_stride = relu_bits_stride;
+        for (int i = 0; i < 8; ++i) {
+            t.buf[i] = bufs[i];
+            t.ld[i] = lds[i];
+        }
+        t.pe = pe;
+        t.ld_pe = ld_pe;
+        return launch_bf16x3_stage_store(a, t, cus, as_stream(stream));
+    }
     return launch_wave_stage_store(a, bufs, lds, pe, ld_pe, relu_bits, relu_bits_stride, cus, as_stream(stream));
+}
+
+extern "C" int stnerf_train_spacenet_fwd(int kind, const void* packed, int64_t n_rays, int ns, const float* xyz, int64_t xyz_ray_stride,
+                                         const float* dirs, int64_t dirs_ray_stride, const float* times, int64_t times_ray_stride,
+                                         float* raw, int64_t raw_ray_stride, float* const* act_host, const int32_t* ld_act_host, float* pe,
+                                         int32_t ld_pe, uint32_t* relu_bits, int64_t relu_bits_stride, uint32_t* queue, float* ray_bias, stnerf_stream_t stream) {
+    return train_spacenet_fwd(false, kind, packed, n_rays, ns, xyz, xyz_ray_stride, dirs, dirs_ray_stride, times, times_ray_stride, raw,
+                              raw_ray_stride, act_host, ld_act_host, pe, ld_pe, relu_bits, relu_bits_stride, queue, ray_bias, stream);
+}
+
+extern "C" int stnerf_train_spacenet_fwd_bf16x3(int kind, const void* packed, int64_t n_rays, int ns, const float* xyz, int64_t xyz_ray_stride,
+                                                const float* dirs, int64_t dirs_ray_stride, const float* times, int64_t times_ray_stride,
+                                                float* raw, int64_t raw_ray_stride, float* const* act_host, const int32_t* ld_act_host,
+                                                float* pe, int32_t ld_pe, uint32_t* relu_bits, int64_t relu_bits_stride, uint32_t* queue,
+                                                float* ray_bias, stnerf_stream_t stream) {
+    return train_spacenet_fwd(true, kind, packed, n_rays, ns, xyz, xyz_ray_stride, dirs, dirs_ray_stride, times, times_ray_stride, raw,
+                              raw_ray_stride, act_host, ld_act_host, pe, ld_pe, relu_bits, relu_bits_stride, queue, ray_bias, stream);
 }
 
 extern "C" int stnerf_train_spacenet_dx(const float* wt, const uint32_t* offsets_host /* rgb1, l[0..6], wsigma, wrgb2 */, const float* d_raw,

@@ -93,6 +93,7 @@ _PROTOS = {
     "stnerf_packed_bytes": (c_i64, [C.c_int]),
     "stnerf_pack_net": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, c_i64]),
     "stnerf_pack_net_device": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, c_i64, C.c_void_p]),
+    "stnerf_pack_net_bf16x3_device": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, c_i64, C.c_void_p]),
     "stnerf_spacenet_fwd": (C.c_int, [C.c_int, C.c_void_p, c_i64, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_i64,
                                       c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, C.c_void_p]),
     "stnerf_rgb_ray_bias": (C.c_int, [C.c_int, C.c_void_p, c_i64, C.c_void_p, C.c_void_p, c_f32p, c_i64, c_f32p, c_i64,
@@ -117,6 +118,8 @@ _PROTOS = {
     "stnerf_train_encode_bwd": (C.c_int, [c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_i64, c_f32p, c_i64, C.c_int, C.c_int, C.c_int, c_f32p,
                                           c_i64, C.c_void_p]),
     "stnerf_train_spacenet_fwd": (C.c_int, [C.c_int, C.c_void_p, c_i64, C.c_int, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64,
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_int32), c_f32p, C.c_int32, C.c_void_p, c_i64, C.c_void_p, c_f32p, C.c_void_p]),
+    "stnerf_train_spacenet_fwd_bf16x3": (C.c_int, [C.c_int, C.c_void_p, c_i64, C.c_int, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64,
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_int32), c_f32p, C.c_int32, C.c_void_p, c_i64, C.c_void_p, c_f32p, C.c_void_p]),
     "stnerf_train_spacenet_dx": (C.c_int, [c_f32p, C.POINTER(C.c_uint32), c_f32p, c_i64, C.c_void_p, c_i64, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                            c_f32p, C.c_int32, C.c_void_p]),

@@ -57,6 +57,19 @@ CHUNK_SAMPLES = min(max(int(os.environ.get("STNERF_TRAIN_CHUNK_SAMPLES", 1 << 18
 # every weight / bias gradient of a network in one launch (stnerf_train_dw_batch); "0": one launch group per layer (the A/B of
 # tools/bench_backward.py)
 DW_BATCH = os.environ.get("STNERF_TRAIN_DW_BATCH", "1") != "0"
+# Arithmetic of the fused SpaceNet forward under autograd ("" = the module's own, which is split bf16 unless the model was built with
+# precision="fp32"): the stage kernel that renders, with the activation tap (csrc/mlp_bf16x3.hip, round 6; 2.3 -> ~1.6 ms per 262,144
+# samples).  "fp32": csrc/mlp_wave.hip's exact-f32 kernel with its tap, as up to round 5.
+TRAIN_FWD = os.environ.get("STNERF_TRAIN_FWD", "")
+
+
+def _train_fwd_precision(module) -> str:
+    """Arithmetic of the fused SpaceNet forward under autograd: the module's own (``precision``: "bf16x3" unless the model was
+    built for exact f32), or what STNERF_TRAIN_FWD names ("fp32" / "bf16x3")."""
+    p = TRAIN_FWD or module.precision
+    if p not in ops.PRECISIONS:
+        raise ValueError(f"STNERF_TRAIN_FWD / precision must be one of {ops.PRECISIONS}, got {p!r}")
+    return p
 
 
 def _dw(dy, x, dw, db, accumulate: bool) -> None:
@@ -148,8 +161,11 @@ class SpaceNetFunction(torch.autograd.Function):
         fused = FUSED_BACKWARD and module.include_input and module.use_dir and not module.deep_rgb
         kept = []
         with torch.no_grad():
-            # exact f32 whatever the module renders with: the backward walks back through the ReLU masks of THIS evaluation
-            packed = module._packed("fp32")
+            # The backward walks back through the ReLU masks of THIS evaluation.  Fused path: the stage kernel of the module's own
+            # arithmetic (split bf16 by default -- the kernel that renders, with the tap; STNERF_TRAIN_FWD=fp32: exact f32 whatever
+            # the module renders with, as up to round 5); per-layer path: exact f32.
+            ctx.fwd_precision = _train_fwd_precision(module) if fused else "fp32"
+            packed = module._packed(ctx.fwd_precision)
             if fused and _may_keep(n * ns * ACT_FLOATS_PER_SAMPLE * 4):
                 dir_w_, time_w_ = 27, (21 if module.use_time else 0)
                 kept = _activation_buffers(n * ns, dir_w_ + time_w_, dev)
@@ -198,7 +214,7 @@ class SpaceNetFunction(torch.autograd.Function):
             # its stage kernel per chunk (recomputation); then the whole d x chain with the gradient carried in registers; only the
             # weight gradients and the encodings' chain rule stay per layer
             wt, offsets = transposed_spacenet(m_, params)
-            packed = m_._packed("fp32")
+            packed = m_._packed(ctx.fwd_precision)      # (the recomputation: the arithmetic of the forward, bit for bit)
             for r0 in range(0, n, rays_per_chunk):
                 r1 = min(n, r0 + rays_per_chunk)
                 M = (r1 - r0) * ns

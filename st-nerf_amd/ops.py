@@ -7,6 +7,7 @@ PyTorch implementation to fall back to.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -164,17 +165,25 @@ def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cud
     nbytes = size_fn(kind)
     if nbytes < 0:
         hip.check(int(nbytes), "stnerf_packed_bytes")
-    if precision == "fp32" and all(t.is_cuda for t in list(weights) + list(biases)):
-        # tensors that live on the GPU are packed there (stnerf_pack_net_device): no D2H / CPU loop / H2D per network -- a training loop
-        # repacks after every optimizer.step()
+    if all(t.is_cuda for t in list(weights) + list(biases)) and not (precision == "bf16x3" and os.environ.get("STNERF_PACK_BF16X3_HOST") == "1"):
+        # tensors that live on the GPU are packed there (stnerf_pack_net_device / stnerf_pack_net_bf16x3_device: the same blobs bit for
+        # bit): no D2H / CPU loop / H2D per network -- a training loop repacks after every optimizer.step().  (The bf16x3 device packer
+        # does not refuse non-finite weights the way the host packer does: STNERF_PACK_BF16X3_HOST=1 keeps the host path.)
         dev = weights[0].device
         ws = [w.detach().to(torch.float32).contiguous() for w in weights]
         bs = [b.detach().to(torch.float32).contiguous() for b in biases]
-        blob = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
         wp = (C.c_void_p * len(ws))(*(w.data_ptr() for w in ws))
         bp = (C.c_void_p * len(bs))(*(b.data_ptr() for b in bs))
+        if precision == "fp32":
+            blob = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            fn, name = lib.stnerf_pack_net_device, "stnerf_pack_net_device"
+        else:       # (the stage kernel streams it by 16-byte LDS-DMA from 1 KB-aligned sections)
+            raw = torch.empty(nbytes + 1024, dtype=torch.uint8, device=dev)
+            off = (-raw.data_ptr()) % 1024
+            blob = raw[off:off + nbytes].view(torch.float32)
+            fn, name = lib.stnerf_pack_net_bf16x3_device, "stnerf_pack_net_bf16x3_device"
         with torch.cuda.device(dev):
-            hip.check(lib.stnerf_pack_net_device(kind, wp, bp, len(ws), hip.dptr(blob), nbytes, hip.stream_ptr()), "stnerf_pack_net_device")
+            hip.check(fn(kind, wp, bp, len(ws), hip.dptr(blob), nbytes, hip.stream_ptr()), name)
         return PackedNet(kind, blob, precision)
     ws = [w.detach().to("cpu", torch.float32).contiguous() for w in weights]
     bs = [b.detach().to("cpu", torch.float32).contiguous() for b in biases]
@@ -677,12 +686,11 @@ def _bit_planes(bits: Tensor, rows: int):
 
 def train_spacenet_fwd(net: PackedNet, xyz: Tensor, dirs: Tensor, times: Optional[Tensor], raw: Tensor, acts: Sequence[Tensor],
                        pe: Tensor, relu_bits: Optional[Tensor] = None) -> None:
-    """The exact-f32 stage kernel on one SpaceNet, every ray, writing each layer's input as it goes: acts[0..6] (rows, 256),
-    acts[7] (rows, 128), pe (rows, 64), rows = n * ns in (ray, sample) order -- views into padded row-major storage -- and
-    relu_bits (8, rows, 8) int32: the ReLU masks as bit planes (stnerf_train_spacenet_fwd).  xyz (n,ns,3), dirs (n,3),
-    times (n,) | None, raw (n,ns,4) out."""
-    if net.precision != "fp32":
-        raise ValueError("the training kernels are exact f32: pack the network 'fp32'")
+    """The stage kernel of the network's arithmetic (exact f32: stnerf_train_spacenet_fwd; split bf16: ..._bf16x3) on one SpaceNet,
+    every ray, writing each layer's input as it goes: acts[0..6] (rows, 256), acts[7] (rows, 128), pe (rows, 64), rows = n * ns in
+    (ray, sample) order -- views into padded row-major storage -- and relu_bits (8, rows, 8) int32: the ReLU masks as bit planes.
+    xyz (n,ns,3), dirs (n,3), times (n,) | None, raw (n,ns,4) out."""
+    entry = "stnerf_train_spacenet_fwd" if net.precision == "fp32" else "stnerf_train_spacenet_fwd_bf16x3"
     n, ns = xyz.shape[0], xyz.shape[1]
     xp, xs = _strided_view_ptr(xyz, (ns, 3), "xyz")
     rp, rs = _strided_view_ptr(raw, (ns, 4), "raw")
@@ -693,9 +701,8 @@ def train_spacenet_fwd(net: PackedNet, xyz: Tensor, dirs: Tensor, times: Optiona
     bp, bstride = _bit_planes(relu_bits, n * ns) if relu_bits is not None else (C.c_void_p(0), 0)
     queue = torch.zeros(1, dtype=torch.int32, device=xyz.device)
     ray_bias = torch.empty(n, 128, dtype=torch.float32, device=xyz.device)
-    hip.check(hip.lib().stnerf_train_spacenet_fwd(net.kind, hip.dptr(net.blob), n, ns, xp, xs, dp, ds, tp, ts, rp, rs, ptrs, lds, pp, ldp,
-                                                  bp, bstride, hip.dptr(queue, torch.int32), hip.dptr(ray_bias),
-                                                  hip.stream_ptr()), "stnerf_train_spacenet_fwd")
+    hip.check(getattr(hip.lib(), entry)(net.kind, hip.dptr(net.blob), n, ns, xp, xs, dp, ds, tp, ts, rp, rs, ptrs, lds, pp, ldp,
+                                        bp, bstride, hip.dptr(queue, torch.int32), hip.dptr(ray_bias), hip.stream_ptr()), entry)
 
 
 def train_spacenet_dx(wt: Tensor, offsets: Sequence[int], d_raw: Tensor, relu_bits: Tensor, dys: Sequence[Tensor], dpe: Optional[Tensor]) -> None:

@@ -379,15 +379,18 @@ def _space_case(use_time, n=37, ns=19, seed=0):
     return net, pos, rays, tm
 
 
-@pytest.mark.parametrize("use_time", [False, True])
-def test_fused_forward_writes_the_activations_the_layerwise_recompute_builds(ops, use_time):
-    """stnerf_train_spacenet_fwd = the inference stage kernel + a tap: its outputs are stnerf_spacenet_fwd's bit for bit, and every
-    layer input it writes out is what the per-layer recomputation (train_encode + train_linear_fwd, round 4) produces."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("use_time, n", [(False, 37), (True, 37), (True, 128)])
+def test_fused_forward_writes_the_activations_the_layerwise_recompute_builds(ops, use_time, n, precision):
+    """stnerf_train_spacenet_fwd[_bf16x3] = the inference stage kernel of that arithmetic + a tap: its outputs are stnerf_spacenet_fwd's
+    bit for bit, and every layer input it writes out is what the per-layer recomputation (train_encode + train_linear_fwd, round 4,
+    exact f32) produces -- within the rounding of an fp32 layer for both arithmetics -- with a ragged last work item (703 rows) and
+    with whole ones (2432)."""
     from stnerf_amd.modeling import autograd as A
-    net, pos, rays, tm = _space_case(use_time)
+    net, pos, rays, tm = _space_case(use_time, n=n)
     n, ns = pos.shape[0], pos.shape[1]
     M = n * ns
-    packed = net._packed("fp32")
+    packed = net._packed(precision)
     dir_w, time_w = 27, 21 if use_time else 0
     Cc, R, T0 = A._buf(M, 320, "cuda"), A._buf(M, 256 + dir_w + time_w, "cuda"), A._buf(M, 128, "cuda")
     Hs, Gs = [A._buf(M, 256, "cuda") for _ in range(3)], [A._buf(M, 256, "cuda") for _ in range(2)]
@@ -400,6 +403,8 @@ def test_fused_forward_writes_the_activations_the_layerwise_recompute_builds(ops
     want = torch.empty(n, ns, 4, device="cuda")
     ops.spacenet_fwd(packed, pos, rays[:, 3:6], tm.reshape(n) if use_time else None, want)
     assert torch.equal(raw, want)
+    # nothing beyond a matrix's 256 columns was touched (rgb_net.1's input keeps its direction / time columns for train_encode)
+    assert bool(torch.isnan(R[:, 256:]).all())
     # the round-4 recomputation, layer by layer
     params = [p.detach() for p in net.training_parameters()]
     W = [A._padded_weight(params[2 * i]) for i in range(10)]

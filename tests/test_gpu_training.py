@@ -229,8 +229,9 @@ def test_teacher_forced_training_step_meets_the_piecewise_bar_end_to_end(ops, na
     ref_vs_64 = {pname: compare_digest(pname, torch.from_numpy(z["grad|" + pname]), d64[pname], rel=GRAD_RTOL) for pname in recorded}
     noisy = {network(pname) for pname, r in ref_vs_64.items() if r > 1.0}
     print(f"    networks where the reference's own fp32 gradients are over the bar against fp64: {sorted(noisy)}")
+    cleared = {}
     for pname, r in sorted(off.items(), key=lambda kv: -kv[1]):
-        hip_vs_64 = compare_digest(pname, syn.tensor_digest(pname, named[pname].grad, meta["grad_samples"]), d64[pname], rel=GRAD_RTOL)
+        hip_vs_64 = cleared[pname] = compare_digest(pname, syn.tensor_digest(pname, named[pname].grad, meta["grad_samples"]), d64[pname], rel=GRAD_RTOL)
         print(f"    {pname}: HIP vs reference {r:.1f} x the bar; against fp64 on the same positions: reference {ref_vs_64[pname]:.1f} x, HIP {hip_vs_64:.1f} x")
         if hip_vs_64 <= TRAINER_CLEAN_FACTOR:
             # within (TRAINER_CLEAN_FACTOR x) the bar of the exact evaluation.  Measured: the head layers of spacenets.0 (stage2.4,
@@ -240,7 +241,12 @@ def test_teacher_forced_training_step_meets_the_piecewise_bar_end_to_end(ops, na
         assert network(pname) in noisy, (pname, r, ref_vs_64[pname], hip_vs_64)
         assert hip_vs_64 <= max(1.0, FP32_NOISE_FACTOR * ref_vs_64[pname], EVENT_RTOL / GRAD_RTOL), (pname, r, ref_vs_64[pname], hip_vs_64)
     assert len(noisy) <= 2, noisy
-    assert all(not p.startswith(("bkgd_spacenet_fine", "spacenets_fine", "spacenets.1", "time_deform_nets.1")) for p in off), sorted(off)
+    # the fine networks, the second performer and its deformation net: over the bar against the reference only where the REFERENCE is that
+    # far from fp64 and the HIP gradient is not (round 6: with the split-bf16 forward the HIP step sits on the fp64 evaluation -- measured
+    # 0.0 x the bar -- where the reference's spacenets_fine.0.stage2.4.weight is 1.0 x off)
+    clean = ("bkgd_spacenet_fine", "spacenets_fine", "spacenets.1", "time_deform_nets.1")
+    assert all(cleared[p] <= 1.0 and ref_vs_64[p] >= 0.9 * off[p] for p in off if p.startswith(clean)), \
+        sorted((p, off[p], cleared[p], ref_vs_64[p]) for p in off if p.startswith(clean))
 
 
 @pytest.mark.parametrize("name", ["train_c3", "train_coarse_only", "train_c4", "train_flags", "train_same_spacenet", "train_bkgd_time"])
