@@ -735,7 +735,18 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     // ---- stage1.2 .. stage2.4: six 256-wide layers, two passes each; stage2.0 (li == 4) takes PE(pos) again behind its 256
     // features (modeling/spacenet.py:45-57,136-138): four more K steps per pass, their B operands split on the spot from the
     // staged encoding (the activation planes are full)
-    auto pe_slots = [&]() __attribute__((always_inline)) {
+    // (The three lambdas below are inlined into the inference kernel by the inliner's own choice; with the tap's code in them it
+    // declines, and a real call passes the wave's 400 live registers through memory.  The tap variant forces them AT THE CALL -- an
+    // attribute on the lambdas themselves changes the inlining order, and with it the code, of the inference kernel.)
+#define BX_INLINED(call)                           \
+    do {                                           \
+        if constexpr (Tap::on) {                   \
+            [[clang::always_inline]] call;         \
+        } else {                                   \
+            call;                                  \
+        }                                          \
+    } while (0)
+    auto pe_slots = [&]() {
         const float4* e4 = reinterpret_cast<const float4*>(encw);
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
@@ -758,39 +769,40 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     };
     // (stage2.0 is peeled out of the layer loop: inside it, as a conditional block, its extra K steps redefine the
     // accumulators on one of two paths and the register allocator answers with ~200 spills)
-    auto layer = [&](int li, auto with_pe) __attribute__((always_inline)) {
+    auto layer = [&](int li, auto with_pe) {
         pass_a_unpark<false, ST>(cx, big, small, act, pk);   // K steps 0 .. 7, the previous layer's second pass -> K steps 8 .. 15
         pass_act<8, 4, false>(cx, big, small, act);
-        if constexpr (decltype(with_pe)::value) pe_slots();
+        if constexpr (decltype(with_pe)::value) BX_INLINED(pe_slots());
         BXP(BXP_PASS);
         finish_park(big, small, pk, cs + BXC_B + 256 * li + 128, lane, tap, li, 0);
         BXP(BXP_PARK);
         pass_b_unpark<ST>(cx, big, small, act, pk);
-        if constexpr (decltype(with_pe)::value) pe_slots();
+        if constexpr (decltype(with_pe)::value) BX_INLINED(pe_slots());
         BXP(BXP_PASS);
     };
-    auto layer_end = [&](int li) __attribute__((always_inline)) {   // (+ the next layer's first C operand; behind stage2.4 comes rgb_net.1, which starts from 0)
+    auto layer_end = [&](int li) {   // (+ the next layer's first C operand; behind stage2.4 comes rgb_net.1, which starts from 0)
         finish_park(big, small, pk, li < 6 ? cs + BXC_B + 256 * (li + 1) : nullptr, lane, tap, li, 128);
         BXP(BXP_PARK);
     };
 #pragma unroll 1
     for (int li = 1; li <= 3; ++li) {
-        layer(li, std::false_type{});
-        layer_end(li);
+        BX_INLINED(layer(li, std::false_type{}));
+        BX_INLINED(layer_end(li));
     }
-    layer(4, std::true_type{});
-    layer_end(4);
+    BX_INLINED(layer(4, std::true_type{}));
+    BX_INLINED(layer_end(4));
     float sigma = 0.f;
 #pragma unroll 1
     for (int li = 5; li <= 6; ++li) {
-        layer(li, std::false_type{});
+        BX_INLINED(layer(li, std::false_type{}));
         if (li == 6) {  // sigma = density_net(h) (:139), raw; the next work item's HBM loads go out in front of it
             mid();
             sigma = sigma_head(big, small, pk, cs + BXC_W_SIGMA, net[L.b_sigma], lane);
             BXP(BXP_SIGMA);
         }
-        layer_end(li);
+        BX_INLINED(layer_end(li));
     }
+#undef BX_INLINED
     // ---- rgb_net: relu -> Linear(283|304, 128) -> relu -> Linear(128, 3) (:80-86); the 256 backbone columns here, the
     // bias + direction / time columns = this sample's row of the ray-bias table (mlp_raybias.hip).  The exact-f32 kernels take
     // that row as the C operand; here it is added BEHIND the K loop: it is an order of magnitude larger than the backbone
