@@ -437,6 +437,19 @@ int stnerf_train_spacenet_fwd_bf16x3(int kind, const void* packed, int64_t n_ray
 int stnerf_train_spacenet_dx(const float* wt, const uint32_t* offsets_host, const float* d_raw, int64_t rows, const uint32_t* relu_bits,
                              int64_t relu_bits_stride, float* const* dy_host, const int32_t* ld_dy_host, float* dpe, int32_t ld_dpe,
                              stnerf_stream_t stream);
+/* stnerf_train_spacenet_dx in split bf16 (round 6; csrc/mlp_bf16x3.hip: train_space_dx_bx_kernel -- the forward kernel's machinery with
+ * the transposed weights as a bf16x3 stream through the LDS ring, the masks fetched per work item by LDS-DMA): same inputs, same dy
+ * matrices, fp32-faithful values.  The weights come as ONE blob, stnerf_pack_dx_bf16x3_device(kind, weights_dev (the network's 10
+ * weight tensors in reference layout, host array of device pointers), 10, with_dpos, dst (1 KB aligned,
+ * stnerf_packed_bytes_dx_bf16x3(kind, with_dpos) bytes)).  with_dpos != 0: the chain goes on to PE(pos) and leaves
+ * dLoss / d PE(pos) as the SUM of two 64-column matrices, dpe (d y0 W_stage1.0) and dpe_skip (d y4 W_stage2.0[:, 256:]) -- the caller
+ * adds them (the exact-f32 kernel carries one through four layers in registers this kernel does not have); with_dpos == 0: both NULL. */
+int64_t stnerf_packed_bytes_dx_bf16x3(int kind, int with_dpos);
+int stnerf_pack_dx_bf16x3_device(int kind, const float* const* weights_dev, int n_tensors, int with_dpos, void* dst_dev, int64_t dst_bytes,
+                                 stnerf_stream_t stream);
+int stnerf_train_spacenet_dx_bf16x3(const void* packed_dx, int with_dpos, const float* d_raw, int64_t rows, const uint32_t* relu_bits,
+                                    int64_t relu_bits_stride, float* const* dy_host, const int32_t* ld_dy_host, float* dpe, int32_t ld_dpe,
+                                    float* dpe_skip, int32_t ld_dpe_skip, stnerf_stream_t stream);
 
 /* The MotionNet's backward (modeling/motion_net.py:20-71 under loss.backward()) as the same two launches (csrc/train_wave.hip):
  *

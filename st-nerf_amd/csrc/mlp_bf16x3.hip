@@ -524,6 +524,7 @@ __device__ __forceinline__ float sigma_head(const f32x16 (&big)[4], const f32x16
         }
     return (float)((double)bias + pair_sum_d((sg.c[0] + sg.c[1]) + (sg.c[2] + sg.c[3])));
 }
+template <int KS0 = 0>
 __device__ __forceinline__ void unpark_act(const Park& pk, bf16x8 (&act)[3][16]) {
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb)
@@ -532,7 +533,7 @@ __device__ __forceinline__ void unpark_act(const Park& pk, bf16x8 (&act)[3][16])
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = park_get(pk.v[16 * fb + 8 * t + j]);
-            split8(v, act[0][2 * fb + t], act[1][2 * fb + t], act[2][2 * fb + t]);
+            split8(v, act[0][KS0 + 2 * fb + t], act[1][KS0 + 2 * fb + t], act[2][KS0 + 2 * fb + t]);
             BX_SB();
         }
 }
@@ -579,9 +580,9 @@ __device__ __forceinline__ void slot_unpark(Ctx& cx, f32x16 (&big)[4], f32x16 (&
     slot<FIRST, BIG0, UnparkHook<FB, KS_OUT>, ST>(cx, big, small, act[0][k], act[1][k], act[2][k], act[0][k + 1], act[1][k + 1], act[2][k + 1], &hook);
 }
 // second pass of a 256-wide layer: 16 K steps, the parked first pass converted on the way
-template <int ST = 0>
+template <int ST = 0, bool BIG0 = false>
 __device__ __forceinline__ void pass_b_unpark(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], bf16x8 (&act)[3][16], const Park& pk) {
-    pass_act<0, 4, true, false, ST>(cx, big, small, act);
+    pass_act<0, 4, true, BIG0, ST>(cx, big, small, act);
     slot_unpark<0, 0>(cx, big, small, act, pk);
     slot_unpark<1, 0>(cx, big, small, act, pk);
     slot_unpark<2, 0>(cx, big, small, act, pk);
@@ -847,6 +848,303 @@ __device__ __forceinline__ float4 space_bx(Ctx& cx, const float* net, const bool
     head3(big, small, cs + BXC_W_RGB2, net + L.b_rgb2, lane, rgb);
     BXP(BXP_RGB_TAIL);
     return make_float4(rgb[0], rgb[1], rgb[2], sigma);
+}
+
+// =============================================================================================
+// The SpaceNet's backward chain in split bf16 (the twin of csrc/train_wave.hip's train_space_dx_kernel):
+// d act_{s-1} = (d act_s * [act_s > 0]) W_s from the heads back to stage1.2 (and on to PE(pos) when the sample points need a
+// gradient), on the machinery of the forward kernel above -- a wave owns 32 rows, the masked gradient of a layer lives in the
+// activation planes as three bf16 pieces, the TRANSPOSED weights come as a bf16x3 stream through the LDS ring
+// (stnerf_pack_dx_bf16x3_device), a 256-wide product runs as two passes of 128 outputs whose results wait in the park.  A layer
+// boundary is { big + small, AND with the ReLU mask, store d y_s (the left operand of the weight gradient), park }: the masks are
+// the bit planes the forward tap wrote, fetched for the item's 128 rows by LDS-DMA at the start of the item (32 KB) and read
+// back eight bytes at a time -- no register is held for them.
+//   order of the stream:  rgb_net.1[:, :256] (K = 128: 8 K steps; 2 passes), stage2.4, stage2.2, stage2.0[:, :256] (+ DPOS: its
+//   PE columns, a HALF pass: 2 blocks x 16 K steps in 4 slots), stage1.6, stage1.4, stage1.2 (+ DPOS: stage1.0, a half pass).
+// d PE(pos) = d y4 W_2.0[:, 256:] + d y0 W_1.0 leaves as two matrices (dpe_skip, dpe): the f32 kernel carries the first through
+// four layers in 32 accumulators this kernel does not have; the caller adds them (one elementwise launch).
+// =============================================================================================
+constexpr int BXD_CONST = 1024;                    // floats: density_net.0's 256 weights | the colour head [3][128] | pad
+constexpr int BXD_W_SIGMA = 0, BXD_W_RGB2 = 256;
+constexpr int BXD_LDS_MASK = WV_NW * 8 * 1024;     // per wave: 8 stages x 32 rows x 32 bytes
+constexpr int BXD_LDS = BX_LDS_RING + BXD_CONST * 4 + BXD_LDS_MASK;
+constexpr int BXD_PARK = 16;                       // VMEM stores of one boundary pass
+
+// This lane's two mask words of a boundary pass, from the LDS copy the item's LDS-DMA filled.  As asm (as the A operands): a
+// ds_read the compiler sees is preceded by s_waitcnt vmcnt(0) -- it cannot tell the weight ring's LDS-DMA in flight from the
+// masks' -- which would drain the ring at every boundary.
+__device__ __forceinline__ uint2 read_mask2(const uint32_t* mask2) {
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    u32x2_ m;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(m) : "v"((uint32_t)(uintptr_t)mask2) : "memory");
+    return make_uint2(m[0], m[1]);
+}
+// The heads' weights, for the same reason as asm, issued one group ahead of their use (LDS returns in order: `keep` = reads of the
+// NEXT group that may stay in flight).
+typedef float bxf32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_issue4(bxf32x4& dst, uint32_t addr, int off /* a constant once the loops are unrolled */) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off) : "memory");
+}
+__device__ __forceinline__ void lds_wait4(bxf32x4& a, int keep) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "i"(keep)); }
+__device__ __forceinline__ void lds_wait4x3(bxf32x4& a, bxf32x4& b, bxf32x4& c, int keep) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "i"(keep));
+}
+// v = (big + small [+ gw * w_sigma]) AND mask -> d y (16 bytes per (fb, q), as the forward tap's layout) and the park
+template <bool SIGMA>
+__device__ __forceinline__ void finish_mask_park(const f32x16 (&big)[4], const f32x16 (&small)[4], Park& pk, const uint32_t* mask2, float* dy,
+                                                 bool valid, float gw, const float* wsig, int lane) {
+    const uint2 m = read_mask2(mask2);
+    float4* dst = reinterpret_cast<float4*>(dy);
+    const uint32_t wa = (uint32_t)(uintptr_t)wsig + 16u * (uint32_t)(lane >> 5);   // quad 2 (4 fb + q) + h of the 128 weights
+    bxf32x4 wq[2];
+    if (SIGMA) lds_issue4(wq[0], wa, 0);
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+        const uint32_t word = fb < 2 ? m.x : m.y;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[4];
+            const int idx = 4 * fb + q;
+            if (SIGMA) {
+                if (idx < 15) lds_issue4(wq[(idx + 1) & 1], wa, 32 * (idx + 1));
+                lds_wait4(wq[idx & 1], idx < 15 ? 1 : 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * q + r;
+                float x = big[fb][i] + small[fb][i];
+                if (SIGMA) x = fmaf(gw, wq[idx & 1][r], x);
+                int mm;     // 0 or -1
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mm) : "v"(word), "n"((fb & 1) * 16 + i));
+                v[r] = __int_as_float(__float_as_int(x) & mm);
+                park_put(pk.v[16 * fb + i], v[r]);
+            }
+            if (valid) dst[fb * 8 + 2 * q] = make_float4(v[0], v[1], v[2], v[3]);
+            if (q & 1) BX_SB();
+        }
+    }
+}
+// the colour head backwards (rgb_net.3, 128 -> 3, modeling/spacenet.py:84-85): d act7[f] = sum_o d rgb[o] W[o][f], masked -> d y7 and
+// K steps 0 .. 7 of the planes
+__device__ __forceinline__ void dx_head_boundary(const float4 g, const float* wrgb2, const uint32_t* mask2, float* dy, bool valid,
+                                                 bf16x8 (&act)[3][16], int lane) {
+    const uint2 m = read_mask2(mask2);
+    float4* dst = reinterpret_cast<float4*>(dy);
+    const uint32_t wa = (uint32_t)(uintptr_t)wrgb2 + 16u * (uint32_t)(lane >> 5);   // quad 2 (4 fb + q) + h of each of the three rows
+    bxf32x4 wq[2][3];
+    lds_issue4(wq[0][0], wa, 0);
+    lds_issue4(wq[0][1], wa, 512);
+    lds_issue4(wq[0][2], wa, 1024);
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+        const uint32_t word = fb < 2 ? m.x : m.y;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v[8];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * t + qq;
+                const int idx = 4 * fb + q;
+                if (idx < 15) {
+                    lds_issue4(wq[(idx + 1) & 1][0], wa, 32 * (idx + 1));
+                    lds_issue4(wq[(idx + 1) & 1][1], wa, 512 + 32 * (idx + 1));
+                    lds_issue4(wq[(idx + 1) & 1][2], wa, 1024 + 32 * (idx + 1));
+                }
+                lds_wait4x3(wq[idx & 1][0], wq[idx & 1][1], wq[idx & 1][2], idx < 15 ? 3 : 0);
+                const bxf32x4 w0 = wq[idx & 1][0], w1 = wq[idx & 1][1], w2 = wq[idx & 1][2];
+                const float x[4] = {g.x * w0[0] + g.y * w1[0] + g.z * w2[0], g.x * w0[1] + g.y * w1[1] + g.z * w2[1],
+                                    g.x * w0[2] + g.y * w1[2] + g.z * w2[2], g.x * w0[3] + g.y * w1[3] + g.z * w2[3]};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int mm;
+                    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mm) : "v"(word), "n"((fb & 1) * 16 + 4 * q + r));
+                    v[4 * qq + r] = __int_as_float(__float_as_int(x[r]) & mm);
+                }
+                if (valid) dst[fb * 8 + 2 * q] = make_float4(v[4 * qq], v[4 * qq + 1], v[4 * qq + 2], v[4 * qq + 3]);
+            }
+            split8(v, act[0][2 * fb + t], act[1][2 * fb + t], act[2][2 * fb + t]);
+            BX_SB();
+        }
+    }
+}
+// one ring slot of a HALF pass (64 outputs = blocks 0, 1): K steps K0 .. K0 + 3
+template <int K0, bool FIRST, int ST = 0>
+__device__ __forceinline__ void slot_half(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], const bf16x8 (&act)[3][16]) {
+    unit<0, FIRST, FIRST>(cx, big[0], small[0], act[0][K0], act[1][K0], act[2][K0]);
+    unit<1, FIRST, FIRST>(cx, big[1], small[1], act[0][K0], act[1][K0], act[2][K0]);
+    unit<2, false>(cx, big[0], small[0], act[0][K0 + 1], act[1][K0 + 1], act[2][K0 + 1]);
+    unit<3, false>(cx, big[1], small[1], act[0][K0 + 1], act[1][K0 + 1], act[2][K0 + 1]);
+    unit<4, false>(cx, big[0], small[0], act[0][K0 + 2], act[1][K0 + 2], act[2][K0 + 2]);
+    unit<5, false>(cx, big[1], small[1], act[0][K0 + 2], act[1][K0 + 2], act[2][K0 + 2]);
+    Dma d;
+    slot_turn<ST>(cx, d);
+    unit<6, false, false, 0>(cx, big[0], small[0], act[0][K0 + 3], act[1][K0 + 3], act[2][K0 + 3], &d);
+    unit<7, false, false, 3>(cx, big[1], small[1], act[0][K0 + 3], act[1][K0 + 3], act[2][K0 + 3], &d);
+    slot_done(cx);
+}
+// d y W[:, PE columns]: 16 K steps of the planes into blocks 0, 1, written out unmasked (PE(pos) has no ReLU)
+template <int ST>
+__device__ __forceinline__ void pe_half_pass(Ctx& cx, f32x16 (&big)[4], f32x16 (&small)[4], const bf16x8 (&act)[3][16], float* dpe_row, bool valid) {
+    slot_half<0, true, ST>(cx, big, small, act);
+    slot_half<4, false, ST>(cx, big, small, act);
+    slot_half<8, false>(cx, big, small, act);
+    slot_half<12, false>(cx, big, small, act);
+    float4* dst = reinterpret_cast<float4*>(dpe_row);
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (valid)
+                dst[fb * 8 + 2 * q] = make_float4(big[fb][4 * q] + small[fb][4 * q], big[fb][4 * q + 1] + small[fb][4 * q + 1],
+                                                  big[fb][4 * q + 2] + small[fb][4 * q + 2], big[fb][4 * q + 3] + small[fb][4 * q + 3]);
+}
+
+struct DxBxArgs {
+    const char* blob;         // stnerf_pack_dx_bf16x3_device: [consts][stream]
+    const float* d_raw;       // [rows][4]: dLoss / d {r, g, b, sigma}
+    const uint32_t* bits;     // the forward tap's ReLU bit planes: [8][.. bits_stride ..], rows x 8 words per stage
+    int64_t bits_stride;
+    float* dy[8];             // dy[s]: dLoss / d (pre-activation of that layer): 256 wide, s = 7: 128
+    int32_t ld_dy[8];
+    float* dpe;               // DPOS: d y0 W_1.0 (64 wide) ...
+    float* dpe_skip;          // ... and d y4 W_2.0[:, 256:]
+    int32_t ld_dpe, ld_dpe_skip;
+    int64_t rows;
+    int32_t n_slots;          // of the stream (DPOS or not: two different blobs)
+};
+
+template <bool DPOS>
+__device__ __forceinline__ void space_dx_bx(Ctx& cx, const DxBxArgs& a, const float* cst, const uint32_t* mk, const float4 g, uint32_t row,
+                                            bool valid, int lane, f32x16 (&big)[4], f32x16 (&small)[4], bf16x8 (&act)[3][16]) {
+    Park pk;
+    // this lane's 16 bytes at column col0 of its row of d y_s (built where it is used: no register is held for it)
+    auto dyrow = [&](int s_, int col0) {
+        int l2 = lane;
+        asm volatile("" : "+v"(l2));
+        return a.dy[s_] + (size_t)row * (size_t)a.ld_dy[s_] + (uint32_t)(col0 + 4 * (l2 >> 5));
+    };
+    auto perow = [&](float* base, int32_t ld) {
+        int l2 = lane;
+        asm volatile("" : "+v"(l2));
+        return base + (size_t)row * (size_t)ld + (uint32_t)(4 * (l2 >> 5));
+    };
+    dx_head_boundary(g, cst + BXD_W_RGB2, mk + 7 * 256, dyrow(7, 0), valid, act, lane);
+    // ---- d act6 = d y7 W_rgb1[:, :256] + d sigma w_sigma (the density head's rank-1 term joins behind the K loop)
+    pass_act<0, 4, true, true, BXD_PARK>(cx, big, small, act);
+    finish_mask_park<true>(big, small, pk, mk + 6 * 256, dyrow(6, 0), valid, g.w, cst + BXD_W_SIGMA, lane);
+    pass_act<0, 4, true, true, BXD_PARK>(cx, big, small, act);
+    unpark_act(pk, act);                     // (in the open, as stage1.0's first pass in the forward kernel)
+    finish_mask_park<true>(big, small, pk, mk + 6 * 256 + 2, dyrow(6, 128), valid, g.w, cst + BXD_W_SIGMA + 128, lane);
+    // ---- six 256 x 256 products: d y_s = mask_s (d y_{s+1} W_{s+1}); s = 3 (stage2.0) with its PE columns between the passes
+    auto layer = [&](int s_, auto with_pe) {
+        pass_a_unpark<true, BXD_PARK>(cx, big, small, act, pk);
+        pass_act<8, 4, false>(cx, big, small, act);
+        finish_mask_park<false>(big, small, pk, mk + s_ * 256, dyrow(s_, 0), valid, 0.f, cst, lane);
+        if constexpr (decltype(with_pe)::value) {
+            pe_half_pass<BXD_PARK>(cx, big, small, act, perow(a.dpe_skip, a.ld_dpe_skip), valid);
+            pass_b_unpark<8, true>(cx, big, small, act, pk);
+        } else {
+            pass_b_unpark<BXD_PARK, true>(cx, big, small, act, pk);
+        }
+        finish_mask_park<false>(big, small, pk, mk + s_ * 256 + 2, dyrow(s_, 128), valid, 0.f, cst, lane);
+    };
+#pragma unroll 1
+    for (int s_ = 5; s_ >= 4; --s_) {
+        [[clang::always_inline]] layer(s_, std::false_type{});
+    }
+    [[clang::always_inline]] layer(3, std::integral_constant<bool, DPOS>{});
+#pragma unroll 1
+    for (int s_ = 2; s_ >= 0; --s_) {
+        [[clang::always_inline]] layer(s_, std::false_type{});
+    }
+    if constexpr (DPOS) {   // d y0 W_1.0: the upper half of d y0 is still parked
+        unpark_act<8>(pk, act);
+        pe_half_pass<BXD_PARK>(cx, big, small, act, perow(a.dpe, a.ld_dpe), valid);
+    }
+}
+
+template <bool DPOS>
+__global__ __launch_bounds__(WV_THREADS, 1) void train_space_dx_bx_kernel(DxBxArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bx[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* ring = smem_bx;
+    float* cst = reinterpret_cast<float*>(smem_bx + BX_LDS_RING);
+    uint32_t* masks = reinterpret_cast<uint32_t*>(smem_bx + BX_LDS_RING + BXD_CONST * 4) + wave * 2048;
+    const int64_t items = (a.rows + WV_ITEM - 1) / WV_ITEM;
+    int64_t item = blockIdx.x;
+    if (item >= items) return;  // (uniform)
+    // the heads' weights: once per workgroup (4 chunks of 1 KB over the four waves)
+    __builtin_amdgcn_global_load_lds(a.blob + wave * BX_CHUNK + lane * 16,
+                                     (__attribute__((address_space(3))) void*)((__attribute__((address_space(3))) char*)(cst) + wave * BX_CHUNK), 16, 0, 0);
+    const char* stream = a.blob + BXD_CONST * 4;
+    Ctx cx;
+    cx.ring = ring;
+    cx.wave = wave;
+    cx.lane = lane;
+    cx.gi = 0;
+    cx.gc = 0;
+    cx.rcur = (uint32_t)(uintptr_t)ring + (uint32_t)lane * 16u;
+    cx.rnext = cx.rcur + BX_SLOT;
+    cx.seg[0] = Seg{stream, (uint32_t)a.n_slots};
+    cx.seg[1] = Seg{nullptr, 0u};
+    cx.seg[2] = Seg{stream, item + gridDim.x < items ? (uint32_t)a.n_slots : 0u};
+    cx.seg[3] = Seg{nullptr, 0u};
+    cx.idle = stream;
+    dma_issue(cx);
+    dma_issue(cx);
+    dma_issue(cx);
+    BX_VMCNT(12);
+    __builtin_amdgcn_s_barrier();
+    a_read<0>(cx.A[0].p[0], cx.rcur);
+    a_read<BX_CHUNK>(cx.A[0].p[1], cx.rcur);
+    a_read<2 * BX_CHUNK>(cx.A[0].p[2], cx.rcur);
+    a_read<BX_UNIT>(cx.A[1].p[0], cx.rcur);
+    a_read<BX_UNIT + BX_CHUNK>(cx.A[1].p[1], cx.rcur);
+    a_read<BX_UNIT + 2 * BX_CHUNK>(cx.A[1].p[2], cx.rcur);
+    f32x16 big[4], small[4];
+    bf16x8 act[3][16];
+    for (; item < items; item += gridDim.x) {
+        const int64_t row64 = item * WV_ITEM + wave * WV_ROWS + (lane & 31);
+        const bool valid = row64 < a.rows;
+        const uint32_t row = (uint32_t)(valid ? row64 : a.rows - 1);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) g = *reinterpret_cast<const float4*>(a.d_raw + (size_t)row * 4);
+        // ---- the item's ReLU masks: per stage the wave's 32 rows are 1 KB contiguous; lane i fetches half-row i & 1 of row i >> 1
+        {
+            int64_t mrow = item * WV_ITEM + wave * WV_ROWS + (lane >> 1);
+            mrow = mrow < a.rows ? mrow : a.rows - 1;
+            const uint32_t* src = a.bits + (size_t)mrow * 8u + 4u * (uint32_t)(lane & 1);
+            auto dst = (__attribute__((address_space(3))) char*)(masks);
+#pragma unroll
+            for (int s_ = 0; s_ < 8; ++s_)
+                __builtin_amdgcn_global_load_lds(src + (size_t)s_ * (size_t)a.bits_stride, (__attribute__((address_space(3))) void*)(dst + s_ * 1024), 16, 0, 0);
+        }
+        BX_VMCNT(0);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        // this lane's words of (stage s, pass hf): mk[s * 256 + 2 hf + {0, 1}]
+        const uint32_t* mk = masks + (ln & 31) * 8 + 4 * (ln >> 5);
+        space_dx_bx<DPOS>(cx, a, cst, mk, g, row, valid, ln, big, small, act);
+        // the stream: the next item's moves up, the one after it joins
+        cx.seg[0] = cx.seg[2];
+        cx.seg[2] = Seg{stream, item + 2 * (int64_t)gridDim.x < items ? (uint32_t)a.n_slots : 0u};
+    }
+    BX_VMCNT(0);  // (no LDS-DMA may outlive the workgroup)
+}
+
+int launch_bf16x3_dx(const DxBxArgs& a, bool dpos, int cus, hipStream_t stream) {
+    const int64_t items = (a.rows + WV_ITEM - 1) / WV_ITEM;
+    const int grid = (int)(items < cus ? items : cus);
+    const void* kfn = dpos ? reinterpret_cast<const void*>(train_space_dx_bx_kernel<true>) : reinterpret_cast<const void*>(train_space_dx_bx_kernel<false>);
+    if (const int rc = reserve_dynamic_lds(kfn, BXD_LDS, "train_spacenet_dx (bf16x3)")) return rc;
+    if (dpos)
+        hipLaunchKernelGGL(train_space_dx_bx_kernel<true>, dim3(grid), dim3(WV_THREADS), BXD_LDS, stream, a);
+    else
+        hipLaunchKernelGGL(train_space_dx_bx_kernel<false>, dim3(grid), dim3(WV_THREADS), BXD_LDS, stream, a);
+    STNERF_CHECK_LAUNCH("train_spacenet_dx (bf16x3)");
+    return STNERF_OK;
 }
 
 __device__ __forceinline__ BxNoTap make_bx_tap(const NoTapArgs&, uint32_t, int64_t, int) { return BxNoTap(); }
@@ -1270,8 +1568,11 @@ struct BxPackPass {
     const float* src;
     int64_t dst;        // stream passes: byte offset of the pass in the blob; copies: float offset in the blob
     int32_t in, n0, ksteps;
-    int32_t mode;       // 0 hidden, 1 staged encoding (limit `lim`), 2 stage2.0 (256 hidden columns, then PE(pos)), 3 plain copy of `ksteps` floats
+    int32_t mode;       // 0 hidden, 1 staged encoding (limit `lim`), 2 stage2.0 (256 hidden columns, then PE(pos)), 3 plain copy of `ksteps` floats,
+                        // 4 TRANSPOSED (the backward chain's A operands): output n = n0 + 32 fb + c is COLUMN n of src (valid below `lim`),
+                        //   K index k = bx_kmap_hidden(..) is its ROW (valid below `klim`); `nblk` blocks per K step (4, a half pass: 2)
     int32_t lim;
+    int32_t klim, nblk;
 };
 struct BxPackTable {
     BxPackPass pass[32];
@@ -1289,11 +1590,30 @@ __global__ void pack_bf16x3_device_kernel(BxPackTable t, char* blob) {
         return;
     }
     uint16_t* d = reinterpret_cast<uint16_t*>(blob + ps.dst);
-    const int total = ps.ksteps * 4 * 512;
+    const int nblk = ps.mode == 4 ? ps.nblk : 4;
+    const int total = ps.ksteps * nblk * 512;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int j = e & 7, lane = (e >> 3) & 63, fb = (e >> 9) & 3, tt = e >> 11;
+        const int j = e & 7, lane = (e >> 3) & 63, fb = (e >> 9) % nblk, tt = (e >> 9) / nblk;
         const int h = lane >> 5, c = lane & 31;
         int k;
+        if (ps.mode == 4) {
+            k = bx_kmap_hidden(tt, h, j);
+            const int n = ps.n0 + 32 * fb + c;
+            uint32_t q0 = 0, q1 = 0, q2 = 0;
+            if (k < ps.klim && n < ps.lim) {
+                const float w = ps.src[(int64_t)k * ps.in + n];
+                q0 = bx_bf16_rne_dev(w);
+                const float r1 = w - __uint_as_float(q0 << 16);
+                q1 = bx_bf16_rne_dev(r1);
+                const float r2 = r1 - __uint_as_float(q1 << 16);
+                q2 = bx_bf16_rne_dev(r2);
+            }
+            uint16_t* u = d + (size_t)(tt * nblk + fb) * (BX_UNIT / 2) + lane * 8 + j;
+            u[0] = (uint16_t)q0;
+            u[BX_CHUNK / 2] = (uint16_t)q1;
+            u[BX_CHUNK] = (uint16_t)q2;
+            continue;
+        }
         if (ps.mode == 0) {
             k = bx_kmap_hidden(tt, h, j);
         } else if (ps.mode == 1) {
@@ -1338,10 +1658,10 @@ extern "C" int stnerf_pack_net_bf16x3_device(int kind, const float* const* W, co
     int n = 0;
     int64_t off = X.stream_off;
     auto pass = [&](const float* w, int in, int n0, int ksteps, int mode, int lim) {
-        t.pass[n++] = BxPackPass{w, off, in, n0, ksteps, mode, lim};
+        t.pass[n++] = BxPackPass{w, off, in, n0, ksteps, mode, lim, 0, 4};
         off += (int64_t)ksteps * 4 * BX_UNIT;
     };
-    auto cpy = [&](const float* src, int count, int cst_off) { t.pass[n++] = BxPackPass{src, X.consts_off / 4 + cst_off, 0, 0, count, 3, 0}; };
+    auto cpy = [&](const float* src, int count, int cst_off) { t.pass[n++] = BxPackPass{src, X.consts_off / 4 + cst_off, 0, 0, count, 3, 0, 0, 4}; };
     if (STNERF_NET_IS_SPACE(kind)) {
         const bool deep = STNERF_NET_IS_DEEP(kind);
         const int nt = deep ? 12 : 10;
@@ -1372,4 +1692,93 @@ extern "C" int stnerf_pack_net_bf16x3_device(int kind, const float* const* W, co
     hipLaunchKernelGGL(pack_bf16x3_device_kernel, dim3(32, n), dim3(256), 0, as_stream(stream), t, static_cast<char*>(dst_dev));
     STNERF_CHECK_LAUNCH("pack_net_bf16x3_device");
     return STNERF_OK;
+}
+
+// The backward chain's blob (train_space_dx_bx_kernel): [consts: density_net.0's 256 weights | the colour head [3][128] | pad to 4 KB]
+// [stream: the transposed weights as bf16 triples in consumption order, 24 KB slots].  with_dpos: with the two half passes that
+// carry the gradient on to PE(pos) (stage2.0's PE columns behind its first pass, stage1.0 at the end) -- a stream without them for
+// networks whose sample points need no gradient.  Tensors as for stnerf_pack_net_device (reference layout, fused-path networks:
+// TKERNEL_INC_RAW, USE_DIR, no deep_rgb).
+extern "C" int64_t stnerf_packed_bytes_dx_bf16x3(int kind, int with_dpos) {
+    if (kind != STNERF_NET_SPACE && kind != STNERF_NET_SPACE_TIME) {
+        set_error("packed_bytes_dx_bf16x3: kind %d (SpaceNets without deep_rgb)", kind);
+        return STNERF_EINVAL;
+    }
+    const int slots = 8 + 6 * 16 + (with_dpos ? 8 : 0);
+    return (int64_t)BXD_CONST * 4 + (int64_t)slots * BX_SLOT;
+}
+
+extern "C" int stnerf_pack_dx_bf16x3_device(int kind, const float* const* W, int n_tensors, int with_dpos, void* dst_dev, int64_t dst_bytes,
+                                            stnerf_stream_t stream) {
+    STNERF_REQUIRE(W && dst_dev, "pack_dx_bf16x3_device: null pointer");
+    const int64_t total = stnerf_packed_bytes_dx_bf16x3(kind, with_dpos);
+    if (total < 0) return (int)total;
+    STNERF_REQUIRE(n_tensors == 10, "pack_dx_bf16x3_device: a SpaceNet without deep_rgb has 10 weight tensors, got %d", n_tensors);
+    for (int i = 0; i < 10; ++i) STNERF_REQUIRE(W[i], "pack_dx_bf16x3_device: tensor %d is null", i);
+    STNERF_REQUIRE(dst_bytes >= total && ((uintptr_t)dst_dev & 1023) == 0, "pack_dx_bf16x3_device: the destination needs %lld bytes, 1 KB aligned",
+                   (long long)total);
+    if (hipMemsetAsync(dst_dev, 0, (size_t)BXD_CONST * 4, as_stream(stream)) != hipSuccess) return STNERF_ELAUNCH;
+    BxPackTable t;
+    memset(&t, 0, sizeof(t));
+    int n = 0;
+    int64_t off = (int64_t)BXD_CONST * 4;
+    auto pass = [&](const float* w, int in, int n0, int ksteps, int nlim, int klim, int nblk) {
+        t.pass[n++] = BxPackPass{w, off, in, n0, ksteps, 4, nlim, klim, nblk};
+        off += (int64_t)ksteps * nblk * BX_UNIT;
+    };
+    t.pass[n++] = BxPackPass{W[7], BXD_W_SIGMA, 0, 0, 256, 3, 0, 0, 4};
+    t.pass[n++] = BxPackPass{W[9], BXD_W_RGB2, 0, 0, 3 * 128, 3, 0, 0, 4};
+    const int in8 = 256 + 27 + (kind == STNERF_NET_SPACE_TIME ? 21 : 0);
+    for (int half = 0; half < 2; ++half) pass(W[8], in8, 128 * half, 8, 256, 128, 4);          // rgb_net.1[:, :256]
+    for (int l = 6; l >= 1; --l) {
+        const int in = l == 4 ? 319 : 256;
+        pass(W[l], in, 0, 16, 256, 256, 4);
+        if (l == 4 && with_dpos) pass(W[4], 319, 256, 16, 319, 256, 2);                        // stage2.0's PE(pos) columns: a half pass
+        pass(W[l], in, 128, 16, 256, 256, 4);
+    }
+    if (with_dpos) pass(W[0], 63, 0, 16, 63, 256, 2);                                          // stage1.0: a half pass
+    STNERF_REQUIRE(off == total && n <= 32, "pack_dx_bf16x3_device: internal: %lld B, expected %lld", (long long)off, (long long)total);
+    hipLaunchKernelGGL(pack_bf16x3_device_kernel, dim3(32, n), dim3(256), 0, as_stream(stream), t, static_cast<char*>(dst_dev));
+    STNERF_CHECK_LAUNCH("pack_dx_bf16x3_device");
+    return STNERF_OK;
+}
+
+// The backward chain in split bf16: see stnerf_train_spacenet_dx (include/stnerf.h); dpe / dpe_skip both or neither.
+extern "C" int stnerf_train_spacenet_dx_bf16x3(const void* packed_dx, int with_dpos, const float* d_raw, int64_t rows, const uint32_t* relu_bits,
+                                               int64_t relu_bits_stride, float* const* dy_host, const int32_t* ld_dy_host, float* dpe,
+                                               int32_t ld_dpe, float* dpe_skip, int32_t ld_dpe_skip, stnerf_stream_t stream) {
+    STNERF_REQUIRE(packed_dx && d_raw && relu_bits && dy_host && ld_dy_host, "train_spacenet_dx_bf16x3: null pointer");
+    STNERF_REQUIRE(rows >= 0 && rows <= 0x7fffff00ll, "train_spacenet_dx_bf16x3: %lld rows (split the batch)", (long long)rows);
+    STNERF_REQUIRE(((uintptr_t)packed_dx & 1023) == 0 && (((uintptr_t)d_raw | (uintptr_t)relu_bits) & 15) == 0 && (relu_bits_stride & 3) == 0 &&
+                       relu_bits_stride >= rows * 8,
+                   "train_spacenet_dx_bf16x3: the packed weights must be 1 KB aligned, d_raw and relu_bits 16-byte (stage stride: a multiple of 4 words, >= 8 x rows)");
+    STNERF_REQUIRE((with_dpos != 0) == (dpe != nullptr) && (dpe != nullptr) == (dpe_skip != nullptr),
+                   "train_spacenet_dx_bf16x3: dpe and dpe_skip come with a with_dpos stream, and only with one");
+    if (rows == 0) return STNERF_OK;
+    DxBxArgs a;
+    memset(&a, 0, sizeof(a));
+    a.blob = static_cast<const char*>(packed_dx);
+    a.d_raw = d_raw;
+    a.bits = relu_bits;
+    a.bits_stride = relu_bits_stride;
+    a.rows = rows;
+    a.n_slots = 8 + 6 * 16 + (with_dpos ? 8 : 0);
+    for (int i = 0; i < 8; ++i) {
+        const int width = i == 7 ? 128 : 256;
+        STNERF_REQUIRE(dy_host[i] && ((uintptr_t)dy_host[i] & 15) == 0 && (ld_dy_host[i] & 3) == 0 && ld_dy_host[i] >= width,
+                       "train_spacenet_dx_bf16x3: matrix %d must be 16-byte aligned with a row stride that is a multiple of 4 floats", i);
+        a.dy[i] = dy_host[i];
+        a.ld_dy[i] = ld_dy_host[i];
+    }
+    if (dpe) {
+        STNERF_REQUIRE((((uintptr_t)dpe | (uintptr_t)dpe_skip) & 15) == 0 && (ld_dpe & 3) == 0 && ld_dpe >= 64 && (ld_dpe_skip & 3) == 0 && ld_dpe_skip >= 64,
+                       "train_spacenet_dx_bf16x3: d PE needs 64 columns, 16-byte aligned");
+        a.dpe = dpe;
+        a.ld_dpe = ld_dpe;
+        a.dpe_skip = dpe_skip;
+        a.ld_dpe_skip = ld_dpe_skip;
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return launch_bf16x3_dx(a, with_dpos != 0, cus, as_stream(stream));
 }

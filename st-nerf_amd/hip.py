@@ -123,6 +123,10 @@ _PROTOS = {
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_int32), c_f32p, C.c_int32, C.c_void_p, c_i64, C.c_void_p, c_f32p, C.c_void_p]),
     "stnerf_train_spacenet_dx": (C.c_int, [c_f32p, C.POINTER(C.c_uint32), c_f32p, c_i64, C.c_void_p, c_i64, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
                                            c_f32p, C.c_int32, C.c_void_p]),
+    "stnerf_packed_bytes_dx_bf16x3": (c_i64, [C.c_int, C.c_int]),
+    "stnerf_pack_dx_bf16x3_device": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, c_i64, C.c_void_p]),
+    "stnerf_train_spacenet_dx_bf16x3": (C.c_int, [C.c_void_p, C.c_int, c_f32p, c_i64, C.c_void_p, c_i64, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                                  c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
     "stnerf_pack_transposed": (C.c_int, [C.POINTER(TransposeSection), C.c_int, c_f32p, c_i64, C.c_void_p]),
     "stnerf_train_motionnet_fwd": (C.c_int, [C.c_void_p, c_f32p, c_i64, C.c_int, c_f32p, c_f32p, C.c_int32, C.POINTER(C.c_void_p),
                                              C.POINTER(C.c_int32), C.c_void_p, c_i64, C.c_void_p]),

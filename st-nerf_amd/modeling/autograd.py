@@ -61,6 +61,7 @@ DW_BATCH = os.environ.get("STNERF_TRAIN_DW_BATCH", "1") != "0"
 # precision="fp32"): the stage kernel that renders, with the activation tap (csrc/mlp_bf16x3.hip, round 6; 2.3 -> ~1.6 ms per 262,144
 # samples).  "fp32": csrc/mlp_wave.hip's exact-f32 kernel with its tap, as up to round 5.
 TRAIN_FWD = os.environ.get("STNERF_TRAIN_FWD", "")
+DX_BF16X3 = os.environ.get("STNERF_TRAIN_DX_BF16X3", "1") != "0"   # (A/B: the exact-f32 d x chain behind a split-bf16 forward)
 
 
 def _train_fwd_precision(module) -> str:
@@ -132,6 +133,16 @@ def transposed_spacenet(module, params) -> tuple:
     W = [params[2 * i] for i in range(len(params) // 2)]
     pad32 = lambda w: (w.shape[1] + 31) // 32 * 32
     return _transposed(module, params, [(W[8][:, :256], 256)] + [(W[i], pad32(W[i])) for i in range(7)] + [(W[7], 0), (W[9], 0)])
+
+
+def dx_blob_bf16x3(module, params, with_dpos: bool) -> torch.Tensor:
+    """The split-bf16 backward chain's weights (ops.pack_dx_bf16x3), cached on the module until a parameter changes."""
+    key = (tuple((p.data_ptr(), p._version) for p in params), bool(with_dpos))
+    cache = getattr(module, "_dx_bx_cache", None)
+    if cache is None or cache[0] != key:
+        W = [params[2 * i] for i in range(len(params) // 2)]
+        cache = module._dx_bx_cache = (key, ops.pack_dx_bf16x3(ops.hip.NET_SPACE_TIME if module.use_time else ops.hip.NET_SPACE, W, with_dpos))
+    return cache[1]
 
 
 def _activation_buffers(rows: int, tail: int, device) -> List[torch.Tensor]:
@@ -213,7 +224,12 @@ class SpaceNetFunction(torch.autograd.Function):
             # ---- fused launches (csrc/train_wave.hip): the layers' inputs come from the forward itself (kept) or from one more run of
             # its stage kernel per chunk (recomputation); then the whole d x chain with the gradient carried in registers; only the
             # weight gradients and the encodings' chain rule stay per layer
-            wt, offsets = transposed_spacenet(m_, params)
+            # the d x chain in the forward's arithmetic: split bf16 (csrc/mlp_bf16x3.hip) or exact f32 (csrc/train_wave.hip)
+            dx_bx = ctx.fwd_precision == "bf16x3" and DX_BF16X3
+            if dx_bx:
+                dx_blob = dx_blob_bf16x3(m_, params, d_pos is not None)
+            else:
+                wt, offsets = transposed_spacenet(m_, params)
             packed = m_._packed(ctx.fwd_precision)      # (the recomputation: the arithmetic of the forward, bit for bit)
             for r0 in range(0, n, rays_per_chunk):
                 r1 = min(n, r0 + rays_per_chunk)
@@ -240,7 +256,13 @@ class SpaceNetFunction(torch.autograd.Function):
                     d_raw[:, 3:] = d_sigma[r0:r1].reshape(M, 1)
                 dys = [_buf(M, 256, dev)[:, :256] for _ in range(7)] + [_buf(M, 128, dev)[:, :128]]
                 dpe = _buf(M, 64, dev)[:, :64] if d_pos is not None else None
-                ops.train_spacenet_dx(wt, offsets, d_raw, bufs[8], dys, dpe)
+                if dx_bx:
+                    dpe_skip = _buf(M, 64, dev)[:, :64] if d_pos is not None else None
+                    ops.train_spacenet_dx_bf16x3(dx_blob, d_raw, bufs[8], dys, dpe, dpe_skip)
+                    if dpe is not None:
+                        dpe += dpe_skip          # (d y0 W_stage1.0 + d y4 W_stage2.0[:, 256:]: see stnerf_train_spacenet_dx_bf16x3)
+                else:
+                    ops.train_spacenet_dx(wt, offsets, d_raw, bufs[8], dys, dpe)
                 acc = r0 > 0
                 xin = [Cc[:, 256:256 + pe], acts[0], acts[1], acts[2], Cc[:, :256 + pe], acts[4], acts[5]]
                 dS = _buf(M, 1, dev)

@@ -720,6 +720,41 @@ def train_spacenet_dx(wt: Tensor, offsets: Sequence[int], d_raw: Tensor, relu_bi
               "stnerf_train_spacenet_dx")
 
 
+def pack_dx_bf16x3(kind: int, weights: Sequence[Tensor], with_dpos: bool) -> Tensor:
+    """The split-bf16 backward chain's weights in one blob (stnerf_pack_dx_bf16x3_device): the network's 10 weight tensors in reference
+    layout (device, fp32) -> a 1 KB-aligned uint8 device tensor.  with_dpos: with the two half passes towards PE(pos)."""
+    lib = hip.lib()
+    nbytes = lib.stnerf_packed_bytes_dx_bf16x3(kind, int(with_dpos))
+    if nbytes < 0:
+        hip.check(int(nbytes), "stnerf_packed_bytes_dx_bf16x3")
+    ws = [w.detach().to(torch.float32).contiguous() for w in weights]
+    if not all(w.is_cuda for w in ws):
+        raise ValueError("pack_dx_bf16x3 packs on the device: the weights must be CUDA tensors")
+    dev = ws[0].device
+    raw = torch.empty(nbytes + 1024, dtype=torch.uint8, device=dev)
+    off = (-raw.data_ptr()) % 1024
+    blob = raw[off:off + nbytes]
+    wp = (C.c_void_p * len(ws))(*(w.data_ptr() for w in ws))
+    with torch.cuda.device(dev):
+        hip.check(lib.stnerf_pack_dx_bf16x3_device(kind, wp, len(ws), int(with_dpos), C.c_void_p(blob.data_ptr()), nbytes, hip.stream_ptr()),
+                  "stnerf_pack_dx_bf16x3_device")
+    return blob
+
+
+def train_spacenet_dx_bf16x3(blob: Tensor, d_raw: Tensor, relu_bits: Tensor, dys: Sequence[Tensor], dpe: Optional[Tensor],
+                             dpe_skip: Optional[Tensor]) -> None:
+    """``train_spacenet_dx`` in split bf16 (stnerf_train_spacenet_dx_bf16x3): blob = ``pack_dx_bf16x3``; dLoss / d PE(pos) leaves as
+    dpe + dpe_skip (both (rows,64)) when the blob was packed with_dpos, else both None."""
+    rows = d_raw.shape[0]
+    bp, bstride = _bit_planes(relu_bits, rows)
+    yp, yld = _matrix_list(dys, "dys")
+    pp, ldp = _mat(dpe, "dpe") if dpe is not None else (C.c_void_p(0), 0)
+    sp, lds_ = _mat(dpe_skip, "dpe_skip") if dpe_skip is not None else (C.c_void_p(0), 0)
+    hip.check(hip.lib().stnerf_train_spacenet_dx_bf16x3(C.c_void_p(blob.data_ptr()), int(dpe is not None), hip.dptr(d_raw, name="d_raw"), rows,
+                                                        bp, bstride, yp, yld, pp, ldp, sp, lds_, hip.stream_ptr()),
+              "stnerf_train_spacenet_dx_bf16x3")
+
+
 def _motion_bit_planes(bits: Tensor, rows: int):
     """(pointer, stage stride in words) of a MotionNet's ReLU bit planes: int32 (5, rows, 4), possibly a row range of a larger launch's."""
     if not bits.is_cuda or bits.dtype != torch.int32 or tuple(bits.shape) != (5, rows, 4) or bits.stride(2) != 1 or bits.stride(1) != 4:

@@ -595,3 +595,42 @@ def test_device_packer_writes_the_host_packers_blob(ops, kind):
     dev = pack({k: v.cuda() for k, v in sd.items()}, "net", "cuda", "fp32")
     assert host.kind == dev.kind and host.blob.shape == dev.blob.shape
     assert torch.equal(host.blob.view(torch.int32), dev.blob.view(torch.int32))
+
+
+@pytest.mark.parametrize("use_time, n, want_dpos", [(True, 37, True), (False, 37, False), (True, 128, True)])
+def test_split_bf16_backward_chain_matches_the_exact_f32_chain(ops, use_time, n, want_dpos):
+    """stnerf_train_spacenet_dx_bf16x3 against stnerf_train_spacenet_dx on the same cotangent and the same ReLU masks (a split-bf16 forward
+    tap's): every layer's pre-activation gradient within 2e-5 of the matrix's largest entry (both are fp32-faithful evaluations of the
+    same chain: measured ~1e-6), exact zeros where the mask is zero in both, d PE(pos) = dpe + dpe_skip likewise; a ragged last work
+    item (703 rows) and whole ones (2432); rows past the end untouched."""
+    from stnerf_amd.modeling import autograd as A
+    net, pos, rays, tm = _space_case(use_time, n=n, seed=5)
+    n, ns = pos.shape[0], pos.shape[1]
+    M = n * ns
+    bufs = A._activation_buffers(M, 48, "cuda")
+    raw = torch.empty(n, ns, 4, device="cuda")
+    ops.train_spacenet_fwd(net._packed("bf16x3"), pos, rays[:, 3:6], tm.reshape(n) if use_time else None, raw, A._act_views(bufs),
+                           bufs[0][:, 256:320], bufs[8])
+    g = torch.Generator().manual_seed(11)
+    d_raw = torch.randn(M, 4, generator=g).cuda()
+    params = [p.detach() for p in net.training_parameters()]
+    wt, offsets = A.transposed_spacenet(net, params)
+    mk = lambda: [torch.full((M + 3, 256), float("nan"), device="cuda")[:M, :256] for _ in range(7)] + [torch.full((M + 3, 128), float("nan"), device="cuda")[:M]]
+    want, got = mk(), mk()
+    dpe_w = torch.empty(M, 64, device="cuda") if want_dpos else None
+    ops.train_spacenet_dx(wt, offsets, d_raw, bufs[8], want, dpe_w)
+    blob = A.dx_blob_bf16x3(net, params, want_dpos)
+    dpe, dpe_skip = (torch.empty(M, 64, device="cuda"), torch.empty(M, 64, device="cuda")) if want_dpos else (None, None)
+    ops.train_spacenet_dx_bf16x3(blob, d_raw, bufs[8], got, dpe, dpe_skip)
+    torch.cuda.synchronize()
+    for s_, (a_, b_) in enumerate(zip(got, want)):
+        assert bool(torch.isfinite(a_).all()), s_
+        scale = float(b_.abs().max())
+        assert scale > 0 and float((a_ - b_).abs().max()) <= 2e-5 * scale, (s_, float((a_ - b_).abs().max()), scale)
+        assert torch.equal(a_ == 0, b_ == 0) or float(((a_ == 0) != (b_ == 0)).float().mean()) < 1e-4, s_
+        assert bool(torch.isnan(a_._base[M:]).all()) if a_._base is not None else True      # (rows past the end: untouched)
+    if want_dpos:
+        total = dpe + dpe_skip
+        scale = float(dpe_w.abs().max())
+        assert float((total - dpe_w).abs().max()) <= 2e-5 * scale, (float((total - dpe_w).abs().max()), scale)
+        assert float(dpe_w[:, 63].abs().max()) == 0.0 and float(total[:, 63].abs().max()) == 0.0      # (the pad column)
