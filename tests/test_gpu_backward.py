@@ -580,10 +580,11 @@ def test_pack_transposed_builds_the_sections_torch_builds(ops):
         ops.pack_transposed(ws, dst[:100])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("kind", ["space", "space_time", "space_time_deep", "space_noinc", "motion"])
-def test_device_packer_writes_the_host_packers_blob(ops, kind):
-    """stnerf_pack_net_device (what a training loop calls after every optimizer.step(): no host round trip) writes the exact-f32
-    blob of stnerf_pack_net bit for bit, for every network flavour."""
+def test_device_packer_writes_the_host_packers_blob(ops, kind, precision):
+    """stnerf_pack_net_device / stnerf_pack_net_bf16x3_device (what a training loop calls after every optimizer.step(): no host round
+    trip) write the blobs of stnerf_pack_net / stnerf_pack_net_bf16x3 bit for bit, for every network flavour."""
     rs = np.random.RandomState(11)
     if kind == "motion":
         sd = syn.motionnet_state("net", rs)
@@ -591,8 +592,9 @@ def test_device_packer_writes_the_host_packers_blob(ops, kind):
     else:
         sd = syn.spacenet_state("net", rs, "time" in kind, deep_rgb="deep" in kind, include_input="noinc" not in kind)
         pack = ops.pack_spacenet
-    host = pack(sd, "net", "cuda", "fp32")
-    dev = pack({k: v.cuda() for k, v in sd.items()}, "net", "cuda", "fp32")
+    host = pack(sd, "net", "cuda", precision)
+    dev = pack({k: v.cuda() for k, v in sd.items()}, "net", "cuda", precision)
+    assert dev.blob.data_ptr() % (1024 if precision == "bf16x3" else 16) == 0
     assert host.kind == dev.kind and host.blob.shape == dev.blob.shape
     assert torch.equal(host.blob.view(torch.int32), dev.blob.view(torch.int32))
 

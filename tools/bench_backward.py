@@ -72,6 +72,16 @@ for name, net, flop in [("SpaceNet (time)", SpaceNet(use_time=True), 930_048), (
         t_old = timed(step, 3)
         A.FUSED_BACKWARD = True
         print(f"{name}: per-layer backward (STNERF_TRAIN_FUSED=0) {1e3 * t_old:.1f} ms; fused {1e3 * t:.1f} ms")
-    # forward (fused inference kernel) + recompute + dX + dW = 4 x the network's FLOPs, 3 of them in csrc/train.hip
-    print(f"{name}: forward + backward of {m} samples {1e3 * t:.1f} ms = {m / t / 1e6:.2f} M samples/s, {4 * flop * m / t / 1e12:.1f} TF/s of network work "
-          f"({4 * flop * m / t / 1e12 / PEAK:.2f} of the f32 MFMA peak)")
+    # forward (with the tap: the activations are kept at this size) + d x + d W = 3 x the network's FLOPs; with STNERF_TRAIN_KEEP_GB=0 the
+    # backward runs the forward once more: 4 x.  (Up to round 6's first profiles this line counted 4 x in both cases.)
+    from stnerf_amd.modeling import autograd as A
+    passes = 3 if A.KEEP_BYTES >= m * 4 * (A.ACT_FLOATS_PER_SAMPLE if "Space" in name else A.MOTION_ACT_FLOATS_PER_SAMPLE) else 4
+    arith = (A.TRAIN_FWD or net.precision) if "Space" in name else "fp32"
+    print(f"{name}: forward + backward of {m} samples {1e3 * t:.2f} ms = {m / t / 1e6:.2f} M samples/s, {passes * flop * m / t / 1e12:.1f} TF/s of network work "
+          f"({passes} x the forward's FLOPs: {'activations kept' if passes == 3 else 'recomputed'}; {passes * flop * m / t / 1e12 / PEAK:.2f} of the f32 MFMA peak; "
+          f"forward / d x arithmetic: {arith})")
+    if "Space" in name and not os.environ.get("ONLY_FUSED") and not A.TRAIN_FWD:     # A/B: the exact-f32 forward tap and d x chain (round 5's)
+        A.TRAIN_FWD = "fp32"
+        t32 = timed(step, 3)
+        A.TRAIN_FWD = ""
+        print(f"{name}: exact-f32 forward tap + d x chain (STNERF_TRAIN_FWD=fp32) {1e3 * t32:.2f} ms; split bf16 {1e3 * t:.2f} ms")
