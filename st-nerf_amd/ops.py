@@ -220,7 +220,7 @@ def pack_spacenet(state: dict, prefix: str, device="cuda", precision: str = "fp3
     (use_time, use_dir, include_input, deep_rgb: modeling/spacenet.py:16-86) is read off the tensor shapes."""
     deep = f"{prefix}.rgb_net.7.weight" in state          # deep_rgb: rgb_net.{1,3,5,7} (modeling/spacenet.py:68-79)
     keys = SPACENET_KEYS + (["rgb_net.5", "rgb_net.7"] if deep else [])
-    on_device = precision == "fp32" and all(state[f"{prefix}.{k}.weight"].is_cuda for k in keys)     # (packed where they live)
+    on_device = all(state[f"{prefix}.{k}.weight"].is_cuda for k in keys)     # (packed where they live, either arithmetic: pack_net)
     ws = [state[f"{prefix}.{k}.weight"].detach().float() if on_device else state[f"{prefix}.{k}.weight"].detach().float().cpu() for k in keys]
     bs = [state[f"{prefix}.{k}.bias"] for k in keys]
     pos_w = ws[0].shape[1]
@@ -246,7 +246,7 @@ def pack_spacenet(state: dict, prefix: str, device="cuda", precision: str = "fp3
 
 
 def pack_motionnet(state: dict, prefix: str, device="cuda", precision: str = "fp32") -> PackedNet:
-    on_device = precision == "fp32" and all(state[f"{prefix}.{k}.weight"].is_cuda for k in MOTIONNET_KEYS)
+    on_device = all(state[f"{prefix}.{k}.weight"].is_cuda for k in MOTIONNET_KEYS)
     ws = [state[f"{prefix}.{k}.weight"].detach().float() if on_device else state[f"{prefix}.{k}.weight"].detach().float().cpu() for k in MOTIONNET_KEYS]
     bs = [state[f"{prefix}.{k}.bias"] for k in MOTIONNET_KEYS]
     if ws[0].shape[1] not in (84, 80):
