@@ -459,10 +459,14 @@ __device__ __forceinline__ void finish_park(f32x16 (&big)[4], const f32x16 (&sma
             for (int r = 0; r < 4; ++r) {
                 v[r] = out_relu(big[fb], small[fb], 4 * q + r);
                 if (PARK) park_put(pk.v[16 * fb + 4 * q + r], v[r]);
+#ifndef STNERF_DEV_TAP_NO_BITS      // (development A/B of what the tap costs: profiles/retired_designs.md)
                 tap_bit(w, v[r], (16 * fb + 4 * q + r) & 31);
+#endif
             }
             // register 4 q + r of block fb <-> feature 32 fb + 8 q + 4 h + r: 16 bytes per (fb, q), the two lanes of a sample side by side
+#ifndef STNERF_DEV_TAP_NO_STORES
             if (valid) dst[fb * 8 + 2 * q] = make_float4(v[0], v[1], v[2], v[3]);
+#endif
             if (q & 1) BX_SB();
         }
         if (fb & 1) {
