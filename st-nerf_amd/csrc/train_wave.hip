@@ -368,6 +368,10 @@ static int train_spacenet_fwd(bool bf16x3, int kind, const void* packed, int64_t
         lds[i] = ld_act_host[i];
     }
     STNERF_REQUIRE(((uintptr_t)pe & 15) == 0 && (ld_pe & 3) == 0 && ld_pe >= 64, "train_spacenet_fwd: the PE matrix needs 64 columns, 16-byte aligned");
+    // (the split-bf16 kernel fetches its weight stream by 16-byte LDS-DMA from 1 KB-aligned sections)
+    STNERF_REQUIRE(!bf16x3 || ((uintptr_t)packed & 1023) == 0, "train_spacenet_fwd_bf16x3: the packed network must be 1 KB aligned");
+    STNERF_REQUIRE(!relu_bits || (((uintptr_t)relu_bits & 15) == 0 && (relu_bits_stride & 3) == 0 && relu_bits_stride >= n_rays * ns * 8),
+                   "train_spacenet_fwd: relu_bits must be 16-byte aligned, its stage stride a multiple of 4 words and >= 8 x rows");
     const bool timed = kind == STNERF_NET_SPACE_TIME;
     if (const int rc = launch_ray_bias(kind, static_cast<const float*>(packed), n_rays, nullptr, nullptr, dirs, dirs_ray_stride, times,
                                        times_ray_stride, ray_bias, as_stream(stream)))
@@ -386,13 +390,7 @@ static int train_spacenet_fwd(bool bf16x3, int kind, const void* packed, int64_t
     a.queue = queue;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    STNERF_REQUIRE(!relu_bits || (((uintptr_t)relu_bits & 15) == 0 && (relu_bits_stride & 3) == 0 && relu_bits_stride >= n_rays * ns * 8),
-                   "train_spacenet_fwd: relu_bits must be 16-byte aligned, its stage stride a multiple of 4 words and >= 8 x rows");
     if (bf16x3) {
-        // (the stream is fetched by 16-byte LDS-DMA from 1 KB-aligned sections; the tap's buffer descriptors cover one work item's rows)
-        STNERF_REQUIRE(((uintptr_t)packed & 1023) == 0, "train_spacenet_fwd_bf16x3: the packed network must be 1 KB aligned");
-        for (int i = 0; i < 8; ++i) STNERF_REQUIRE(ld_act_host[i] <= (1 << 20), "train_spacenet_fwd_bf16x3: row stride %d of matrix %d", ld_act_host[i], i);
-        STNERF_REQUIRE(ld_pe <= (1 << 20), "train_spacenet_fwd_bf16x3: row stride %d of the PE matrix", ld_pe);
         StoreTapArgs t;
         t.bits = relu_bits;
         t.bits_stride = relu_bits_stride;

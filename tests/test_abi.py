@@ -239,6 +239,42 @@ def test_training_batch_entries_check_their_arguments_on_the_host(lib):
     assert lib.stnerf_pack_transposed(sec, 2, fake, 1 << 20, None) == hip.EINVAL
 
 
+def test_split_bf16_training_entries_check_their_arguments_on_the_host(lib):
+    """Round 6's split-bf16 training entries: sizes and argument errors before any launch (no GPU here)."""
+    fake = 1 << 20                                     # (1 KB aligned, never dereferenced)
+    null = C.c_void_p(0)
+    # the backward chain's blob: 4 KB of head weights + 24 KB slots: rgb_net.1 8, six 256 x 256 layers 16 each, with d pos two half passes of 4
+    assert lib.stnerf_packed_bytes_dx_bf16x3(hip.NET_SPACE, 0) == 4096 + (8 + 96) * 24576
+    assert lib.stnerf_packed_bytes_dx_bf16x3(hip.NET_SPACE_TIME, 1) == 4096 + (8 + 96 + 8) * 24576
+    assert lib.stnerf_packed_bytes_dx_bf16x3(hip.NET_SPACE_TIME_DEEP, 0) == hip.EINVAL and "deep_rgb" in hip.last_error()
+    assert lib.stnerf_packed_bytes_dx_bf16x3(hip.NET_MOTION, 0) == hip.EINVAL
+    ptrs = (C.c_void_p * 10)(*([fake] * 10))
+    nbytes = lib.stnerf_packed_bytes_dx_bf16x3(hip.NET_SPACE, 1)
+    assert lib.stnerf_pack_dx_bf16x3_device(hip.NET_SPACE, ptrs, 9, 1, fake, nbytes, None) == hip.EINVAL and "10 weight tensors" in hip.last_error()
+    assert lib.stnerf_pack_dx_bf16x3_device(hip.NET_SPACE, ptrs, 10, 1, fake, nbytes - 1, None) == hip.EINVAL
+    assert lib.stnerf_pack_dx_bf16x3_device(hip.NET_SPACE, ptrs, 10, 1, fake + 16, nbytes, None) == hip.EINVAL and "1 KB aligned" in hip.last_error()
+    assert lib.stnerf_pack_net_bf16x3_device(hip.NET_SPACE, ptrs, ptrs, 10, fake + 16, 1 << 30, None) == hip.EINVAL and "1 KB aligned" in hip.last_error()
+    assert lib.stnerf_pack_net_bf16x3_device(99, ptrs, ptrs, 10, fake, 1 << 30, None) == hip.EINVAL
+    dys = (C.c_void_p * 8)(*([fake] * 8))
+    lds = (C.c_int32 * 8)(*([256] * 7 + [128]))
+    dx = lambda blob, dpos, dpe, skip, rows=1000, stride=8000: lib.stnerf_train_spacenet_dx_bf16x3(blob, dpos, fake, rows, fake, stride, dys, lds, dpe, 64, skip, 64, None)
+    assert dx(fake + 16, 0, null, null) == hip.EINVAL and "1 KB aligned" in hip.last_error()
+    assert dx(fake, 1, null, null) == hip.EINVAL and "with_dpos" in hip.last_error()              # a d pos stream without its two matrices
+    assert dx(fake, 0, fake, fake) == hip.EINVAL
+    assert dx(fake, 1, fake, null) == hip.EINVAL
+    assert dx(fake, 0, null, null, stride=7000) == hip.EINVAL                                       # stage stride < 8 x rows
+    assert dx(fake, 0, null, null, rows=0) == hip.OK                                                # nothing to do: no launch
+    lds[3] = 250
+    assert dx(fake, 0, null, null) == hip.EINVAL and "matrix 3" in hip.last_error()
+    # the forward: as stnerf_train_spacenet_fwd, plus the blob's alignment
+    acts = (C.c_void_p * 8)(*([fake] * 8))
+    lda = (C.c_int32 * 8)(*([256] * 7 + [128]))
+    fwd = lambda packed, kind=hip.NET_SPACE: lib.stnerf_train_spacenet_fwd_bf16x3(kind, packed, 10, 4, fake, 12, fake, 3, null, 0, fake, 16, acts, lda, fake, 64, null, 0, fake, fake, None)
+    assert fwd(fake + 16) == hip.EINVAL and "1 KB aligned" in hip.last_error()
+    assert fwd(fake, hip.NET_SPACE_TIME) == hip.EINVAL and "frame-id" in hip.last_error()
+    assert fwd(fake, hip.NET_SPACE_DEEP) == hip.EINVAL
+
+
 def test_composite_launch_plan(lib):
     """stnerf_composite_plan: the sizing arithmetic of the compositor's launches (render.hip: plan_composite) on the CPU.
     Every BASELINE shape takes the register / insertion-merge kernels; the single-layer pre-pass needs scratch; a merged

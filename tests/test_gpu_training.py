@@ -166,8 +166,8 @@ FP32_NOISE_FACTOR = 3.0
 CONDITIONED_RTOL = 1e-3   # networks behind a MotionNet or the resampler: see the test's docstring (the conditioning of sin(2^9 x), not of the kernels)
 
 
-@pytest.mark.parametrize("name", ["train_tf_c3", "train_tf_trainer"])
-def test_teacher_forced_training_step_meets_the_piecewise_bar_end_to_end(ops, name):
+@pytest.mark.parametrize("name, train_fwd", [("train_tf_c3", ""), ("train_tf_c3", "fp32"), ("train_tf_trainer", "")])
+def test_teacher_forced_training_step_meets_the_piecewise_bar_end_to_end(ops, monkeypatch, name, train_fwd):
     """The whole step -- forward, loss, loss.backward() through both stages -- with every network evaluated ON WHAT THE REFERENCE'S WAS:
     make_golden.py --grads --teacher recorded, inside the reference's own do_train iteration, every layer's new fine depths
     (modeling/layered_rfrender.py:460) and the deformed points handed to the performer SpaceNets (:355-356, :509-510); model.replay feeds
@@ -177,6 +177,10 @@ def test_teacher_forced_training_step_meets_the_piecewise_bar_end_to_end(ops, na
     at those identical points, likewise.  train_tf_trainer is the trainer's own batch (2000 rays, 90 + 30 samples, two performers:
     configs/config_taekwondo.yml:6,52-53).  Gradients are compared as digests (tensors of <= 4096 entries whole; larger ones as absmax,
     norm, row / column sums and 512 seeded entries: stnerf_amd.synthetic.tensor_digest)."""
+    # (train_fwd: "" = the fused SpaceNet forward and gradient chain in the model's own arithmetic, split bf16; "fp32": the exact-f32 pair --
+    # STNERF_TRAIN_FWD -- at the same bars)
+    from stnerf_amd.modeling import autograd as A
+    monkeypatch.setattr(A, "TRAIN_FWD", train_fwd)
     model, out, loss, parts, z, meta = training_step(name)
     assert meta["teacher"]
     # forward: every output image of both stages against the reference's, every ray (the fine stage sits on the reference's samples)
