@@ -27,7 +27,14 @@
 //   * PE, bias, ReLU, heads, outputs: fp32, as in the exact-f32 kernels; rgb_net.1's direction / time columns come per
 //     ray from mlp_raybias.hip (exact f32) as the layer's C operand.
 //
-// Reference: modeling/spacenet.py:16-160, modeling/motion_net.py:7-71, modeling/layered_rfrender.py:340-418,495-576.
+// Three kernels are built from this machinery (round 6): the stage kernel of the render path (mlp_bf16x3_stage_kernel<DEEP, NoTapArgs>);
+// the same kernel with the training tap (<false, StoreTapArgs>: every layer's post-ReLU output and its mask bits written out as the
+// rows pass -- stnerf_train_spacenet_fwd_bf16x3); and the backward chain d x = (d y AND mask) W over the TRANSPOSED weights as a
+// second bf16x3 stream (train_space_dx_bx_kernel -- stnerf_train_spacenet_dx_bf16x3).  Packers: host (stnerf_pack_net_bf16x3) and
+// device (stnerf_pack_net_bf16x3_device, stnerf_pack_dx_bf16x3_device) at the end of the file.
+//
+// Reference: modeling/spacenet.py:16-160, modeling/motion_net.py:7-71, modeling/layered_rfrender.py:340-418,495-576; training:
+// engine/layered_trainer.py:281 (loss.backward() through modeling/spacenet.py:101-160).
 #include <stdlib.h>
 #include <string.h>
 
@@ -121,7 +128,13 @@ struct BxStoreTap {
 constexpr int BX_TAP_PARK = 18;   // VMEM stores of one park: 16 x 16 B of activations + two mask words
 constexpr int BX_TAP_PE = 8;
 __device__ __forceinline__ uint32_t tap_row_in_item(const BxStoreTap& tap, int lane) { return (uint32_t)(tap.wave * WV_ROWS + (lane & 31)); }
-__device__ __forceinline__ bool tap_valid(const BxStoreTap& tap, int lane) { return tap_row_in_item(tap, lane) < tap.nrows; }
+__device__ __forceinline__ bool tap_valid(const BxStoreTap& tap, int lane) {
+#ifdef STNERF_DEV_TAP_ALWAYS_VALID      // (development A/B: what the per-store validity branches cost; launches of whole items only)
+    return true;
+#else
+    return tap_row_in_item(tap, lane) < tap.nrows;
+#endif
+}
 // this lane's 16 bytes of (stage, column col0) of its row; stage: 0 .. 7 or TAP_PE
 __device__ __forceinline__ float* tap_row(const BxStoreTap& tap, int stage, int col0, int lane) {
     // (opaque here: the per-lane addresses of all fifteen boundaries are loop invariants of the item loop -- hoisted, they are live
@@ -1111,7 +1124,11 @@ __global__ __launch_bounds__(WV_THREADS, 1) void train_space_dx_bx_kernel(DxBxAr
     bf16x8 act[3][16];
     for (; item < items; item += gridDim.x) {
         const int64_t row64 = item * WV_ITEM + wave * WV_ROWS + (lane & 31);
+#ifdef STNERF_DEV_TAP_ALWAYS_VALID
+        const bool valid = true;
+#else
         const bool valid = row64 < a.rows;
+#endif
         const uint32_t row = (uint32_t)(valid ? row64 : a.rows - 1);
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid) g = *reinterpret_cast<const float4*>(a.d_raw + (size_t)row * 4);

@@ -13,6 +13,10 @@
 //                               values in both kernels), fetched at the start of an item; at every layer boundary the masked
 //                               gradient -- the pre-activation gradient d y_s the weight gradients need -- is written out once.
 //
+// (Round 6: both launches also exist in split bf16 -- csrc/mlp_bf16x3.hip: the stage kernel with a tap and train_space_dx_bx_kernel --
+// and that pair is what modeling/autograd.py runs unless the model was built for exact f32; the forward's entry point is here, the chain's
+// beside its kernel.)
+//
 // What is left to per-layer launches are the weight gradients dW_s = d y_s^T x_s (csrc/train.hip: a reduction over ALL rows that
 // no 128-row item can finish on its own) and the encodings' chain rule.
 //
