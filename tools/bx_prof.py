@@ -24,12 +24,21 @@ names = ["top (consts DMA, barrier)", "motion: encoding + first C", "motion: K p
 ideal = {2: 19 * 48 * 32, 5: 112 * 48 * 32}
 cases = {"bkgd only": [dict(space=bk, motion=None, xyz=xyz, raw=raw)],
          "performer fused with motion": [dict(space=sp, motion=mo, xyz=xyz, raw=raw, times=times)]}
+# (round 6) the training forward: the same kernel with the activation tap, on the performer SpaceNet alone -- beside the plain launch of it
+from stnerf_amd.modeling import autograd as A
+bufs = A._activation_buffers(n * ns, 48, "cuda")
+cases["performer SpaceNet alone"] = [dict(space=sp, motion=None, xyz=xyz, raw=raw, times=times)]
+cases["performer SpaceNet alone, WITH THE TRAINING TAP"] = "tap"
 buf = (C.c_ulonglong * 16)()
 for name, ls in cases.items():
-    ops.mlp_stage(ls, dirs, ns, sigmoid_rgb=True); torch.cuda.synchronize()
+    if ls == "tap":
+        run = lambda: ops.train_spacenet_fwd(sp, xyz, dirs, times, raw, A._act_views(bufs), bufs[0][:, 256:320], bufs[8])
+    else:
+        run = lambda: ops.mlp_stage(ls, dirs, ns, sigmoid_rgb=True)
+    run(); torch.cuda.synchronize()
     lib.stnerf_debug_bx_phases(buf, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); ops.mlp_stage(ls, dirs, ns, sigmoid_rgb=True); e1.record(); torch.cuda.synchronize()
+    e0.record(); run(); e1.record(); torch.cuda.synchronize()
     lib.stnerf_debug_bx_phases(buf, 1)
     items = buf[12]
     tot = sum(buf[i] for i in range(12))
