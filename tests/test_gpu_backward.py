@@ -380,12 +380,12 @@ def _space_case(use_time, n=37, ns=19, seed=0):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-@pytest.mark.parametrize("use_time, n", [(False, 37), (True, 37), (True, 128)])
+@pytest.mark.parametrize("use_time, n", [(False, 37), (True, 37), (True, 128), (True, 1)])
 def test_fused_forward_writes_the_activations_the_layerwise_recompute_builds(ops, use_time, n, precision):
     """stnerf_train_spacenet_fwd[_bf16x3] = the inference stage kernel of that arithmetic + a tap: its outputs are stnerf_spacenet_fwd's
     bit for bit, and every layer input it writes out is what the per-layer recomputation (train_encode + train_linear_fwd, round 4,
-    exact f32) produces -- within the rounding of an fp32 layer for both arithmetics -- with a ragged last work item (703 rows) and
-    with whole ones (2432)."""
+    exact f32) produces -- within the rounding of an fp32 layer for both arithmetics -- with a ragged last work item (703 rows),
+    with whole ones (2432) and with a single ray (19 rows: less than one wave)."""
     from stnerf_amd.modeling import autograd as A
     net, pos, rays, tm = _space_case(use_time, n=n)
     n, ns = pos.shape[0], pos.shape[1]
@@ -599,12 +599,12 @@ def test_device_packer_writes_the_host_packers_blob(ops, kind, precision):
     assert torch.equal(host.blob.view(torch.int32), dev.blob.view(torch.int32))
 
 
-@pytest.mark.parametrize("use_time, n, want_dpos", [(True, 37, True), (False, 37, False), (True, 128, True)])
+@pytest.mark.parametrize("use_time, n, want_dpos", [(True, 37, True), (False, 37, False), (True, 128, True), (True, 1, True), (False, 7, False)])
 def test_split_bf16_backward_chain_matches_the_exact_f32_chain(ops, use_time, n, want_dpos):
     """stnerf_train_spacenet_dx_bf16x3 against stnerf_train_spacenet_dx on the same cotangent and the same ReLU masks (a split-bf16 forward
     tap's): every layer's pre-activation gradient within 2e-5 of the matrix's largest entry (both are fp32-faithful evaluations of the
     same chain: measured ~1e-6), exact zeros where the mask is zero in both, d PE(pos) = dpe + dpe_skip likewise; a ragged last work
-    item (703 rows) and whole ones (2432); rows past the end untouched."""
+    item (703 rows), whole ones (2432), 19 and 133 rows; rows past the end untouched."""
     from stnerf_amd.modeling import autograd as A
     net, pos, rays, tm = _space_case(use_time, n=n, seed=5)
     n, ns = pos.shape[0], pos.shape[1]
