@@ -177,6 +177,7 @@ struct Ctx {
     uint32_t gc;        // slots consumed so far
     char* ring;
     int wave, lane;
+    bool st_on;         // training kernels: this wave issues the boundary stores its slot turns count in (slot_turn<ST>)
     ABuf A[4];
 };
 
@@ -316,9 +317,20 @@ __device__ __forceinline__ void unit(Ctx& cx, f32x16& big, f32x16& small, const 
 
 // Between units 5 and 6 of a slot: the next slot has landed everywhere and the previous one is free everywhere (every wave
 // has issued -- and, to get here, completed -- its reads of it); the fetch three slots ahead goes into its place.
-template <int ST = 0>   // ST: VMEM stores this wave issued behind the DMA of the slot it is waiting for (the training tap)
+// ST: VMEM stores this wave issued behind the DMA of the slot it is waiting for (the training kernels' boundary stores).  The
+// immediate must never exceed 6 + the stores really in flight, or the wait no longer covers the wave's share of the LDS-DMA: a
+// wave whose 32 rows are all past the end of the launch branches around its conditional stores (and a launch without mask planes
+// skips two per boundary) -- such a wave runs with st_on == false and waits for vmcnt(6), which is always sufficient.
+template <int ST = 0>
 __device__ __forceinline__ void slot_turn(Ctx& cx, Dma& d) {
-    BX_VMCNT(6 + ST);
+    if constexpr (ST > 0) {
+        if (cx.st_on)      // (wave-uniform: a scalar branch)
+            BX_VMCNT(6 + ST);
+        else
+            BX_VMCNT(6);
+    } else {
+        BX_VMCNT(6);
+    }
     __builtin_amdgcn_s_barrier();
     dma_begin(cx, d);
     BX_SB();
@@ -1130,6 +1142,7 @@ __global__ __launch_bounds__(WV_THREADS, 1) void train_space_dx_bx_kernel(DxBxAr
         const bool valid = row64 < a.rows;
 #endif
         const uint32_t row = (uint32_t)(valid ? row64 : a.rows - 1);
+        cx.st_on = item * WV_ITEM + wave * WV_ROWS < a.rows;     // (some row of the wave's 32 inside the launch: its stores are issued)
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid) g = *reinterpret_cast<const float4*>(a.d_raw + (size_t)row * 4);
         // ---- the item's ReLU masks: per stage the wave's 32 rows are 1 KB contiguous; lane i fetches half-row i & 1 of row i >> 1
@@ -1168,6 +1181,10 @@ int launch_bf16x3_dx(const DxBxArgs& a, bool dpos, int cus, hipStream_t stream) 
     return STNERF_OK;
 }
 
+// does this wave issue every store of a boundary?  (some row of its 32 inside the launch, mask planes wanted)
+__device__ __forceinline__ bool tap_wave_stores(const BxStoreTap& tap, const StoreTapArgs& t) {
+    return (uint32_t)(tap.wave * WV_ROWS) < tap.nrows && t.bits != nullptr;
+}
 __device__ __forceinline__ BxNoTap make_bx_tap(const NoTapArgs&, uint32_t, int64_t, int) { return BxNoTap(); }
 __device__ __forceinline__ BxStoreTap make_bx_tap(const StoreTapArgs& t, uint32_t item, int64_t rows, int wave) {
     // (training launches one network: items of queue slot 0 are rows 128 item ..)
@@ -1307,6 +1324,7 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_bf16x3_stage_kernel(StageAr
     cx.lane = lane;
     cx.gi = 0;
     cx.gc = 0;
+    cx.st_on = false;
     cx.rcur = (uint32_t)(uintptr_t)ring + (uint32_t)lane * 16u;   // LDS byte address of the ring + lane * 16
     cx.rnext = cx.rcur + BX_SLOT;
     segs_of(it0, cx.seg[0], cx.seg[1]);
@@ -1373,6 +1391,7 @@ __global__ __launch_bounds__(WV_THREADS, 1) void mlp_bf16x3_stage_kernel(StageAr
             if (ly.motion) motion_bx(cx, ly.motion, cm, encw, p, cur.tv, ly.motion_flags, ln, big, small, act BXP_ARG);
         }
         const auto tap = make_bx_tap(targs, it0, a.n_rays * a.ns, wave);
+        if constexpr (TAP) cx.st_on = tap_wave_stores(tap, targs);
         float4 o = space_bx<DEEP>(cx, ly.space, ly.use_time != 0, cs, encw, p, ly.raybias, cur.ray, ln, big, small, act,
                                   [&]() {
                                       if constexpr (TAP) {

@@ -403,6 +403,15 @@ def test_fused_forward_writes_the_activations_the_layerwise_recompute_builds(ops
     want = torch.empty(n, ns, 4, device="cuda")
     ops.spacenet_fwd(packed, pos, rays[:, 3:6], tm.reshape(n) if use_time else None, want)
     assert torch.equal(raw, want)
+    # without mask planes (relu_bits is optional): the same outputs and activations, bit for bit
+    again = [torch.full_like(b, float("nan")) for b in [Cc, R, T0] + Hs + Gs]
+    acts2 = [again[3], again[4], again[5], again[0][:, :256], again[6], again[7], again[1][:, :256], again[2]]
+    raw2 = torch.empty_like(raw)
+    ops.train_spacenet_fwd(packed, pos, rays[:, 3:6], tm.reshape(n) if use_time else None, raw2, acts2, again[0][:, 256:320], None)
+    assert torch.equal(raw2, raw)
+    for a_, b_ in zip(acts2, acts):
+        assert torch.equal(a_[:, :128], b_[:, :128]) and torch.equal(a_, b_)
+    assert torch.equal(again[0][:, 256:320], Cc[:, 256:320])
     # nothing beyond a matrix's 256 columns was touched (rgb_net.1's input keeps its direction / time columns for train_encode)
     assert bool(torch.isnan(R[:, 256:]).all())
     # the round-4 recomputation, layer by layer
