@@ -178,6 +178,15 @@ def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cud
             blob = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
             fn, name = lib.stnerf_pack_net_device, "stnerf_pack_net_device"
         else:       # (the stage kernel streams it by 16-byte LDS-DMA from 1 KB-aligned sections)
+            # The host packer refuses what cannot be split into three bf16 pieces (NaN, inf, |w| > 3.3895e38: include/stnerf.h).  Packing on
+            # the device, the same refusal costs a host <- device synchronisation: paid where a model is packed to RENDER (once per weight
+            # version), not inside a training step (autograd enabled: the step would wait for the GPU after every optimizer.step(); a
+            # non-finite weight there gives NaN outputs and a NaN loss).
+            if not torch.is_grad_enabled():
+                worst = float(torch.stack([t.abs().max() if t.numel() else t.new_zeros(()) for t in ws + bs]).nan_to_num(nan=float("inf")).max())
+                if not worst <= 3.3895313892515355e38:
+                    raise ValueError(f"stnerf_pack_net_bf16x3_device: a weight or bias is not finite or exceeds bf16's range (|w| <= 3.3895e38): "
+                                     f"{worst:g} -- use the exact-f32 packing (precision='fp32') for such a network")
             raw = torch.empty(nbytes + 1024, dtype=torch.uint8, device=dev)
             off = (-raw.data_ptr()) % 1024
             blob = raw[off:off + nbytes].view(torch.float32)

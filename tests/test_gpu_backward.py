@@ -645,3 +645,22 @@ def test_split_bf16_backward_chain_matches_the_exact_f32_chain(ops, use_time, n,
         scale = float(dpe_w.abs().max())
         assert float((total - dpe_w).abs().max()) <= 2e-5 * scale, (float((total - dpe_w).abs().max()), scale)
         assert float(dpe_w[:, 63].abs().max()) == 0.0 and float(total[:, 63].abs().max()) == 0.0      # (the pad column)
+
+
+def test_device_bf16x3_packer_refuses_unsplittable_weights_when_packing_to_render(ops):
+    """A model whose tensors live on the GPU is packed there; outside autograd (packing to render) the packer refuses what the host packer
+    refuses -- NaN, inf, |w| > 3.3895e38 (include/stnerf.h) -- with a ValueError; inside a training step (autograd enabled) it does not
+    synchronise and packs (NaN pieces: a NaN loss)."""
+    sd = {k: v.cuda() for k, v in syn.spacenet_state("net", np.random.RandomState(3), True).items()}
+    with torch.no_grad():
+        ops.pack_spacenet(sd, "net", "cuda", "bf16x3")
+        for bad in (float("nan"), float("inf"), -3.39e38):
+            sd2 = dict(sd)
+            w = sd["net.stage1.4.weight"].clone()
+            w[5, 7] = bad
+            sd2["net.stage1.4.weight"] = w
+            with pytest.raises(ValueError, match="not finite or exceeds"):
+                ops.pack_spacenet(sd2, "net", "cuda", "bf16x3")
+            ops.pack_spacenet(sd2, "net", "cuda", "fp32")          # (the exact-f32 packing takes any value)
+    with torch.enable_grad():
+        ops.pack_spacenet(sd2, "net", "cuda", "bf16x3")
