@@ -176,7 +176,8 @@ class SpaceNetFunction(torch.autograd.Function):
             # arithmetic (split bf16 by default -- the kernel that renders, with the tap; STNERF_TRAIN_FWD=fp32: exact f32 whatever
             # the module renders with, as up to round 5); per-layer path: exact f32.
             ctx.fwd_precision = _train_fwd_precision(module) if fused else "fp32"
-            packed = module._packed(ctx.fwd_precision)
+            with ops.training_pack():
+                packed = module._packed(ctx.fwd_precision)
             if fused and _may_keep(n * ns * ACT_FLOATS_PER_SAMPLE * 4):
                 dir_w_, time_w_ = 27, (21 if module.use_time else 0)
                 kept = _activation_buffers(n * ns, dir_w_ + time_w_, dev)
@@ -230,7 +231,8 @@ class SpaceNetFunction(torch.autograd.Function):
                 dx_blob = dx_blob_bf16x3(m_, params, d_pos is not None)
             else:
                 wt, offsets = transposed_spacenet(m_, params)
-            packed = m_._packed(ctx.fwd_precision)      # (the recomputation: the arithmetic of the forward, bit for bit)
+            with ops.training_pack():
+                packed = m_._packed(ctx.fwd_precision)      # (the recomputation: the arithmetic of the forward, bit for bit)
             for r0 in range(0, n, rays_per_chunk):
                 r1 = min(n, r0 + rays_per_chunk)
                 M = (r1 - r0) * ns

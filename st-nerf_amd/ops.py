@@ -153,6 +153,19 @@ class PackedNet:
         return self.kind in (hip.NET_SPACE_TIME, hip.NET_SPACE_TIME_DEEP)
 
 
+_PACK_CHECK = [True]
+
+
+class training_pack:
+    """Context of the packs a training step makes (modeling/autograd.py): no finiteness check -- no synchronisation -- in the device bf16x3 packer."""
+
+    def __enter__(self):
+        self.prev, _PACK_CHECK[0] = _PACK_CHECK[0], False
+
+    def __exit__(self, *exc):
+        _PACK_CHECK[0] = self.prev
+
+
 def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cuda", precision: str = "fp32") -> PackedNet:
     """Repack reference-layout nn.Linear tensors (host copy) and upload.  precision: "fp32" (exact f32 MFMA) or "bf16x3"
     (three bf16 pieces per operand, six MFMAs, two accumulators: the full fp32 significand and exponent range; the stage
@@ -180,9 +193,9 @@ def pack_net(kind: int, weights: List[Tensor], biases: List[Tensor], device="cud
         else:       # (the stage kernel streams it by 16-byte LDS-DMA from 1 KB-aligned sections)
             # The host packer refuses what cannot be split into three bf16 pieces (NaN, inf, |w| > 3.3895e38: include/stnerf.h).  Packing on
             # the device, the same refusal costs a host <- device synchronisation: paid where a model is packed to RENDER (once per weight
-            # version), not inside a training step (autograd enabled: the step would wait for the GPU after every optimizer.step(); a
-            # non-finite weight there gives NaN outputs and a NaN loss).
-            if not torch.is_grad_enabled():
+            # version), not inside a training step (``training_pack()``, modeling/autograd.py: the step would wait for the GPU after every
+            # optimizer.step(); a non-finite weight there gives NaN outputs and a NaN loss).
+            if _PACK_CHECK[0]:
                 worst = float(torch.stack([t.abs().max() if t.numel() else t.new_zeros(()) for t in ws + bs]).nan_to_num(nan=float("inf")).max())
                 if not worst <= 3.3895313892515355e38:
                     raise ValueError(f"stnerf_pack_net_bf16x3_device: a weight or bias is not finite or exceeds bf16's range (|w| <= 3.3895e38): "

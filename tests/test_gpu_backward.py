@@ -648,11 +648,11 @@ def test_split_bf16_backward_chain_matches_the_exact_f32_chain(ops, use_time, n,
 
 
 def test_device_bf16x3_packer_refuses_unsplittable_weights_when_packing_to_render(ops):
-    """A model whose tensors live on the GPU is packed there; outside autograd (packing to render) the packer refuses what the host packer
-    refuses -- NaN, inf, |w| > 3.3895e38 (include/stnerf.h) -- with a ValueError; inside a training step (autograd enabled) it does not
-    synchronise and packs (NaN pieces: a NaN loss)."""
+    """A model whose tensors live on the GPU is packed there; packing to render, the packer refuses what the host packer refuses -- NaN,
+    inf, |w| > 3.3895e38 (include/stnerf.h) -- with a ValueError; inside a training step (ops.training_pack(), modeling/autograd.py) it
+    does not synchronise and packs (NaN pieces: a NaN loss)."""
     sd = {k: v.cuda() for k, v in syn.spacenet_state("net", np.random.RandomState(3), True).items()}
-    with torch.no_grad():
+    if True:
         ops.pack_spacenet(sd, "net", "cuda", "bf16x3")
         for bad in (float("nan"), float("inf"), -3.39e38):
             sd2 = dict(sd)
@@ -662,5 +662,5 @@ def test_device_bf16x3_packer_refuses_unsplittable_weights_when_packing_to_rende
             with pytest.raises(ValueError, match="not finite or exceeds"):
                 ops.pack_spacenet(sd2, "net", "cuda", "bf16x3")
             ops.pack_spacenet(sd2, "net", "cuda", "fp32")          # (the exact-f32 packing takes any value)
-    with torch.enable_grad():
+    with ops.training_pack():
         ops.pack_spacenet(sd2, "net", "cuda", "bf16x3")
